@@ -1,0 +1,243 @@
+/* libtextreid_hip.so -- C ABI of the MI355X (gfx950) encode-and-match kernels.
+ *
+ * Drop-in boundary.  The reference (BrandonHanx/TextReID)
+ * is pure Python on PyTorch and has no FFI of its own: every device kernel it
+ * runs is dispatched implicitly by torch ops.  Each entry point below therefore
+ * cites the reference call site (file:line under the reference root) whose
+ * torch op(s) it replaces.  The Python host (textreid_amd/) binds these with
+ * ctypes; INTEGRATION.md shows the binding a reference maintainer would add.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; every buffer is DEVICE memory owned by the
+ *    caller (PyTorch's caching allocator) and merely borrowed for the call;
+ *  - asynchronous: work is enqueued on `stream` (a hipStream_t passed as void*)
+ *    and the call returns; no device synchronisation, no host reads of device data;
+ *  - return 0 on success, negative TRID_E_* for argument errors, positive =
+ *    hipError_t from the launch; trid_last_error_string() gives the message
+ *    (thread-local);
+ *  - re-entrant, no global mutable state;
+ *  - activations are NHWC ("[B,H,W,C]" row-major), matrices row-major, fp32.
+ */
+#ifndef TEXTREID_HIP_H
+#define TEXTREID_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TRID_OK 0
+#define TRID_E_INVALID (-1)
+#define TRID_E_UNSUPPORTED (-2)
+
+#define TRID_VERSION 100
+
+int trid_version(void);
+const char* trid_arch(void); /* "gfx950" */
+const char* trid_last_error_string(void);
+
+/* ------------------------------------------------------------------------- *
+ * Dense contraction family (fp32 MFMA).  C[m,n] (+)= alpha*sum_k A(m,k)B(k,n) + bias[n]
+ * Replaces: nn.Conv2d 1x1/3x3 fwd+bwd (m_resnet.py:18-27,41-47,161-170),
+ * nn.Linear / F.linear (m_resnet.py:114-133, head.py:50-51,126-145), nn.GRU's
+ * input/hidden projections (gru.py:36-43,76), torch.matmul / einsum
+ * (losses.py:52-53,112; head.py:160-170; evaluation.py:120).
+ * ------------------------------------------------------------------------- */
+enum {
+    TRID_A_KC = 0,   /* A[m*lda + k] */
+    TRID_A_MC = 1,   /* A[k*lda + m] */
+    TRID_A_CONV = 2, /* A = NHWC image [Bimg,H,W,Cin]; m = pixel, k = (tap,c); 3x3, stride 1, pad 1 */
+    TRID_B_KC = 0,   /* B[n*ldb + k]  (weights [N,K]) */
+    TRID_B_NC = 1,   /* B[k*ldb + n] */
+    TRID_B_CONV = 2  /* B = NHWC image; k = pixel, n = (tap,c)  (weight gradient of a 3x3 conv) */
+};
+
+typedef struct trid_gemm_desc {
+    const float* A;
+    const float* B;
+    float* C;
+    int32_t M, N, K;
+    int64_t lda, ldb, ldc;
+    int64_t strideA, strideB, strideC; /* batch strides, elements */
+    int32_t batch;                     /* >= 1 */
+    int32_t splits;                    /* split-K factor; split s writes C + s*strideSplit */
+    int64_t strideSplit;
+    int32_t a_mode, b_mode;
+    float alpha;
+    int32_t accumulate; /* C += ... */
+    const float* bias;  /* [N] or NULL */
+    int64_t strideBias; /* batch stride of bias, elements */
+    float* stats;       /* NULL, or [ceil(M/128)][N][2] per-tile column (mean, M2) partials */
+    int32_t H, W, Cin;  /* conv gather geometry */
+} trid_gemm_desc;
+
+int trid_gemm_f32(const trid_gemm_desc* d, void* stream);
+
+/* C[i] (+)= sum_s slab[s*strideSplit + i], i < n (n % 4 == 0) */
+int trid_slab_reduce_f32(const float* slab, float* C, long long n, int splits, long long strideSplit,
+                         int accumulate, void* stream);
+
+/* w [N][T][C] -> wt [C][T][N]; flip != 0 reverses the tap order (3x3 dgrad = conv
+ * with 180-degree rotated, transposed filters).  autograd of nn.Conv2d. */
+int trid_weight_transpose_f32(const float* w, float* wt, int N, int T, int C, int flip, void* stream);
+
+/* Stem conv1 (3x3, stride 2, pad 1, NCHW input, m_resnet.py:161-163,205) as
+ * im2col: col[m][c*9+ky*3+kx], m = (b,yo,xo), row stride ldcol (>= Cin*9, padded
+ * columns zero-filled). */
+int trid_stem_im2col_f32(const float* img, float* col, int B, int Cin, int H, int W, int Ho, int Wo,
+                         int ldcol, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * BatchNorm2d (train: batch statistics + running update; eval: running stats),
+ * ReLU, residual add, AvgPool2d(2).  m_resnet.py:19-29,38-49,57-66,164-171.
+ * ------------------------------------------------------------------------- */
+/* Merge per-tile (mean,M2) partials (rows_per_part rows each, last one ragged)
+ * into batch mean / biased var; write mean, invstd, scale=gamma*invstd,
+ * shift=beta-mean*scale; update running stats (unbiased var, momentum). */
+int trid_bn_finalize_f32(const float* partials, int nparts, int rows_per_part, long long M, int C,
+                         const float* gamma, const float* beta, float* running_mean, float* running_var,
+                         float momentum, float eps, float* mean, float* invstd, float* scale, float* shift,
+                         void* stream);
+/* eval mode: scale/shift from running statistics */
+int trid_bn_eval_coeffs_f32(const float* gamma, const float* beta, const float* running_mean,
+                            const float* running_var, float eps, float* scale, float* shift, int C, void* stream);
+/* out = act( y*scale[c]+shift[c] + (res ? (rscale ? res*rscale[c]+rshift[c] : res) : 0) ) */
+int trid_bn_apply_f32(const float* y, const float* scale, const float* shift, const float* res,
+                      const float* rscale, const float* rshift, float* out, long long M, int C, int relu,
+                      void* stream);
+/* out[b,y/2,x/2,c] = mean over 2x2 of act(y*scale+shift)   (scale==NULL: plain pooling of y) */
+int trid_bn_apply_pool2_f32(const float* y, const float* scale, const float* shift, float* out, int B, int H,
+                            int W, int C, int relu, void* stream);
+/* dx[b,y,x,c] (+)= 0.25*g[b,y/2,x/2,c] */
+int trid_avgpool2_bwd_f32(const float* g, float* dx, int B, int H, int W, int C, int accumulate, void* stream);
+
+/* BatchNorm backward.  g is dL/d(out).  mask_mode: 0 none, 1 recompute
+ * (y*scale+shift > 0), 2 from `act` (> 0).  pooled != 0: g has shape
+ * [B,H/2,W/2,C] and the effective gradient is 0.25*g[b,y/2,x/2,c] (AvgPool2d(2)
+ * after the activation).  Step 1 reduces dbeta = sum gm, dgamma = sum gm*xhat
+ * (workspace: ws floats >= trid_bn_bwd_ws_floats(C)); step 2 writes
+ * dy = scale*(gm - dbeta/M - xhat*dgamma/M) and optionally dres = gm. */
+long long trid_bn_bwd_ws_floats(int C);
+int trid_bn_bwd_reduce_f32(const float* g, const float* y, const float* act, const float* mean,
+                           const float* invstd, const float* scale, const float* shift, int mask_mode,
+                           int pooled, int B, int H, int W, int C, float* dgamma, float* dbeta, float* ws,
+                           void* stream);
+int trid_bn_bwd_apply_f32(const float* g, const float* y, const float* act, const float* mean,
+                          const float* invstd, const float* scale, const float* shift, const float* dgamma,
+                          const float* dbeta, int mask_mode, int pooled, int B, int H, int W, int C, float* dy,
+                          float* dres, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Attention pool (m_resnet.py:103-135), token-0 query only.
+ * ------------------------------------------------------------------------- */
+/* tok[b,0,:] = mean_t x[b,t,:] + pos[0]; tok[b,1+t,:] = x[b,t,:] + pos[1+t] */
+int trid_attnpool_tokens_f32(const float* x, const float* pos, float* tok, int B, int T, int C, void* stream);
+/* dx[b,t,:] = dtok[b,1+t,:] + dtok[b,0,:]/T ; dpos[t,:] = sum_b dtok[b,t,:] */
+int trid_attnpool_tokens_bwd_f32(const float* dtok, float* dx, float* dpos, int B, int T, int C, void* stream);
+/* row softmax over the first n columns of each row (ld >= n), in place; pad columns zeroed */
+int trid_softmax_rows_f32(float* s, long long rows, int n, int ld, void* stream);
+/* ds = p * (dp - sum_j p_j dp_j), row-wise; writes into ds (may alias dp) */
+int trid_softmax_rows_bwd_f32(const float* p, const float* dp, float* ds, long long rows, int n, int ld,
+                              void* stream);
+/* out[n] (+)= sum_m x[m*ld + n] */
+int trid_colsum_f32(const float* x, float* out, long long M, int N, long long ld, int accumulate, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Text encoder (gru.py:48-82): table gather, masked BiGRU cell, max over time.
+ * ------------------------------------------------------------------------- */
+/* x[b*L + t, :] = table[tokens[b*ldtok + t], :]  for t < L */
+int trid_embedding_gather_f32(const float* table, const int64_t* tokens, float* x, int B, int L, int ldtok, int E,
+                              long long vocab, void* stream);
+/* One time step of both directions.  s = step index; direction d processes
+ * t = s (d=0) or t = Lmax-1-s (d=1).  gi: [B*L, 2*3H] input projections (row
+ * b*L+t, col d*3H + gate*H + j); gh: [2,B,3H]; h: [2,B,H] updated in place;
+ * saved gates (r,z,n,hn) -> gates[s] [2,B,4H] and previous state -> hprev[s]
+ * [2,B,H] (NULL to skip, e.g. key encoder); running max over time in
+ * maxv/argt [B,2H] (column d*H+j). */
+int trid_gru_cell_fwd_f32(const float* gi, const float* gh, float* h, const int64_t* lengths, float* gates,
+                          float* hprev, float* maxv, int32_t* argt, int s, int Lmax, int L, int B, int Hd,
+                          void* stream);
+/* maxv/argt init: 0/-1 when length < Lmax (a zero pad row enters the max, gru.py:63) else -inf/-1 */
+int trid_gru_max_init_f32(float* maxv, int32_t* argt, const int64_t* lengths, int Lmax, int B, int Hd, void* stream);
+/* Backward of one step (reverse order of s).  dh [2,B,H] carries dL/dh; adds the
+ * max-pool gradient dout[b, d*H+j] where argt == t; writes dgi rows into dGi
+ * [B*L, 2*3H], dgh [2,B,3H]; dh <- dh*z (+ pass-through when inactive). */
+int trid_gru_cell_bwd_f32(const float* dout, const int32_t* argt, const float* gates, const float* hprev,
+                          const int64_t* lengths, float* dh, float* dGi, float* dgh, int s, int Lmax, int L,
+                          int B, int Hd, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Embedding head and losses (head.py:126-175, losses.py, moco_head/loss.py).
+ * ------------------------------------------------------------------------- */
+/* y = x / max(||x||_2, eps) row-wise; inv_norm[rows] saved */
+int trid_l2norm_rows_f32(const float* x, float* y, float* inv_norm, long long rows, int C, float eps, void* stream);
+/* dx = (dy - y * <dy,y>) * inv_norm  (+ dx if accumulate) */
+int trid_l2norm_rows_bwd_f32(const float* dy, const float* y, const float* inv_norm, float* dx, long long rows,
+                             int C, int accumulate, void* stream);
+/* flag[k] = 1 if id_queue[k] equals any ids[i] (head.py:148-157: one shared column set per batch) */
+int trid_queue_hit_mask(const int64_t* id_queue, const int64_t* ids, uint8_t* flag, int K, int B, void* stream);
+/* InfoNCE over [pos | masked negs]/T with label 0 (losses.py:206-217).
+ * S: [B, ldS] similarity of queries vs the K queue rows (raw dot products), in
+ * place becomes dL/dS (already scaled by gscale/(B*T)); pos[b] = <q_b, key_b>;
+ * outputs loss_rows[b] = lse - pos/T and dpos[b]. */
+int trid_infonce_rows_f32(float* S, const float* pos, const uint8_t* hit, float* loss_rows, float* dpos, int B,
+                          int K, int ldS, float invT, float gscale, void* stream);
+/* rowdot[b] = <x_b, y_b> */
+int trid_rowdot_f32(const float* x, const float* y, float* out, long long rows, int C, void* stream);
+/* dx[b,:] (+)= s[b]*y[b,:] */
+int trid_rowscale_add_f32(const float* s, const float* y, float* dx, long long rows, int C, int accumulate,
+                          void* stream);
+/* Label-smoothed CE rows (losses.py:6-39 via :42-62).  logits [rows, ld] (first
+ * n valid); in place -> dlogits scaled by gscale/rows_per_loss; loss_rows[r] =
+ * -(1-eps)*logp[label] - eps/n * sum_j logp_j. */
+int trid_smooth_ce_rows_f32(float* logits, const int64_t* labels, float* loss_rows, long long rows, int n, int ld,
+                            float epsilon, float gscale, void* stream);
+/* projection [C, N] -> column-normalised copies pn [C, ldn] and pnt [ldn, C]; inv_norm[N] */
+int trid_colnorm_f32(const float* proj, float* pn, float* pnt, float* inv_norm, int C, int N, int ldn, void* stream);
+/* dproj[c,j] = (dpnt[j,c] - pnt[j,c]*<dpnt[j,:],pnt[j,:]>) * inv_norm[j] */
+int trid_colnorm_bwd_f32(const float* dpnt, const float* pnt, const float* inv_norm, float* dproj, int C, int N,
+                         int ldn, void* stream);
+/* Global-align loss elementwise part (losses.py:102-128): S [B, ldS] cosine
+ * matrix in place -> dL/dS (scaled by gscale); loss_rows[b] = row sum of the
+ * softplus terms * 2/B. */
+int trid_global_align_rows_f32(float* S, const int64_t* ids, float* loss_rows, int B, int ldS, float alpha,
+                               float beta, float scale_pos, float scale_neg, float gscale, void* stream);
+/* out[0] (+)= scale * sum_i x[i] */
+int trid_sum_f32(const float* x, float* out, long long n, float scale, int accumulate, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * MoCo state: momentum update, enqueue (head.py:73-109), optimiser.
+ * ------------------------------------------------------------------------- */
+/* Multi-tensor k = m*k + (1-m)*q.  ptr tables are DEVICE arrays of n_tensors
+ * addresses; chunk table: chunk c covers elements [chunk_off[c], +chunk_len) of
+ * tensor chunk_tensor[c]. */
+int trid_ema_multi_f32(const uint64_t* k_ptrs, const uint64_t* q_ptrs, const int64_t* sizes,
+                       const int32_t* chunk_tensor, const int64_t* chunk_off, int n_chunks, int chunk_len, float m,
+                       void* stream);
+/* Multi-tensor Adam / AdamW step (torch.optim.Adam semantics, lib/solver/build.py:6-40:
+ * per-tensor lr and weight decay).  step_size = lr/(1-b1^t), bc2 = sqrt(1-b2^t). */
+int trid_adam_multi_f32(const uint64_t* p_ptrs, const uint64_t* g_ptrs, const uint64_t* m_ptrs,
+                        const uint64_t* v_ptrs, const int64_t* sizes, const float* lrs, const float* wds,
+                        const int32_t* chunk_tensor, const int64_t* chunk_off, int n_chunks, int chunk_len,
+                        float beta1, float beta2, float eps, float bias_c1, float bias_c2, int decoupled,
+                        void* stream);
+/* Ring-buffer push at device-resident pointer: queue row-major [K, C]
+ * (transpose of the reference's [C,K], so the push is one contiguous slab). */
+int trid_enqueue_f32(float* v_queue, float* t_queue, int64_t* id_queue, int64_t* ptr, const float* v_keys,
+                     const float* t_keys, const int64_t* ids, int K, int C, int B, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Retrieval (evaluation.py:11-37,117-120): per-query top-k over a gallery shard.
+ * ------------------------------------------------------------------------- */
+/* sim = q @ g.T for q [Q,C], g [G,C] (both L2-normalised by the caller), fused
+ * per-row top-k (k <= 16) sorted descending, ties -> lower index first.
+ * out_val [Q,k] f32, out_idx [Q,k] i64 (+ idx_offset).  ws floats >= trid_topk_ws_floats(Q,G,k). */
+long long trid_topk_ws_floats(int Q, int G, int k);
+int trid_sim_topk_f32(const float* q, const float* g, float* out_val, int64_t* out_idx, int Q, int G, int C,
+                      int k, long long idx_offset, float* ws, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TEXTREID_HIP_H */

@@ -1,0 +1,229 @@
+"""GPU parity of the individual HIP kernels (through the C ABI) against plain
+PyTorch fp32 CPU references of the same ops, on seeded inputs.  Tolerance for the
+fp32 MFMA contractions: 2e-5 relative to the output scale (north_star allows 1e-3)."""
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+import oracle.fill as OF  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from textreid_amd import ops as o
+
+    return o
+
+
+def R(name, *shape, scale=1.0):
+    return OF.randn(name, shape, 0, scale)
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def dev(t):
+    return t.cuda().contiguous()
+
+
+TOL = 2e-5
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 200, 132), (1024, 64, 256), (70, 32, 36), (32, 2048, 64), (4096, 96, 512), (193, 24, 2048)])
+def test_gemm_nt_bias(ops, M, N, K):
+    x, w, b = R("x", M, K), R("w", N, K), R("b", N)
+    y = ops.linear(dev(x), dev(w), dev(b))
+    assert rel(y, x @ w.t() + b) < TOL
+
+
+def test_gemm_accumulate_alpha(ops):
+    x, w, c = R("x", 200, 64), R("w", 72, 64), R("c", 200, 72)
+    out = dev(c)
+    ops.linear(dev(x), dev(w), out=out, alpha=0.5, accumulate=True)
+    assert rel(out, c + 0.5 * (x @ w.t())) < TOL
+
+
+def test_gemm_strided_rows(ops):
+    # token-0 rows of a [B, T, C] tensor (attention-pool query)
+    tok = R("tok", 8, 13, 64)
+    w = R("w", 40, 64)
+    y = ops.linear(dev(tok)[:, 0], dev(w))
+    assert rel(y, tok[:, 0] @ w.t()) < TOL
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 256, 96), (40, 2048, 196), (256, 64, 11008)])
+def test_gemm_nn(ops, M, N, K):
+    a, b = R("a", M, K), R("b", K, N)
+    assert rel(ops.matmul_nn(dev(a), dev(b)), a @ b) < TOL
+
+
+@pytest.mark.parametrize("K,Ma,Nb", [(4096, 64, 256), (50000, 128, 128), (777, 32, 64), (12288, 256, 2048), (256, 11008, 256)])
+def test_gemm_tn_splitk(ops, K, Ma, Nb):
+    a, b = R("a", K, Ma), R("b", K, Nb)
+    ref = (a.double().t() @ b.double()).float()
+    assert rel(ops.matmul_tn(dev(a), dev(b)), ref) < TOL
+
+
+def test_gemm_batched(ops):
+    # per-image scores: U[b] [32,K] x tok[b] [T,K]^T
+    Bt, Hh, T, K = 5, 32, 196, 128
+    U, tok = R("U", Bt, Hh, K), R("tok", Bt, T, K)
+    out = torch.empty(Bt, Hh, T, device="cuda")
+    ops.gemm(dev(U), dev(tok), out, Hh, T, K, K, K, T, batch=Bt, strideA=Hh * K, strideB=T * K, strideC=Hh * T)
+    assert rel(out, torch.einsum("bhk,btk->bht", U, tok)) < TOL
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def ohwi(w):
+    return w.permute(0, 2, 3, 1).contiguous().reshape(w.shape[0], -1)
+
+
+@pytest.mark.parametrize("B,C,H,W,N", [(2, 16, 12, 8, 32), (3, 64, 24, 8, 64), (2, 8, 48, 16, 8), (4, 32, 10, 6, 128), (1, 128, 96, 32, 128)])
+def test_conv3x3_fwd_dgrad_wgrad(ops, B, C, H, W, N):
+    x, w, gy = R("cx", B, C, H, W), R("cw", N, C, 3, 3, scale=0.1), R("cg", B, N, H, W)
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    y_ref = F.conv2d(xr, wr, padding=1)
+    y_ref.backward(gy)
+    xd, wd, gd = dev(nhwc(x)), dev(ohwi(w)), dev(nhwc(gy))
+    y, st = ops.conv3x3(xd, wd, stats=True)
+    assert rel(y.permute(0, 3, 1, 2), y_ref) < TOL
+    # dgrad = conv with rotated/transposed weights
+    wt = ops.weight_transpose(wd, N, 9, C, flip=True)
+    dx = ops.conv3x3(gd, wt)
+    assert rel(dx.permute(0, 3, 1, 2), xr.grad) < TOL
+    dw = ops.conv3x3_wgrad(gd, xd)
+    assert rel(dw, ohwi(wr.grad)) < TOL
+    # BN statistics partials -> finalize == batch stats
+    gamma, beta = R("g", N).abs() + 0.5, R("b", N)
+    rm, rv = torch.zeros(N), torch.ones(N)
+    bst = ops.bn_finalize(st, B * H * W, dev(gamma), dev(beta), rmd := dev(rm), rvd := dev(rv))
+    yr = y_ref.detach()
+    mean, var = yr.mean((0, 2, 3)), yr.var((0, 2, 3), unbiased=False)
+    assert rel(bst.mean, mean) < 1e-5 and rel(bst.invstd, 1 / torch.sqrt(var + 1e-5)) < 1e-5
+    F.batch_norm(yr, rm, rv, gamma, beta, True, 0.1, 1e-5)
+    assert rel(rmd, rm) < 1e-5 and rel(rvd, rv) < 1e-5
+
+
+@pytest.mark.parametrize("B,C,H,W,N", [(2, 64, 12, 8, 256), (4, 256, 6, 2, 64), (3, 16, 24, 8, 16)])
+def test_conv1x1_all(ops, B, C, H, W, N):
+    x, w, gy = R("px", B, C, H, W), R("pw", N, C, 1, 1, scale=0.2), R("pg", B, N, H, W)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    y_ref = F.conv2d(xr, wr)
+    y_ref.backward(gy)
+    xd, wd, gd = dev(nhwc(x)), dev(w.reshape(N, C)), dev(nhwc(gy))
+    assert rel(ops.conv1x1(xd, wd).permute(0, 3, 1, 2), y_ref) < TOL
+    wt = ops.weight_transpose(wd, N, 1, C, flip=False)
+    assert rel(ops.conv1x1(gd, wt).permute(0, 3, 1, 2), xr.grad) < TOL
+    assert rel(ops.conv1x1_wgrad(gd, xd), wr.grad.reshape(N, C)) < TOL
+
+
+def test_stem_im2col_conv(ops):
+    x, w = R("sx", 3, 3, 24, 16), R("sw", 8, 3, 3, 3)
+    col, Ho, Wo = ops.stem_im2col(dev(x))
+    wp = torch.zeros(8, 28)
+    wp[:, :27] = w.reshape(8, 27)
+    y = ops.linear(col, dev(wp)).reshape(3, Ho, Wo, 8)
+    assert rel(y.permute(0, 3, 1, 2), F.conv2d(x, w, stride=2, padding=1)) < TOL
+
+
+@pytest.mark.parametrize("C", [8, 64, 2048])
+@pytest.mark.parametrize("mode", ["relu", "plain", "res", "res_bn", "pool"])
+def test_bn_fwd_bwd(ops, C, mode):
+    B, H, W = 3, 8, 4
+    y = R("by", B, C, H, W) * 2 + 0.3
+    gamma, beta = R("bg", C).abs() + 0.5, R("bb", C, scale=0.3)
+    res = R("br", B, C, H, W)
+    g_out = R("bgo", B, C, H // (2 if mode == "pool" else 1), W // (2 if mode == "pool" else 1))
+    yr = y.clone().requires_grad_(True)
+    gr, br_ = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    rr = res.clone().requires_grad_(True)
+    z = F.batch_norm(yr, None, None, gr, br_, True, 0.1, 1e-5)
+    if mode == "relu":
+        out = F.relu(z)
+    elif mode == "plain":
+        out = z
+    elif mode == "res":
+        out = F.relu(z + rr)
+    elif mode == "res_bn":
+        g2, b2 = R("g2", C).abs() + 0.5, R("b2", C)
+        out = F.relu(z + F.batch_norm(rr, None, None, g2, b2, True, 0.1, 1e-5))
+    else:
+        out = F.avg_pool2d(F.relu(z), 2)
+    out.backward(g_out)
+
+    yd = dev(nhwc(y))
+    # statistics through the GEMM epilogue are tested elsewhere; here use an identity 1x1 conv
+    eye = torch.eye(C)
+    y2, st_part = ops.conv1x1(yd, dev(eye), stats=True)
+    assert rel(y2, yd) < 1e-6
+    st = ops.bn_finalize(st_part, B * H * W, dev(gamma), dev(beta), None, None)
+    god = dev(nhwc(g_out))
+    if mode in ("relu", "plain"):
+        o = ops.bn_apply(yd, st, relu=(mode == "relu"))
+        dy, dg, db, _ = ops.bn_bwd(god, yd, st, None, 1 if mode == "relu" else 0)
+    elif mode == "res":
+        o = ops.bn_apply(yd, st, relu=True, res=dev(nhwc(res)))
+        dy, dg, db, dres = ops.bn_bwd(god, yd, st, None, 2, act=o, want_dres=True)
+        assert rel(dres.permute(0, 3, 1, 2), rr.grad) < 1e-5
+    elif mode == "res_bn":
+        rd = dev(nhwc(res))
+        r2, rp = ops.conv1x1(rd, dev(eye), stats=True)
+        st2 = ops.bn_finalize(rp, B * H * W, dev(g2), dev(b2), None, None)
+        o = ops.bn_apply(yd, st, relu=True, res=rd, res_st=st2)
+        dy, dg, db, _ = ops.bn_bwd(god, yd, st, None, 2, act=o)
+        dyr, _, _, _ = ops.bn_bwd(god, rd, st2, None, 2, act=o)
+        assert rel(dyr.permute(0, 3, 1, 2), rr.grad) < 2e-5
+    else:
+        o = ops.bn_apply_pool2(yd, st, relu=True)
+        dy, dg, db, _ = ops.bn_bwd(god, yd, st, None, 1, pooled=True)
+    assert rel(o.permute(0, 3, 1, 2), out) < 1e-5
+    assert rel(dy.permute(0, 3, 1, 2), yr.grad) < 2e-5
+    assert rel(dg, gr.grad) < 2e-5 and rel(db, br_.grad) < 2e-5
+
+
+def test_bn_eval_and_pool(ops):
+    C = 32
+    y = R("ey", 2, C, 6, 4)
+    gamma, beta, rm, rv = R("eg", C), R("eb", C), R("em", C), R("ev", C).abs() + 0.5
+    st = ops.bn_eval_coeffs(dev(gamma), dev(beta), dev(rm), dev(rv))
+    o = ops.bn_apply(dev(nhwc(y)), st, relu=True)
+    assert rel(o.permute(0, 3, 1, 2), F.relu(F.batch_norm(y, rm, rv, gamma, beta, False, 0.1, 1e-5))) < 1e-5
+    p = ops.bn_apply_pool2(dev(nhwc(y)), None)
+    assert rel(p.permute(0, 3, 1, 2), F.avg_pool2d(y, 2)) < 1e-6
+    g = R("pg", 2, C, 3, 2)
+    dx = ops.avgpool2_bwd(dev(nhwc(g)))
+    yr = y.clone().requires_grad_(True)
+    F.avg_pool2d(yr, 2).backward(g)
+    assert rel(dx.permute(0, 3, 1, 2), yr.grad) < 1e-6
+
+
+def test_small_ops(ops):
+    x = R("sx", 37, 256)
+    y, inv = ops.l2norm_rows(dev(x))
+    xr = x.clone().requires_grad_(True)
+    yr = F.normalize(xr, dim=1)
+    g = R("sg", 37, 256)
+    yr.backward(g)
+    assert rel(y, yr) < 1e-6
+    assert rel(ops.l2norm_rows_bwd(dev(g), y, inv), xr.grad) < 1e-5
+    assert rel(ops.rowdot(dev(x), dev(g)), (x * g).sum(1)) < 1e-5
+    assert rel(ops.colsum(dev(x)), x.sum(0)) < 1e-5
+    s = R("ss", 20, 196)
+    p = ops.softmax_rows_(dev(s), 193)
+    sr = s[:, :193].clone().requires_grad_(True)
+    pr = torch.softmax(sr, dim=1)
+    assert rel(p[:, :193], pr) < 1e-6 and float(p[:, 193:].abs().max()) == 0.0
+    dp = R("sd", 20, 196)
+    pr.backward(dp[:, :193])
+    assert rel(ops.softmax_rows_bwd(p, dev(dp), 193)[:, :193], sr.grad) < 1e-5

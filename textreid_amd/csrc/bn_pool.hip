@@ -1,0 +1,450 @@
+// BatchNorm2d (train / eval), ReLU, residual add, AvgPool2d(2), their backward
+// passes, the dgrad weight transform and the stem im2col.  All HBM-bound
+// streaming kernels over NHWC fp32: 16-byte accesses, grid-stride, channel
+// index = element index mod C so loads are fully coalesced.
+// Reference: m_resnet.py:19-29,38-49,57-66,161-171 (+ their autograd).
+
+#include "common.h"
+
+namespace trid {
+
+// ---------------------------------------------------------------- weight transform
+__global__ void weight_transpose_kernel(const float* __restrict__ w, float* __restrict__ wt, int N, int T, int C,
+                                        int flip) {
+    __shared__ float tile[32][33];
+    const int t = blockIdx.z;
+    const int tt = flip ? (T - 1 - t) : t;
+    const int c0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int i = ty; i < 32; i += 8) {
+        const int n = n0 + i, c = c0 + tx;
+        tile[i][tx] = (n < N && c < C) ? w[((long long)n * T + t) * C + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, n = n0 + tx;
+        if (c < C && n < N) wt[((long long)c * T + tt) * N + n] = tile[tx][i];
+    }
+}
+
+// ---------------------------------------------------------------- stem im2col
+__global__ void stem_im2col_kernel(const float* __restrict__ img, float* __restrict__ col, int B, int Cin, int H,
+                                   int W, int Ho, int Wo, int ldcol, long long total) {
+    const int kk = Cin * 9;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const long long m = idx / ldcol;
+        const int j = (int)(idx - m * ldcol);
+        float v = 0.f;
+        if (j < kk) {
+            const int c = j / 9, r = j - c * 9, ky = r / 3, kx = r - ky * 3;
+            const int xo = (int)(m % Wo);
+            const long long q = m / Wo;
+            const int yo = (int)(q % Ho);
+            const int b = (int)(q / Ho);
+            const int y = 2 * yo - 1 + ky, x = 2 * xo - 1 + kx;
+            if (y >= 0 && y < H && x >= 0 && x < W) v = img[(((long long)b * Cin + c) * H + y) * W + x];
+        }
+        col[idx] = v;
+    }
+}
+
+// ---------------------------------------------------------------- BN finalize
+// One workgroup per channel: Chan-merge the per-tile (n, mean, M2) partials in fp64.
+__global__ void bn_finalize_kernel(const float* __restrict__ partials, int nparts, int rows_per_part, long long M,
+                                   int C, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* __restrict__ running_mean, float* __restrict__ running_var, float momentum,
+                                   float eps, float* __restrict__ mean_out, float* __restrict__ invstd_out,
+                                   float* __restrict__ scale_out, float* __restrict__ shift_out) {
+    const int c = blockIdx.x;
+    const int tid = threadIdx.x;
+    double n = 0.0, mean = 0.0, m2 = 0.0;
+    for (int p = tid; p < nparts; p += blockDim.x) {
+        const long long rows_left = M - (long long)p * rows_per_part;
+        const double nb = (double)(rows_left < rows_per_part ? rows_left : rows_per_part);
+        const double mb = partials[((long long)p * C + c) * 2 + 0];
+        const double qb = partials[((long long)p * C + c) * 2 + 1];
+        const double nt = n + nb;
+        const double d = mb - mean;
+        mean += d * (nb / nt);
+        m2 += qb + d * d * (n * nb / nt);
+        n = nt;
+    }
+    __shared__ double sn[256], sm[256], sq[256];
+    sn[tid] = n; sm[tid] = mean; sq[tid] = m2;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (tid < off) {
+            const double na = sn[tid], nb = sn[tid + off];
+            const double nt = na + nb;
+            if (nt > 0.0) {
+                const double d = sm[tid + off] - sm[tid];
+                sm[tid] += d * (nb / nt);
+                sq[tid] += sq[tid + off] + d * d * (na * nb / nt);
+                sn[tid] = nt;
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const double nt = sn[0];
+        const double mu = sm[0];
+        const double var = sq[0] / nt;
+        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float g = gamma[c], b = beta[c];
+        const float sc = g * invstd;
+        mean_out[c] = (float)mu;
+        invstd_out[c] = invstd;
+        scale_out[c] = sc;
+        shift_out[c] = b - (float)mu * sc;
+        if (running_mean != nullptr) {
+            const double unb = nt > 1.0 ? sq[0] / (nt - 1.0) : var;
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+        }
+    }
+}
+
+__global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, const float* rm, const float* rv,
+                                      float eps, float* scale, float* shift, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) {
+        const float invstd = 1.f / sqrtf(rv[c] + eps);
+        const float sc = gamma[c] * invstd;
+        scale[c] = sc;
+        shift[c] = beta[c] - rm[c] * sc;
+    }
+}
+
+// ---------------------------------------------------------------- BN apply (+res, +relu)
+__device__ __forceinline__ float4 affine4(float4 v, float4 s, float4 t) {
+    return make_float4(fmaf(v.x, s.x, t.x), fmaf(v.y, s.y, t.y), fmaf(v.z, s.z, t.z), fmaf(v.w, s.w, t.w));
+}
+__device__ __forceinline__ float4 relu4(float4 v) {
+    return make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+}
+
+__global__ void bn_apply_kernel(const float4* __restrict__ y, const float4* __restrict__ scale,
+                                const float4* __restrict__ shift, const float4* __restrict__ res,
+                                const float4* __restrict__ rscale, const float4* __restrict__ rshift,
+                                float4* __restrict__ out, long long total4, int CQ, int relu) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int cq = (int)(i % CQ);
+        float4 v = affine4(y[i], scale[cq], shift[cq]);
+        if (res != nullptr) {
+            float4 r = res[i];
+            if (rscale != nullptr) r = affine4(r, rscale[cq], rshift[cq]);
+            v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+        }
+        if (relu) v = relu4(v);
+        out[i] = v;
+    }
+}
+
+__global__ void bn_apply_pool2_kernel(const float4* __restrict__ y, const float4* __restrict__ scale,
+                                      const float4* __restrict__ shift, float4* __restrict__ out, int B, int H, int W,
+                                      int CQ, int relu, long long total4) {
+    const int Ho = H / 2, Wo = W / 2;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int cq = (int)(i % CQ);
+        long long p = i / CQ;
+        const int xo = (int)(p % Wo);
+        p /= Wo;
+        const int yo = (int)(p % Ho);
+        const int b = (int)(p / Ho);
+        float4 s = make_float4(1.f, 1.f, 1.f, 1.f), t = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (scale != nullptr) { s = scale[cq]; t = shift[cq]; }
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                float4 v = y[(((long long)b * H + 2 * yo + dy) * W + 2 * xo + dx) * CQ + cq];
+                v = affine4(v, s, t);
+                if (relu) v = relu4(v);
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+        out[i] = make_float4(acc.x * 0.25f, acc.y * 0.25f, acc.z * 0.25f, acc.w * 0.25f);
+    }
+}
+
+__global__ void avgpool2_bwd_kernel(const float4* __restrict__ g, float4* __restrict__ dx, int B, int H, int W, int CQ,
+                                    int accumulate, long long total4) {
+    const int Ho = H / 2, Wo = W / 2;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int cq = (int)(i % CQ);
+        long long p = i / CQ;
+        const int x = (int)(p % W);
+        p /= W;
+        const int yy = (int)(p % H);
+        const int b = (int)(p / H);
+        float4 v = g[(((long long)b * Ho + yy / 2) * Wo + x / 2) * CQ + cq];
+        v.x *= 0.25f; v.y *= 0.25f; v.z *= 0.25f; v.w *= 0.25f;
+        if (accumulate) {
+            float4 o = dx[i];
+            v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+        }
+        dx[i] = v;
+    }
+}
+
+// ---------------------------------------------------------------- BN backward
+struct BnBwdArgs {
+    const float4* g;
+    const float4* y;
+    const float4* act;
+    const float4* mean;
+    const float4* invstd;
+    const float4* scale;
+    const float4* shift;
+    int mask_mode, pooled;
+    int B, H, W, CQ;
+    long long total4;  // B*H*W*CQ
+    FastDiv fdW, fdH;
+};
+
+// masked effective gradient and xhat for element i (channel quad cq)
+__device__ __forceinline__ void bn_bwd_elem(const BnBwdArgs& a, long long i, int cq, float4& gm, float4& xh) {
+    float4 g;
+    if (a.pooled) {
+        const uint32_t p = (uint32_t)(i / a.CQ);
+        const uint32_t q = fdiv(p, a.fdW);
+        const int x = (int)(p - q * a.W);
+        const uint32_t b = fdiv(q, a.fdH);
+        const int yy = (int)(q - b * a.H);
+        g = a.g[(((long long)b * (a.H / 2) + yy / 2) * (a.W / 2) + x / 2) * a.CQ + cq];
+        g.x *= 0.25f; g.y *= 0.25f; g.z *= 0.25f; g.w *= 0.25f;
+    } else {
+        g = a.g[i];
+    }
+    const float4 yv = a.y[i];
+    const float4 mu = a.mean[cq], is = a.invstd[cq];
+    xh = make_float4((yv.x - mu.x) * is.x, (yv.y - mu.y) * is.y, (yv.z - mu.z) * is.z, (yv.w - mu.w) * is.w);
+    if (a.mask_mode == 1) {
+        const float4 z = affine4(yv, a.scale[cq], a.shift[cq]);
+        g.x = z.x > 0.f ? g.x : 0.f; g.y = z.y > 0.f ? g.y : 0.f;
+        g.z = z.z > 0.f ? g.z : 0.f; g.w = z.w > 0.f ? g.w : 0.f;
+    } else if (a.mask_mode == 2) {
+        const float4 z = a.act[i];
+        g.x = z.x > 0.f ? g.x : 0.f; g.y = z.y > 0.f ? g.y : 0.f;
+        g.z = z.z > 0.f ? g.z : 0.f; g.w = z.w > 0.f ? g.w : 0.f;
+    }
+    gm = g;
+}
+
+// grid*256 is a multiple of CQ, so a thread always sees the same channel quad.
+// ws layout: [grid][CW][8] with CW = min(CQ,256) quads covered by a block.
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a, float* __restrict__ ws) {
+    const int tid = threadIdx.x;
+    const long long T = (long long)gridDim.x * 256;
+    const long long t0 = (long long)blockIdx.x * 256 + tid;
+    const int cq = (int)(t0 % a.CQ);
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+    for (long long i = t0; i < a.total4; i += T) {
+        float4 gm, xh;
+        bn_bwd_elem(a, i, cq, gm, xh);
+        s1.x += gm.x; s1.y += gm.y; s1.z += gm.z; s1.w += gm.w;
+        s2.x = fmaf(gm.x, xh.x, s2.x); s2.y = fmaf(gm.y, xh.y, s2.y);
+        s2.z = fmaf(gm.z, xh.z, s2.z); s2.w = fmaf(gm.w, xh.w, s2.w);
+    }
+    __shared__ float red[256][9];
+    red[tid][0] = s1.x; red[tid][1] = s1.y; red[tid][2] = s1.z; red[tid][3] = s1.w;
+    red[tid][4] = s2.x; red[tid][5] = s2.y; red[tid][6] = s2.z; red[tid][7] = s2.w;
+    __syncthreads();
+    const int CW = a.CQ < 256 ? a.CQ : 256;
+    if (tid < CW) {
+        float acc[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+        for (int r = tid; r < 256; r += CW)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[k] += red[r][k];
+        float* dst = ws + ((long long)blockIdx.x * CW + tid) * 8;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) dst[k] = acc[k];
+    }
+}
+
+// one thread per channel: sum the block partials that cover its quad (fp64 accumulate)
+__global__ void bn_bwd_reduce_final_kernel(const float* __restrict__ ws, int nblk, int CQ, float* __restrict__ dgamma,
+                                           float* __restrict__ dbeta, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const int q = c >> 2, e = c & 3;
+    const int CW = CQ < 256 ? CQ : 256;
+    const int S = CQ / CW;  // channel-quad slices; block b covers slice b % S
+    const int slice = q / CW, ql = q % CW;
+    double s1 = 0.0, s2 = 0.0;
+    for (int b = slice; b < nblk; b += S) {
+        const float* src = ws + ((long long)b * CW + ql) * 8;
+        s1 += src[e];
+        s2 += src[4 + e];
+    }
+    dbeta[c] = (float)s1;
+    dgamma[c] = (float)s2;
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a, const float4* __restrict__ dgamma,
+                                                           const float4* __restrict__ dbeta, float invM,
+                                                           float4* __restrict__ dy, float4* __restrict__ dres) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < a.total4; i += (long long)gridDim.x * 256) {
+        const int cq = (int)(i % a.CQ);
+        float4 gm, xh;
+        bn_bwd_elem(a, i, cq, gm, xh);
+        const float4 sc = a.scale[cq], dg = dgamma[cq], db = dbeta[cq];
+        float4 o;
+        o.x = sc.x * (gm.x - db.x * invM - xh.x * dg.x * invM);
+        o.y = sc.y * (gm.y - db.y * invM - xh.y * dg.y * invM);
+        o.z = sc.z * (gm.z - db.z * invM - xh.z * dg.z * invM);
+        o.w = sc.w * (gm.w - db.w * invM - xh.w * dg.w * invM);
+        dy[i] = o;
+        if (dres != nullptr) dres[i] = gm;
+    }
+}
+
+static int bn_bwd_grid(long long total4, int CQ) {
+    // multiple of S = CQ/min(CQ,256) so that grid*256 % CQ == 0
+    const int CW = CQ < 256 ? CQ : 256;
+    const int S = CQ / CW;
+    long long g = (total4 + 256LL * 8 - 1) / (256LL * 8);
+    if (g > 1024) g = 1024;
+    if (g < 1) g = 1;
+    g = (g + S - 1) / S * S;
+    return (int)g;
+}
+
+}  // namespace trid
+
+using namespace trid;
+
+extern "C" int trid_weight_transpose_f32(const float* w, float* wt, int N, int T, int C, int flip, void* stream) {
+    TRID_REQUIRE(w && wt && N > 0 && T > 0 && C > 0, "trid_weight_transpose_f32: bad arguments");
+    dim3 grid((C + 31) / 32, (N + 31) / 32, T);
+    hipLaunchKernelGGL(weight_transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, w, wt, N, T, C, flip);
+    return check_launch("trid_weight_transpose_f32");
+}
+
+extern "C" int trid_stem_im2col_f32(const float* img, float* col, int B, int Cin, int H, int W, int Ho, int Wo,
+                                    int ldcol, void* stream) {
+    TRID_REQUIRE(img && col && B > 0 && Cin > 0 && ldcol >= Cin * 9, "trid_stem_im2col_f32: bad arguments");
+    TRID_REQUIRE(Ho == (H + 1) / 2 && Wo == (W + 1) / 2, "trid_stem_im2col_f32: Ho/Wo must be ceil(H/2), ceil(W/2)");
+    const long long total = (long long)B * Ho * Wo * ldcol;
+    hipLaunchKernelGGL(stem_im2col_kernel, dim3(grid_for(total, 256 * 4, 8192)), dim3(256), 0, (hipStream_t)stream, img,
+                       col, B, Cin, H, W, Ho, Wo, ldcol, total);
+    return check_launch("trid_stem_im2col_f32");
+}
+
+extern "C" int trid_bn_finalize_f32(const float* partials, int nparts, int rows_per_part, long long M, int C,
+                                    const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                    float momentum, float eps, float* mean, float* invstd, float* scale, float* shift,
+                                    void* stream) {
+    TRID_REQUIRE(partials && gamma && beta && mean && invstd && scale && shift, "trid_bn_finalize_f32: null pointer");
+    TRID_REQUIRE(nparts > 0 && rows_per_part > 0 && C > 0 && M > (long long)(nparts - 1) * rows_per_part &&
+                     M <= (long long)nparts * rows_per_part,
+                 "trid_bn_finalize_f32: nparts=%d rows_per_part=%d inconsistent with M=%lld", nparts, rows_per_part, M);
+    TRID_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "trid_bn_finalize_f32: running stats both or none");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, partials, nparts, rows_per_part, M,
+                       C, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift);
+    return check_launch("trid_bn_finalize_f32");
+}
+
+extern "C" int trid_bn_eval_coeffs_f32(const float* gamma, const float* beta, const float* running_mean,
+                                       const float* running_var, float eps, float* scale, float* shift, int C,
+                                       void* stream) {
+    TRID_REQUIRE(gamma && beta && running_mean && running_var && scale && shift && C > 0, "trid_bn_eval_coeffs_f32: bad arguments");
+    hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, gamma, beta,
+                       running_mean, running_var, eps, scale, shift, C);
+    return check_launch("trid_bn_eval_coeffs_f32");
+}
+
+extern "C" int trid_bn_apply_f32(const float* y, const float* scale, const float* shift, const float* res,
+                                 const float* rscale, const float* rshift, float* out, long long M, int C, int relu,
+                                 void* stream) {
+    TRID_REQUIRE(y && scale && shift && out && M > 0 && C > 0 && C % 4 == 0, "trid_bn_apply_f32: bad arguments (C%%4)");
+    TRID_REQUIRE((rscale == nullptr) == (rshift == nullptr), "trid_bn_apply_f32: rscale/rshift both or none");
+    TRID_REQUIRE(aligned16(y) && aligned16(out) && aligned16(scale) && aligned16(shift) && (!res || aligned16(res)), "trid_bn_apply_f32: 16-byte alignment");
+    const long long total4 = M * (C / 4);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(total4, 256 * 4)), dim3(256), 0, (hipStream_t)stream,
+                       (const float4*)y, (const float4*)scale, (const float4*)shift, (const float4*)res,
+                       (const float4*)rscale, (const float4*)rshift, (float4*)out, total4, C / 4, relu);
+    return check_launch("trid_bn_apply_f32");
+}
+
+extern "C" int trid_bn_apply_pool2_f32(const float* y, const float* scale, const float* shift, float* out, int B, int H,
+                                       int W, int C, int relu, void* stream) {
+    TRID_REQUIRE(y && out && B > 0 && H % 2 == 0 && W % 2 == 0 && C % 4 == 0, "trid_bn_apply_pool2_f32: bad arguments");
+    TRID_REQUIRE((scale == nullptr) == (shift == nullptr), "trid_bn_apply_pool2_f32: scale/shift both or none");
+    const long long total4 = (long long)B * (H / 2) * (W / 2) * (C / 4);
+    hipLaunchKernelGGL(bn_apply_pool2_kernel, dim3(grid_for(total4, 256 * 2)), dim3(256), 0, (hipStream_t)stream,
+                       (const float4*)y, (const float4*)scale, (const float4*)shift, (float4*)out, B, H, W, C / 4, relu,
+                       total4);
+    return check_launch("trid_bn_apply_pool2_f32");
+}
+
+extern "C" int trid_avgpool2_bwd_f32(const float* g, float* dx, int B, int H, int W, int C, int accumulate,
+                                     void* stream) {
+    TRID_REQUIRE(g && dx && B > 0 && H % 2 == 0 && W % 2 == 0 && C % 4 == 0, "trid_avgpool2_bwd_f32: bad arguments");
+    const long long total4 = (long long)B * H * W * (C / 4);
+    hipLaunchKernelGGL(avgpool2_bwd_kernel, dim3(grid_for(total4, 256 * 4)), dim3(256), 0, (hipStream_t)stream,
+                       (const float4*)g, (float4*)dx, B, H, W, C / 4, accumulate, total4);
+    return check_launch("trid_avgpool2_bwd_f32");
+}
+
+extern "C" long long trid_bn_bwd_ws_floats(int C) {
+    const int CQ = C / 4;
+    const int CW = CQ < 256 ? CQ : 256;
+    return (long long)(1024 + 8) * CW * 8;
+}
+
+static int bn_bwd_fill(BnBwdArgs& a, const float* g, const float* y, const float* act, const float* mean,
+                       const float* invstd, const float* scale, const float* shift, int mask_mode, int pooled, int B,
+                       int H, int W, int C) {
+    TRID_REQUIRE(g && y && mean && invstd && scale && shift, "bn_bwd: null pointer");
+    TRID_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "bn_bwd: bad shape");
+    const int CQ = C / 4;
+    TRID_REQUIRE(256 % CQ == 0 || CQ % 256 == 0, "bn_bwd: C/4 must divide 256 or be a multiple of 256 (C=%d)", C);
+    TRID_REQUIRE(mask_mode >= 0 && mask_mode <= 2 && (mask_mode != 2 || act), "bn_bwd: bad mask mode");
+    TRID_REQUIRE(!pooled || (H % 2 == 0 && W % 2 == 0), "bn_bwd: pooled needs even H,W");
+    TRID_REQUIRE((long long)B * H * W < (1LL << 31), "bn_bwd: too many pixels");
+    a.g = (const float4*)g; a.y = (const float4*)y; a.act = (const float4*)act;
+    a.mean = (const float4*)mean; a.invstd = (const float4*)invstd;
+    a.scale = (const float4*)scale; a.shift = (const float4*)shift;
+    a.mask_mode = mask_mode; a.pooled = pooled;
+    a.B = B; a.H = H; a.W = W; a.CQ = CQ;
+    a.total4 = (long long)B * H * W * CQ;
+    a.fdW = make_fastdiv((uint32_t)W);
+    a.fdH = make_fastdiv((uint32_t)H);
+    return TRID_OK;
+}
+
+extern "C" int trid_bn_bwd_reduce_f32(const float* g, const float* y, const float* act, const float* mean,
+                                      const float* invstd, const float* scale, const float* shift, int mask_mode,
+                                      int pooled, int B, int H, int W, int C, float* dgamma, float* dbeta, float* ws,
+                                      void* stream) {
+    BnBwdArgs a;
+    int rc = bn_bwd_fill(a, g, y, act, mean, invstd, scale, shift, mask_mode, pooled, B, H, W, C);
+    if (rc) return rc;
+    TRID_REQUIRE(dgamma && dbeta && ws, "trid_bn_bwd_reduce_f32: null output");
+    const int grid = bn_bwd_grid(a.total4, a.CQ);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, ws);
+    hipLaunchKernelGGL(bn_bwd_reduce_final_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, ws, grid,
+                       a.CQ, dgamma, dbeta, C);
+    return check_launch("trid_bn_bwd_reduce_f32");
+}
+
+extern "C" int trid_bn_bwd_apply_f32(const float* g, const float* y, const float* act, const float* mean,
+                                     const float* invstd, const float* scale, const float* shift, const float* dgamma,
+                                     const float* dbeta, int mask_mode, int pooled, int B, int H, int W, int C,
+                                     float* dy, float* dres, void* stream) {
+    BnBwdArgs a;
+    int rc = bn_bwd_fill(a, g, y, act, mean, invstd, scale, shift, mask_mode, pooled, B, H, W, C);
+    if (rc) return rc;
+    TRID_REQUIRE(dgamma && dbeta && dy, "trid_bn_bwd_apply_f32: null pointer");
+    const float invM = 1.f / (float)((long long)B * H * W);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(a.total4, 256 * 4)), dim3(256), 0, (hipStream_t)stream, a,
+                       (const float4*)dgamma, (const float4*)dbeta, invM, (float4*)dy, (float4*)dres);
+    return check_launch("trid_bn_bwd_apply_f32");
+}

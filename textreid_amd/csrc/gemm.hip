@@ -1,0 +1,471 @@
+// fp32 MFMA GEMM / implicit-GEMM convolution family for gfx950 (CDNA4).
+//
+// One register-staged, LDS-tiled kernel template covers every dense contraction
+// on the encode-and-match path:
+//   C[m,n] (+)= alpha * sum_k A(m,k) * B(k,n)  (+ bias[n])
+// with operand "loader modes" instead of CUDA-style transposed copies:
+//   A_KC   A[m*lda + k]            rows K-contiguous       (activations, NT / NN)
+//   A_MC   A[k*lda + m]            rows M-contiguous       (dY in weight-gradient, TN)
+//   A_CONV NHWC image gather, k=(tap,c), 3x3 stride 1 pad 1 (implicit-GEMM fwd / dgrad)
+//   B_KC   B[n*ldb + k]            weights [N,K]            (NT)
+//   B_NC   B[k*ldb + n]            rows N-contiguous        (NN / TN)
+//   B_CONV NHWC image gather on rows k=pixel, n=(tap,c)     (implicit-GEMM wgrad)
+// Arithmetic: v_mfma_f32_32x32x2_f32 (exact fp32, 64 FLOP/clk/SIMD).  Both LDS
+// tiles are stored k-major ([k][m], [k][n]) so every MFMA operand fetch is a
+// conflict-free ds_read_b32 of 32 consecutive floats per half-wave.
+// Epilogues: alpha, bias, accumulate, split-K slabs, and per-column
+// (count-weighted mean, M2) partials for train-mode BatchNorm statistics.
+//
+// Reference ops served (file:line in /root/reference): every nn.Conv2d /
+// nn.Linear / matmul on the hot path -- m_resnet.py:18-27,41-47,161-170 (convs),
+// :114-133 (attention-pool projections), gru.py:36-43 (GRU projections),
+// head.py:50-51,159-170 (embed layers, queue logits), losses.py:52-53,109-112.
+
+#include "common.h"
+
+namespace trid {
+
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+enum { A_KC = 0, A_MC = 1, A_CONV = 2 };
+enum { B_KC = 0, B_NC = 1, B_CONV = 2 };
+
+struct GemmParams {
+    const float* A;
+    const float* B;
+    float* C;
+    int M, N, K;
+    long long lda, ldb, ldc;
+    long long sA, sB, sC;  // batch strides (elements)
+    int batch, splits;     // gridDim.z = batch * splits
+    int k_chunk;           // K range per split (multiple of BK)
+    long long sSplit;      // C offset per split (slab stride, elements)
+    float alpha;
+    int accumulate;
+    const float* bias;  // [N] or null
+    long long sBias;
+    float* stats;       // [mblocks][N][2] (mean, M2) or null
+    int H, W, Cin;      // conv geometry (A_CONV: M=Bimg*H*W,K=9*Cin; B_CONV: K=Bimg*H*W,N=9*Cin)
+    FastDiv fdW, fdH, fdC;
+    int mblocks, nblocks;
+};
+
+constexpr int BK = 32;
+constexpr int NTHREADS = 256;
+
+template <int AMODE, int BMODE, int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmParams p) {
+    static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    static_assert(TM >= 1 && TN >= 1, "wave tile must hold a 32x32 MFMA tile");
+    constexpr int LDA = BM + (AMODE == A_MC ? 4 : 1);
+    constexpr int LDB = BN + (BMODE == B_KC ? 1 : 4);
+    constexpr int NA = BM * BK / 4 / NTHREADS;  // float4 per thread per tile
+    constexpr int NB = BN * BK / 4 / NTHREADS;
+    static_assert(NA >= 1 && NB >= 1, "tile too small for 256 threads");
+
+    __shared__ __attribute__((aligned(16))) float smem[BK * LDA + BK * LDB];
+    float* As = smem;
+    float* Bs = smem + BK * LDA;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+    // XCD-aware tile order: n fastest so tiles sharing an A panel sit on one XCD's L2.
+    const uint32_t nwg = (uint32_t)p.mblocks * (uint32_t)p.nblocks;
+    const uint32_t lid = xcd_remap(blockIdx.x, nwg);
+    const int mb = lid / p.nblocks, nb = lid % p.nblocks;
+    const int m0 = mb * BM, n0 = nb * BN;
+    const int z = blockIdx.z;
+    const int bz = z / p.splits, sz = z % p.splits;
+    const int k_begin = sz * p.k_chunk;
+    const int k_end = min(p.K, k_begin + p.k_chunk);
+
+    const float* __restrict__ A = p.A + (long long)bz * p.sA;
+    const float* __restrict__ Bp = p.B + (long long)bz * p.sB;
+    float* __restrict__ C = p.C + (long long)bz * p.sC + (long long)sz * p.sSplit;
+    const float* __restrict__ bias = p.bias ? p.bias + (long long)bz * p.sBias : nullptr;
+
+    // ---- per-thread loader state -------------------------------------------------
+    // K-contiguous A: thread owns k-quad kq and rows ra[i];  M-contiguous: m-quad, k rows.
+    constexpr int A_QPR = (AMODE == A_MC) ? BM / 4 : BK / 4;  // quads per tile row
+    constexpr int A_RPP = NTHREADS / A_QPR;                   // rows per pass
+    const int a_q = tid % A_QPR, a_r = tid / A_QPR;
+    constexpr int B_QPR = (BMODE == B_KC) ? BK / 4 : BN / 4;
+    constexpr int B_RPP = NTHREADS / B_QPR;
+    const int b_q = tid % B_QPR, b_r = tid / B_QPR;
+
+    // A_CONV: per-row pixel coordinates
+    int a_y[NA], a_x[NA];
+    if (AMODE == A_CONV) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            int m = m0 + a_r + i * A_RPP;
+            uint32_t q = fdiv((uint32_t)m, p.fdW);
+            a_x[i] = m - (int)q * p.W;
+            uint32_t b = fdiv(q, p.fdH);
+            a_y[i] = (int)q - (int)b * p.H;
+        }
+    }
+    // B_CONV: per-thread fixed column quad -> (tap, c)
+    int b_dy = 0, b_dx = 0, b_c = 0;
+    bool b_colok = true;
+    if (BMODE == B_CONV) {
+        int j = n0 + 4 * b_q;
+        b_colok = j < p.N;
+        uint32_t tap = fdiv((uint32_t)j, p.fdC);
+        b_c = j - (int)tap * p.Cin;
+        b_dy = (int)tap / 3 - 1;
+        b_dx = (int)tap % 3 - 1;
+    }
+
+    float4 ra[NA], rb[NB];
+
+    auto load_tiles = [&](int k0) {
+        // ---- A ----
+        if (AMODE == A_KC) {
+            const int k = k0 + 4 * a_q;
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                const int m = m0 + a_r + i * A_RPP;
+                if (m < p.M && k < k_end)
+                    ra[i] = *reinterpret_cast<const float4*>(A + (long long)m * p.lda + k);
+                else
+                    ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        } else if (AMODE == A_CONV) {
+            const int k = k0 + 4 * a_q;
+            const uint32_t tap = fdiv((uint32_t)k, p.fdC);
+            const int c = k - (int)tap * p.Cin;
+            const int dy = (int)tap / 3 - 1, dx = (int)tap % 3 - 1;
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                const int m = m0 + a_r + i * A_RPP;
+                const int yy = a_y[i] + dy, xx = a_x[i] + dx;
+                if (m < p.M && k < k_end && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W)
+                    ra[i] = *reinterpret_cast<const float4*>(A + (long long)(m + dy * p.W + dx) * p.Cin + c);
+                else
+                    ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        } else {  // A_MC
+            const int m = m0 + 4 * a_q;
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                const int k = k0 + a_r + i * A_RPP;
+                if (m < p.M && k < k_end)
+                    ra[i] = *reinterpret_cast<const float4*>(A + (long long)k * p.lda + m);
+                else
+                    ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        // ---- B ----
+        if (BMODE == B_KC) {
+            const int k = k0 + 4 * b_q;
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int n = n0 + b_r + i * B_RPP;
+                if (n < p.N && k < k_end)
+                    rb[i] = *reinterpret_cast<const float4*>(Bp + (long long)n * p.ldb + k);
+                else
+                    rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        } else if (BMODE == B_NC) {
+            const int n = n0 + 4 * b_q;
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int k = k0 + b_r + i * B_RPP;
+                if (n < p.N && k < k_end)
+                    rb[i] = *reinterpret_cast<const float4*>(Bp + (long long)k * p.ldb + n);
+                else
+                    rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        } else {  // B_CONV: row k is a pixel
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int k = k0 + b_r + i * B_RPP;
+                uint32_t q = fdiv((uint32_t)k, p.fdW);
+                const int x = k - (int)q * p.W;
+                uint32_t b = fdiv(q, p.fdH);
+                const int y = (int)q - (int)b * p.H;
+                const int yy = y + b_dy, xx = x + b_dx;
+                if (b_colok && k < k_end && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W)
+                    rb[i] = *reinterpret_cast<const float4*>(Bp + (long long)(k + b_dy * p.W + b_dx) * p.Cin + b_c);
+                else
+                    rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    };
+
+    auto store_tiles = [&]() {
+        if (AMODE == A_MC) {
+#pragma unroll
+            for (int i = 0; i < NA; ++i)
+                *reinterpret_cast<float4*>(As + (a_r + i * A_RPP) * LDA + 4 * a_q) = ra[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                const int r = a_r + i * A_RPP;
+                As[(4 * a_q + 0) * LDA + r] = ra[i].x;
+                As[(4 * a_q + 1) * LDA + r] = ra[i].y;
+                As[(4 * a_q + 2) * LDA + r] = ra[i].z;
+                As[(4 * a_q + 3) * LDA + r] = ra[i].w;
+            }
+        }
+        if (BMODE == B_KC) {
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int r = b_r + i * B_RPP;
+                Bs[(4 * b_q + 0) * LDB + r] = rb[i].x;
+                Bs[(4 * b_q + 1) * LDB + r] = rb[i].y;
+                Bs[(4 * b_q + 2) * LDB + r] = rb[i].z;
+                Bs[(4 * b_q + 3) * LDB + r] = rb[i].w;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NB; ++i)
+                *reinterpret_cast<float4*>(Bs + (b_r + i * B_RPP) * LDB + 4 * b_q) = rb[i];
+        }
+    };
+
+    v16f acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int a_off = wm * WM + (lane & 31);
+    const int b_off = wn * WN + (lane & 31);
+    const int khalf = lane >> 5;
+
+    if (k_begin < k_end) {
+        load_tiles(k_begin);
+        store_tiles();
+        __syncthreads();
+        for (int k0 = k_begin; k0 < k_end; k0 += BK) {
+            const bool more = (k0 + BK) < k_end;
+            if (more) load_tiles(k0 + BK);  // global loads in flight under the MFMAs
+#pragma unroll
+            for (int kk = 0; kk < BK / 2; ++kk) {
+                const int k = 2 * kk + khalf;
+                float a[TM], b[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[i] = As[k * LDA + a_off + i * 32];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[j] = Bs[k * LDB + b_off + j * 32];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+            __syncthreads();
+            if (more) {
+                store_tiles();
+                __syncthreads();
+            }
+        }
+    }
+
+    // ---- epilogue ------------------------------------------------------------------
+    const int row_base = m0 + wm * WM + 4 * khalf;
+    const int col_base = n0 + wn * WN + (lane & 31);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = col_base + j * 32;
+        const float bv = (bias != nullptr && col < p.N) ? bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row_base + i * 32 + (r & 3) + 8 * (r >> 2);
+                float v = p.alpha * acc[i][j][r] + bv;
+                if (row < p.M && col < p.N) {
+                    float* dst = C + (long long)row * p.ldc + col;
+                    if (p.accumulate) v += *dst;
+                    *dst = v;
+                }
+                acc[i][j][r] = v;
+            }
+        }
+    }
+
+    if (p.stats != nullptr) {
+        // Per-column (mean, M2) over this tile's valid rows: two register passes,
+        // half-wave exchange, then across the WAVES_M waves through LDS.
+        __syncthreads();
+        float* red = smem;  // [WAVES_M][BN]
+        const int cnt = min(BM, p.M - m0);
+        const float inv = 1.f / (float)cnt;
+        float mean[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = row_base + i * 32 + (r & 3) + 8 * (r >> 2);
+                    if (row < p.M) s += acc[i][j][r];
+                }
+            s += __shfl_xor(s, 32, 64);
+            if (khalf == 0) red[wm * BN + wn * WN + j * 32 + (lane & 31)] = s;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < WAVES_M; ++w) s += red[w * BN + wn * WN + j * 32 + (lane & 31)];
+            mean[j] = s * inv;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = row_base + i * 32 + (r & 3) + 8 * (r >> 2);
+                    const float d = acc[i][j][r] - mean[j];
+                    if (row < p.M) s += d * d;
+                }
+            s += __shfl_xor(s, 32, 64);
+            if (khalf == 0) red[wm * BN + wn * WN + j * 32 + (lane & 31)] = s;
+        }
+        __syncthreads();
+        if (wm == 0 && khalf == 0) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int cl = wn * WN + j * 32 + (lane & 31);
+                float s = 0.f;
+#pragma unroll
+                for (int w = 0; w < WAVES_M; ++w) s += red[w * BN + cl];
+                const int col = n0 + cl;
+                if (col < p.N) {
+                    float* dst = p.stats + ((long long)mb * p.N + col) * 2;
+                    dst[0] = mean[j];
+                    dst[1] = s;
+                }
+            }
+        }
+    }
+}
+
+// ---- split-K slab reduction: C[i] = sum_s slab[s][i] (+ C[i]) ---------------------
+__global__ void slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ C, long long n4,
+                                   int splits, long long sSplit, int accumulate) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+         i += (long long)gridDim.x * blockDim.x) {
+        float4 s = reinterpret_cast<const float4*>(slab)[i];
+        for (int k = 1; k < splits; ++k) {
+            float4 t = reinterpret_cast<const float4*>(slab + (long long)k * sSplit)[i];
+            s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+        }
+        if (accumulate) {
+            float4 t = reinterpret_cast<float4*>(C)[i];
+            s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+        }
+        reinterpret_cast<float4*>(C)[i] = s;
+    }
+}
+
+template <int AMODE, int BMODE, int BM, int BN, int WAVES_M, int WAVES_N>
+static int launch(GemmParams& p, hipStream_t stream) {
+    p.mblocks = (p.M + BM - 1) / BM;
+    p.nblocks = (p.N + BN - 1) / BN;
+    dim3 grid((unsigned)(p.mblocks * p.nblocks), 1, (unsigned)(p.batch * p.splits));
+    hipLaunchKernelGGL((gemm_kernel<AMODE, BMODE, BM, BN, WAVES_M, WAVES_N>), grid, dim3(NTHREADS), 0, stream, p);
+    return check_launch("trid_gemm_f32");
+}
+
+template <int AMODE, int BMODE>
+static int dispatch_tile(GemmParams& p, hipStream_t stream) {
+    // tile choice: fill 128-wide tiles when the dimension allows, shrink otherwise.
+    // The BatchNorm-statistics epilogue always runs on 128-row tiles so that the
+    // caller knows the partial count: ceil(M/128).
+    int bm = p.M >= 96 ? 128 : (p.M > 32 ? 64 : 32);
+    const int bn = p.N >= 96 ? 128 : (p.N > 32 ? 64 : 32);
+    if (p.stats != nullptr) bm = 128;
+    if (bm == 128) {
+        if (bn == 128) return launch<AMODE, BMODE, 128, 128, 2, 2>(p, stream);
+        if (bn == 64) return launch<AMODE, BMODE, 128, 64, 2, 2>(p, stream);
+        return launch<AMODE, BMODE, 128, 32, 4, 1>(p, stream);
+    }
+    if (bn == 128) {
+        if (bm == 64) return launch<AMODE, BMODE, 64, 128, 2, 2>(p, stream);
+        return launch<AMODE, BMODE, 32, 128, 1, 4>(p, stream);
+    }
+    return launch<AMODE, BMODE, 64, 64, 2, 2>(p, stream);  // small x small, masked
+}
+
+}  // namespace trid
+
+using namespace trid;
+
+extern "C" int trid_gemm_f32(const trid_gemm_desc* d, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    TRID_REQUIRE(d != nullptr, "trid_gemm_f32: null descriptor");
+    TRID_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "trid_gemm_f32: empty problem M=%d N=%d K=%d", d->M, d->N, d->K);
+    TRID_REQUIRE(d->A && d->B && d->C, "trid_gemm_f32: null operand");
+    TRID_REQUIRE(aligned16(d->A) && aligned16(d->B) && aligned16(d->C), "trid_gemm_f32: operands must be 16-byte aligned");
+    TRID_REQUIRE(d->a_mode >= 0 && d->a_mode <= 2 && d->b_mode >= 0 && d->b_mode <= 2, "trid_gemm_f32: bad loader mode");
+    TRID_REQUIRE(d->batch >= 1 && d->splits >= 1, "trid_gemm_f32: batch/splits must be >= 1");
+    GemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.A = d->A; p.B = d->B; p.C = d->C;
+    p.M = d->M; p.N = d->N; p.K = d->K;
+    p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc;
+    p.sA = d->strideA; p.sB = d->strideB; p.sC = d->strideC;
+    p.batch = d->batch; p.splits = d->splits;
+    p.alpha = d->alpha; p.accumulate = d->accumulate;
+    p.bias = d->bias; p.sBias = d->strideBias; p.stats = d->stats;
+    p.H = d->H; p.W = d->W; p.Cin = d->Cin;
+    // contiguous-direction alignment (float4 loads)
+    if (d->a_mode == A_KC) TRID_REQUIRE(d->K % 4 == 0 && d->lda % 4 == 0, "A_KC needs K%%4==0 and lda%%4==0 (K=%d lda=%lld)", d->K, d->lda);
+    if (d->a_mode == A_MC) TRID_REQUIRE(d->M % 4 == 0 && d->lda % 4 == 0, "A_MC needs M%%4==0 and lda%%4==0 (M=%d)", d->M);
+    if (d->b_mode == B_KC) TRID_REQUIRE(d->K % 4 == 0 && d->ldb % 4 == 0, "B_KC needs K%%4==0 and ldb%%4==0 (K=%d ldb=%lld)", d->K, d->ldb);
+    if (d->b_mode == B_NC) TRID_REQUIRE(d->N % 4 == 0 && d->ldb % 4 == 0, "B_NC needs N%%4==0 and ldb%%4==0 (N=%d)", d->N);
+    if (d->a_mode == A_CONV || d->b_mode == B_CONV) {
+        TRID_REQUIRE(d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cin % 4 == 0, "conv gather needs H,W>0 and Cin%%4==0");
+        if (d->a_mode == A_CONV) TRID_REQUIRE(d->K == 9 * d->Cin && d->M % (d->H * d->W) == 0, "A_CONV: K must be 9*Cin and M a multiple of H*W");
+        if (d->b_mode == B_CONV) TRID_REQUIRE(d->N == 9 * d->Cin && d->K % (d->H * d->W) == 0, "B_CONV: N must be 9*Cin and K a multiple of H*W");
+        p.fdW = make_fastdiv((uint32_t)d->W);
+        p.fdH = make_fastdiv((uint32_t)d->H);
+        p.fdC = make_fastdiv((uint32_t)d->Cin);
+    }
+    TRID_REQUIRE(!(d->stats && (d->splits != 1 || d->batch != 1)), "stats epilogue needs splits==1, batch==1");
+    TRID_REQUIRE(!(d->splits > 1 && (d->accumulate || d->bias)), "split-K writes raw slabs: no bias/accumulate");
+    int kc = (d->K + d->splits - 1) / d->splits;
+    kc = (kc + BK - 1) / BK * BK;
+    p.k_chunk = kc;
+    p.sSplit = d->strideSplit;
+
+    int rc;
+    const int am = d->a_mode, bm = d->b_mode;
+    if (am == A_KC && bm == B_KC) rc = dispatch_tile<A_KC, B_KC>(p, stream);
+    else if (am == A_CONV && bm == B_KC) rc = dispatch_tile<A_CONV, B_KC>(p, stream);
+    else if (am == A_KC && bm == B_NC) rc = dispatch_tile<A_KC, B_NC>(p, stream);
+    else if (am == A_MC && bm == B_NC) rc = dispatch_tile<A_MC, B_NC>(p, stream);
+    else if (am == A_MC && bm == B_CONV) rc = dispatch_tile<A_MC, B_CONV>(p, stream);
+    else {
+        set_error("trid_gemm_f32: unsupported loader combination a=%d b=%d", am, bm);
+        return TRID_E_UNSUPPORTED;
+    }
+    return rc;
+}
+
+extern "C" int trid_slab_reduce_f32(const float* slab, float* C, long long n, int splits, long long strideSplit,
+                                    int accumulate, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    TRID_REQUIRE(slab && C && n > 0 && splits >= 1, "trid_slab_reduce_f32: bad arguments");
+    TRID_REQUIRE(n % 4 == 0 && strideSplit % 4 == 0 && aligned16(slab) && aligned16(C), "trid_slab_reduce_f32: needs 16-byte alignment and n%%4==0");
+    const long long n4 = n / 4;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid_for(n4, 256, 2048)), dim3(256), 0, stream, slab, C, n4, splits, strideSplit, accumulate);
+    return check_launch("trid_slab_reduce_f32");
+}

@@ -1,0 +1,323 @@
+// Embedding head and loss kernels: L2 row normalisation, the batch-wide queue
+// hit mask, masked InfoNCE rows, label-smoothed cross-entropy rows, projection
+// column normalisation, global-align softplus terms, small reductions.
+// Reference: head.py:126-175, losses.py:6-62,102-128,206-217, moco_head/loss.py.
+// The [rows, K] similarity / logit matrices are produced by trid_gemm_f32; the
+// kernels here turn them into per-row losses and, in place, into dL/dlogits, so
+// that the backward pass is two more GEMMs and no second softmax.
+
+#include "common.h"
+
+namespace trid {
+
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    float s = 0.f;
+    for (int i = 0; i < nw; ++i) s += red[i];
+    return s;
+}
+__device__ __forceinline__ float block_max(float v, float* red) {
+    v = wave_max(v);
+    const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    float s = -INFINITY;
+    for (int i = 0; i < nw; ++i) s = fmaxf(s, red[i]);
+    return s;
+}
+
+// one wave per row
+__global__ void l2norm_rows_kernel(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ inv_norm,
+                                   long long rows, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + row * C;
+    float s = 0.f;
+    for (int j = lane; j < C; j += 64) s = fmaf(xr[j], xr[j], s);
+    s = wave_sum(s);
+    const float inv = 1.f / fmaxf(sqrtf(s), eps);
+    for (int j = lane; j < C; j += 64) y[row * C + j] = xr[j] * inv;
+    if (lane == 0 && inv_norm != nullptr) inv_norm[row] = inv;
+}
+
+__global__ void l2norm_rows_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                       const float* __restrict__ inv_norm, float* __restrict__ dx, long long rows, int C,
+                                       int accumulate) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* dr = dy + row * C;
+    const float* yr = y + row * C;
+    float d = 0.f;
+    for (int j = lane; j < C; j += 64) d = fmaf(dr[j], yr[j], d);
+    d = wave_sum(d);
+    const float inv = inv_norm[row];
+    for (int j = lane; j < C; j += 64) {
+        const float v = (dr[j] - yr[j] * d) * inv;
+        dx[row * C + j] = accumulate ? dx[row * C + j] + v : v;
+    }
+}
+
+__global__ void queue_hit_mask_kernel(const int64_t* __restrict__ id_queue, const int64_t* __restrict__ ids,
+                                      uint8_t* __restrict__ flag, int K, int B) {
+    extern __shared__ int64_t sid[];
+    for (int i = threadIdx.x; i < B; i += blockDim.x) sid[i] = ids[i];
+    __syncthreads();
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    const int64_t v = id_queue[k];
+    bool hit = false;
+    for (int i = 0; i < B; ++i) hit |= (sid[i] == v);
+    flag[k] = hit ? 1 : 0;
+}
+
+// one workgroup per query row
+__global__ __launch_bounds__(256) void infonce_rows_kernel(float* __restrict__ S, const float* __restrict__ pos,
+                                                           const uint8_t* __restrict__ hit,
+                                                           float* __restrict__ loss_rows, float* __restrict__ dpos,
+                                                           int K, int ldS, float invT, float gs) {
+    __shared__ float red[8];
+    const int b = blockIdx.x;
+    float* r = S + (long long)b * ldS;
+    const float p = pos[b] * invT;
+    float m = p;
+    for (int k = threadIdx.x; k < K; k += 256)
+        if (!hit[k]) m = fmaxf(m, r[k] * invT);
+    m = block_max(m, red);
+    float l = 0.f;
+    for (int k = threadIdx.x; k < K; k += 256)
+        if (!hit[k]) l += expf(r[k] * invT - m);
+    l = block_sum(l, red) + expf(p - m);
+    const float lse = m + logf(l);
+    for (int k = threadIdx.x; k < K; k += 256) r[k] = hit[k] ? 0.f : expf(r[k] * invT - lse) * gs;
+    if (threadIdx.x == 0) {
+        loss_rows[b] = lse - p;
+        dpos[b] = (expf(p - lse) - 1.f) * gs;
+    }
+}
+
+__global__ void rowdot_kernel(const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ out,
+                              long long rows, int C) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float d = 0.f;
+    for (int j = lane; j < C; j += 64) d = fmaf(x[row * C + j], y[row * C + j], d);
+    d = wave_sum(d);
+    if (lane == 0) out[row] = d;
+}
+
+__global__ void rowscale_add_kernel(const float* __restrict__ s, const float* __restrict__ y, float* __restrict__ dx,
+                                    long long rows, int C, int accumulate) {
+    const long long total = rows * C;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const float v = s[i / C] * y[i];
+        dx[i] = accumulate ? dx[i] + v : v;
+    }
+}
+
+// one workgroup per row; in place logits -> dlogits
+__global__ __launch_bounds__(256) void smooth_ce_rows_kernel(float* __restrict__ logits,
+                                                             const int64_t* __restrict__ labels,
+                                                             float* __restrict__ loss_rows, int n, int ld, float eps,
+                                                             float gs) {
+    __shared__ float red[8];
+    const long long row = blockIdx.x;
+    float* r = logits + row * ld;
+    const int y = (int)labels[row];
+    float m = -INFINITY, sum = 0.f;
+    for (int j = threadIdx.x; j < n; j += 256) {
+        const float v = r[j];
+        m = fmaxf(m, v);
+        sum += v;
+    }
+    m = block_max(m, red);
+    sum = block_sum(sum, red);
+    float l = 0.f;
+    for (int j = threadIdx.x; j < n; j += 256) l += expf(r[j] - m);
+    l = block_sum(l, red);
+    const float lse = m + logf(l);
+    const float sy = r[y];
+    __syncthreads();
+    const float un = eps / (float)n;
+    for (int j = threadIdx.x; j < ld; j += 256) {
+        float g = 0.f;
+        if (j < n) g = (expf(r[j] - lse) - un - (j == y ? (1.f - eps) : 0.f)) * gs;
+        r[j] = g;
+    }
+    if (threadIdx.x == 0) loss_rows[row] = -(1.f - eps) * (sy - lse) - un * (sum - (float)n * lse);
+}
+
+// projection [C,N]: thread per column
+__global__ void colnorm_kernel(const float* __restrict__ proj, float* __restrict__ pn, float* __restrict__ pnt,
+                               float* __restrict__ inv_norm, int C, int N, int ldn) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= ldn) return;
+    if (j >= N) {
+        for (int c = 0; c < C; ++c) {
+            pn[(long long)c * ldn + j] = 0.f;
+            pnt[(long long)j * C + c] = 0.f;
+        }
+        return;
+    }
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) {
+        const float v = proj[(long long)c * N + j];
+        s = fmaf(v, v, s);
+    }
+    const float inv = 1.f / fmaxf(sqrtf(s), 1e-12f);
+    inv_norm[j] = inv;
+    for (int c = 0; c < C; ++c) {
+        const float v = proj[(long long)c * N + j] * inv;
+        pn[(long long)c * ldn + j] = v;
+        pnt[(long long)j * C + c] = v;
+    }
+}
+
+// one wave per column j: dproj[c,j] = (dpnt[j,c] - pnt[j,c]*<dpnt_j,pnt_j>)*inv_j
+__global__ void colnorm_bwd_kernel(const float* __restrict__ dpnt, const float* __restrict__ pnt,
+                                   const float* __restrict__ inv_norm, float* __restrict__ dproj, int C, int N) {
+    const int lane = threadIdx.x & 63;
+    const int j = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (j >= N) return;
+    const float* dr = dpnt + (long long)j * C;
+    const float* pr = pnt + (long long)j * C;
+    float d = 0.f;
+    for (int c = lane; c < C; c += 64) d = fmaf(dr[c], pr[c], d);
+    d = wave_sum(d);
+    const float inv = inv_norm[j];
+    for (int c = lane; c < C; c += 64) dproj[(long long)c * N + j] = (dr[c] - pr[c] * d) * inv;
+}
+
+// one workgroup per row of the cosine matrix
+__global__ __launch_bounds__(256) void global_align_rows_kernel(float* __restrict__ S, const int64_t* __restrict__ ids,
+                                                                float* __restrict__ loss_rows, int B, int ldS,
+                                                                float alpha, float beta, float sp, float sn, float gs) {
+    __shared__ float red[8];
+    const int i = blockIdx.x;
+    float* r = S + (long long)i * ldS;
+    const int64_t idi = ids[i];
+    float acc = 0.f;
+    for (int j = threadIdx.x; j < B; j += 256) {
+        const float s = r[j];
+        float l, g;
+        if (ids[j] == idi) {
+            const float e = expf(-sp * (s - alpha));
+            l = logf(1.f + e);
+            g = -sp * e / (1.f + e);
+        } else {
+            const float e = expf(sn * (s - beta));
+            l = logf(1.f + e);
+            g = sn * e / (1.f + e);
+        }
+        acc += l;
+        r[j] = g * gs;
+    }
+    acc = block_sum(acc, red);
+    if (threadIdx.x == 0) loss_rows[i] = acc * 2.f / (float)B;
+}
+
+__global__ __launch_bounds__(256) void sum_kernel(const float* __restrict__ x, float* __restrict__ out, long long n,
+                                                  float scale, int accumulate) {
+    __shared__ float red[8];
+    float s = 0.f;
+    for (long long i = threadIdx.x; i < n; i += 256) s += x[i];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) out[0] = accumulate ? out[0] + s * scale : s * scale;
+}
+
+}  // namespace trid
+
+using namespace trid;
+
+extern "C" int trid_l2norm_rows_f32(const float* x, float* y, float* inv_norm, long long rows, int C, float eps,
+                                    void* stream) {
+    TRID_REQUIRE(x && y && rows > 0 && C > 0, "trid_l2norm_rows_f32: bad arguments");
+    hipLaunchKernelGGL(l2norm_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, y,
+                       inv_norm, rows, C, eps);
+    return check_launch("trid_l2norm_rows_f32");
+}
+
+extern "C" int trid_l2norm_rows_bwd_f32(const float* dy, const float* y, const float* inv_norm, float* dx,
+                                        long long rows, int C, int accumulate, void* stream) {
+    TRID_REQUIRE(dy && y && inv_norm && dx && rows > 0 && C > 0, "trid_l2norm_rows_bwd_f32: bad arguments");
+    hipLaunchKernelGGL(l2norm_rows_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, dy, y,
+                       inv_norm, dx, rows, C, accumulate);
+    return check_launch("trid_l2norm_rows_bwd_f32");
+}
+
+extern "C" int trid_queue_hit_mask(const int64_t* id_queue, const int64_t* ids, uint8_t* flag, int K, int B,
+                                   void* stream) {
+    TRID_REQUIRE(id_queue && ids && flag && K > 0 && B > 0 && B <= 8192, "trid_queue_hit_mask: bad arguments");
+    hipLaunchKernelGGL(queue_hit_mask_kernel, dim3((K + 255) / 256), dim3(256), (size_t)B * sizeof(int64_t),
+                       (hipStream_t)stream, id_queue, ids, flag, K, B);
+    return check_launch("trid_queue_hit_mask");
+}
+
+extern "C" int trid_infonce_rows_f32(float* S, const float* pos, const uint8_t* hit, float* loss_rows, float* dpos,
+                                     int B, int K, int ldS, float invT, float gscale, void* stream) {
+    TRID_REQUIRE(S && pos && hit && loss_rows && dpos && B > 0 && K > 0 && ldS >= K, "trid_infonce_rows_f32: bad arguments");
+    hipLaunchKernelGGL(infonce_rows_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, S, pos, hit, loss_rows, dpos, K,
+                       ldS, invT, gscale * invT / (float)B);
+    return check_launch("trid_infonce_rows_f32");
+}
+
+extern "C" int trid_rowdot_f32(const float* x, const float* y, float* out, long long rows, int C, void* stream) {
+    TRID_REQUIRE(x && y && out && rows > 0 && C > 0, "trid_rowdot_f32: bad arguments");
+    hipLaunchKernelGGL(rowdot_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, y, out,
+                       rows, C);
+    return check_launch("trid_rowdot_f32");
+}
+
+extern "C" int trid_rowscale_add_f32(const float* s, const float* y, float* dx, long long rows, int C, int accumulate,
+                                     void* stream) {
+    TRID_REQUIRE(s && y && dx && rows > 0 && C > 0, "trid_rowscale_add_f32: bad arguments");
+    hipLaunchKernelGGL(rowscale_add_kernel, dim3(grid_for(rows * C, 256)), dim3(256), 0, (hipStream_t)stream, s, y, dx,
+                       rows, C, accumulate);
+    return check_launch("trid_rowscale_add_f32");
+}
+
+extern "C" int trid_smooth_ce_rows_f32(float* logits, const int64_t* labels, float* loss_rows, long long rows, int n,
+                                       int ld, float epsilon, float gscale, void* stream) {
+    TRID_REQUIRE(logits && labels && loss_rows && rows > 0 && n > 0 && ld >= n, "trid_smooth_ce_rows_f32: bad arguments");
+    hipLaunchKernelGGL(smooth_ce_rows_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, logits, labels,
+                       loss_rows, n, ld, epsilon, gscale);
+    return check_launch("trid_smooth_ce_rows_f32");
+}
+
+extern "C" int trid_colnorm_f32(const float* proj, float* pn, float* pnt, float* inv_norm, int C, int N, int ldn,
+                                void* stream) {
+    TRID_REQUIRE(proj && pn && pnt && inv_norm && C > 0 && N > 0 && ldn >= N, "trid_colnorm_f32: bad arguments");
+    hipLaunchKernelGGL(colnorm_kernel, dim3((ldn + 255) / 256), dim3(256), 0, (hipStream_t)stream, proj, pn, pnt, inv_norm,
+                       C, N, ldn);
+    return check_launch("trid_colnorm_f32");
+}
+
+extern "C" int trid_colnorm_bwd_f32(const float* dpnt, const float* pnt, const float* inv_norm, float* dproj, int C,
+                                    int N, int ldn, void* stream) {
+    TRID_REQUIRE(dpnt && pnt && inv_norm && dproj && C > 0 && N > 0 && ldn >= N, "trid_colnorm_bwd_f32: bad arguments");
+    hipLaunchKernelGGL(colnorm_bwd_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, dpnt, pnt, inv_norm,
+                       dproj, C, N);
+    return check_launch("trid_colnorm_bwd_f32");
+}
+
+extern "C" int trid_global_align_rows_f32(float* S, const int64_t* ids, float* loss_rows, int B, int ldS, float alpha,
+                                          float beta, float scale_pos, float scale_neg, float gscale, void* stream) {
+    TRID_REQUIRE(S && ids && loss_rows && B > 0 && ldS >= B, "trid_global_align_rows_f32: bad arguments");
+    hipLaunchKernelGGL(global_align_rows_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, S, ids, loss_rows, B, ldS,
+                       alpha, beta, scale_pos, scale_neg, gscale * 2.f / (float)B);
+    return check_launch("trid_global_align_rows_f32");
+}
+
+extern "C" int trid_sum_f32(const float* x, float* out, long long n, float scale, int accumulate, void* stream) {
+    TRID_REQUIRE(x && out && n > 0, "trid_sum_f32: bad arguments");
+    hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, x, out, n, scale, accumulate);
+    return check_launch("trid_sum_f32");
+}

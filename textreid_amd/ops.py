@@ -1,0 +1,311 @@
+"""Tensor-level wrappers over the C ABI (no autograd here).
+
+Every function takes fp32 CUDA tensors, allocates outputs through PyTorch's
+caching allocator (plumbing) and enqueues the HIP kernels of
+libtextreid_hip.so on the current stream.  Nothing in this module computes
+with torch ops, and nothing falls back to the CPU: a CPU tensor raises.
+"""
+
+import ctypes
+import math
+
+import torch
+
+from . import lib as L
+from .lib import GemmDesc, call
+
+A_KC, A_MC, A_CONV = L.TRID_A_KC, L.TRID_A_MC, L.TRID_A_CONV
+B_KC, B_NC, B_CONV = L.TRID_B_KC, L.TRID_B_NC, L.TRID_B_CONV
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+STATS_ROWS = 128  # rows per BatchNorm-statistics partial (GEMM tile height)
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("textreid_amd kernels need CUDA (HIP) tensors; got a CPU tensor -- there is no CPU fallback")
+    return t.data_ptr()
+
+
+def empty(shape, like=None, dtype=torch.float32, device=None):
+    return torch.empty(shape, dtype=dtype, device=device if device is not None else like.device)
+
+
+# --------------------------------------------------------------------------- GEMM
+def gemm(A, B, C, M, N, K, lda, ldb, ldc, a_mode=A_KC, b_mode=B_KC, alpha=1.0, accumulate=False, bias=None,
+         stats=None, batch=1, strideA=0, strideB=0, strideC=0, splits=1, strideSplit=0, conv=None, a_off=0, b_off=0,
+         c_off=0, strideBias=0, bias_off=0):
+    """Raw descriptor call.  a_off/b_off/c_off are element offsets into A/B/C."""
+    d = GemmDesc()
+    d.A = _p(A) + 4 * a_off
+    d.B = _p(B) + 4 * b_off
+    d.C = _p(C) + 4 * c_off
+    d.M, d.N, d.K = M, N, K
+    d.lda, d.ldb, d.ldc = lda, ldb, ldc
+    d.strideA, d.strideB, d.strideC = strideA, strideB, strideC
+    d.batch, d.splits, d.strideSplit = batch, splits, strideSplit
+    d.a_mode, d.b_mode = a_mode, b_mode
+    d.alpha = alpha
+    d.accumulate = 1 if accumulate else 0
+    d.bias = (_p(bias) + 4 * bias_off) if bias is not None else None
+    d.strideBias = strideBias
+    d.stats = _p(stats)
+    if conv is not None:
+        d.H, d.W, d.Cin = conv
+    call("trid_gemm_f32", ctypes.addressof(d), stream())
+
+
+def linear(x, w, bias=None, out=None, alpha=1.0, accumulate=False):
+    """y[M,N] = alpha * x[M,K] @ w[N,K]^T + bias.  x may be a strided row view."""
+    M, K = x.shape
+    N = w.shape[0]
+    if out is None:
+        out = empty((M, N), x)
+    gemm(x, w, out, M, N, K, x.stride(0), w.stride(0), out.stride(0), alpha=alpha, accumulate=accumulate, bias=bias)
+    return out
+
+
+def matmul_nn(a, b, out=None, alpha=1.0, accumulate=False):
+    """out[M,N] = a[M,K] @ b[K,N] (b rows N-contiguous)."""
+    M, K = a.shape
+    N = b.shape[1]
+    if out is None:
+        out = empty((M, N), a)
+    gemm(a, b, out, M, N, K, a.stride(0), b.stride(0), out.stride(0), b_mode=B_NC, alpha=alpha, accumulate=accumulate)
+    return out
+
+
+def _wgrad_splits(tiles, K):
+    return max(1, min(int(math.ceil(1024.0 / max(tiles, 1))), K // 512))
+
+
+def matmul_tn(a, b, out=None, alpha=1.0):
+    """out[Ma,Nb] = a[K,Ma]^T @ b[K,Nb]  (weight-gradient form, split-K over K)."""
+    K, Ma = a.shape
+    Nb = b.shape[1]
+    if out is None:
+        out = empty((Ma, Nb), a)
+    tiles = ((Ma + 127) // 128) * ((Nb + 127) // 128)
+    splits = _wgrad_splits(tiles, K)
+    if splits == 1 or out.stride(0) != Nb:
+        gemm(a, b, out, Ma, Nb, K, a.stride(0), b.stride(0), out.stride(0), a_mode=A_MC, b_mode=B_NC, alpha=alpha)
+        return out
+    slab = empty((splits, Ma, Nb), a)
+    gemm(a, b, slab, Ma, Nb, K, a.stride(0), b.stride(0), Nb, a_mode=A_MC, b_mode=B_NC, alpha=alpha, splits=splits,
+         strideSplit=Ma * Nb)
+    call("trid_slab_reduce_f32", _p(slab), _p(out), Ma * Nb, splits, Ma * Nb, 0, stream())
+    return out
+
+
+def stats_buffer(M, N, like):
+    return empty(((M + STATS_ROWS - 1) // STATS_ROWS, N, 2), like)
+
+
+def conv1x1(x, w, stats=False):
+    """x [B,H,W,C] NHWC (or [M,C]), w [N,C] -> y [.., N]; optional BN partials."""
+    C = x.shape[-1]
+    M = x.numel() // C
+    N = w.shape[0]
+    y = empty(x.shape[:-1] + (N,), x)
+    st = stats_buffer(M, N, x) if stats else None
+    gemm(x, w, y, M, N, C, C, w.stride(0), N, stats=st)
+    return (y, st) if stats else y
+
+
+def conv3x3(x, w, stats=False):
+    """x [B,H,W,C] NHWC, w [N, 9*C] (tap-major, channel-minor = OHWI) -> y [B,H,W,N]."""
+    Bi, H, W, C = x.shape
+    N = w.shape[0]
+    M = Bi * H * W
+    y = empty((Bi, H, W, N), x)
+    st = stats_buffer(M, N, x) if stats else None
+    gemm(x, w, y, M, N, 9 * C, C, 9 * C, N, a_mode=A_CONV, stats=st, conv=(H, W, C))
+    return (y, st) if stats else y
+
+
+def conv1x1_wgrad(dy, x):
+    """dW [N,C] = dy[M,N]^T @ x[M,C]."""
+    N, C = dy.shape[-1], x.shape[-1]
+    return matmul_tn(dy.reshape(-1, N), x.reshape(-1, C))
+
+
+def conv3x3_wgrad(dy, x):
+    """dW [N, 9*C] for the 3x3/s1/p1 conv; dy [B,H,W,N], x [B,H,W,C]."""
+    Bi, H, W, C = x.shape
+    N = dy.shape[-1]
+    M = Bi * H * W
+    J = 9 * C
+    out = empty((N, J), x)
+    tiles = ((N + 127) // 128) * ((J + 127) // 128)
+    splits = _wgrad_splits(tiles, M)
+    if splits == 1:
+        gemm(dy, x, out, N, J, M, N, C, J, a_mode=A_MC, b_mode=B_CONV, conv=(H, W, C))
+        return out
+    slab = empty((splits, N, J), x)
+    gemm(dy, x, slab, N, J, M, N, C, J, a_mode=A_MC, b_mode=B_CONV, conv=(H, W, C), splits=splits, strideSplit=N * J)
+    call("trid_slab_reduce_f32", _p(slab), _p(out), N * J, splits, N * J, 0, stream())
+    return out
+
+
+def weight_transpose(w, N, T, C, flip):
+    """w [N][T][C] -> [C][T][N] (taps reversed when flip): dgrad weights."""
+    wt = empty((C, T * N), w)
+    call("trid_weight_transpose_f32", _p(w), _p(wt), N, T, C, 1 if flip else 0, stream())
+    return wt
+
+
+def stem_im2col(img, ldcol=28):
+    Bi, Cin, H, W = img.shape
+    Ho, Wo = (H + 1) // 2, (W + 1) // 2
+    col = empty((Bi * Ho * Wo, ldcol), img)
+    call("trid_stem_im2col_f32", _p(img), _p(col), Bi, Cin, H, W, Ho, Wo, ldcol, stream())
+    return col, Ho, Wo
+
+
+# --------------------------------------------------------------------------- BatchNorm
+class BNState:
+    """Per-layer BatchNorm coefficients produced by the forward pass."""
+
+    __slots__ = ("mean", "invstd", "scale", "shift")
+
+    def __init__(self, C, like):
+        buf = empty((4, C), like)
+        self.mean, self.invstd, self.scale, self.shift = buf[0], buf[1], buf[2], buf[3]
+
+
+def bn_finalize(partials, M, gamma, beta, running_mean, running_var, momentum=BN_MOMENTUM, eps=BN_EPS):
+    C = gamma.numel()
+    st = BNState(C, gamma)
+    call("trid_bn_finalize_f32", _p(partials), partials.shape[0], STATS_ROWS, M, C, _p(gamma), _p(beta),
+         _p(running_mean), _p(running_var), momentum, eps, _p(st.mean), _p(st.invstd), _p(st.scale), _p(st.shift),
+         stream())
+    return st
+
+
+def bn_eval_coeffs(gamma, beta, running_mean, running_var, eps=BN_EPS):
+    C = gamma.numel()
+    st = BNState(C, gamma)
+    call("trid_bn_eval_coeffs_f32", _p(gamma), _p(beta), _p(running_mean), _p(running_var), eps, _p(st.scale),
+         _p(st.shift), C, stream())
+    return st
+
+
+def bn_apply(y, st, relu=True, res=None, res_st=None, out=None):
+    C = y.shape[-1]
+    M = y.numel() // C
+    if out is None:
+        out = torch.empty_like(y)
+    call("trid_bn_apply_f32", _p(y), _p(st.scale), _p(st.shift), _p(res), _p(res_st.scale) if res_st else None,
+         _p(res_st.shift) if res_st else None, _p(out), M, C, 1 if relu else 0, stream())
+    return out
+
+
+def bn_apply_pool2(y, st, relu=True):
+    """avgpool2(act(bn(y))) ; st=None -> plain 2x2 average pooling."""
+    Bi, H, W, C = y.shape
+    out = empty((Bi, H // 2, W // 2, C), y)
+    call("trid_bn_apply_pool2_f32", _p(y), _p(st.scale) if st else None, _p(st.shift) if st else None, _p(out), Bi, H, W,
+         C, 1 if (relu and st is not None) else 0, stream())
+    return out
+
+
+def avgpool2_bwd(g, dx=None, accumulate=False):
+    Bi, Ho, Wo, C = g.shape
+    if dx is None:
+        dx = empty((Bi, Ho * 2, Wo * 2, C), g)
+    call("trid_avgpool2_bwd_f32", _p(g), _p(dx), Bi, Ho * 2, Wo * 2, C, 1 if accumulate else 0, stream())
+    return dx
+
+
+_ws_cache = {}
+
+
+def _bn_ws(C, like):
+    key = (C, like.device)
+    ws = _ws_cache.get(key)
+    if ws is None:
+        ws = empty((L.load().trid_bn_bwd_ws_floats(C),), like)
+        _ws_cache[key] = ws
+    return ws
+
+
+def bn_bwd(g, y, st, gamma_like, mask_mode, act=None, pooled=False, want_dres=False):
+    """BatchNorm backward.  g: dL/d(out) ([B,H/2,W/2,C] when pooled).  Returns
+    (dy, dgamma, dbeta, dres)."""
+    Bi, H, W, C = y.shape
+    dg = empty((2, C), y)
+    dgamma, dbeta = dg[0], dg[1]
+    ws = _bn_ws(C, y)
+    call("trid_bn_bwd_reduce_f32", _p(g), _p(y), _p(act), _p(st.mean), _p(st.invstd), _p(st.scale), _p(st.shift),
+         mask_mode, 1 if pooled else 0, Bi, H, W, C, _p(dgamma), _p(dbeta), _p(ws), stream())
+    dy = torch.empty_like(y)
+    dres = torch.empty_like(y) if want_dres else None
+    call("trid_bn_bwd_apply_f32", _p(g), _p(y), _p(act), _p(st.mean), _p(st.invstd), _p(st.scale), _p(st.shift),
+         _p(dgamma), _p(dbeta), mask_mode, 1 if pooled else 0, Bi, H, W, C, _p(dy), _p(dres), stream())
+    return dy, dgamma, dbeta, dres
+
+
+# --------------------------------------------------------------------------- small ops
+def colsum(x2d, out=None, accumulate=False):
+    M, N = x2d.shape
+    if out is None:
+        out = empty((N,), x2d)
+    call("trid_colsum_f32", _p(x2d), _p(out), M, N, x2d.stride(0), 1 if accumulate else 0, stream())
+    return out
+
+
+def softmax_rows_(s, n):
+    rows, ld = s.numel() // s.shape[-1], s.shape[-1]
+    call("trid_softmax_rows_f32", _p(s), rows, n, ld, stream())
+    return s
+
+
+def softmax_rows_bwd(p, dp, n, out=None):
+    rows, ld = p.numel() // p.shape[-1], p.shape[-1]
+    if out is None:
+        out = torch.empty_like(p)
+    call("trid_softmax_rows_bwd_f32", _p(p), _p(dp), _p(out), rows, n, ld, stream())
+    return out
+
+
+def l2norm_rows(x, eps=1e-12):
+    rows, C = x.shape
+    y = torch.empty_like(x)
+    inv = empty((rows,), x)
+    call("trid_l2norm_rows_f32", _p(x), _p(y), _p(inv), rows, C, eps, stream())
+    return y, inv
+
+
+def l2norm_rows_bwd(dy, y, inv, dx=None, accumulate=False):
+    rows, C = y.shape
+    if dx is None:
+        dx = torch.empty_like(y)
+    call("trid_l2norm_rows_bwd_f32", _p(dy), _p(y), _p(inv), _p(dx), rows, C, 1 if accumulate else 0, stream())
+    return dx
+
+
+def rowdot(x, y):
+    rows, C = x.shape
+    out = empty((rows,), x)
+    call("trid_rowdot_f32", _p(x), _p(y), _p(out), rows, C, stream())
+    return out
+
+
+def rowscale_add(s, y, dx=None, accumulate=False):
+    rows, C = y.shape
+    if dx is None:
+        dx = torch.empty_like(y)
+    call("trid_rowscale_add_f32", _p(s), _p(y), _p(dx), rows, C, 1 if accumulate else 0, stream())
+    return dx
+
+
+def sum_to(x, out, scale=1.0, accumulate=False):
+    call("trid_sum_f32", _p(x), _p(out), x.numel(), scale, 1 if accumulate else 0, stream())
+    return out
