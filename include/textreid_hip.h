@@ -131,10 +131,13 @@ int trid_bn_bwd_apply_f32(const float* g, const float* y, const float* act, cons
 /* ------------------------------------------------------------------------- *
  * Attention pool (m_resnet.py:103-135), token-0 query only.
  * ------------------------------------------------------------------------- */
-/* tok[b,0,:] = mean_t x[b,t,:] + pos[0]; tok[b,1+t,:] = x[b,t,:] + pos[1+t] */
-int trid_attnpool_tokens_f32(const float* x, const float* pos, float* tok, int B, int T, int C, void* stream);
+/* tok [B,ldt,C]: tok[b,0,:] = mean_t x[b,t,:] + pos[0]; tok[b,1+t,:] = x[b,t,:] + pos[1+t];
+ * rows T+1..ldt-1 are zero padding (ldt multiple of 4 keeps the token axis float4-addressable) */
+int trid_attnpool_tokens_f32(const float* x, const float* pos, float* tok, int B, int T, int C, int ldt,
+                             void* stream);
 /* dx[b,t,:] = dtok[b,1+t,:] + dtok[b,0,:]/T ; dpos[t,:] = sum_b dtok[b,t,:] */
-int trid_attnpool_tokens_bwd_f32(const float* dtok, float* dx, float* dpos, int B, int T, int C, void* stream);
+int trid_attnpool_tokens_bwd_f32(const float* dtok, float* dx, float* dpos, int B, int T, int C, int ldt,
+                                 void* stream);
 /* row softmax over the first n columns of each row (ld >= n), in place; pad columns zeroed */
 int trid_softmax_rows_f32(float* s, long long rows, int n, int ld, void* stream);
 /* ds = p * (dp - sum_j p_j dp_j), row-wise; writes into ds (may alias dp) */
@@ -152,12 +155,13 @@ int trid_embedding_gather_f32(const float* table, const int64_t* tokens, float* 
 /* One time step of both directions.  s = step index; direction d processes
  * t = s (d=0) or t = Lmax-1-s (d=1).  gi: [B*L, 2*3H] input projections (row
  * b*L+t, col d*3H + gate*H + j); gh: [2,B,3H]; h: [2,B,H] updated in place;
- * saved gates (r,z,n,hn) -> gates[s] [2,B,4H] and previous state -> hprev[s]
- * [2,B,H] (NULL to skip, e.g. key encoder); running max over time in
+ * saved gates (r,z,n,hn) -> gates [B,4H] per direction at gates + d*gates_dstride,
+ * previous state -> hprev [B,H] at hprev + d*hprev_dstride (NULL to skip, e.g.
+ * the key encoder); running max over time in
  * maxv/argt [B,2H] (column d*H+j). */
 int trid_gru_cell_fwd_f32(const float* gi, const float* gh, float* h, const int64_t* lengths, float* gates,
                           float* hprev, float* maxv, int32_t* argt, int s, int Lmax, int L, int B, int Hd,
-                          void* stream);
+                          long long gates_dstride, long long hprev_dstride, void* stream);
 /* maxv/argt init: 0/-1 when length < Lmax (a zero pad row enters the max, gru.py:63) else -inf/-1 */
 int trid_gru_max_init_f32(float* maxv, int32_t* argt, const int64_t* lengths, int Lmax, int B, int Hd, void* stream);
 /* Backward of one step (reverse order of s).  dh [2,B,H] carries dL/dh; adds the
@@ -165,7 +169,8 @@ int trid_gru_max_init_f32(float* maxv, int32_t* argt, const int64_t* lengths, in
  * [B*L, 2*3H], dgh [2,B,3H]; dh <- dh*z (+ pass-through when inactive). */
 int trid_gru_cell_bwd_f32(const float* dout, const int32_t* argt, const float* gates, const float* hprev,
                           const int64_t* lengths, float* dh, float* dGi, float* dgh, int s, int Lmax, int L,
-                          int B, int Hd, void* stream);
+                          int B, int Hd, long long gates_dstride, long long hprev_dstride, long long dgh_dstride,
+                          void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Embedding head and losses (head.py:126-175, losses.py, moco_head/loss.py).
@@ -193,7 +198,8 @@ int trid_rowscale_add_f32(const float* s, const float* y, float* dx, long long r
  * -(1-eps)*logp[label] - eps/n * sum_j logp_j. */
 int trid_smooth_ce_rows_f32(float* logits, const int64_t* labels, float* loss_rows, long long rows, int n, int ld,
                             float epsilon, float gscale, void* stream);
-/* projection [C, N] -> column-normalised copies pn [C, ldn] and pnt [ldn, C]; inv_norm[N] */
+/* projection [C, N] -> column-normalised copies pn [C, ldn] (optional, may be NULL) and
+ * pnt [ldn, C] (class-major, zero rows for the ldn-N padding); inv_norm[N] */
 int trid_colnorm_f32(const float* proj, float* pn, float* pnt, float* inv_norm, int C, int N, int ldn, void* stream);
 /* dproj[c,j] = (dpnt[j,c] - pnt[j,c]*<dpnt[j,:],pnt[j,:]>) * inv_norm[j] */
 int trid_colnorm_bwd_f32(const float* dpnt, const float* pnt, const float* inv_norm, float* dproj, int C, int N,
@@ -203,6 +209,9 @@ int trid_colnorm_bwd_f32(const float* dpnt, const float* pnt, const float* inv_n
  * softplus terms * 2/B. */
 int trid_global_align_rows_f32(float* S, const int64_t* ids, float* loss_rows, int B, int ldS, float alpha,
                                float beta, float scale_pos, float scale_neg, float gscale, void* stream);
+/* out = g3[0]*a + g3[1]*b + g3[2]*c, g3 device-resident upstream gradients (b, c may be NULL) */
+int trid_axpby3_f32(float* out, const float* a, const float* b, const float* c, const float* g3, long long n,
+                    void* stream);
 /* out[0] (+)= scale * sum_i x[i] */
 int trid_sum_f32(const float* x, float* out, long long n, float scale, int accumulate, void* stream);
 

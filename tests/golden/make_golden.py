@@ -55,6 +55,13 @@ ref_eval = importlib.util.module_from_spec(spec_eval)
 spec_eval.loader.exec_module(ref_eval)
 
 
+WARM = 25
+
+
+def f32(d):
+    return {k: (np.asarray(v).astype(np.float32) if np.asarray(v).dtype == np.float64 and k.startswith('truth:') else v) for k, v in d.items()}
+
+
 def rel(a, b):
     a, b = a.detach().double(), b.detach().double()
     return float((a - b).abs().max() / (b.abs().max() + 1e-30))
@@ -136,21 +143,45 @@ def gen_visual(tag, spec, B, seed, grads=()):
     with torch.no_grad():
         out["out_eval"] = m(x).numpy()
 
-    # oracle check
-    st = oracle_state(OV.state_shapes(spec), seed)
-    for k in st:
-        if OV.is_param(k):
-            st[k].requires_grad_(True)
-    yo = OV.visual_forward(st, x, spec, True)
-    check("out_train", yo, y)
-    (yo * w_out).sum().backward()
-    for g in grads:
-        check("grad " + g, st[g].grad, named[g].grad, 1e-4)
-    check("bn1.running_mean", st["bn1.running_mean"], sd_after["bn1.running_mean"])
-    check("last running_var", st[last], sd_after[last])
+    # warm running statistics: WARM more train-mode forwards, then eval (well-conditioned eval check)
+    m.train()
     with torch.no_grad():
-        check("out_eval", OV.visual_forward(st, x, spec, False), torch.from_numpy(out["out_eval"]))
-    np.savez_compressed(os.path.join(HERE, "visual_%s.npz" % tag), **out)
+        for _ in range(WARM):
+            m(x)
+        m.eval()
+        out["out_eval_warm"] = m(x).numpy()
+
+    # oracle check (fp32) + fp64 oracle = "truth" used by the noise-aware GPU criterion
+    for dt in (torch.float32, torch.float64):
+        st = oracle_state(OV.state_shapes(spec), seed)
+        for k in st:
+            if st[k].dtype.is_floating_point:
+                st[k] = st[k].to(dt)
+            if OV.is_param(k):
+                st[k].requires_grad_(True)
+        xx = x.to(dt)
+        yo = OV.visual_forward(st, xx, spec, True)
+        (yo * w_out.to(dt)).sum().backward()
+        with torch.no_grad():
+            ye = OV.visual_forward(st, xx, spec, False)
+            for _ in range(WARM):
+                OV.visual_forward(st, xx, spec, True)
+            yw = OV.visual_forward(st, xx, spec, False)
+        if dt == torch.float32:
+            check("out_train", yo, y)
+            for g in grads:
+                check("grad " + g, st[g].grad, named[g].grad, 1e-4)
+            check("bn1.running_mean (after warm)", st["bn1.running_mean"], m.state_dict()["bn1.running_mean"])
+            check("out_eval", ye, torch.from_numpy(out["out_eval"]), 1e-4)
+            check("out_eval_warm", yw, torch.from_numpy(out["out_eval_warm"]), 1e-4)
+        else:
+            out["truth:out_train"] = yo.detach().numpy()
+            out["truth:out_eval"] = ye.numpy()
+            out["truth:out_eval_warm"] = yw.numpy()
+            for g in grads:
+                out["truth:grad:" + g] = st[g].grad.numpy()
+            print("  noise(ref fp32 vs fp64): out_train %.1e out_eval %.1e warm %.1e" % (rel(y, yo), rel(torch.from_numpy(out["out_eval"]), ye), rel(torch.from_numpy(out["out_eval_warm"]), yw)))
+    np.savez_compressed(os.path.join(HERE, "visual_%s.npz" % tag), **f32(out))
 
 
 def gen_text(seed=3):
@@ -283,7 +314,46 @@ def gen_head(seed=5, steps=3):
     check("eval v", eo[0], ev[0], 2e-4)
     check("eval t", eo[1], ev[1], 2e-4)
     out["eval_v"], out["eval_t"] = ev[0].numpy(), ev[1].numpy()
-    np.savez_compressed(os.path.join(HERE, "head.npz"), **out)
+
+    # fp64 oracle trajectory = "truth" for the noise-aware GPU criterion
+    t64 = head_truth(out, filled, spec, table, (hidden, embed, vocab, Lpad, C, K, NC, B, seed, steps), 0.9)
+    for k, v in t64.items():
+        out["truth:" + k] = v
+        if k in out:
+            print("  noise(ref fp32 vs fp64) %-40s %.1e" % (k, rel(torch.from_numpy(np.asarray(out[k])).double(), torch.from_numpy(v))))
+    np.savez_compressed(os.path.join(HERE, "head.npz"), **f32(out))
+
+
+def head_truth(out, filled, spec, table, dims, m):
+    hidden, embed, vocab, Lpad, C, K, NC, B, seed, steps = dims
+    dt = torch.float64
+    st = {k: (v.clone().to(dt) if v.dtype.is_floating_point else v.clone()) for k, v in filled.items()}
+    tr = OH.trainable_names(st)
+    groups = []
+    for k in tr:
+        st[k].requires_grad_(True)
+        lr, wd = (2e-3, 0.0) if "bias" in k else (1e-3, 4e-5)
+        groups.append({"params": [st[k]], "lr": lr, "weight_decay": wd})
+    opt = torch.optim.Adam(groups, lr=1e-3, betas=(0.9, 0.999), eps=1e-8)
+    res = {}
+    for s in range(steps):
+        x, tok, ln, ids = (torch.from_numpy(out["%s%d" % (k, s)]) for k in ("images", "tokens", "lengths", "ids"))
+        ld = OH.train_forward(st, spec, table.to(dt), x.to(dt), tok, ln, ids, m=m, epsilon=0.1)
+        opt.zero_grad()
+        sum(ld.values()).backward()
+        if s == 0:
+            for k in out:
+                if k.startswith("grad0:"):
+                    res[k] = st[k[6:]].grad.numpy().copy()
+        opt.step()
+        for k in ld:
+            res["loss%d:%s" % (s, k)] = ld[k].detach().numpy()
+    for k in out:
+        if k.startswith("final:") and st[k[6:]].dtype.is_floating_point:
+            res[k] = st[k[6:]].detach().numpy().copy()
+    ev = OH.eval_forward(st, spec, table.to(dt), x.to(dt), tok, ln)
+    res["eval_v"], res["eval_t"] = ev[0].numpy(), ev[1].numpy()
+    return res
 
 
 def gen_losses(seed=11):

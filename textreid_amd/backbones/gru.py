@@ -1,0 +1,142 @@
+"""Token-embedding + bias-free BiGRU + max-over-time text encoder on the HIP library.
+
+Operator surface of the reference ``lib/models/backbones/gru.py`` (``GRU``
+:8-88, ``build_gru`` :91-117): ``forward(list[Caption]) -> [B, 2*hidden]``,
+``out_channels``, parameters ``gru.weight_{ih,hh}_l0[_reverse]`` (the nn.GRU is
+a parameter holder; its forward is never called), frozen ``vocab_dict`` table as
+a plain attribute.  Instead of sort/pack/pad (gru.py:66-82, one host sync), the
+recurrence runs as a masked time loop: per step one batched fp32 MFMA GEMM
+(h @ W_hh^T, both directions) and one fused gate/state/max kernel; the
+zero-pad-enters-the-max behaviour of gru.py:63 is reproduced by the max init.
+"""
+
+import os
+
+import numpy as np
+import torch
+from torch import nn
+
+from .. import ops
+from ..caption import CaptionBatch
+
+
+def load_vocab_dict(root, use_onehot):
+    names = {"bert_c4": "bert_vocab_c4.npy", "bert_l2": "bert_vocab_l2.npy", "clip_vit": "clip_vocab_vit.npy",
+             "clip_rn50x4": "clip_vocab_rn50x4.npy"}
+    if use_onehot not in names:
+        raise NotImplementedError(use_onehot)
+    return np.load(os.path.join(root, "./datasets/cuhkpedes", names[use_onehot]))
+
+
+class _GRUFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mod, tokens, lengths, lmax, w_ih_f, w_hh_f, w_ih_r, w_hh_r):
+        save = any(ctx.needs_input_grad)
+        B = tokens.shape[0]
+        H = w_hh_f.shape[1]
+        E = w_ih_f.shape[1]
+        L = lmax
+        table = mod.vocab_dict
+        st = ops.stream()
+        x = ops.empty((B * L, E), table)
+        ops.call("trid_embedding_gather_f32", ops._p(table), ops._p(tokens), ops._p(x), B, L, tokens.stride(0), E,
+                 table.shape[0], st)
+        gi = ops.empty((B * L, 6 * H), table)
+        ops.gemm(x, w_ih_f, gi, B * L, 3 * H, E, E, E, 6 * H)
+        ops.gemm(x, w_ih_r, gi, B * L, 3 * H, E, E, E, 6 * H, c_off=3 * H)
+        whh = torch.stack([w_hh_f.detach(), w_hh_r.detach()])  # [2,3H,H] (plumbing copy)
+        h = torch.zeros(2, B, H, device=table.device)
+        gh = ops.empty((2, B, 3 * H), table)
+        maxv = ops.empty((B, 2 * H), table)
+        argt = torch.empty(B, 2 * H, dtype=torch.int32, device=table.device)
+        ops.call("trid_gru_max_init_f32", ops._p(maxv), ops._p(argt), ops._p(lengths), L, B, H, st)
+        gates = ops.empty((2, L, B, 4 * H), table) if save else None
+        hprev = ops.empty((2, L, B, H), table) if save else None
+        for s in range(L):
+            ops.gemm(h, whh, gh, B, 3 * H, H, H, H, 3 * H, batch=2, strideA=B * H, strideB=3 * H * H,
+                     strideC=B * 3 * H)
+            ops.call("trid_gru_cell_fwd_f32", ops._p(gi), ops._p(gh), ops._p(h), ops._p(lengths),
+                     (ops._p(gates) + 4 * s * B * 4 * H) if save else None,
+                     (ops._p(hprev) + 4 * s * B * H) if save else None, ops._p(maxv), ops._p(argt), s, L, L, B, H,
+                     L * B * 4 * H, L * B * H, st)
+        if save:
+            ctx.saved = (x, whh, gates, hprev, argt, lengths, B, H, E, L)
+        return maxv
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, whh, gates, hprev, argt, lengths, B, H, E, L = ctx.saved
+        ctx.saved = None
+        dout = dout.contiguous()
+        st = ops.stream()
+        dh = torch.zeros(2, B, H, device=dout.device)
+        dGi = ops.empty((B * L, 6 * H), dout)
+        dgh = ops.empty((2, L, B, 3 * H), dout)
+        for s in range(L - 1, -1, -1):
+            ops.call("trid_gru_cell_bwd_f32", ops._p(dout), ops._p(argt), ops._p(gates) + 4 * s * B * 4 * H,
+                     ops._p(hprev) + 4 * s * B * H, ops._p(lengths), ops._p(dh), ops._p(dGi),
+                     ops._p(dgh) + 4 * s * B * 3 * H, s, L, L, B, H, L * B * 4 * H, L * B * H, L * B * 3 * H, st)
+            # dh[d] += dgh[d,s] @ W_hh[d]
+            ops.gemm(dgh, whh, dh, B, H, 3 * H, 3 * H, H, H, b_mode=ops.B_NC, batch=2, strideA=L * B * 3 * H,
+                     strideB=3 * H * H, strideC=B * H, accumulate=True, a_off=s * B * 3 * H)
+        # dW_hh[d] = sum_{s,b} dgh[d,s,b,:]^T hprev[d,s,b,:]
+        KK = L * B
+        splits = max(1, min(8, KK // 512))
+        dwhh = ops.empty((2, 3 * H, H), dout)
+        dwih = ops.empty((2, 3 * H, E), dout)
+        if splits == 1:
+            ops.gemm(dgh, hprev, dwhh, 3 * H, H, KK, 3 * H, H, H, a_mode=ops.A_MC, b_mode=ops.B_NC, batch=2,
+                     strideA=KK * 3 * H, strideB=KK * H, strideC=3 * H * H)
+            ops.gemm(dGi, x, dwih, 3 * H, E, KK, 6 * H, E, E, a_mode=ops.A_MC, b_mode=ops.B_NC, batch=2,
+                     strideA=3 * H, strideB=0, strideC=3 * H * E)
+        else:
+            slab = ops.empty((splits, 2, 3 * H, max(H, E)), dout)
+            n = 2 * 3 * H * H
+            ops.gemm(dgh, hprev, slab, 3 * H, H, KK, 3 * H, H, H, a_mode=ops.A_MC, b_mode=ops.B_NC, batch=2,
+                     strideA=KK * 3 * H, strideB=KK * H, strideC=3 * H * H, splits=splits, strideSplit=n)
+            ops.call("trid_slab_reduce_f32", ops._p(slab), ops._p(dwhh), n, splits, n, 0, st)
+            n = 2 * 3 * H * E
+            ops.gemm(dGi, x, slab, 3 * H, E, KK, 6 * H, E, E, a_mode=ops.A_MC, b_mode=ops.B_NC, batch=2,
+                     strideA=3 * H, strideB=0, strideC=3 * H * E, splits=splits, strideSplit=n)
+            ops.call("trid_slab_reduce_f32", ops._p(slab), ops._p(dwih), n, splits, n, 0, st)
+        return None, None, None, None, dwih[0], dwhh[0], dwih[1], dwhh[1]
+
+
+class GRU(nn.Module):
+    def __init__(self, hidden_dim, vocab_size, embed_size, num_layers, drop_out, bidirectional, use_onehot, root,
+                 vocab_dict=None):
+        super().__init__()
+        if use_onehot == "yes" or vocab_size != embed_size or num_layers != 1 or not bidirectional:
+            raise NotImplementedError("HIP text encoder covers the MoCo configs: frozen table, 1-layer BiGRU")
+        self.use_onehot = use_onehot
+        self.embed = None
+        if vocab_dict is None:
+            vocab_dict = load_vocab_dict(root, use_onehot)
+        vocab_dict = torch.as_tensor(vocab_dict).float()
+        assert vocab_size == vocab_dict.shape[1]
+        dev = "cuda" if torch.cuda.is_available() else "cpu"
+        self.vocab_dict = vocab_dict.to(dev).contiguous()  # plain attribute, as gru.py:34
+        self.gru = nn.GRU(embed_size, hidden_dim, num_layers=num_layers, dropout=drop_out,
+                          bidirectional=bidirectional, bias=False)
+        self.out_channels = hidden_dim * 2
+
+    def forward(self, captions):
+        cb = CaptionBatch.from_list(captions)
+        if not cb.tokens.is_cuda:
+            raise RuntimeError("textreid_amd.GRU runs on the HIP kernel library only (CUDA tensors); no CPU fallback")
+        if self.vocab_dict.device != cb.tokens.device:
+            self.vocab_dict = self.vocab_dict.to(cb.tokens.device)
+        g = self.gru
+        return _GRUFn.apply(self, cb.tokens.contiguous(), cb.lengths.contiguous(), cb.max_len, g.weight_ih_l0,
+                            g.weight_hh_l0, g.weight_ih_l0_reverse, g.weight_hh_l0_reverse)
+
+
+def build_gru(cfg, bidirectional, vocab_dict=None):
+    model = GRU(cfg.MODEL.GRU.NUM_UNITS, cfg.MODEL.GRU.VOCABULARY_SIZE, cfg.MODEL.GRU.EMBEDDING_SIZE,
+                cfg.MODEL.GRU.NUM_LAYER, 1 - cfg.MODEL.GRU.DROPOUT_KEEP_PROB, bidirectional, cfg.MODEL.GRU.ONEHOT,
+                cfg.ROOT, vocab_dict=vocab_dict)
+    if cfg.MODEL.FREEZE:
+        model.gru.eval()
+        for p in model.gru.parameters():
+            p.requires_grad = False
+    return model

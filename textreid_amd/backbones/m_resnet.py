@@ -1,0 +1,434 @@
+"""CLIP ModifiedResNet image encoder on the MI355X kernel library.
+
+Operator surface of the reference ``lib/models/backbones/m_resnet.py``
+(``ModifiedResNet`` :138-217, ``Bottleneck`` :11-67, ``AttentionPool2d`` :70-135,
+``modified_resnet50/101`` :246-291, ``build_m_resnet`` :294-307): same module
+tree, parameter names, shapes and ``out_channels``, so reference / CLIP state
+dicts load unchanged.  The torch ``nn.Conv2d`` / ``nn.BatchNorm2d`` /
+``nn.Linear`` objects below are parameter holders only -- their ``forward`` is
+never called.  The whole encoder is ONE ``autograd.Function`` whose forward and
+backward are explicit sequences of HIP kernel launches (NHWC activations,
+implicit-GEMM convolutions, BatchNorm statistics from the GEMM epilogue,
+attention pool evaluated for the token-0 query only).
+"""
+
+import logging
+import math
+import os
+from collections import OrderedDict
+
+import torch
+from torch import nn
+
+from .. import ops
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.avgpool = nn.AvgPool2d(stride) if stride > 1 else nn.Identity()
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = None
+        self.stride = stride
+        if stride > 1 or inplanes != planes * 4:
+            self.downsample = nn.Sequential(
+                OrderedDict(
+                    [
+                        ("-1", nn.AvgPool2d(stride)),
+                        ("0", nn.Conv2d(inplanes, planes * 4, 1, stride=1, bias=False)),
+                        ("1", nn.BatchNorm2d(planes * 4)),
+                    ]
+                )
+            )
+        assert stride in (1, 2), "AvgPool2d(stride) is implemented for stride 1 and 2"
+
+    def forward(self, x):  # pragma: no cover - the encoder runs as one fused Function
+        raise RuntimeError("Bottleneck is a parameter holder; call ModifiedResNet.forward")
+
+
+class AttentionPool2d(nn.Module):
+    def __init__(self, spacial_dim, embed_dim, num_heads, output_dim=None):
+        super().__init__()
+        self.spacial_dim = spacial_dim
+        self.proj_conv = None
+        self.positional_embedding = nn.Parameter(
+            torch.randn(spacial_dim[0] * spacial_dim[1] + 1, embed_dim) / embed_dim ** 0.5
+        )
+        self.k_proj = nn.Linear(embed_dim, embed_dim)
+        self.q_proj = nn.Linear(embed_dim, embed_dim)
+        self.v_proj = nn.Linear(embed_dim, embed_dim)
+        self.c_proj = nn.Linear(embed_dim, output_dim or embed_dim)
+        self.num_heads = num_heads
+
+    def forward(self, x):  # pragma: no cover
+        raise RuntimeError("AttentionPool2d is a parameter holder; call ModifiedResNet.forward")
+
+
+def _w3x3(conv):
+    """[N,C,3,3] parameter -> [N, 9*C] tap-major/channel-minor view (a free view
+    when the parameter is channels_last, which build/ctor arrange)."""
+    w = conv.weight
+    N, C = w.shape[0], w.shape[1]
+    return w.permute(0, 2, 3, 1).contiguous().reshape(N, 9 * C)
+
+
+def _g3x3(dw, N, C):
+    """[N, 9*C] gradient -> [N,C,3,3]-shaped (channels_last strided) tensor."""
+    return dw.view(N, 3, 3, C).permute(0, 3, 1, 2)
+
+
+def _bn_coeffs(bn, partials, M, training):
+    if training:
+        st = ops.bn_finalize(partials, M, bn.weight, bn.bias, bn.running_mean, bn.running_var)
+        bn.num_batches_tracked += 1
+        return st
+    return ops.bn_eval_coeffs(bn.weight, bn.bias, bn.running_mean, bn.running_var)
+
+
+class _EncoderFn(torch.autograd.Function):
+    """forward(images, module, *params) -> [B, out_dim]; grads for every parameter."""
+
+    @staticmethod
+    def forward(ctx, images, mod, *params):
+        save = any(ctx.needs_input_grad[2:])
+        out, saved = mod._run_forward(images, save)
+        ctx.mod = mod
+        ctx.saved = saved
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        mod, saved = ctx.mod, ctx.saved
+        ctx.saved = None
+        if saved is None:
+            raise RuntimeError("backward through an encoder forward that did not save activations")
+        grads = mod._run_backward(saved, gout.contiguous())
+        return (None, None) + tuple(grads)
+
+
+class ModifiedResNet(nn.Module):
+    def __init__(self, layers, output_dim, heads, last_stride=1, input_resolution=(224, 224), width=64):
+        super().__init__()
+        self.output_dim = output_dim
+        self.out_channels = output_dim
+        self.input_resolution = input_resolution
+        self.conv1 = nn.Conv2d(3, width // 2, kernel_size=3, stride=2, padding=1, bias=False)
+        self.bn1 = nn.BatchNorm2d(width // 2)
+        self.conv2 = nn.Conv2d(width // 2, width // 2, kernel_size=3, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(width // 2)
+        self.conv3 = nn.Conv2d(width // 2, width, kernel_size=3, padding=1, bias=False)
+        self.bn3 = nn.BatchNorm2d(width)
+        self.avgpool = nn.AvgPool2d(2)
+        self.relu = nn.ReLU(inplace=True)
+        self._inplanes = width
+        self.layer1 = self._make_layer(width, layers[0])
+        self.layer2 = self._make_layer(width * 2, layers[1], stride=2)
+        self.layer3 = self._make_layer(width * 4, layers[2], stride=2)
+        self.layer4 = self._make_layer(width * 8, layers[3], stride=last_stride)
+        embed_dim = width * 32
+        down_ratio = 16 if last_stride == 1 else 32
+        spacial_dim = (input_resolution[0] // down_ratio, input_resolution[1] // down_ratio)
+        self.attnpool = AttentionPool2d(spacial_dim, embed_dim, heads, output_dim)
+        self._to_channels_last()
+
+    def _make_layer(self, planes, blocks, stride=1):
+        layers = [Bottleneck(self._inplanes, planes, stride)]
+        self._inplanes = planes * 4
+        for _ in range(1, blocks):
+            layers.append(Bottleneck(self._inplanes, planes))
+        return nn.Sequential(*layers)
+
+    def _to_channels_last(self):
+        # 3x3 filters live in OHWI memory (channels_last) so the kernels read them in place
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d) and m.kernel_size == (3, 3) and m.in_channels % 4 == 0:
+                m.weight.data = m.weight.data.contiguous(memory_format=torch.channels_last)
+
+    def blocks(self):
+        for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
+            for blk in layer:
+                yield blk
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x):
+        if not x.is_cuda:
+            raise RuntimeError("textreid_amd.ModifiedResNet runs on the HIP kernel library only (CUDA tensors); no CPU fallback")
+        x = x.type(self.conv1.weight.dtype).contiguous()
+        params = list(self.parameters())
+        return _EncoderFn.apply(x, self, *params)
+
+    def _run_forward(self, images, save):
+        training = self.training
+        B = images.shape[0]
+        S = {"B": B} if save else None
+        # ---- stem (m_resnet.py:199-207)
+        col, Ho, Wo = ops.stem_im2col(images)
+        c1 = self.conv1.weight
+        w1p = torch.zeros(c1.shape[0], col.shape[1], device=c1.device, dtype=c1.dtype)
+        w1p[:, : c1[0].numel()] = c1.detach().reshape(c1.shape[0], -1)
+        y1, p1 = ops.conv1x1(col, w1p, stats=True) if training else (ops.conv1x1(col, w1p), None)
+        st1 = _bn_coeffs(self.bn1, p1, y1.shape[0], training)
+        y1 = y1.view(B, Ho, Wo, -1)
+        a1 = ops.bn_apply(y1, st1, relu=True)
+        w2 = _w3x3(self.conv2)
+        y2, p2 = ops.conv3x3(a1, w2, stats=True) if training else (ops.conv3x3(a1, w2), None)
+        st2 = _bn_coeffs(self.bn2, p2, B * Ho * Wo, training)
+        a2 = ops.bn_apply(y2, st2, relu=True)
+        w3 = _w3x3(self.conv3)
+        y3, p3 = ops.conv3x3(a2, w3, stats=True) if training else (ops.conv3x3(a2, w3), None)
+        st3 = _bn_coeffs(self.bn3, p3, B * Ho * Wo, training)
+        x = ops.bn_apply_pool2(y3, st3, relu=True)
+        if save:
+            S["stem"] = (col, y1, st1, a1, y2, st2, a2, y3, st3)
+        # ---- residual layers (m_resnet.py:54-67)
+        if save:
+            S["blocks"] = []
+        for blk in self.blocks():
+            stride = blk.stride
+            wa = blk.conv1.weight.view(blk.conv1.out_channels, -1)
+            ya, pa = ops.conv1x1(x, wa, stats=True) if training else (ops.conv1x1(x, wa), None)
+            Ma = ya.numel() // ya.shape[-1]
+            sta = _bn_coeffs(blk.bn1, pa, Ma, training)
+            aa = ops.bn_apply(ya, sta, relu=True)
+            wb = _w3x3(blk.conv2)
+            yb, pb = ops.conv3x3(aa, wb, stats=True) if training else (ops.conv3x3(aa, wb), None)
+            stb = _bn_coeffs(blk.bn2, pb, Ma, training)
+            ab = ops.bn_apply_pool2(yb, stb, relu=True) if stride > 1 else ops.bn_apply(yb, stb, relu=True)
+            wc = blk.conv3.weight.view(blk.conv3.out_channels, -1)
+            yc, pc = ops.conv1x1(ab, wc, stats=True) if training else (ops.conv1x1(ab, wc), None)
+            Mc = yc.numel() // yc.shape[-1]
+            stc = _bn_coeffs(blk.bn3, pc, Mc, training)
+            xd = yd = std = None
+            if blk.downsample is not None:
+                xd = ops.bn_apply_pool2(x, None) if stride > 1 else x
+                wd = blk.downsample[1].weight.view(blk.downsample[1].out_channels, -1)
+                yd, pd = ops.conv1x1(xd, wd, stats=True) if training else (ops.conv1x1(xd, wd), None)
+                std = _bn_coeffs(blk.downsample[2], pd, Mc, training)
+                out = ops.bn_apply(yc, stc, relu=True, res=yd, res_st=std)
+            else:
+                out = ops.bn_apply(yc, stc, relu=True, res=x)
+            if save:
+                S["blocks"].append((x, ya, sta, aa, yb, stb, ab, yc, stc, xd, yd, std, out))
+            x = out
+            if getattr(self, "_debug_taps", None) is not None:
+                self._debug_taps[len(self._debug_taps)] = out
+        # ---- attention pool (m_resnet.py:103-135), token-0 query only
+        feat, asave = self._attnpool_forward(x, save)
+        if save:
+            S["attn"] = asave
+        return feat, S
+
+    def _attnpool_forward(self, x, save):
+        ap = self.attnpool
+        B, H, W, C = x.shape
+        T = H * W
+        T1 = T + 1
+        T1p = (T1 + 3) // 4 * 4
+        heads = ap.num_heads
+        hd = C // heads
+        scale = float(hd) ** -0.5
+        tok = ops.empty((B, T1p, C), x)
+        ops.call("trid_attnpool_tokens_f32", ops._p(x), ops._p(ap.positional_embedding), ops._p(tok), B, T, C, T1p,
+                 ops.stream())
+        q = ops.linear(tok[:, 0], ap.q_proj.weight, ap.q_proj.bias)  # [B,C]
+        # U[b,h,:] = scale * q[b,h,:] @ Wk[h]  (k bias is softmax-invariant and dropped)
+        U = ops.empty((B, heads, C), x)
+        ops.gemm(q, ap.k_proj.weight, U, B, C, hd, C, C, heads * C, b_mode=ops.B_NC, alpha=scale, batch=heads,
+                 strideA=hd, strideB=hd * C, strideC=C)
+        # S[b,h,t] = U[b,h,:] . tok[b,t,:]
+        P = ops.empty((B, heads, T1p), x)
+        ops.gemm(U, tok, P, heads, T1p, C, C, C, T1p, batch=B, strideA=heads * C, strideB=T1p * C, strideC=heads * T1p)
+        ops.softmax_rows_(P, T1)
+        # Z[b,h,:] = sum_t P[b,h,t] tok[b,t,:]
+        Z = ops.empty((B, heads, C), x)
+        ops.gemm(P, tok, Z, heads, C, T1p, T1p, C, C, b_mode=ops.B_NC, batch=B, strideA=heads * T1p, strideB=T1p * C,
+                 strideC=heads * C)
+        # o[b, h*hd+d] = Wv[h*hd+d,:] . Z[b,h,:] + bv
+        o = ops.empty((B, C), x)
+        ops.gemm(Z, ap.v_proj.weight, o, B, hd, C, heads * C, C, C, batch=heads, strideA=C, strideB=hd * C, strideC=hd,
+                 bias=ap.v_proj.bias, strideBias=hd)
+        out = ops.linear(o, ap.c_proj.weight, ap.c_proj.bias)
+        return out, ((x.shape, tok, q, U, P, Z, o) if save else None)
+
+    # ------------------------------------------------------------------ backward
+    def _attnpool_backward(self, asave, gout, G):
+        ap = self.attnpool
+        xshape, tok, q, U, P, Z, o = asave
+        B, H, W, C = xshape
+        T = H * W
+        T1 = T + 1
+        T1p = tok.shape[1]
+        heads = ap.num_heads
+        hd = C // heads
+        scale = float(hd) ** -0.5
+        Wq, Wk, Wv, Wc = ap.q_proj.weight, ap.k_proj.weight, ap.v_proj.weight, ap.c_proj.weight
+        # c_proj
+        do = ops.matmul_nn(gout, Wc)  # [B,C]
+        G[id(Wc)] = ops.matmul_tn(gout, o)
+        G[id(ap.c_proj.bias)] = ops.colsum(gout)
+        G[id(ap.v_proj.bias)] = ops.colsum(do)  # sum_t P = 1
+        # dWv[h*hd+d, c] = sum_b do[b,h*hd+d] Z[b,h,c]
+        dWv = torch.empty_like(Wv)
+        ops.gemm(do, Z, dWv, hd, C, B, C, heads * C, C, a_mode=ops.A_MC, b_mode=ops.B_NC, batch=heads, strideA=hd,
+                 strideB=C, strideC=hd * C)
+        G[id(Wv)] = dWv
+        # dZ[b,h,c] = sum_d do[b,h*hd+d] Wv[h*hd+d,c]
+        dZ = ops.empty((B, heads, C), tok)
+        ops.gemm(do, Wv, dZ, B, C, hd, C, C, heads * C, b_mode=ops.B_NC, batch=heads, strideA=hd, strideB=hd * C,
+                 strideC=C)
+        # dP[b,h,t] = dZ[b,h,:] . tok[b,t,:]
+        dP = ops.empty((B, heads, T1p), tok)
+        ops.gemm(dZ, tok, dP, heads, T1p, C, C, C, T1p, batch=B, strideA=heads * C, strideB=T1p * C,
+                 strideC=heads * T1p)
+        dS = ops.softmax_rows_bwd(P, dP, T1, out=dP)
+        # dtok[b,t,:] = sum_h P[b,h,t] dZ[b,h,:] + dS[b,h,t] U[b,h,:]
+        dtok = ops.empty((B, T1p, C), tok)
+        ops.gemm(P, dZ, dtok, T1p, C, heads, T1p, C, C, a_mode=ops.A_MC, b_mode=ops.B_NC, batch=B,
+                 strideA=heads * T1p, strideB=heads * C, strideC=T1p * C)
+        ops.gemm(dS, U, dtok, T1p, C, heads, T1p, C, C, a_mode=ops.A_MC, b_mode=ops.B_NC, batch=B,
+                 strideA=heads * T1p, strideB=heads * C, strideC=T1p * C, accumulate=True)
+        # dU[b,h,:] = sum_t dS[b,h,t] tok[b,t,:]
+        dU = ops.empty((B, heads, C), tok)
+        ops.gemm(dS, tok, dU, heads, C, T1p, T1p, C, C, b_mode=ops.B_NC, batch=B, strideA=heads * T1p,
+                 strideB=T1p * C, strideC=heads * C)
+        # dq[b,h*hd+d] = scale * dU[b,h,:] . Wk[h*hd+d,:]
+        dq = ops.empty((B, C), tok)
+        ops.gemm(dU, Wk, dq, B, hd, C, heads * C, C, C, alpha=scale, batch=heads, strideA=C, strideB=hd * C, strideC=hd)
+        # dWk[h*hd+d, c] = scale * sum_b q[b,h*hd+d] dU[b,h,c]
+        dWk = torch.empty_like(Wk)
+        ops.gemm(q, dU, dWk, hd, C, B, C, heads * C, C, a_mode=ops.A_MC, b_mode=ops.B_NC, alpha=scale, batch=heads,
+                 strideA=hd, strideB=C, strideC=hd * C)
+        G[id(Wk)] = dWk
+        G[id(ap.k_proj.bias)] = torch.zeros_like(ap.k_proj.bias)  # softmax is shift-invariant: exactly zero
+        # q projection (token 0)
+        ops.gemm(dq, Wq, dtok, B, C, C, C, C, T1p * C, b_mode=ops.B_NC, accumulate=True)
+        G[id(Wq)] = ops.matmul_tn(dq, tok[:, 0])
+        G[id(ap.q_proj.bias)] = ops.colsum(dq)
+        dx = ops.empty((B, H, W, C), tok)
+        dpos = torch.empty_like(ap.positional_embedding)
+        ops.call("trid_attnpool_tokens_bwd_f32", ops._p(dtok), ops._p(dx), ops._p(dpos), B, T, C, T1p, ops.stream())
+        G[id(ap.positional_embedding)] = dpos
+        return dx
+
+    def _run_backward(self, S, gout):
+        G = {}
+        B = S["B"]
+        g = self._attnpool_backward(S["attn"], gout, G)
+        S["attn"] = None
+        blocks = list(self.blocks())
+        dbg = getattr(self, "_debug_grads", None)
+        for blk, rec in zip(reversed(blocks), reversed(S["blocks"])):
+            x, ya, sta, aa, yb, stb, ab, yc, stc, xd, yd, std, out = rec
+            if dbg is not None:
+                dbg.append(g)
+            stride = blk.stride
+            has_down = blk.downsample is not None
+            dyc, dg, db, dres = ops.bn_bwd(g, yc, stc, None, 2, act=out, want_dres=not has_down)
+            G[id(blk.bn3.weight)], G[id(blk.bn3.bias)] = dg, db
+            if has_down:
+                dyd, dg, db, _ = ops.bn_bwd(g, yd, std, None, 2, act=out)
+                G[id(blk.downsample[2].weight)], G[id(blk.downsample[2].bias)] = dg, db
+            wc = blk.conv3.weight.view(blk.conv3.out_channels, -1)
+            dab = ops.matmul_nn(dyc.view(-1, dyc.shape[-1]), wc).view(ab.shape)
+            G[id(blk.conv3.weight)] = ops.conv1x1_wgrad(dyc, ab).view_as(blk.conv3.weight)
+            dyb, dg, db, _ = ops.bn_bwd(dab, yb, stb, None, 1, pooled=stride > 1)
+            G[id(blk.bn2.weight)], G[id(blk.bn2.bias)] = dg, db
+            planes = blk.conv2.out_channels
+            wbt = ops.weight_transpose(_w3x3(blk.conv2), planes, 9, planes, flip=True)
+            daa = ops.conv3x3(dyb, wbt)
+            G[id(blk.conv2.weight)] = _g3x3(ops.conv3x3_wgrad(dyb, aa), planes, planes)
+            dya, dg, db, _ = ops.bn_bwd(daa, ya, sta, None, 1)
+            G[id(blk.bn1.weight)], G[id(blk.bn1.bias)] = dg, db
+            wa = blk.conv1.weight.view(blk.conv1.out_channels, -1)
+            if has_down:
+                wd = blk.downsample[1].weight.view(blk.downsample[1].out_channels, -1)
+                dxd = ops.matmul_nn(dyd.view(-1, dyd.shape[-1]), wd).view(xd.shape)
+                G[id(blk.downsample[1].weight)] = ops.conv1x1_wgrad(dyd, xd).view_as(blk.downsample[1].weight)
+                dx = ops.avgpool2_bwd(dxd) if stride > 1 else dxd
+            else:
+                dx = dres
+            ops.matmul_nn(dya.view(-1, dya.shape[-1]), wa, out=dx.view(-1, dx.shape[-1]), accumulate=True)
+            G[id(blk.conv1.weight)] = ops.conv1x1_wgrad(dya, x).view_as(blk.conv1.weight)
+            g = dx
+        S["blocks"] = None
+        # ---- stem
+        col, y1, st1, a1, y2, st2, a2, y3, st3 = S["stem"]
+        dy3, dg, db, _ = ops.bn_bwd(g, y3, st3, None, 1, pooled=True)
+        G[id(self.bn3.weight)], G[id(self.bn3.bias)] = dg, db
+        c3o, c3i = self.conv3.out_channels, self.conv3.in_channels
+        w3t = ops.weight_transpose(_w3x3(self.conv3), c3o, 9, c3i, flip=True)
+        da2 = ops.conv3x3(dy3, w3t)
+        G[id(self.conv3.weight)] = _g3x3(ops.conv3x3_wgrad(dy3, a2), c3o, c3i)
+        dy2, dg, db, _ = ops.bn_bwd(da2, y2, st2, None, 1)
+        G[id(self.bn2.weight)], G[id(self.bn2.bias)] = dg, db
+        c2o, c2i = self.conv2.out_channels, self.conv2.in_channels
+        w2t = ops.weight_transpose(_w3x3(self.conv2), c2o, 9, c2i, flip=True)
+        da1 = ops.conv3x3(dy2, w2t)
+        G[id(self.conv2.weight)] = _g3x3(ops.conv3x3_wgrad(dy2, a1), c2o, c2i)
+        dy1, dg, db, _ = ops.bn_bwd(da1, y1, st1, None, 1)
+        G[id(self.bn1.weight)], G[id(self.bn1.bias)] = dg, db
+        dw1 = ops.conv1x1_wgrad(dy1, col)  # [32, 28]
+        c1 = self.conv1.weight
+        G[id(c1)] = dw1[:, : c1[0].numel()].reshape(c1.shape)
+        return [G.get(id(p)) for p in self.parameters()]
+
+
+def resize_pos_embed(posemb, gs_new):
+    """CLIP 7x7 positional grid -> target grid, bilinear (m_resnet.py:220-233).
+    Host-side checkpoint ingestion (torch interpolate = plumbing, runs once)."""
+    import torch.nn.functional as F
+
+    logging.getLogger("PersonSearch.train").info("Resized position embedding to %s", (gs_new,))
+    tok, grid = posemb[:1], posemb[1:]
+    gs_old = int(math.sqrt(len(grid)))
+    grid = grid.reshape(1, gs_old, gs_old, -1).permute(0, 3, 1, 2)
+    grid = F.interpolate(grid, size=gs_new, mode="bilinear", align_corners=False)
+    grid = grid.permute(0, 2, 3, 1).reshape(gs_new[0] * gs_new[1], -1)
+    return torch.cat([tok, grid], dim=0)
+
+
+def state_filter(state_dict, final_stage_resolution):
+    out = {}
+    for k, v in state_dict.items():
+        if k.startswith("visual."):
+            k = k[7:]
+        if k == "attnpool.positional_embedding" and final_stage_resolution != (7, 7):
+            v = resize_pos_embed(v, final_stage_resolution)
+        out[k] = v
+    return out
+
+
+def _load_clip(model, pretrained_path):
+    if pretrained_path and os.path.exists(pretrained_path):
+        p = torch.jit.load(pretrained_path, map_location="cpu").state_dict()
+        model.load_state_dict(state_filter(p, model.attnpool.spacial_dim), strict=False)
+    elif pretrained_path:
+        logging.getLogger("PersonSearch.train").warning("CLIP weights %s not found: random init", pretrained_path)
+    return model
+
+
+def modified_resnet50(input_resolution, last_stride, pretrained_path=None):
+    m = ModifiedResNet([3, 4, 6, 3], 1024, 32, last_stride, input_resolution)
+    return _load_clip(m, pretrained_path)
+
+
+def modified_resnet101(input_resolution, last_stride, pretrained_path=None):
+    m = ModifiedResNet([3, 4, 23, 3], 512, 32, last_stride, input_resolution)
+    return _load_clip(m, pretrained_path)
+
+
+def build_m_resnet(cfg):
+    res = (cfg.INPUT.HEIGHT, cfg.INPUT.WIDTH)
+    if cfg.MODEL.VISUAL_MODEL in ["m_resnet50", "m_resnet"]:
+        return modified_resnet50(res, cfg.MODEL.RESNET.RES5_STRIDE, os.path.join(cfg.ROOT, "pretrained/clip/RN50.pt"))
+    if cfg.MODEL.VISUAL_MODEL == "m_resnet101":
+        return modified_resnet101(res, cfg.MODEL.RESNET.RES5_STRIDE, os.path.join(cfg.ROOT, "pretrained/clip/RN101.pt"))
+    raise NotImplementedError(cfg.MODEL.VISUAL_MODEL)

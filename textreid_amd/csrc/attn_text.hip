@@ -9,13 +9,14 @@ namespace trid {
 
 // tok[b,0,:] = mean_t x[b,t,:] + pos[0] ; tok[b,1+t,:] = x[b,t,:] + pos[1+t]
 __global__ void attnpool_tokens_kernel(const float4* __restrict__ x, const float4* __restrict__ pos,
-                                       float4* __restrict__ tok, int B, int T, int CQ) {
+                                       float4* __restrict__ tok, int B, int T, int CQ, int ldt) {
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= (long long)B * CQ) return;
     const int cq = (int)(gid % CQ);
     const int b = (int)(gid / CQ);
     const float4* xb = x + (long long)b * T * CQ + cq;
-    float4* tb = tok + (long long)b * (T + 1) * CQ + cq;
+    float4* tb = tok + (long long)b * ldt * CQ + cq;
+    for (int t = T + 1; t < ldt; ++t) tb[(long long)t * CQ] = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int t = 0; t < T; ++t) {
         const float4 v = xb[(long long)t * CQ];
@@ -29,7 +30,7 @@ __global__ void attnpool_tokens_kernel(const float4* __restrict__ x, const float
 }
 
 __global__ void attnpool_tokens_bwd_dx_kernel(const float4* __restrict__ dtok, float4* __restrict__ dx, int B, int T,
-                                              int CQ) {
+                                              int CQ, int ldt) {
     const long long total = (long long)B * T * CQ;
     const float inv = 1.f / (float)T;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
@@ -38,19 +39,19 @@ __global__ void attnpool_tokens_bwd_dx_kernel(const float4* __restrict__ dtok, f
         const long long bt = i / CQ;
         const int t = (int)(bt % T);
         const long long b = bt / T;
-        const float4 a = dtok[(b * (T + 1) + t + 1) * CQ + cq];
-        const float4 m = dtok[(b * (T + 1)) * CQ + cq];
+        const float4 a = dtok[(b * ldt + t + 1) * CQ + cq];
+        const float4 m = dtok[(b * ldt) * CQ + cq];
         dx[i] = make_float4(a.x + m.x * inv, a.y + m.y * inv, a.z + m.z * inv, a.w + m.w * inv);
     }
 }
 
 __global__ void attnpool_tokens_bwd_dpos_kernel(const float4* __restrict__ dtok, float4* __restrict__ dpos, int B,
-                                                int T1, int CQ) {
+                                                int T1, int CQ, int ldt) {
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= (long long)T1 * CQ) return;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int b = 0; b < B; ++b) {
-        const float4 v = dtok[(long long)b * T1 * CQ + gid];
+        const float4 v = dtok[(long long)b * ldt * CQ + gid];
         s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
     dpos[gid] = s;
@@ -133,7 +134,7 @@ __global__ void gru_max_init_kernel(float* __restrict__ maxv, int32_t* __restric
 __global__ void gru_cell_fwd_kernel(const float* __restrict__ gi, const float* __restrict__ gh, float* __restrict__ h,
                                     const int64_t* __restrict__ lengths, float* __restrict__ gates,
                                     float* __restrict__ hprev, float* __restrict__ maxv, int32_t* __restrict__ argt,
-                                    int s, int Lmax, int L, int B, int Hd) {
+                                    int s, int Lmax, int L, int B, int Hd, long long gates_ds, long long hprev_ds) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= 2 * B * Hd) return;
     const int j = i % Hd;
@@ -142,7 +143,7 @@ __global__ void gru_cell_fwd_kernel(const float* __restrict__ gi, const float* _
     const int t = d == 0 ? s : Lmax - 1 - s;
     const bool active = (long long)t < lengths[b];
     const float hp = h[i];
-    if (hprev != nullptr) hprev[i] = hp;
+    if (hprev != nullptr) hprev[(long long)d * hprev_ds + (long long)b * Hd + j] = hp;
     if (!active) return;
     const float* gir = gi + ((long long)b * L + t) * (6 * Hd) + (long long)d * 3 * Hd;
     const float* ghr = gh + ((long long)d * B + b) * (3 * Hd);
@@ -153,7 +154,7 @@ __global__ void gru_cell_fwd_kernel(const float* __restrict__ gi, const float* _
     const float hnew = (1.f - z) * n + z * hp;
     h[i] = hnew;
     if (gates != nullptr) {
-        float* gs = gates + ((long long)d * B + b) * (4 * Hd);
+        float* gs = gates + (long long)d * gates_ds + (long long)b * (4 * Hd);
         gs[j] = r; gs[Hd + j] = z; gs[2 * Hd + j] = n; gs[3 * Hd + j] = hn_lin;
     }
     const int mc = b * 2 * Hd + d * Hd + j;
@@ -169,7 +170,7 @@ __global__ void gru_cell_bwd_kernel(const float* __restrict__ dout, const int32_
                                     const float* __restrict__ gates, const float* __restrict__ hprev,
                                     const int64_t* __restrict__ lengths, float* __restrict__ dh,
                                     float* __restrict__ dGi, float* __restrict__ dgh, int s, int Lmax, int L, int B,
-                                    int Hd) {
+                                    int Hd, long long gates_ds, long long hprev_ds, long long dgh_ds) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= 2 * B * Hd) return;
     const int j = i % Hd;
@@ -178,7 +179,7 @@ __global__ void gru_cell_bwd_kernel(const float* __restrict__ dout, const int32_
     const int t = d == 0 ? s : Lmax - 1 - s;
     const bool active = (long long)t < lengths[b];
     float* dgir = dGi + ((long long)b * L + t) * (6 * Hd) + (long long)d * 3 * Hd;
-    float* dghr = dgh + ((long long)d * B + b) * (3 * Hd);
+    float* dghr = dgh + (long long)d * dgh_ds + (long long)b * (3 * Hd);
     if (!active) {
         dgir[j] = 0.f; dgir[Hd + j] = 0.f; dgir[2 * Hd + j] = 0.f;
         dghr[j] = 0.f; dghr[Hd + j] = 0.f; dghr[2 * Hd + j] = 0.f;
@@ -187,9 +188,9 @@ __global__ void gru_cell_bwd_kernel(const float* __restrict__ dout, const int32_
     float dhv = dh[i];
     const int mc = b * 2 * Hd + d * Hd + j;
     if (argt[mc] == t) dhv += dout[mc];
-    const float* gs = gates + ((long long)d * B + b) * (4 * Hd);
+    const float* gs = gates + (long long)d * gates_ds + (long long)b * (4 * Hd);
     const float r = gs[j], z = gs[Hd + j], n = gs[2 * Hd + j], hn_lin = gs[3 * Hd + j];
-    const float hp = hprev[i];
+    const float hp = hprev[(long long)d * hprev_ds + (long long)b * Hd + j];
     const float dn_pre = dhv * (1.f - z) * (1.f - n * n);
     const float dz_pre = dhv * (hp - n) * z * (1.f - z);
     const float dr_pre = dn_pre * hn_lin * r * (1.f - r);
@@ -202,24 +203,24 @@ __global__ void gru_cell_bwd_kernel(const float* __restrict__ dout, const int32_
 
 using namespace trid;
 
-extern "C" int trid_attnpool_tokens_f32(const float* x, const float* pos, float* tok, int B, int T, int C,
+extern "C" int trid_attnpool_tokens_f32(const float* x, const float* pos, float* tok, int B, int T, int C, int ldt,
                                         void* stream) {
-    TRID_REQUIRE(x && pos && tok && B > 0 && T > 0 && C > 0 && C % 4 == 0, "trid_attnpool_tokens_f32: bad arguments");
+    TRID_REQUIRE(x && pos && tok && B > 0 && T > 0 && C > 0 && C % 4 == 0 && ldt >= T + 1, "trid_attnpool_tokens_f32: bad arguments");
     const long long n = (long long)B * (C / 4);
     hipLaunchKernelGGL(attnpool_tokens_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const float4*)x, (const float4*)pos, (float4*)tok, B, T, C / 4);
+                       (const float4*)x, (const float4*)pos, (float4*)tok, B, T, C / 4, ldt);
     return check_launch("trid_attnpool_tokens_f32");
 }
 
-extern "C" int trid_attnpool_tokens_bwd_f32(const float* dtok, float* dx, float* dpos, int B, int T, int C,
+extern "C" int trid_attnpool_tokens_bwd_f32(const float* dtok, float* dx, float* dpos, int B, int T, int C, int ldt,
                                             void* stream) {
-    TRID_REQUIRE(dtok && dx && dpos && B > 0 && T > 0 && C % 4 == 0, "trid_attnpool_tokens_bwd_f32: bad arguments");
+    TRID_REQUIRE(dtok && dx && dpos && B > 0 && T > 0 && C % 4 == 0 && ldt >= T + 1, "trid_attnpool_tokens_bwd_f32: bad arguments");
     const long long total = (long long)B * T * (C / 4);
     hipLaunchKernelGGL(attnpool_tokens_bwd_dx_kernel, dim3(grid_for(total, 256 * 2)), dim3(256), 0, (hipStream_t)stream,
-                       (const float4*)dtok, (float4*)dx, B, T, C / 4);
+                       (const float4*)dtok, (float4*)dx, B, T, C / 4, ldt);
     const long long n = (long long)(T + 1) * (C / 4);
     hipLaunchKernelGGL(attnpool_tokens_bwd_dpos_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
-                       (hipStream_t)stream, (const float4*)dtok, (float4*)dpos, B, T + 1, C / 4);
+                       (hipStream_t)stream, (const float4*)dtok, (float4*)dpos, B, T + 1, C / 4, ldt);
     return check_launch("trid_attnpool_tokens_bwd_f32");
 }
 
@@ -267,22 +268,23 @@ extern "C" int trid_gru_max_init_f32(float* maxv, int32_t* argt, const int64_t* 
 
 extern "C" int trid_gru_cell_fwd_f32(const float* gi, const float* gh, float* h, const int64_t* lengths, float* gates,
                                      float* hprev, float* maxv, int32_t* argt, int s, int Lmax, int L, int B, int Hd,
-                                     void* stream) {
+                                     long long gates_dstride, long long hprev_dstride, void* stream) {
     TRID_REQUIRE(gi && gh && h && lengths && maxv && argt, "trid_gru_cell_fwd_f32: null pointer");
     TRID_REQUIRE(s >= 0 && s < Lmax && Lmax <= L && B > 0 && Hd > 0, "trid_gru_cell_fwd_f32: bad step/shape");
     const int n = 2 * B * Hd;
     hipLaunchKernelGGL(gru_cell_fwd_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, gi, gh, h, lengths,
-                       gates, hprev, maxv, argt, s, Lmax, L, B, Hd);
+                       gates, hprev, maxv, argt, s, Lmax, L, B, Hd, gates_dstride, hprev_dstride);
     return check_launch("trid_gru_cell_fwd_f32");
 }
 
 extern "C" int trid_gru_cell_bwd_f32(const float* dout, const int32_t* argt, const float* gates, const float* hprev,
                                      const int64_t* lengths, float* dh, float* dGi, float* dgh, int s, int Lmax, int L,
-                                     int B, int Hd, void* stream) {
+                                     int B, int Hd, long long gates_dstride, long long hprev_dstride,
+                                     long long dgh_dstride, void* stream) {
     TRID_REQUIRE(dout && argt && gates && hprev && lengths && dh && dGi && dgh, "trid_gru_cell_bwd_f32: null pointer");
     TRID_REQUIRE(s >= 0 && s < Lmax && Lmax <= L && B > 0 && Hd > 0, "trid_gru_cell_bwd_f32: bad step/shape");
     const int n = 2 * B * Hd;
     hipLaunchKernelGGL(gru_cell_bwd_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, dout, argt, gates,
-                       hprev, lengths, dh, dGi, dgh, s, Lmax, L, B, Hd);
+                       hprev, lengths, dh, dGi, dgh, s, Lmax, L, B, Hd, gates_dstride, hprev_dstride, dgh_dstride);
     return check_launch("trid_gru_cell_bwd_f32");
 }

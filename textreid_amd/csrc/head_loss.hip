@@ -162,7 +162,7 @@ __global__ void colnorm_kernel(const float* __restrict__ proj, float* __restrict
     if (j >= ldn) return;
     if (j >= N) {
         for (int c = 0; c < C; ++c) {
-            pn[(long long)c * ldn + j] = 0.f;
+            if (pn) pn[(long long)c * ldn + j] = 0.f;
             pnt[(long long)j * C + c] = 0.f;
         }
         return;
@@ -176,7 +176,7 @@ __global__ void colnorm_kernel(const float* __restrict__ proj, float* __restrict
     inv_norm[j] = inv;
     for (int c = 0; c < C; ++c) {
         const float v = proj[(long long)c * N + j] * inv;
-        pn[(long long)c * ldn + j] = v;
+        if (pn) pn[(long long)c * ldn + j] = v;
         pnt[(long long)j * C + c] = v;
     }
 }
@@ -233,9 +233,29 @@ __global__ __launch_bounds__(256) void sum_kernel(const float* __restrict__ x, f
     if (threadIdx.x == 0) out[0] = accumulate ? out[0] + s * scale : s * scale;
 }
 
+// out = g[0]*a + g[1]*b + g[2]*c with device-resident scalars (b, c optional)
+__global__ void axpby3_kernel(float* __restrict__ out, const float* __restrict__ a, const float* __restrict__ b,
+                              const float* __restrict__ c, const float* __restrict__ g, long long n) {
+    const float g0 = g[0], g1 = b ? g[1] : 0.f, g2 = c ? g[2] : 0.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float v = g0 * a[i];
+        if (b) v = fmaf(g1, b[i], v);
+        if (c) v = fmaf(g2, c[i], v);
+        out[i] = v;
+    }
+}
+
 }  // namespace trid
 
 using namespace trid;
+
+extern "C" int trid_axpby3_f32(float* out, const float* a, const float* b, const float* c, const float* g3,
+                               long long n, void* stream) {
+    TRID_REQUIRE(out && a && g3 && n > 0, "trid_axpby3_f32: bad arguments");
+    hipLaunchKernelGGL(axpby3_kernel, dim3(grid_for(n, 256 * 4, 2048)), dim3(256), 0, (hipStream_t)stream, out, a, b, c, g3,
+                       n);
+    return check_launch("trid_axpby3_f32");
+}
 
 extern "C" int trid_l2norm_rows_f32(const float* x, float* y, float* inv_norm, long long rows, int C, float eps,
                                     void* stream) {
@@ -294,7 +314,7 @@ extern "C" int trid_smooth_ce_rows_f32(float* logits, const int64_t* labels, flo
 
 extern "C" int trid_colnorm_f32(const float* proj, float* pn, float* pnt, float* inv_norm, int C, int N, int ldn,
                                 void* stream) {
-    TRID_REQUIRE(proj && pn && pnt && inv_norm && C > 0 && N > 0 && ldn >= N, "trid_colnorm_f32: bad arguments");
+    TRID_REQUIRE(proj && pnt && inv_norm && C > 0 && N > 0 && ldn >= N, "trid_colnorm_f32: bad arguments");
     hipLaunchKernelGGL(colnorm_kernel, dim3((ldn + 255) / 256), dim3(256), 0, (hipStream_t)stream, proj, pn, pnt, inv_norm,
                        C, N, ldn);
     return check_launch("trid_colnorm_f32");

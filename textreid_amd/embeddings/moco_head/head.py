@@ -1,0 +1,162 @@
+"""Cross-modal MoCo head on the HIP kernel library.
+
+Operator surface of the reference ``lib/models/embeddings/moco_head/head.py``
+(``MoCoHead`` :10-183, ``build_moco_head`` :186): ``forward(images, captions)``
+returns ``{"instance_loss","infonce_loss","global_align_loss"}`` in training and
+``[v_embed, t_embed]`` in eval; same parameter / buffer names and shapes
+(queues ``[C,K]``, ``id_queue [1,K]``, ``queue_ptr [1]``) so reference
+checkpoints load.  ``FC=False`` (the shipped MoCo configs).
+
+MI355X design points: the feature queues live row-major ``[K,C]`` in HBM (the
+registered ``[C,K]`` buffers are transposed views of that storage), so the
+similarity GEMM streams 1 KB rows and the enqueue is one contiguous slab write
+at a device-resident pointer (no ``int(queue_ptr)`` sync); the momentum update
+is a single multi-tensor kernel; the batch-wide negative filter is a per-column
+flag consumed by the InfoNCE row kernel instead of nonzero/unique/gather.
+"""
+
+import copy
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from ... import losses, ops
+from ...caption import CaptionBatch
+from ...parallel import gather_embeddings, world_size
+from .loss import make_loss_evaluator
+
+EMA_CHUNK = 65536
+
+
+class _EmaPlan:
+    """Device pointer / chunk tables for the multi-tensor EMA kernel."""
+
+    def __init__(self, pairs, device):
+        k_ptrs = np.array([k.data_ptr() for _, k in pairs], dtype=np.uint64)
+        q_ptrs = np.array([q.data_ptr() for q, _ in pairs], dtype=np.uint64)
+        sizes = np.array([k.numel() for _, k in pairs], dtype=np.int64)
+        ct, co = [], []
+        for i, n in enumerate(sizes):
+            for off in range(0, int(n), EMA_CHUNK):
+                ct.append(i)
+                co.append(off)
+        self.key = (tuple(k_ptrs.tolist()), tuple(q_ptrs.tolist()))
+        self.k_ptrs = torch.from_numpy(k_ptrs.view(np.int64)).to(device)
+        self.q_ptrs = torch.from_numpy(q_ptrs.view(np.int64)).to(device)
+        self.sizes = torch.from_numpy(sizes).to(device)
+        self.chunk_tensor = torch.tensor(ct, dtype=torch.int32, device=device)
+        self.chunk_off = torch.tensor(co, dtype=torch.int64, device=device)
+        self.n_chunks = len(ct)
+
+
+class MoCoHead(nn.Module):
+    def __init__(self, cfg, visual_model, textual_model):
+        super().__init__()
+        self.embed_size = cfg.MODEL.EMBEDDING.FEATURE_SIZE
+        self.K = cfg.MODEL.MOCO.K
+        self.m = cfg.MODEL.MOCO.M
+        self.fc = cfg.MODEL.MOCO.FC
+        if self.fc:
+            raise NotImplementedError("MODEL.MOCO.FC=True is not on the accelerated path (shipped MoCo configs use FC=False)")
+        self.v_encoder_q = visual_model
+        self.t_encoder_q = textual_model
+        self.v_encoder_k = copy.deepcopy(visual_model)
+        self.t_encoder_k = copy.deepcopy(textual_model)
+        for p in self.v_encoder_k.parameters():
+            p.requires_grad = False
+        for p in self.t_encoder_k.parameters():
+            p.requires_grad = False
+        self.v_embed_layer = nn.Linear(visual_model.out_channels, self.embed_size)
+        self.t_embed_layer = nn.Linear(textual_model.out_channels, self.embed_size)
+        # queues: storage [K,C] row-major, registered as the reference-shaped [C,K] transposed views
+        tq = torch.nn.functional.normalize(torch.rand(self.embed_size, self.K), dim=0)
+        vq = torch.nn.functional.normalize(torch.rand(self.embed_size, self.K), dim=0)
+        self.register_buffer("t_queue", tq.t().contiguous().t())
+        self.register_buffer("v_queue", vq.t().contiguous().t())
+        self.register_buffer("id_queue", -torch.ones((1, self.K), dtype=torch.long))
+        self.register_buffer("queue_ptr", torch.zeros(1, dtype=torch.long))
+        self.loss_evaluator = make_loss_evaluator(cfg)
+        self._ema_plan = None
+        self._init_weight()
+
+    def _init_weight(self):
+        # head.py:64-71 iterates self.modules(), which includes the encoders' attnpool projections
+        for m in self.modules():
+            if isinstance(m, nn.Linear):
+                nn.init.kaiming_normal_(m.weight, a=0, mode="fan_out")
+                nn.init.constant_(m.bias, 0)
+            elif isinstance(m, nn.BatchNorm1d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+
+    # ---------------------------------------------------------------- state helpers
+    def _queue_kc(self, name):
+        """Row-major [K,C] storage behind the registered [C,K] buffer."""
+        buf = getattr(self, name)
+        kc = buf.t()
+        if not kc.is_contiguous():  # e.g. after a load that replaced the buffer: re-layout once
+            kc = kc.contiguous()
+            setattr(self, name, kc.t())
+        return kc
+
+    def _ema_pairs(self):
+        pairs = list(zip(self.v_encoder_q.parameters(), self.v_encoder_k.parameters()))
+        pairs += list(zip(self.t_encoder_q.parameters(), self.t_encoder_k.parameters()))
+        return pairs
+
+    @torch.no_grad()
+    def _momentum_update_key_encoder(self):
+        pairs = self._ema_pairs()
+        key = (tuple(k.data_ptr() for _, k in pairs), tuple(q.data_ptr() for q, _ in pairs))
+        if self._ema_plan is None or self._ema_plan.key != key:
+            for q, k in pairs:
+                if not (q.is_contiguous() or q.is_contiguous(memory_format=torch.channels_last)) or q.stride() != k.stride():
+                    raise RuntimeError("EMA pairs must share a dense memory layout")
+            self._ema_plan = _EmaPlan(pairs, pairs[0][0].device)
+        pl = self._ema_plan
+        ops.call("trid_ema_multi_f32", ops._p(pl.k_ptrs), ops._p(pl.q_ptrs), ops._p(pl.sizes), ops._p(pl.chunk_tensor),
+                 ops._p(pl.chunk_off), pl.n_chunks, EMA_CHUNK, float(self.m), ops.stream())
+
+    @torch.no_grad()
+    def _dequeue_and_enqueue(self, v_keys, t_keys, id_keys):
+        B = v_keys.shape[0]
+        assert self.K % B == 0  # head.py:101
+        vq, tq = self._queue_kc("v_queue"), self._queue_kc("t_queue")
+        ops.call("trid_enqueue_f32", ops._p(vq), ops._p(tq), ops._p(self.id_queue), ops._p(self.queue_ptr),
+                 ops._p(v_keys.contiguous()), ops._p(t_keys.contiguous()), ops._p(id_keys.long().contiguous()), self.K,
+                 self.embed_size, B, ops.stream())
+
+    # ---------------------------------------------------------------- forward
+    def forward(self, images, captions):
+        cb = CaptionBatch.from_list(captions)
+        v_feat = self.v_encoder_q(images)
+        t_feat = self.t_encoder_q(cb)
+        if self.training:
+            v_embed = losses.linear(v_feat, self.v_embed_layer.weight, self.v_embed_layer.bias)
+            t_embed = losses.linear(t_feat, self.t_embed_layer.weight, self.t_embed_layer.bias)
+            id_q = cb.ids.long()
+            with torch.no_grad():
+                self._momentum_update_key_encoder()
+                vk_feat = self.v_encoder_k(images)
+                tk_feat = self.t_encoder_k(cb)
+                v_embed_k = losses.l2_normalize(losses.linear(vk_feat, self.v_embed_layer.weight, self.v_embed_layer.bias))
+                t_embed_k = losses.l2_normalize(losses.linear(tk_feat, self.t_embed_layer.weight, self.t_embed_layer.bias))
+            if world_size() > 1:
+                # one packed RCCL all-gather; every rank then evaluates the GLOBAL losses
+                v_embed, t_embed, v_embed_k, t_embed_k, id_q = gather_embeddings(v_embed, t_embed, v_embed_k, t_embed_k, id_q)
+            v_embed_q = losses.l2_normalize(v_embed)
+            t_embed_q = losses.l2_normalize(t_embed)
+            out = self.loss_evaluator.forward_fused(
+                v_embed, t_embed, v_embed_q, t_embed_q, v_embed_k, t_embed_k, id_q,
+                self._queue_kc("t_queue"), self._queue_kc("v_queue"), self.id_queue,
+            )
+            self._dequeue_and_enqueue(v_embed_k, t_embed_k, id_q)
+            return out
+        v_embed = losses.linear(v_feat, self.v_embed_layer.weight, self.v_embed_layer.bias)
+        t_embed = losses.linear(t_feat, self.t_embed_layer.weight, self.t_embed_layer.bias)
+        return [v_embed, t_embed]
+
+
+def build_moco_head(cfg, visual_model, textual_model):
+    return MoCoHead(cfg, visual_model, textual_model)

@@ -1,0 +1,221 @@
+"""Losses of the MoCo configs on the HIP kernel library.
+
+Same call surface as the reference ``lib/models/losses.py``:
+``instance_loss`` (:42-62, with ``CrossEntropyLabelSmooth`` :6-39),
+``global_align_loss`` (:102-128) and ``infonce_loss`` (:206-217); plus
+``queue_infonce_loss``, the fused form the MoCo head uses (queue similarity +
+batch-wide negative filter + InfoNCE, reference head.py:148-170 followed by
+losses.py:206-217) that never builds the gathered negative matrices.
+
+Each loss is one ``autograd.Function``: the forward launches the similarity /
+logit GEMMs and a row kernel that emits the per-row loss and, in place,
+dL/dlogits; the gradient GEMMs run right away (the logits never outlive the
+forward) and backward only scales by the incoming gradient on device.
+"""
+
+import torch
+
+from . import ops
+from .ops import call, _p, stream
+
+
+def _pad16(n):
+    return (n + 15) // 16 * 16
+
+
+def _scaled(g, a):
+    """g (0-d device tensor) * a, through the axpby3 kernel (no host sync)."""
+    out = torch.empty_like(a)
+    call("trid_axpby3_f32", _p(out), _p(a), None, None, _p(g.reshape(1).float().contiguous()), a.numel(), stream())
+    return out
+
+
+def _check(*ts):
+    for t in ts:
+        if not t.is_cuda:
+            raise RuntimeError("textreid_amd losses run on the HIP kernel library only (CUDA tensors); no CPU fallback")
+
+
+class _InstanceLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, projection, v, t, labels, epsilon):
+        C, N = projection.shape
+        B = v.shape[0]
+        ldn = _pad16(N)
+        proj = projection.detach().contiguous()
+        pnt = ops.empty((ldn, C), v)
+        invn = ops.empty((N,), v)
+        call("trid_colnorm_f32", _p(proj), None, _p(pnt), _p(invn), C, N, ldn, stream())
+        E2 = torch.cat([v.detach(), t.detach()], dim=0).contiguous()
+        logits = ops.linear(E2, pnt)  # [2B, ldn]
+        labels2 = torch.cat([labels, labels]).long().contiguous()
+        rows = ops.empty((2 * B,), v)
+        call("trid_smooth_ce_rows_f32", _p(logits), _p(labels2), _p(rows), 2 * B, N, ldn, float(epsilon), 1.0 / B,
+             stream())
+        loss = ops.empty((1,), v)
+        ops.sum_to(rows, loss, 1.0 / B)
+        dE2 = ops.matmul_nn(logits, pnt)
+        dpnt = ops.matmul_tn(logits, E2)
+        dproj = ops.empty((C, N), v)
+        call("trid_colnorm_bwd_f32", _p(dpnt), _p(pnt), _p(invn), _p(dproj), C, N, ldn, stream())
+        ctx.saved = (dproj, dE2, B)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        dproj, dE2, B = ctx.saved
+        ctx.saved = None
+        return _scaled(g, dproj), _scaled(g, dE2[:B]), _scaled(g, dE2[B:]), None, None
+
+
+def instance_loss(projection, visual_embed, textual_embed, labels, scale=1, norm=False, epsilon=0.0):
+    if scale != 1 or norm:
+        raise NotImplementedError("instance_loss: only scale=1, norm=False (the call at moco_head/loss.py:23-29)")
+    _check(projection, visual_embed, textual_embed, labels)
+    return _InstanceLossFn.apply(projection, visual_embed, textual_embed, labels, epsilon)
+
+
+class _GlobalAlignFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, v, t, labels, alpha, beta, scale_pos, scale_neg):
+        B, C = v.shape
+        if B % 4:
+            raise RuntimeError("global_align_loss kernel needs a batch that is a multiple of 4 (got %d)" % B)
+        vn, inv_v = ops.l2norm_rows(v.detach().contiguous())
+        tn, inv_t = ops.l2norm_rows(t.detach().contiguous())
+        S = ops.linear(vn, tn)  # [B,B] cosine
+        rows = ops.empty((B,), v)
+        call("trid_global_align_rows_f32", _p(S), _p(labels.long().contiguous()), _p(rows), B, B, float(alpha),
+             float(beta), float(scale_pos), float(scale_neg), 1.0, stream())
+        loss = ops.empty((1,), v)
+        ops.sum_to(rows, loss, 1.0)
+        dvn = ops.matmul_nn(S, tn)
+        dtn = ops.matmul_tn(S, vn)
+        dv = ops.l2norm_rows_bwd(dvn, vn, inv_v)
+        dt = ops.l2norm_rows_bwd(dtn, tn, inv_t)
+        ctx.saved = (dv, dt)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        dv, dt = ctx.saved
+        ctx.saved = None
+        return _scaled(g, dv), _scaled(g, dt), None, None, None, None, None
+
+
+def global_align_loss(visual_embed, textual_embed, labels, alpha=0.6, beta=0.4, scale_pos=10, scale_neg=40):
+    _check(visual_embed, textual_embed, labels)
+    return _GlobalAlignFn.apply(visual_embed, textual_embed, labels, alpha, beta, scale_pos, scale_neg)
+
+
+class _InfoNCEFn(torch.autograd.Function):
+    """CE over [pos | neg]/T with label 0 for materialised logits (reference call surface)."""
+
+    @staticmethod
+    def forward(ctx, v_pos, v_neg, t_pos, t_neg, T):
+        B = v_pos.shape[0]
+        loss = ops.empty((1,), v_pos)
+        outs = []
+        for i, (pos, neg) in enumerate(((v_pos, v_neg), (t_pos, t_neg))):
+            S = neg.detach().clone().contiguous()
+            K = S.shape[1]
+            hit = torch.zeros(K, dtype=torch.uint8, device=S.device)
+            rows = ops.empty((B,), S)
+            dpos = ops.empty((B,), S)
+            call("trid_infonce_rows_f32", _p(S), _p(pos.detach().reshape(-1).contiguous()), _p(hit), _p(rows), _p(dpos),
+                 B, K, K, 1.0 / T, 1.0, stream())
+            ops.sum_to(rows, loss, 1.0 / B, accumulate=i > 0)
+            outs += [dpos.view(B, 1), S]
+        ctx.saved = outs
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        dvp, dvn, dtp, dtn = ctx.saved
+        ctx.saved = None
+        return _scaled(g, dvp), _scaled(g, dvn), _scaled(g, dtp), _scaled(g, dtn), None
+
+
+def infonce_loss(v_pos, v_neg, t_pos, t_neg, T=0.07):
+    _check(v_pos, v_neg, t_pos, t_neg)
+    return _InfoNCEFn.apply(v_pos, v_neg, t_pos, t_neg, T)
+
+
+class _QueueInfoNCEFn(torch.autograd.Function):
+    """v_q,t_q [B,C] normalised queries; v_k,t_k keys; queues row-major [K,C]."""
+
+    @staticmethod
+    def forward(ctx, v_q, t_q, v_k, t_k, ids, t_queue, v_queue, id_queue, T):
+        B, C = v_q.shape
+        K = t_queue.shape[0]
+        hit = torch.empty(K, dtype=torch.uint8, device=v_q.device)
+        call("trid_queue_hit_mask", _p(id_queue), _p(ids.long().contiguous()), _p(hit), K, B, stream())
+        loss = ops.empty((1,), v_q)
+        grads = []
+        for i, (q, key, queue) in enumerate(((v_q, t_k, t_queue), (t_q, v_k, v_queue))):
+            q = q.detach().contiguous()
+            key = key.detach().contiguous()
+            S = ops.linear(q, queue)  # [B,K] raw dot products
+            pos = ops.rowdot(q, key)
+            rows = ops.empty((B,), q)
+            dpos = ops.empty((B,), q)
+            call("trid_infonce_rows_f32", _p(S), _p(pos), _p(hit), _p(rows), _p(dpos), B, K, K, 1.0 / T, 1.0, stream())
+            ops.sum_to(rows, loss, 1.0 / B, accumulate=i > 0)
+            dq = ops.matmul_nn(S, queue)
+            ops.rowscale_add(dpos, key, dq, accumulate=True)
+            grads.append(dq)
+        ctx.saved = grads
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        dv, dt = ctx.saved
+        ctx.saved = None
+        return _scaled(g, dv), _scaled(g, dt), None, None, None, None, None, None, None
+
+
+def queue_infonce_loss(v_q, t_q, v_k, t_k, ids, t_queue, v_queue, id_queue, T=0.07):
+    _check(v_q, t_q, v_k, t_k, ids, t_queue, v_queue, id_queue)
+    return _QueueInfoNCEFn.apply(v_q, t_q, v_k, t_k, ids, t_queue, v_queue, id_queue, T)
+
+
+class _L2NormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        y, inv = ops.l2norm_rows(x.detach().contiguous())
+        ctx.saved = (y, inv)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, inv = ctx.saved
+        return ops.l2norm_rows_bwd(dy.contiguous(), y, inv)
+
+
+def l2_normalize(x):
+    """F.normalize(x, dim=1) (head.py:128-129)."""
+    _check(x)
+    return _L2NormFn.apply(x)
+
+
+class _LinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b):
+        xd = x.detach().contiguous()
+        ctx.saved = (xd, w)
+        return ops.linear(xd, w.detach(), b.detach() if b is not None else None)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved
+        dy = dy.contiguous()
+        dx = ops.matmul_nn(dy, w.detach()) if ctx.needs_input_grad[0] else None
+        dw = ops.matmul_tn(dy, x) if ctx.needs_input_grad[1] else None
+        db = ops.colsum(dy) if ctx.needs_input_grad[2] else None
+        return dx, dw, db
+
+
+def linear(x, weight, bias=None):
+    """F.linear on the MFMA GEMM (embed layers, head.py:50-51)."""
+    _check(x, weight)
+    return _LinearFn.apply(x, weight, bias)

@@ -1,0 +1,99 @@
+"""Data-parallel pieces: one process per GPU, torch.distributed over RCCL/xGMI.
+
+The train step shards the mini-batch across ranks.  Each rank encodes its
+shard (BatchNorm statistics stay rank-local, as the reference's
+``broadcast_buffers=False``, train_net.py:54-55), then ONE packed all-gather
+moves ``[B_local, 4*C + 1]`` floats per rank (v_embed, t_embed, v_key, t_key,
+id) so every rank evaluates the three losses on the GLOBAL batch against its
+replicated queue.  Backward needs no collective for the embeddings: each rank
+already holds dL/d(e_local), the local rows of the gathered gradient.
+Gradients of pre-gather parameters are then SUM-reduced across ranks
+(``GradReducer``), post-gather parameters (the instance-loss projection) are
+identical on every rank and are not reduced.  SURVEY.md section 8e.
+"""
+
+import torch
+import torch.distributed as dist
+
+
+def world_size():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def rank():
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+class _GatherRows(torch.autograd.Function):
+    """all_gather along dim 0; backward returns the local rows of the gradient
+    (no collective, no scaling: the loss is evaluated in full on every rank)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        W = world_size()
+        ctx.rows = x.shape[0]
+        out = torch.empty((W * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+        dist.all_gather_into_tensor(out, x.contiguous())
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        r = rank()
+        return g[r * ctx.rows : (r + 1) * ctx.rows].contiguous()
+
+
+def gather_embeddings(v_embed, t_embed, v_key, t_key, ids):
+    """Packed all-gather of the four [B,C] embedding blocks and the ids.
+    Gradients flow to v_embed / t_embed only (keys are detached)."""
+    B, C = v_embed.shape
+    packed = torch.cat([v_embed, t_embed, v_key.detach(), t_key.detach(), ids.to(v_embed.dtype).view(B, 1)], dim=1)
+    g = _GatherRows.apply(packed)
+    v, t, vk, tk = g[:, :C], g[:, C : 2 * C], g[:, 2 * C : 3 * C].detach(), g[:, 3 * C : 4 * C].detach()
+    gid = g[:, 4 * C].detach().round().long()
+    return v.contiguous(), t.contiguous(), vk.contiguous(), tk.contiguous(), gid
+
+
+class GradReducer:
+    """Bucketed SUM all-reduce of parameter gradients on a side stream.
+
+    ``reduce(params)`` flattens the gradients of ``params`` into ~bucket_mb
+    buckets in the given order (call it with parameters in reverse execution
+    order so the last layers go first), all-reduces each bucket asynchronously
+    and copies the result back; ``wait()`` joins before the optimiser step.
+    xGMI is point-to-point (7 links per GPU), so buckets are large (default
+    64 MB) to stay bandwidth- rather than latency-bound per link.
+    """
+
+    def __init__(self, bucket_mb=64):
+        self.bucket_elems = int(bucket_mb * (1 << 20) // 4)
+        self._pending = []
+
+    def reduce(self, params):
+        if world_size() == 1:
+            return
+        bucket, n = [], 0
+        for p in params:
+            if p.grad is None:
+                continue
+            bucket.append(p)
+            n += p.numel()
+            if n >= self.bucket_elems:
+                self._launch(bucket)
+                bucket, n = [], 0
+        if bucket:
+            self._launch(bucket)
+
+    def _launch(self, bucket):
+        flat = torch.cat([p.grad.reshape(-1) for p in bucket])
+        work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
+        self._pending.append((work, flat, bucket))
+
+    def wait(self):
+        for work, flat, bucket in self._pending:
+            work.wait()
+            off = 0
+            for p in bucket:
+                n = p.numel()
+                p.grad.copy_(flat[off : off + n].view_as(p.grad))
+                off += n
+        self._pending = []
