@@ -101,6 +101,8 @@ def load():
             "libtextreid_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C textreid_amd/csrc`. There is no CPU fallback." % LIB_PATH
         )
+    import torch  # noqa: F401  (load PyTorch's HIP runtime first so both share one libamdhip64)
+
     lib = ctypes.CDLL(LIB_PATH)
     for name, (ret, sig) in DECLS.items():
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch

@@ -26,6 +26,24 @@ def stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+# Optional live profiling hook (bench.py): when PROFILE is a dict with a "match"
+# predicate, every matching GEMM launch is bracketed by events on the launch stream.
+PROFILE = None
+
+
+def _gemm_tile(M, N, stats):
+    """Mirror of dispatch_tile() in csrc/gemm.hip."""
+    bm = 128 if M >= 96 else (64 if M > 32 else 32)
+    bn = 128 if N >= 96 else (64 if N > 32 else 32)
+    if stats:
+        bm = 128
+    if bm == 128:
+        return (128, bn)
+    if bn == 128:
+        return (bm, 128)
+    return (64, 64)
+
+
 def _p(t):
     if t is None:
         return None
@@ -59,6 +77,16 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, a_mode=A_KC, b_mode=B_KC, alpha=1.0, a
     d.stats = _p(stats)
     if conv is not None:
         d.H, d.W, d.Cin = conv
+    prof = PROFILE
+    if prof is not None:
+        key = (a_mode, b_mode) + _gemm_tile(M, N, stats is not None)
+        if prof["match"](key):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            call("trid_gemm_f32", ctypes.addressof(d), stream())
+            e1.record()
+            prof["events"].append((key, 2.0 * M * N * K * batch, e0, e1))
+            return
     call("trid_gemm_f32", ctypes.addressof(d), stream())
 
 
