@@ -46,13 +46,14 @@ def synth_batch(B, step, device, seed, vocab=49408, Lpad=105, L=64):
     return images.to(device), tokens.to(device), lengths.to(device), ids.to(device)
 
 
-def cpu_baseline(sample_b=16, steps=2):
+def cpu_baseline(sample_b=32, steps=3):
     """Oracle (port of the reference train step incl. Adam) on the host cores."""
     import oracle.fill as OF
     import oracle.head as OH
     import oracle.visual as OV
 
     ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    ncpu = min(ncpu, int(os.environ.get("TRID_CPU_THREADS", "32")))  # more threads only adds sync overhead at this size
     torch.set_num_threads(ncpu)
     log("cpu_baseline: %d usable cores (os.cpu_count=%s)" % (ncpu, os.cpu_count()))
     spec, K, C, NC = OV.RN50, 8192, 256, 11003

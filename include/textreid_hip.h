@@ -218,12 +218,13 @@ int trid_sum_f32(const float* x, float* out, long long n, float scale, int accum
 /* ------------------------------------------------------------------------- *
  * MoCo state: momentum update, enqueue (head.py:73-109), optimiser.
  * ------------------------------------------------------------------------- */
-/* Multi-tensor k = m*k + (1-m)*q.  ptr tables are DEVICE arrays of n_tensors
- * addresses; chunk table: chunk c covers elements [chunk_off[c], +chunk_len) of
- * tensor chunk_tensor[c]. */
+/* Multi-tensor k = k*m + q*one_minus_m (two rounded products + one rounded sum, the
+ * reference's op order; one_minus_m is passed so the host can form 1-m in double as
+ * Python does).  ptr tables are DEVICE arrays of n_tensors addresses; chunk table:
+ * chunk c covers elements [chunk_off[c], +chunk_len) of tensor chunk_tensor[c]. */
 int trid_ema_multi_f32(const uint64_t* k_ptrs, const uint64_t* q_ptrs, const int64_t* sizes,
                        const int32_t* chunk_tensor, const int64_t* chunk_off, int n_chunks, int chunk_len, float m,
-                       void* stream);
+                       float one_minus_m, void* stream);
 /* Multi-tensor Adam / AdamW step (torch.optim.Adam semantics, lib/solver/build.py:6-40:
  * per-tensor lr and weight decay).  step_size = lr/(1-b1^t), bc2 = sqrt(1-b2^t). */
 int trid_adam_multi_f32(const uint64_t* p_ptrs, const uint64_t* g_ptrs, const uint64_t* m_ptrs,
@@ -245,6 +246,17 @@ int trid_enqueue_f32(float* v_queue, float* t_queue, int64_t* id_queue, int64_t*
 long long trid_topk_ws_floats(int Q, int G, int k);
 int trid_sim_topk_f32(const float* q, const float* g, float* out_val, int64_t* out_idx, int Q, int G, int C,
                       int k, long long idx_offset, float* ws, void* stream);
+
+/* per-row top-k of a given similarity matrix (rank(get_mAP=False), evaluation.py:17-19) */
+int trid_topk_rows_f32(const float* sim, int ld, int Q, int G, int k, float* out_val, int64_t* out_idx,
+                       void* stream);
+/* per-row full descending argsort (rank(get_mAP=True), evaluation.py:14); G <= 16384 */
+int trid_argsort_rows_desc_f32(const float* sim, int ld, int Q, int G, int64_t* out_idx, void* stream);
+/* matches = g_pids[indices] == q_pids; first_hit[q] = rank of the first match (INT_MAX if none);
+ * ap[q] = average precision over the R ranked items (NaN without relevant items);
+ * cmc[t] = 100*mean(first_hit < topk[t])  (evaluation.py:20-36) */
+int trid_rank_metrics(const int64_t* indices, const int64_t* q_pids, const int64_t* g_pids, int Q, int R,
+                      int32_t* first_hit, float* ap, const int64_t* topk, int ntopk, float* cmc, void* stream);
 
 #ifdef __cplusplus
 }

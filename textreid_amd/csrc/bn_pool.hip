@@ -268,23 +268,38 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a, float* 
     }
 }
 
-// one thread per channel: sum the block partials that cover its quad (fp64 accumulate)
-__global__ void bn_bwd_reduce_final_kernel(const float* __restrict__ ws, int nblk, int CQ, float* __restrict__ dgamma,
-                                           float* __restrict__ dbeta, int C) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    const int q = c >> 2, e = c & 3;
+// one workgroup per channel quad: sum the block partials that cover it
+__global__ __launch_bounds__(256) void bn_bwd_reduce_final_kernel(const float* __restrict__ ws, int nblk, int CQ,
+                                                                  float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                  int C) {
+    const int q = blockIdx.x;
     const int CW = CQ < 256 ? CQ : 256;
     const int S = CQ / CW;  // channel-quad slices; block b covers slice b % S
     const int slice = q / CW, ql = q % CW;
-    double s1 = 0.0, s2 = 0.0;
-    for (int b = slice; b < nblk; b += S) {
-        const float* src = ws + ((long long)b * CW + ql) * 8;
-        s1 += src[e];
-        s2 += src[4 + e];
+    float acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+    for (int b = slice + S * threadIdx.x; b < nblk; b += S * 256) {
+        const float4* src = reinterpret_cast<const float4*>(ws + ((long long)b * CW + ql) * 8);
+        const float4 u = src[0], v = src[1];
+        acc[0] += u.x; acc[1] += u.y; acc[2] += u.z; acc[3] += u.w;
+        acc[4] += v.x; acc[5] += v.y; acc[6] += v.z; acc[7] += v.w;
     }
-    dbeta[c] = (float)s1;
-    dgamma[c] = (float)s2;
+    __shared__ float red[4][8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = wave_sum(acc[k]);
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) red[threadIdx.x >> 6][k] = acc[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 8) {
+        const float s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        const int c = 4 * q + (threadIdx.x & 3);
+        if (c < C) {
+            if (threadIdx.x < 4) dbeta[c] = s; else dgamma[c] = s;
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a, const float4* __restrict__ dgamma,
@@ -430,8 +445,8 @@ extern "C" int trid_bn_bwd_reduce_f32(const float* g, const float* y, const floa
     TRID_REQUIRE(dgamma && dbeta && ws, "trid_bn_bwd_reduce_f32: null output");
     const int grid = bn_bwd_grid(a.total4, a.CQ);
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, ws);
-    hipLaunchKernelGGL(bn_bwd_reduce_final_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, ws, grid,
-                       a.CQ, dgamma, dbeta, C);
+    hipLaunchKernelGGL(bn_bwd_reduce_final_kernel, dim3(a.CQ), dim3(256), 0, (hipStream_t)stream, ws, grid, a.CQ, dgamma,
+                       dbeta, C);
     return check_launch("trid_bn_bwd_reduce_f32");
 }
 

@@ -13,7 +13,10 @@ __global__ __launch_bounds__(256) void ema_multi_kernel(const uint64_t* __restri
                                                         const uint64_t* __restrict__ q_ptrs,
                                                         const int64_t* __restrict__ sizes,
                                                         const int32_t* __restrict__ chunk_tensor,
-                                                        const int64_t* __restrict__ chunk_off, int chunk_len, float m) {
+                                                        const int64_t* __restrict__ chunk_off, int chunk_len, float m,
+                                                        float om) {
+    // This file is compiled with -ffp-contract=off (Makefile): mul, mul, add stay separately
+    // rounded, so the EMA is bit-identical to the reference's three torch ops.
     const int c = blockIdx.x;
     const int ti = chunk_tensor[c];
     const long long off = chunk_off[c];
@@ -21,13 +24,13 @@ __global__ __launch_bounds__(256) void ema_multi_kernel(const uint64_t* __restri
     const float* __restrict__ q = reinterpret_cast<const float*>(q_ptrs[ti]) + off;
     long long n = sizes[ti] - off;
     if (n > chunk_len) n = chunk_len;
-    const float om = 1.f - m;
     if (((reinterpret_cast<uintptr_t>(k) | reinterpret_cast<uintptr_t>(q)) & 15u) == 0) {
         const long long n4 = n >> 2;
         for (long long i = threadIdx.x; i < n4; i += 256) {
             float4 a = reinterpret_cast<float4*>(k)[i];
             const float4 b = reinterpret_cast<const float4*>(q)[i];
-            // param_k*m + param_q*(1-m), same association as the reference
+            // param_k*m + param_q*(1-m): two rounded products, one rounded sum (no FMA
+            // contraction), so the result is bit-identical to the reference's torch ops
             a.x = a.x * m + b.x * om; a.y = a.y * m + b.y * om;
             a.z = a.z * m + b.z * om; a.w = a.w * m + b.w * om;
             reinterpret_cast<float4*>(k)[i] = a;
@@ -93,11 +96,11 @@ using namespace trid;
 
 extern "C" int trid_ema_multi_f32(const uint64_t* k_ptrs, const uint64_t* q_ptrs, const int64_t* sizes,
                                   const int32_t* chunk_tensor, const int64_t* chunk_off, int n_chunks, int chunk_len,
-                                  float m, void* stream) {
+                                  float m, float one_minus_m, void* stream) {
     TRID_REQUIRE(k_ptrs && q_ptrs && sizes && chunk_tensor && chunk_off && n_chunks > 0 && chunk_len > 0 && chunk_len % 4 == 0,
                  "trid_ema_multi_f32: bad arguments");
     hipLaunchKernelGGL(ema_multi_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, k_ptrs, q_ptrs, sizes,
-                       chunk_tensor, chunk_off, chunk_len, m);
+                       chunk_tensor, chunk_off, chunk_len, m, one_minus_m);
     return check_launch("trid_ema_multi_f32");
 }
 

@@ -64,6 +64,87 @@ __global__ __launch_bounds__(256) void topk_merge_rows_kernel(const float* __res
     }
 }
 
+// Full descending argsort of each row (evaluation.py:14): one workgroup per row,
+// bitonic network over (value, index) pairs in LDS; ties -> lower index first.
+__global__ __launch_bounds__(256) void argsort_rows_desc_kernel(const float* __restrict__ sim, int ld, int G, int P,
+                                                                long long* __restrict__ out_idx) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float* sv = reinterpret_cast<float*>(smem_raw);
+    int* si = reinterpret_cast<int*>(sv + P);
+    const long long row = blockIdx.x;
+    const float* r = sim + row * ld;
+    for (int i = threadIdx.x; i < P; i += 256) {
+        sv[i] = i < G ? r[i] : -INFINITY;
+        si[i] = i < G ? i : 0x7fffffff;
+    }
+    __syncthreads();
+    for (int k = 2; k <= P; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < P; i += 256) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const float a = sv[i], b = sv[l];
+                    const int ia = si[i], ib = si[l];
+                    // "a should come before b" in the final descending order
+                    const bool a_first = a > b || (a == b && ia < ib);
+                    const bool up = (i & k) == 0;  // this sub-sequence sorted in final order?
+                    if (up ? !a_first : a_first) {
+                        sv[i] = b; sv[l] = a;
+                        si[i] = ib; si[l] = ia;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = threadIdx.x; i < G; i += 256) out_idx[row * G + i] = si[i];
+}
+
+// One wave per query: first-hit rank (CMC) and average precision over R ranked gallery ids.
+__global__ void rank_metrics_kernel(const long long* __restrict__ indices, const int64_t* __restrict__ q_pids,
+                                    const int64_t* __restrict__ g_pids, int Q, int R, int32_t* __restrict__ first_hit,
+                                    float* __restrict__ ap) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= Q) return;
+    const int64_t qp = q_pids[row];
+    int carried = 0, first = 0x7fffffff;
+    float acc = 0.f;
+    for (int c = 0; c < R; c += 64) {
+        const int i = c + lane;
+        bool m = false;
+        if (i < R) m = g_pids[indices[(long long)row * R + i]] == qp;
+        const unsigned long long bal = __ballot(m);
+        if (m) {
+            const int before = __popcll(bal & ((1ull << lane) - 1ull));
+            acc += (float)(carried + before + 1) / (float)(i + 1);
+        }
+        if (bal != 0ull && first == 0x7fffffff) first = c + __ffsll((long long)bal) - 1;
+        carried += __popcll(bal);
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) {
+        first_hit[row] = first;
+        ap[row] = acc / (float)carried;  // NaN when the query has no relevant gallery item, as the reference
+    }
+}
+
+// cmc[t] = 100 * mean(first_hit < topk[t])
+__global__ __launch_bounds__(256) void cmc_kernel(const int32_t* __restrict__ first_hit, int Q,
+                                                  const int64_t* __restrict__ topk, int ntopk, float* __restrict__ cmc) {
+    __shared__ float red[4];
+    for (int t = 0; t < ntopk; ++t) {
+        const int kk = (int)topk[t];
+        float s = 0.f;
+        for (int i = threadIdx.x; i < Q; i += 256) s += first_hit[i] < kk ? 1.f : 0.f;
+        s = wave_sum(s);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) cmc[t] = 100.f * (red[0] + red[1] + red[2] + red[3]) / (float)Q;
+    }
+}
+
 }  // namespace trid
 
 using namespace trid;
@@ -110,4 +191,48 @@ extern "C" int trid_sim_topk_f32(const float* q, const float* g, float* out_val,
         if (rc) return rc;
     }
     return TRID_OK;
+}
+
+extern "C" int trid_topk_rows_f32(const float* sim, int ld, int Q, int G, int k, float* out_val, int64_t* out_idx,
+                                  void* stream) {
+    TRID_REQUIRE(sim && out_val && out_idx && Q > 0 && G > 0 && ld >= G, "trid_topk_rows_f32: bad arguments");
+    TRID_REQUIRE(k >= 1 && k <= TOPK_MAX && k <= G, "trid_topk_rows_f32: k must be in [1,%d] and <= G", TOPK_MAX);
+    const dim3 grid((Q + 3) / 4), block(256);
+#define TRID_TOPK_CASE(KK)                                                                                         \
+    case KK:                                                                                                       \
+        hipLaunchKernelGGL(topk_merge_rows_kernel<KK>, grid, block, 0, (hipStream_t)stream, sim, ld, Q, G, 0LL, out_val, \
+                           (long long*)out_idx, 1);                                                                \
+        break;
+    switch (k) {
+        TRID_TOPK_CASE(1) TRID_TOPK_CASE(2) TRID_TOPK_CASE(3) TRID_TOPK_CASE(4) TRID_TOPK_CASE(5) TRID_TOPK_CASE(6)
+        TRID_TOPK_CASE(7) TRID_TOPK_CASE(8) TRID_TOPK_CASE(9) TRID_TOPK_CASE(10) TRID_TOPK_CASE(11) TRID_TOPK_CASE(12)
+        TRID_TOPK_CASE(13) TRID_TOPK_CASE(14) TRID_TOPK_CASE(15) TRID_TOPK_CASE(16)
+    }
+#undef TRID_TOPK_CASE
+    return check_launch("trid_topk_rows_f32");
+}
+
+extern "C" int trid_argsort_rows_desc_f32(const float* sim, int ld, int Q, int G, int64_t* out_idx, void* stream) {
+    TRID_REQUIRE(sim && out_idx && Q > 0 && G > 0 && ld >= G, "trid_argsort_rows_desc_f32: bad arguments");
+    int P = 2;
+    while (P < G) P <<= 1;
+    TRID_REQUIRE(P <= 16384, "trid_argsort_rows_desc_f32: gallery of %d exceeds the in-LDS sort limit (16384); use top-k", G);
+    const size_t lds = (size_t)P * 8;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)argsort_rows_desc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { set_error("trid_argsort_rows_desc_f32: cannot reserve %zu B of LDS", lds); return (int)e; }
+    }
+    hipLaunchKernelGGL(argsort_rows_desc_kernel, dim3(Q), dim3(256), lds, (hipStream_t)stream, sim, ld, G, P,
+                       (long long*)out_idx);
+    return check_launch("trid_argsort_rows_desc_f32");
+}
+
+extern "C" int trid_rank_metrics(const int64_t* indices, const int64_t* q_pids, const int64_t* g_pids, int Q, int R,
+                                 int32_t* first_hit, float* ap, const int64_t* topk, int ntopk, float* cmc, void* stream) {
+    TRID_REQUIRE(indices && q_pids && g_pids && first_hit && ap && topk && cmc && Q > 0 && R > 0 && ntopk > 0,
+                 "trid_rank_metrics: bad arguments");
+    hipLaunchKernelGGL(rank_metrics_kernel, dim3((Q + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const long long*)indices,
+                       q_pids, g_pids, Q, R, first_hit, ap);
+    hipLaunchKernelGGL(cmc_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, first_hit, Q, topk, ntopk, cmc);
+    return check_launch("trid_rank_metrics");
 }

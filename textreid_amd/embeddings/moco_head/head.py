@@ -116,7 +116,7 @@ class MoCoHead(nn.Module):
             self._ema_plan = _EmaPlan(pairs, pairs[0][0].device)
         pl = self._ema_plan
         ops.call("trid_ema_multi_f32", ops._p(pl.k_ptrs), ops._p(pl.q_ptrs), ops._p(pl.sizes), ops._p(pl.chunk_tensor),
-                 ops._p(pl.chunk_off), pl.n_chunks, EMA_CHUNK, float(self.m), ops.stream())
+                 ops._p(pl.chunk_off), pl.n_chunks, EMA_CHUNK, float(self.m), 1.0 - float(self.m), ops.stream())
 
     @torch.no_grad()
     def _dequeue_and_enqueue(self, v_keys, t_keys, id_keys):

@@ -1,0 +1,62 @@
+"""Device-agnostic counterpart of the reference train loop (``lib/engine/trainer.py:38-139``):
+same op order per step -- model(images, captions) -> sum(loss_dict) -> zero_grad ->
+backward -> step -- per-epoch scheduler.step(), evaluation every EVALUATE_PERIOD
+epochs with rerank=False, best / periodic checkpoints.  Differences: gradients of
+pre-gather parameters are SUM-reduced over RCCL by ``GradReducer`` (the reference's
+DDP path crashes), and logging reads losses every ``log_period``
+steps instead of forcing a device sync every step."""
+
+import logging
+import time
+
+import torch
+
+from ..parallel import GradReducer, world_size
+from .inference import inference
+
+
+def train_step(model, optimizer, images, captions, reducer=None, pre_gather=None):
+    loss_dict = model(images, captions)
+    losses = sum(loss for loss in loss_dict.values())
+    optimizer.zero_grad()
+    losses.backward()
+    if reducer is not None and world_size() > 1:
+        reducer.reduce(pre_gather)
+        reducer.wait()
+    optimizer.step()
+    return loss_dict, losses
+
+
+def do_train(model, data_loader, data_loader_val, optimizer, scheduler, checkpointer, meters, device,
+             checkpoint_period, evaluate_period, arguments, log_period=20):
+    logger = logging.getLogger("PersonSearch.trainer")
+    logger.info("Start training")
+    max_epoch, epoch, iteration = arguments["max_epoch"], arguments["epoch"], arguments["iteration"]
+    reducer = GradReducer()
+    pre_gather = [p for n, p in model.named_parameters() if p.requires_grad and "loss_evaluator" not in n][::-1]
+    best_top1 = 0.0
+    start = time.time()
+    while epoch < max_epoch:
+        epoch += 1
+        model.train()
+        arguments["epoch"] = epoch
+        for step, (images, captions, _) in enumerate(data_loader):
+            iteration += 1
+            arguments["iteration"] = iteration
+            images = images.to(device)
+            captions = captions.to(device) if hasattr(captions, "to") else [c.to(device) for c in captions]
+            loss_dict, losses = train_step(model, optimizer, images, captions, reducer, pre_gather)
+            if meters is not None and iteration % log_period == 0:
+                meters.update(loss=float(losses), **{k: float(v) for k, v in loss_dict.items()})
+                logger.info("epoch [%d][%d/%d] %s lr: %.6f", epoch, step, len(data_loader), str(meters),
+                            optimizer.param_groups[-1]["lr"])
+        scheduler.step()
+        if data_loader_val is not None and epoch % evaluate_period == 0:
+            top1 = inference(model, data_loader_val[0], device=device, save_data=False, rerank=False)
+            if top1 is not None and float(top1) > best_top1:
+                best_top1 = float(top1)
+                if checkpointer is not None:
+                    checkpointer.save("best", **arguments)
+        if checkpointer is not None and epoch % checkpoint_period == 0:
+            checkpointer.save("epoch_{:d}".format(epoch), **arguments)
+    logger.info("Total training time: %.1fs", time.time() - start)

@@ -1,0 +1,135 @@
+"""Retrieval match + rank metric on the HIP library.
+
+Surface of the reference ``lib/data/metrics/evaluation.py``: ``rank(similarity,
+q_pids, g_pids, topk, get_mAP)`` (:11-37) and ``evaluation(dataset, predictions,
+output_folder, topk, save_data, rerank)`` (:76-173, ``rerank=False`` path; the
+k-reciprocal re-rank :40-65 is the "next" row f3).  ``similarity_topk`` is the
+fused form for large galleries (config 5): the [Q,G] matrix is never kept, only
+per-query top-k (value, index) pairs; with ``world_size > 1`` the gallery is
+sharded by rows and the per-shard top-k lists are merged after one all-gather.
+"""
+
+import logging
+import os
+
+import numpy as np
+import torch
+
+from . import ops
+from .ops import _p, call, stream
+
+
+def l2_normalize_rows(x):
+    y, _ = ops.l2norm_rows(x.contiguous())
+    return y
+
+
+def similarity(text_embed, image_embed):
+    """normalise + text @ image.T (evaluation.py:117-120)."""
+    return ops.linear(l2_normalize_rows(text_embed), l2_normalize_rows(image_embed))
+
+
+def rank(similarity, q_pids, g_pids, topk=(1, 5, 10), get_mAP=True):
+    if not similarity.is_cuda:
+        raise RuntimeError("textreid_amd.evaluation.rank runs on the HIP kernel library only (CUDA tensors); no CPU fallback")
+    dev = similarity.device
+    topk_t = torch.as_tensor(topk, dtype=torch.int64, device=dev)
+    max_rank = int(max(topk)) if not torch.is_tensor(topk) else int(topk.max())
+    sim = similarity.contiguous().float()
+    Q, G = sim.shape
+    if get_mAP:
+        indices = torch.empty(Q, G, dtype=torch.int64, device=dev)
+        call("trid_argsort_rows_desc_f32", _p(sim), G, Q, G, _p(indices), stream())
+    else:
+        vals = torch.empty(Q, max_rank, dtype=torch.float32, device=dev)
+        indices = torch.empty(Q, max_rank, dtype=torch.int64, device=dev)
+        call("trid_topk_rows_f32", _p(sim), G, Q, G, max_rank, _p(vals), _p(indices), stream())
+    return _metrics(indices, q_pids, g_pids, topk_t, get_mAP)
+
+
+def _metrics(indices, q_pids, g_pids, topk_t, get_mAP):
+    dev = indices.device
+    Q, R = indices.shape
+    first = torch.empty(Q, dtype=torch.int32, device=dev)
+    ap = torch.empty(Q, dtype=torch.float32, device=dev)
+    cmc = torch.empty(topk_t.numel(), dtype=torch.float32, device=dev)
+    call("trid_rank_metrics", _p(indices), _p(q_pids.to(dev).long().contiguous()), _p(g_pids.to(dev).long().contiguous()),
+         Q, R, _p(first), _p(ap), _p(topk_t), topk_t.numel(), _p(cmc), stream())
+    if not get_mAP:
+        return cmc, indices
+    mAP = torch.empty(1, dtype=torch.float32, device=dev)
+    ops.sum_to(ap, mAP, 100.0 / Q)
+    return cmc, mAP[0], indices
+
+
+def similarity_topk(text_embed, image_embed, k=10, normalize=True):
+    """Per-query top-k of text @ image.T without materialising [Q,G]; gallery rows
+    sharded across ranks when torch.distributed is initialised (each rank passes
+    its OWN shard of image_embed; returned indices are global, rank-major)."""
+    from .parallel import rank as dist_rank, world_size
+
+    q = l2_normalize_rows(text_embed) if normalize else text_embed.contiguous()
+    g = l2_normalize_rows(image_embed) if normalize else image_embed.contiguous()
+    Q, C = q.shape
+    G = g.shape[0]
+    W = world_size()
+    vals = torch.empty(Q, k, dtype=torch.float32, device=q.device)
+    idx = torch.empty(Q, k, dtype=torch.int64, device=q.device)
+    ws = ops.empty((ops.L.load().trid_topk_ws_floats(Q, G, k),), q)
+    offset = 0
+    if W > 1:
+        import torch.distributed as dist
+
+        sizes = [torch.zeros(1, dtype=torch.int64, device=q.device) for _ in range(W)]
+        dist.all_gather(sizes, torch.tensor([G], dtype=torch.int64, device=q.device))
+        offset = int(sum(int(s) for s in sizes[: dist_rank()]))
+    call("trid_sim_topk_f32", _p(q), _p(g), _p(vals), _p(idx), Q, G, C, k, offset, _p(ws), stream())
+    if W == 1:
+        return vals, idx
+    import torch.distributed as dist
+
+    av = torch.empty(W, Q, k, dtype=torch.float32, device=q.device)
+    ai = torch.empty(W, Q, k, dtype=torch.int64, device=q.device)
+    dist.all_gather_into_tensor(av, vals)
+    dist.all_gather_into_tensor(ai, idx)
+    cand_v = av.permute(1, 0, 2).reshape(Q, W * k).contiguous()
+    cand_i = ai.permute(1, 0, 2).reshape(Q, W * k).contiguous()
+    sel = torch.empty(Q, k, dtype=torch.int64, device=q.device)
+    call("trid_topk_rows_f32", _p(cand_v), W * k, Q, W * k, k, _p(vals), _p(sel), stream())
+    return vals, torch.gather(cand_i, 1, sel)
+
+
+def get_unique(image_ids):
+    keep = {}
+    for i, image_id in enumerate(image_ids):
+        keep.setdefault(image_id, i)
+    return torch.tensor(list(keep.values()))
+
+
+def evaluation(dataset, predictions, output_folder, topk, save_data=True, rerank=False):
+    if rerank:
+        raise NotImplementedError("k-reciprocal re-rank (evaluation.py:40-65) is not on the accelerated path yet")
+    logger = logging.getLogger("PersonSearch.inference")
+    image_ids, pids, image_global, text_global = [], [], [], []
+    for idx, prediction in predictions.items():
+        image_id, pid = dataset.get_id_info(idx)
+        image_ids.append(image_id)
+        pids.append(pid)
+        image_global.append(prediction[0])
+        text_global.append(prediction[1])
+    dev = image_global[0].device
+    image_pid = torch.tensor(pids, device=dev)
+    text_pid = torch.tensor(pids, device=dev)
+    image_global = torch.stack(image_global, dim=0)
+    text_global = torch.stack(text_global, dim=0)
+    keep = get_unique(image_ids).to(dev)
+    image_global = image_global[keep]
+    image_pid = image_pid[keep]
+    sim = similarity(text_global, image_global)
+    if save_data:
+        np.savez(os.path.join(output_folder, "inference_data.npz"), image_pid=image_pid.cpu().numpy(),
+                 text_pid=text_pid.cpu().numpy(), similarity=sim.cpu().numpy())
+    t2i_cmc, _ = rank(sim, text_pid, image_pid, topk, get_mAP=False)
+    i2t_cmc, _ = rank(sim.t().contiguous(), image_pid, text_pid, topk, get_mAP=False)
+    logger.info("topk %s  t2i %s  i2t %s", list(topk), t2i_cmc.tolist(), i2t_cmc.tolist())
+    return t2i_cmc[0]
