@@ -65,9 +65,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmParams p) {
     constexpr int NB = BN * BK / 4 / NTHREADS;
     static_assert(NA >= 1 && NB >= 1, "tile too small for 256 threads");
 
-    __shared__ __attribute__((aligned(16))) float smem[BK * LDA + BK * LDB];
-    float* As = smem;
-    float* Bs = smem + BK * LDA;
+    // two LDS stages (A tile + B tile each): one barrier per K-tile
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int STAGE = BK * LDA + BK * LDB;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmParams p) {
         }
     };
 
-    auto store_tiles = [&]() {
+    auto store_tiles = [&](float* __restrict__ As, float* __restrict__ Bs) {
         if (AMODE == A_MC) {
 #pragma unroll
             for (int i = 0; i < NA; ++i)
@@ -244,30 +244,45 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmParams p) {
 
     if (k_begin < k_end) {
         load_tiles(k_begin);
-        store_tiles();
+        store_tiles(smem, smem + BK * LDA);
         __syncthreads();
-        for (int k0 = k_begin; k0 < k_end; k0 += BK) {
+        int cur = 0;
+        for (int k0 = k_begin; k0 < k_end; k0 += BK, cur ^= 1) {
             const bool more = (k0 + BK) < k_end;
             if (more) load_tiles(k0 + BK);  // global loads in flight under the MFMAs
+            const float* __restrict__ As = smem + cur * STAGE;
+            const float* __restrict__ Bs = As + BK * LDA;
+            // software-pipelined operand fetch: fragments of step kk+1 are read from LDS
+            // before the MFMAs of step kk issue
+            float a[2][TM], b[2][TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[0][i] = As[khalf * LDA + a_off + i * 32];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[0][j] = Bs[khalf * LDB + b_off + j * 32];
 #pragma unroll
             for (int kk = 0; kk < BK / 2; ++kk) {
-                const int k = 2 * kk + khalf;
-                float a[TM], b[TN];
+                const int c = kk & 1, n = c ^ 1;
+                if (kk + 1 < BK / 2) {
+                    const int k = 2 * (kk + 1) + khalf;
 #pragma unroll
-                for (int i = 0; i < TM; ++i) a[i] = As[k * LDA + a_off + i * 32];
+                    for (int i = 0; i < TM; ++i) a[n][i] = As[k * LDA + a_off + i * 32];
 #pragma unroll
-                for (int j = 0; j < TN; ++j) b[j] = Bs[k * LDB + b_off + j * 32];
+                    for (int j = 0; j < TN; ++j) b[n][j] = Bs[k * LDB + b_off + j * 32];
+                }
+                // pin the order: hipcc otherwise sinks the prefetch reads next to their use
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][i], b[c][j], acc[i][j], 0, 0, 0);
+                if (kk == BK / 4 && more) {
+                    // next tile -> the other LDS stage, in the shadow of the remaining MFMAs
+                    float* nb = smem + (cur ^ 1) * STAGE;
+                    store_tiles(nb, nb + BK * LDA);
+                }
             }
             __syncthreads();
-            if (more) {
-                store_tiles();
-                __syncthreads();
-            }
         }
     }
 
@@ -280,15 +295,20 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmParams p) {
         const float bv = (bias != nullptr && col < p.N) ? bias[col] : 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
+            float oldv[16];
+            if (p.accumulate) {  // gather the old values first: 16 independent loads in flight
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = row_base + i * 32 + (r & 3) + 8 * (r >> 2);
+                    oldv[r] = (row < p.M && col < p.N) ? C[(long long)row * p.ldc + col] : 0.f;
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = row_base + i * 32 + (r & 3) + 8 * (r >> 2);
                 float v = p.alpha * acc[i][j][r] + bv;
-                if (row < p.M && col < p.N) {
-                    float* dst = C + (long long)row * p.ldc + col;
-                    if (p.accumulate) v += *dst;
-                    *dst = v;
-                }
+                if (p.accumulate) v += oldv[r];
+                if (row < p.M && col < p.N) C[(long long)row * p.ldc + col] = v;
                 acc[i][j][r] = v;
             }
         }
@@ -380,7 +400,20 @@ static int launch(GemmParams& p, hipStream_t stream) {
     p.mblocks = (p.M + BM - 1) / BM;
     p.nblocks = (p.N + BN - 1) / BN;
     dim3 grid((unsigned)(p.mblocks * p.nblocks), 1, (unsigned)(p.batch * p.splits));
-    hipLaunchKernelGGL((gemm_kernel<AMODE, BMODE, BM, BN, WAVES_M, WAVES_N>), grid, dim3(NTHREADS), 0, stream, p);
+    constexpr int LDA = BM + (AMODE == A_MC ? 4 : 1);
+    constexpr int LDB = BN + (BMODE == B_KC ? 1 : 4);
+    constexpr size_t lds = 2 * (size_t)(BK * LDA + BK * LDB) * sizeof(float);
+    static bool attr_done = false;  // idempotent; a benign race sets it twice at worst
+    if (!attr_done && lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel<AMODE, BMODE, BM, BN, WAVES_M, WAVES_N>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
+            set_error("trid_gemm_f32: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
+            return (int)e;
+        }
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((gemm_kernel<AMODE, BMODE, BM, BN, WAVES_M, WAVES_N>), grid, dim3(NTHREADS), lds, stream, p);
     return check_launch("trid_gemm_f32");
 }
 
