@@ -128,18 +128,41 @@ class MoCoHead(nn.Module):
                  self.embed_size, B, ops.stream())
 
     # ---------------------------------------------------------------- forward
+    def _side_stream(self, device):
+        st = getattr(self, "_text_stream", None)
+        if st is None or st.device != device:
+            st = torch.cuda.Stream(device=device)
+            self._text_stream = st
+        return st
+
     def forward(self, images, captions):
         cb = CaptionBatch.from_list(captions)
-        v_feat = self.v_encoder_q(images)
-        t_feat = self.t_encoder_q(cb)
+        if not images.is_cuda:
+            raise RuntimeError("textreid_amd.MoCoHead runs on the HIP kernel library only (CUDA tensors); no CPU fallback")
         if self.training:
+            # The text encoders are a chain of ~130 tiny launch-bound kernels per pass: they run on a
+            # side HIP stream underneath the (CU-filling) image encoders.  The momentum update only
+            # reads query parameters, which do not change during the forward, so doing it first is
+            # equivalent to the reference order (head.py:133) and lets the key text encoder start early.
+            main = torch.cuda.current_stream()
+            side = self._side_stream(images.device)
+            with torch.no_grad():
+                self._momentum_update_key_encoder()
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                t_feat = self.t_encoder_q(cb)
+                with torch.no_grad():
+                    tk_feat = self.t_encoder_k(cb)
+            v_feat = self.v_encoder_q(images)
+            with torch.no_grad():
+                vk_feat = self.v_encoder_k(images)
+            main.wait_stream(side)
+            t_feat.record_stream(main)
+            tk_feat.record_stream(main)
             v_embed = losses.linear(v_feat, self.v_embed_layer.weight, self.v_embed_layer.bias)
             t_embed = losses.linear(t_feat, self.t_embed_layer.weight, self.t_embed_layer.bias)
             id_q = cb.ids.long()
             with torch.no_grad():
-                self._momentum_update_key_encoder()
-                vk_feat = self.v_encoder_k(images)
-                tk_feat = self.t_encoder_k(cb)
                 v_embed_k = losses.l2_normalize(losses.linear(vk_feat, self.v_embed_layer.weight, self.v_embed_layer.bias))
                 t_embed_k = losses.l2_normalize(losses.linear(tk_feat, self.t_embed_layer.weight, self.t_embed_layer.bias))
             if world_size() > 1:
@@ -153,6 +176,8 @@ class MoCoHead(nn.Module):
             )
             self._dequeue_and_enqueue(v_embed_k, t_embed_k, id_q)
             return out
+        v_feat = self.v_encoder_q(images)
+        t_feat = self.t_encoder_q(cb)
         v_embed = losses.linear(v_feat, self.v_embed_layer.weight, self.v_embed_layer.bias)
         t_embed = losses.linear(t_feat, self.t_embed_layer.weight, self.t_embed_layer.bias)
         return [v_embed, t_embed]
