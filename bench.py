@@ -206,7 +206,7 @@ def main():
             },
             "roofline": {
                 "bound": "mfma",
-                "kernel": "trid::gemm_kernel<A_CONV,B_KC,128,128,2,2> (3x3 implicit-GEMM conv fwd+dgrad, fp32 MFMA 32x32x2)",
+                "kernel": "trid::gemm_kernel<A_CONV,B_KC,128,128,2,4> (3x3 implicit-GEMM conv fwd+dgrad, fp32 MFMA 32x32x2)",
                 "achieved": achieved,
                 "peak": F32_MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s",

@@ -21,6 +21,8 @@
 // :114-133 (attention-pool projections), gru.py:36-43 (GRU projections),
 // head.py:50-51,159-170 (embed layers, queue logits), losses.py:52-53,109-112.
 
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace trid {
@@ -51,11 +53,11 @@ struct GemmParams {
 };
 
 constexpr int BK = 32;
-constexpr int NTHREADS = 256;
 
 template <int AMODE, int BMODE, int BM, int BN, int WAVES_M, int WAVES_N>
-__global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmParams p) {
-    static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void gemm_kernel(GemmParams p) {
+    constexpr int NTHREADS = WAVES_M * WAVES_N * 64;
+    static_assert(NTHREADS == 256 || NTHREADS == 512, "4 or 8 waves per workgroup");
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     constexpr int TM = WM / 32, TN = WN / 32;
     static_assert(TM >= 1 && TN >= 1, "wave tile must hold a 32x32 MFMA tile");
@@ -413,7 +415,7 @@ static int launch(GemmParams& p, hipStream_t stream) {
         }
         attr_done = true;
     }
-    hipLaunchKernelGGL((gemm_kernel<AMODE, BMODE, BM, BN, WAVES_M, WAVES_N>), grid, dim3(NTHREADS), lds, stream, p);
+    hipLaunchKernelGGL((gemm_kernel<AMODE, BMODE, BM, BN, WAVES_M, WAVES_N>), grid, dim3(WAVES_M * WAVES_N * 64), lds, stream, p);
     return check_launch("trid_gemm_f32");
 }
 
@@ -426,7 +428,11 @@ static int dispatch_tile(GemmParams& p, hipStream_t stream) {
     const int bn = p.N >= 96 ? 128 : (p.N > 32 ? 64 : 32);
     if (p.stats != nullptr) bm = 128;
     if (bm == 128) {
-        if (bn == 128) return launch<AMODE, BMODE, 128, 128, 2, 2>(p, stream);
+        if (bn == 128) {
+            static const bool four = getenv("TRID_GEMM4") != nullptr;  // A/B switch: 4-wave 64x64 wave tiles
+            if (!four) return launch<AMODE, BMODE, 128, 128, 2, 4>(p, stream);
+            return launch<AMODE, BMODE, 128, 128, 2, 2>(p, stream);
+        }
         if (bn == 64) return launch<AMODE, BMODE, 128, 64, 2, 2>(p, stream);
         return launch<AMODE, BMODE, 128, 32, 4, 1>(p, stream);
     }

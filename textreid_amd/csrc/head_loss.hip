@@ -155,29 +155,46 @@ __global__ __launch_bounds__(256) void smooth_ce_rows_kernel(float* __restrict__
     if (threadIdx.x == 0) loss_rows[row] = -(1.f - eps) * (sy - lse) - un * (sum - (float)n * lse);
 }
 
-// projection [C,N]: thread per column
-__global__ void colnorm_kernel(const float* __restrict__ proj, float* __restrict__ pn, float* __restrict__ pnt,
-                               float* __restrict__ inv_norm, int C, int N, int ldn) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= ldn) return;
-    if (j >= N) {
-        for (int c = 0; c < C; ++c) {
-            if (pn) pn[(long long)c * ldn + j] = 0.f;
-            pnt[(long long)j * C + c] = 0.f;
-        }
-        return;
-    }
+// projection [C,N] -> pn [C,ldn] (optional) and pnt [ldn,C]: one workgroup per 64 columns.
+// Reads are coalesced along N, the transposed write goes through an LDS tile.
+__global__ __launch_bounds__(256) void colnorm_kernel(const float* __restrict__ proj, float* __restrict__ pn,
+                                                      float* __restrict__ pnt, float* __restrict__ inv_norm, int C, int N,
+                                                      int ldn) {
+    __shared__ float tile[64][65];
+    __shared__ float part[4][64];
+    __shared__ float invs[64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int j0 = blockIdx.x * 64;
+    const int j = j0 + cl;
     float s = 0.f;
-    for (int c = 0; c < C; ++c) {
-        const float v = proj[(long long)c * N + j];
-        s = fmaf(v, v, s);
+    if (j < N)
+        for (int c = rl; c < C; c += 4) {
+            const float v = proj[(long long)c * N + j];
+            s = fmaf(v, v, s);
+        }
+    part[rl][cl] = s;
+    __syncthreads();
+    if (rl == 0) {
+        const float t = part[0][cl] + part[1][cl] + part[2][cl] + part[3][cl];
+        const float inv = j < N ? 1.f / fmaxf(sqrtf(t), 1e-12f) : 0.f;
+        invs[cl] = inv;
+        if (j < N) inv_norm[j] = inv;
     }
-    const float inv = 1.f / fmaxf(sqrtf(s), 1e-12f);
-    inv_norm[j] = inv;
-    for (int c = 0; c < C; ++c) {
-        const float v = proj[(long long)c * N + j] * inv;
-        if (pn) pn[(long long)c * ldn + j] = v;
-        pnt[(long long)j * C + c] = v;
+    __syncthreads();
+    const float inv = invs[cl];
+    for (int c0 = 0; c0 < C; c0 += 64) {
+        for (int c = c0 + rl; c < c0 + 64 && c < C; c += 4) {
+            const float v = j < N ? proj[(long long)c * N + j] * inv : 0.f;
+            if (pn != nullptr && j < ldn) pn[(long long)c * ldn + j] = v;
+            tile[c - c0][cl] = v;
+        }
+        __syncthreads();
+        // write pnt rows j0..j0+63, columns c0..c0+63: lanes along c
+        for (int jj = rl; jj < 64; jj += 4) {
+            const int c = c0 + cl;
+            if (j0 + jj < ldn && c < C) pnt[(long long)(j0 + jj) * C + c] = tile[cl][jj];
+        }
+        __syncthreads();
     }
 }
 
@@ -315,8 +332,8 @@ extern "C" int trid_smooth_ce_rows_f32(float* logits, const int64_t* labels, flo
 extern "C" int trid_colnorm_f32(const float* proj, float* pn, float* pnt, float* inv_norm, int C, int N, int ldn,
                                 void* stream) {
     TRID_REQUIRE(proj && pnt && inv_norm && C > 0 && N > 0 && ldn >= N, "trid_colnorm_f32: bad arguments");
-    hipLaunchKernelGGL(colnorm_kernel, dim3((ldn + 255) / 256), dim3(256), 0, (hipStream_t)stream, proj, pn, pnt, inv_norm,
-                       C, N, ldn);
+    hipLaunchKernelGGL(colnorm_kernel, dim3((ldn + 63) / 64), dim3(256), 0, (hipStream_t)stream, proj, pn, pnt, inv_norm, C,
+                       N, ldn);
     return check_launch("trid_colnorm_f32");
 }
 

@@ -101,12 +101,22 @@ def linear(x, w, bias=None, out=None, alpha=1.0, accumulate=False):
 
 
 def matmul_nn(a, b, out=None, alpha=1.0, accumulate=False):
-    """out[M,N] = a[M,K] @ b[K,N] (b rows N-contiguous)."""
+    """out[M,N] = a[M,K] @ b[K,N] (b rows N-contiguous).  Skinny outputs with a long
+    K (loss gradients: [B,K_queue]x[K_queue,C]) are split over K into slabs so the
+    launch fills the chip instead of running a serial K loop on a handful of CUs."""
     M, K = a.shape
     N = b.shape[1]
     if out is None:
         out = empty((M, N), a)
-    gemm(a, b, out, M, N, K, a.stride(0), b.stride(0), out.stride(0), b_mode=B_NC, alpha=alpha, accumulate=accumulate)
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    splits = min(K // 128, (256 + tiles - 1) // tiles) if (tiles < 64 and K >= 1024 and out.stride(0) == N) else 1
+    if splits <= 1:
+        gemm(a, b, out, M, N, K, a.stride(0), b.stride(0), out.stride(0), b_mode=B_NC, alpha=alpha,
+             accumulate=accumulate)
+        return out
+    slab = empty((splits, M, N), a)
+    gemm(a, b, slab, M, N, K, a.stride(0), b.stride(0), N, b_mode=B_NC, alpha=alpha, splits=splits, strideSplit=M * N)
+    call("trid_slab_reduce_f32", _p(slab), _p(out), M * N, splits, M * N, 1 if accumulate else 0, stream())
     return out
 
 
