@@ -128,11 +128,11 @@ class MoCoHead(nn.Module):
                  self.embed_size, B, ops.stream())
 
     # ---------------------------------------------------------------- forward
-    def _side_stream(self, device):
-        st = getattr(self, "_text_stream", None)
+    def _side_stream(self, device, which="_text_stream"):
+        st = getattr(self, which, None)
         if st is None or st.device != device:
             st = torch.cuda.Stream(device=device)
-            self._text_stream = st
+            setattr(self, which, st)
         return st
 
     def forward(self, images, captions):
@@ -153,12 +153,18 @@ class MoCoHead(nn.Module):
                 t_feat = self.t_encoder_q(cb)
                 with torch.no_grad():
                     tk_feat = self.t_encoder_k(cb)
-            v_feat = self.v_encoder_q(images)
-            with torch.no_grad():
+            # The key image encoder (no_grad) runs on a second side stream: its HBM-bound
+            # BatchNorm / pooling passes overlap the MFMA-bound GEMMs of the query encoder.
+            side_k = self._side_stream(images.device, "_key_stream")
+            side_k.wait_stream(main)
+            with torch.cuda.stream(side_k), torch.no_grad():
                 vk_feat = self.v_encoder_k(images)
+            v_feat = self.v_encoder_q(images)
             main.wait_stream(side)
+            main.wait_stream(side_k)
             t_feat.record_stream(main)
             tk_feat.record_stream(main)
+            vk_feat.record_stream(main)
             v_embed = losses.linear(v_feat, self.v_embed_layer.weight, self.v_embed_layer.bias)
             t_embed = losses.linear(t_feat, self.t_embed_layer.weight, self.t_embed_layer.bias)
             id_q = cb.ids.long()
