@@ -26,6 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak
 
 
 def log(msg):
@@ -157,7 +158,8 @@ def main():
         torch.cuda.synchronize()
         log("warmup step %d done" % i)
     # live roofline of the dominant kernel: 3x3 implicit-GEMM conv, 128x128 tiles
-    dom = (ops.A_CONV, ops.B_KC, 128, 128)
+    split = ops.GEMM_PRECISION in (3, 6)
+    dom = (ops.A_CONV, ops.B_KC, 128, 128, split)
     ops.PROFILE = {"match": lambda key: key == dom, "events": []}
     if world > 1:
         dist.barrier()
@@ -165,11 +167,12 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         last = step(args.warmup + i)
+    t_host = time.perf_counter() - t0
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
-    log("timed region: %.3fs for %d steps" % (dt, args.steps))
+    log("timed region: %.3fs for %d steps (host enqueue time %.3fs)" % (dt, args.steps, t_host))
     prof, ops.PROFILE = ops.PROFILE, None
     tmax = torch.tensor([dt], device=device)
     if world > 1:
@@ -182,6 +185,31 @@ def main():
     nlaunch = len(prof["events"])
     achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
 
+    prec = ops.GEMM_PRECISION
+    if prec in (3, 6):
+        # the dominant kernel executes `prec` bf16 MFMA products per fp32 multiply-add
+        peak = BF16_MFMA_PEAK_TFLOPS / prec
+        kname = "trid::gemm_bf16s_kernel<A_CONV,B_KC,%d planes> (3x3 implicit-GEMM conv fwd+dgrad; fp32 operands split into bf16 planes, %d bf16 MFMA 32x32x16 products per multiply-add, fp32 accumulate)" % (prec // 2, prec)
+        peak_note = "dense bf16 MFMA peak 2500 TFLOP/s / %d products = fp32-equivalent peak" % prec
+        arith = "fp32 operands and accumulation; products evaluated as %d bf16 MFMA terms of a %d-way bf16 split (dropped terms <= 2^-%d)" % (prec, prec // 2, 26 if prec == 6 else 17)
+    else:
+        peak = F32_MFMA_PEAK_TFLOPS
+        kname = "trid::gemm_kernel<A_CONV,B_KC,128,128,2,4> (3x3 implicit-GEMM conv fwd+dgrad, fp32 MFMA 32x32x2)"
+        peak_note = "fp32-input MFMA dense peak"
+        arith = "exact fp32-input MFMA"
+    roofline = {
+        "bound": "mfma",
+        "kernel": kname,
+        "achieved": achieved,
+        "peak": peak,
+        "unit": "TFLOP/s",
+        "frac": achieved / peak,
+        "traffic": None,
+        "peak_note": peak_note,
+        "launches": nlaunch,
+        "avg_launch_ms": ms / max(nlaunch, 1),
+        "algorithmic_gflop_per_launch": flops / max(nlaunch, 1) / 1e9,
+    }
     if rank == 0:
         out = {
             "metric": "image-text pairs/sec (train), CLIP-RN50 + BiGRU MoCo step, bs128/GPU",
@@ -202,20 +230,10 @@ def main():
                 "global_batch": B * world,
                 "parallelism": "dp%d" % world,
                 "optimizer": "Adam (fused multi-tensor)",
+                "gemm_arithmetic": arith,
                 "final_loss": loss_val,
             },
-            "roofline": {
-                "bound": "mfma",
-                "kernel": "trid::gemm_kernel<A_CONV,B_KC,128,128,2,4> (3x3 implicit-GEMM conv fwd+dgrad, fp32 MFMA 32x32x2)",
-                "achieved": achieved,
-                "peak": F32_MFMA_PEAK_TFLOPS,
-                "unit": "TFLOP/s",
-                "frac": achieved / F32_MFMA_PEAK_TFLOPS,
-                "traffic": None,
-                "launches": nlaunch,
-                "avg_launch_ms": ms / max(nlaunch, 1),
-                "algorithmic_gflop_per_launch": flops / max(nlaunch, 1) / 1e9,
-            },
+            "roofline": roofline,
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()

@@ -70,6 +70,10 @@ typedef struct trid_gemm_desc {
     int64_t strideBias; /* batch stride of bias, elements */
     float* stats;       /* NULL, or [ceil(M/128)][N][2] per-tile column (mean, M2) partials */
     int32_t H, W, Cin;  /* conv gather geometry */
+    int32_t precision;  /* 0: exact fp32-input MFMA; 6 / 3: fp32 operands split on the fly into 3 / 2 bf16
+                         * planes, 6 / 3 bf16 MFMAs per product, fp32 accumulate (6 is fp32-class, dropped
+                         * terms <= 2^-26; 3 drops ~2^-17).  Shapes the split kernel does not cover fall
+                         * back to 0. */
 } trid_gemm_desc;
 
 int trid_gemm_f32(const trid_gemm_desc* d, void* stream);

@@ -227,3 +227,27 @@ def test_small_ops(ops):
     dp = R("sd", 20, 196)
     pr.backward(dp[:, :193])
     assert rel(ops.softmax_rows_bwd(p, dev(dp), 193)[:, :193], sr.grad) < 1e-5
+
+
+@pytest.mark.parametrize("prec,tol", [(0, 2e-5), (6, 2e-5), (3, 1e-3)])
+def test_gemm_arithmetic_modes(ops, prec, tol):
+    """precision 0 = exact fp32-input MFMA, 6 = 3-plane bf16 split (fp32-class), 3 = 2-plane."""
+    old = ops.GEMM_PRECISION
+    ops.GEMM_PRECISION = prec
+    try:
+        x, w, b = R("mx", 512, 264), R("mw", 200, 264), R("mb", 200)
+        assert rel(ops.linear(dev(x), dev(w), dev(b)), x @ w.t() + b) < tol
+        a, bb = R("ma", 4096, 128), R("mbb", 4096, 256)
+        assert rel(ops.matmul_tn(dev(a), dev(bb)), (a.double().t() @ bb.double()).float()) < tol
+        xc, wc, gy = R("mcx", 2, 64, 24, 8), R("mcw", 128, 64, 3, 3, scale=0.1), R("mcg", 2, 128, 24, 8)
+        xr, wr = xc.clone().requires_grad_(True), wc.clone().requires_grad_(True)
+        y_ref = F.conv2d(xr, wr, padding=1)
+        y_ref.backward(gy)
+        y, st = ops.conv3x3(dev(nhwc(xc)), dev(ohwi(wc)), stats=True)
+        assert rel(y.permute(0, 3, 1, 2), y_ref) < tol
+        assert rel(ops.conv3x3_wgrad(dev(nhwc(gy)), dev(nhwc(xc))), ohwi(wr.grad)) < tol
+        # large-magnitude / tiny-magnitude operands: the split must stay relative-accurate
+        big, small = R("mbig", 256, 256) * 1e4, R("msm", 256, 256) * 1e-6
+        assert rel(ops.linear(dev(big), dev(small)), big @ small.t()) < tol
+    finally:
+        ops.GEMM_PRECISION = old

@@ -23,36 +23,10 @@
 
 #include <stdlib.h>
 
-#include "common.h"
+#include "gemm_common.h"
 
 namespace trid {
 
-typedef float v16f __attribute__((ext_vector_type(16)));
-
-enum { A_KC = 0, A_MC = 1, A_CONV = 2 };
-enum { B_KC = 0, B_NC = 1, B_CONV = 2 };
-
-struct GemmParams {
-    const float* A;
-    const float* B;
-    float* C;
-    int M, N, K;
-    long long lda, ldb, ldc;
-    long long sA, sB, sC;  // batch strides (elements)
-    int batch, splits;     // gridDim.z = batch * splits
-    int k_chunk;           // K range per split (multiple of BK)
-    long long sSplit;      // C offset per split (slab stride, elements)
-    float alpha;
-    int accumulate;
-    const float* bias;  // [N] or null
-    long long sBias;
-    float* stats;       // [mblocks][N][2] (mean, M2) or null
-    int H, W, Cin;      // conv geometry (A_CONV: M=Bimg*H*W,K=9*Cin; B_CONV: K=Bimg*H*W,N=9*Cin)
-    FastDiv fdW, fdH, fdC;
-    int mblocks, nblocks;
-};
-
-constexpr int BK = 32;
 
 template <int AMODE, int BMODE, int BM, int BN, int WAVES_M, int WAVES_N>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void gemm_kernel(GemmParams p) {
@@ -487,6 +461,11 @@ extern "C" int trid_gemm_f32(const trid_gemm_desc* d, void* stream_) {
 
     int rc;
     const int am = d->a_mode, bm = d->b_mode;
+    if ((d->precision == 3 || d->precision == 6) && d->K % 8 == 0 && d->K >= 32 && d->M >= 96 && d->N >= 96 &&
+        (am != A_CONV || d->Cin % 8 == 0)) {
+        rc = gemm_bf16_dispatch(p, am, bm, d->precision, stream);
+        if (rc != TRID_E_UNSUPPORTED) return rc;
+    }
     if (am == A_KC && bm == B_KC) rc = dispatch_tile<A_KC, B_KC>(p, stream);
     else if (am == A_CONV && bm == B_KC) rc = dispatch_tile<A_CONV, B_KC>(p, stream);
     else if (am == A_KC && bm == B_NC) rc = dispatch_tile<A_KC, B_NC>(p, stream);

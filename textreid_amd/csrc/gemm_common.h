@@ -1,0 +1,38 @@
+// Shared definitions of the GEMM / implicit-GEMM kernel family (gemm.hip, gemm_bf16.hip).
+#pragma once
+#include "common.h"
+
+namespace trid {
+
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+enum { A_KC = 0, A_MC = 1, A_CONV = 2 };
+enum { B_KC = 0, B_NC = 1, B_CONV = 2 };
+
+struct GemmParams {
+    const float* A;
+    const float* B;
+    float* C;
+    int M, N, K;
+    long long lda, ldb, ldc;
+    long long sA, sB, sC;  // batch strides (elements)
+    int batch, splits;     // gridDim.z = batch * splits
+    int k_chunk;           // K range per split (multiple of BK)
+    long long sSplit;      // C offset per split (slab stride, elements)
+    float alpha;
+    int accumulate;
+    const float* bias;  // [N] or null
+    long long sBias;
+    float* stats;       // [mblocks][N][2] (mean, M2) or null
+    int H, W, Cin;      // conv geometry (A_CONV: M=Bimg*H*W,K=9*Cin; B_CONV: K=Bimg*H*W,N=9*Cin)
+    FastDiv fdW, fdH, fdC;
+    int mblocks, nblocks;
+};
+
+constexpr int BK = 32;
+
+// split-precision variants (gemm_bf16.hip): fp32 operands split on the fly into 2 or 3
+// bf16 planes, 3 or 6 bf16 MFMAs per product, fp32 accumulation
+int gemm_bf16_dispatch(GemmParams& p, int a_mode, int b_mode, int precision, hipStream_t stream);
+
+}  // namespace trid

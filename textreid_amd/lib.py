@@ -43,6 +43,7 @@ class GemmDesc(ctypes.Structure):
         ("H", ctypes.c_int32),
         ("W", ctypes.c_int32),
         ("Cin", ctypes.c_int32),
+        ("precision", ctypes.c_int32),
     ]
 
 

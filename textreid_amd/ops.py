@@ -20,6 +20,13 @@ B_KC, B_NC, B_CONV = L.TRID_B_KC, L.TRID_B_NC, L.TRID_B_CONV
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
 STATS_ROWS = 128  # rows per BatchNorm-statistics partial (GEMM tile height)
+# GEMM arithmetic (trid_gemm_desc.precision):
+#   6 (default): fp32 operands split on the fly into 3 bf16 planes, 6 bf16 MFMA products per
+#      multiply-add, fp32 accumulate -- dropped terms <= 2^-26, i.e. fp32-class results (parity
+#      tests pass at the same error level as the exact path) at ~1.5x the fp32-MFMA rate;
+#   0: exact fp32-input MFMA (v_mfma_f32_32x32x2_f32);
+#   3: 2 planes / 3 products (~2^-17 per product): faster, NOT parity-safe, never the default.
+GEMM_PRECISION = int(__import__("os").environ.get("TRID_GEMM_PRECISION", "6"))
 
 
 def stream():
@@ -29,6 +36,12 @@ def stream():
 # Optional live profiling hook (bench.py): when PROFILE is a dict with a "match"
 # predicate, every matching GEMM launch is bracketed by events on the launch stream.
 PROFILE = None
+
+
+def _uses_split(M, N, K, a_mode, conv):
+    """Mirror of the split-kernel eligibility test in trid_gemm_f32()."""
+    return (GEMM_PRECISION in (3, 6) and K % 8 == 0 and K >= 32 and M >= 96 and N >= 96
+            and (a_mode != A_CONV or conv[2] % 8 == 0))
 
 
 def _gemm_tile(M, N, stats):
@@ -77,9 +90,11 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, a_mode=A_KC, b_mode=B_KC, alpha=1.0, a
     d.stats = _p(stats)
     if conv is not None:
         d.H, d.W, d.Cin = conv
+    d.precision = GEMM_PRECISION
     prof = PROFILE
     if prof is not None:
-        key = (a_mode, b_mode) + _gemm_tile(M, N, stats is not None)
+        split = _uses_split(M, N, K, a_mode, conv)
+        key = (a_mode, b_mode) + ((128, 128) if split else _gemm_tile(M, N, stats is not None)) + (split,)
         if prof["match"](key):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
