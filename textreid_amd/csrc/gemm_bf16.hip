@@ -14,53 +14,78 @@
 // row, slot = kgroup*(128+1) + row, one image per plane -> every MFMA operand fetch is one
 // conflict-free ds_read_b128 per plane.
 
+#include <stdlib.h>
+
 #include "gemm_common.h"
 
 namespace trid {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int T_ROWS = 128;          // BM = BN
-constexpr int R1 = T_ROWS + 1;       // padded slots per k-group
-constexpr int PLANE = 4 * R1;        // slots per plane (BK/8 = 4 k-groups)
-constexpr int NT = 512;
+constexpr int BN_T = 128;             // tile width
+constexpr int NT = 512;               // 8 waves
+// LDS image of one operand tile with R rows: 16-byte slots, slot = kgroup*(R+1) + row, one image per plane
+__host__ __device__ constexpr int plane_slots(int R) { return 4 * (R + 1); }
 
-template <int NPL>
+// two fp32 -> one dword of two bf16 (round-to-nearest-even); `lo` lands in bits 0..15
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+
+template <int NPL, int PLANE>
 __device__ __forceinline__ void split_store(const float (&v)[8], uint4* __restrict__ dst) {
-    // dst: plane 0 slot; planes are PLANE slots apart
-    unsigned short h[NPL][8];
+    // dst: plane 0 slot; planes are PLANE slots apart.  Per pair of values: one packed convert
+    // per plane, residuals formed exactly in fp32 (x - float(bf16(x)) is representable).
+    unsigned w[NPL][4];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        float r = v[j];
+    for (int q = 0; q < 4; ++q) {
+        float r0 = v[2 * q], r1 = v[2 * q + 1];
 #pragma unroll
         for (int pl = 0; pl < NPL; ++pl) {
-            const __bf16 b = (__bf16)r;  // round-to-nearest-even
-            h[pl][j] = __builtin_bit_cast(unsigned short, b);
-            r -= (float)b;  // exact in fp32
+            const unsigned h = cvt_pk_bf16(r0, r1);
+            w[pl][q] = h;
+            if (pl + 1 < NPL) {
+                r0 -= __builtin_bit_cast(float, h << 16);
+                r1 -= __builtin_bit_cast(float, h & 0xffff0000u);
+            }
         }
     }
 #pragma unroll
-    for (int pl = 0; pl < NPL; ++pl) {
-        uint4 u;
-        u.x = (unsigned)h[pl][0] | ((unsigned)h[pl][1] << 16);
-        u.y = (unsigned)h[pl][2] | ((unsigned)h[pl][3] << 16);
-        u.z = (unsigned)h[pl][4] | ((unsigned)h[pl][5] << 16);
-        u.w = (unsigned)h[pl][6] | ((unsigned)h[pl][7] << 16);
-        dst[pl * PLANE] = u;
-    }
+    for (int pl = 0; pl < NPL; ++pl) dst[pl * PLANE] = make_uint4(w[pl][0], w[pl][1], w[pl][2], w[pl][3]);
 }
 
-template <int AMODE, int BMODE, int NPL>
+// predicated loads without divergent branches: read from a always-valid address, then select
+__device__ __forceinline__ float4 ld4_if(bool ok, const float* __restrict__ p, const float* __restrict__ safe) {
+    const float4 v = *reinterpret_cast<const float4*>(ok ? p : safe);
+    return ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+__device__ __forceinline__ float ld1_if(bool ok, const float* __restrict__ p, const float* __restrict__ safe) {
+    const float v = *(ok ? p : safe);
+    return ok ? v : 0.f;
+}
+
+// BM = 128: 2x4 waves (64x32 per wave), one LDS stage, 2 workgroups per CU.
+// BM = 256: 4x2 waves (64x64 per wave), two LDS stages (one barrier per K-tile), 1 workgroup per CU:
+//           25 % less LDS write traffic and half the LDS reads per MFMA.
+template <int AMODE, int BMODE, int NPL, int BM>
 __global__ __launch_bounds__(NT) void gemm_bf16s_kernel(GemmParams p) {
-    constexpr int BM = T_ROWS, BN = T_ROWS;
+    constexpr int BN = BN_T;
+    constexpr int WAVES_N = (BM == 256) ? 2 : 4;
+    constexpr int WN = BN / WAVES_N;  // 64 or 32
+    constexpr int TN = WN / 32;       // 2 or 1
+    constexpr int STAGES = (BM == 256) ? 2 : 1;
+    constexpr int PA = plane_slots(BM), PB = plane_slots(BN);
+    constexpr int RA1 = BM + 1, RB1 = BN + 1;
+    constexpr int STAGE = NPL * (PA + PB);  // slots per stage
+    constexpr int APASS = BM / 128;         // loader passes over the A rows
     extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
-    uint4* As = smem4;
-    uint4* Bs = smem4 + NPL * PLANE;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int wm = wave >> 2, wn = wave & 3;  // 2 x 4 waves, wave tile 64 x 32
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int khalf = lane >> 5;
 
     const uint32_t nwg = (uint32_t)p.mblocks * (uint32_t)p.nblocks;
@@ -83,13 +108,16 @@ __global__ __launch_bounds__(NT) void gemm_bf16s_kernel(GemmParams p) {
     const int a_kg = A_K ? (tid & 3) : (tid >> 7), a_row = A_K ? (tid >> 2) : (tid & 127);
     const int b_kg = B_K ? (tid & 3) : (tid >> 7), b_row = B_K ? (tid >> 2) : (tid & 127);
 
-    int a_y = 0, a_x = 0;
+    int a_y[APASS], a_x[APASS];
     if (AMODE == A_CONV) {
-        const int m = m0 + a_row;
-        const uint32_t q = fdiv((uint32_t)m, p.fdW);
-        a_x = m - (int)q * p.W;
-        const uint32_t b = fdiv(q, p.fdH);
-        a_y = (int)q - (int)b * p.H;
+#pragma unroll
+        for (int ps = 0; ps < APASS; ++ps) {
+            const int m = m0 + a_row + ps * 128;
+            const uint32_t q = fdiv((uint32_t)m, p.fdW);
+            a_x[ps] = m - (int)q * p.W;
+            const uint32_t b = fdiv(q, p.fdH);
+            a_y[ps] = (int)q - (int)b * p.H;
+        }
     }
     int b_dy = 0, b_dx = 0, b_c = 0;
     if (BMODE == B_CONV) {
@@ -100,60 +128,52 @@ __global__ __launch_bounds__(NT) void gemm_bf16s_kernel(GemmParams p) {
         b_dx = (int)tap % 3 - 1;
     }
 
-    float ra[8], rb[8];
+    float ra[APASS][8], rb[8];
 
     auto load_tiles = [&](int k0) {
         // ---- A ----
-        if (AMODE == A_KC) {
-            const int m = m0 + a_row, k = k0 + 8 * a_kg;
-            if (m < p.M && k < k_end) {
-                const float4 u = *reinterpret_cast<const float4*>(A + (long long)m * p.lda + k);
-                const float4 v = *reinterpret_cast<const float4*>(A + (long long)m * p.lda + k + 4);
-                ra[0] = u.x; ra[1] = u.y; ra[2] = u.z; ra[3] = u.w; ra[4] = v.x; ra[5] = v.y; ra[6] = v.z; ra[7] = v.w;
-            } else {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) ra[j] = 0.f;
-            }
-        } else if (AMODE == A_CONV) {
-            const int m = m0 + a_row, k = k0 + 8 * a_kg;
-            const uint32_t tap = fdiv((uint32_t)k, p.fdC);
-            const int c = k - (int)tap * p.Cin;
-            const int dy = (int)tap / 3 - 1, dx = (int)tap % 3 - 1;
-            const int yy = a_y + dy, xx = a_x + dx;
-            if (m < p.M && k < k_end && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) {
+        for (int ps = 0; ps < APASS; ++ps) {
+            const int m = m0 + a_row + ps * 128;
+            if (AMODE == A_KC) {
+                const int k = k0 + 8 * a_kg;
+                const bool ok = m < p.M && k < k_end;
+                const float* src = A + (long long)m * p.lda + k;
+                const float4 u = ld4_if(ok, src, A), v = ld4_if(ok, src + 4, A);
+                ra[ps][0] = u.x; ra[ps][1] = u.y; ra[ps][2] = u.z; ra[ps][3] = u.w;
+                ra[ps][4] = v.x; ra[ps][5] = v.y; ra[ps][6] = v.z; ra[ps][7] = v.w;
+            } else if (AMODE == A_CONV) {
+                const int k = k0 + 8 * a_kg;
+                const uint32_t tap = fdiv((uint32_t)k, p.fdC);
+                const int c = k - (int)tap * p.Cin;
+                const int dy = (int)tap / 3 - 1, dx = (int)tap % 3 - 1;
+                const int yy = a_y[ps] + dy, xx = a_x[ps] + dx;
+                const bool ok = m < p.M && k < k_end && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
                 const float* src = A + (long long)(m + dy * p.W + dx) * p.Cin + c;
-                const float4 u = *reinterpret_cast<const float4*>(src);
-                const float4 v = *reinterpret_cast<const float4*>(src + 4);
-                ra[0] = u.x; ra[1] = u.y; ra[2] = u.z; ra[3] = u.w; ra[4] = v.x; ra[5] = v.y; ra[6] = v.z; ra[7] = v.w;
-            } else {
+                const float4 u = ld4_if(ok, src, A), v = ld4_if(ok, src + 4, A);
+                ra[ps][0] = u.x; ra[ps][1] = u.y; ra[ps][2] = u.z; ra[ps][3] = u.w;
+                ra[ps][4] = v.x; ra[ps][5] = v.y; ra[ps][6] = v.z; ra[ps][7] = v.w;
+            } else {  // A_MC: A[k*lda + m], lanes along m
 #pragma unroll
-                for (int j = 0; j < 8; ++j) ra[j] = 0.f;
-            }
-        } else {  // A_MC: A[k*lda + m], lanes along m
-            const int m = m0 + a_row;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int k = k0 + 8 * a_kg + j;
-                ra[j] = (m < p.M && k < k_end) ? A[(long long)k * p.lda + m] : 0.f;
+                for (int j = 0; j < 8; ++j) {
+                    const int k = k0 + 8 * a_kg + j;
+                    ra[ps][j] = ld1_if(m < p.M && k < k_end, A + (long long)k * p.lda + m, A);
+                }
             }
         }
         // ---- B ----
         if (BMODE == B_KC) {
             const int n = n0 + b_row, k = k0 + 8 * b_kg;
-            if (n < p.N && k < k_end) {
-                const float4 u = *reinterpret_cast<const float4*>(Bp + (long long)n * p.ldb + k);
-                const float4 v = *reinterpret_cast<const float4*>(Bp + (long long)n * p.ldb + k + 4);
-                rb[0] = u.x; rb[1] = u.y; rb[2] = u.z; rb[3] = u.w; rb[4] = v.x; rb[5] = v.y; rb[6] = v.z; rb[7] = v.w;
-            } else {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) rb[j] = 0.f;
-            }
+            const bool ok = n < p.N && k < k_end;
+            const float* src = Bp + (long long)n * p.ldb + k;
+            const float4 u = ld4_if(ok, src, Bp), v = ld4_if(ok, src + 4, Bp);
+            rb[0] = u.x; rb[1] = u.y; rb[2] = u.z; rb[3] = u.w; rb[4] = v.x; rb[5] = v.y; rb[6] = v.z; rb[7] = v.w;
         } else if (BMODE == B_NC) {
             const int n = n0 + b_row;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int k = k0 + 8 * b_kg + j;
-                rb[j] = (n < p.N && k < k_end) ? Bp[(long long)k * p.ldb + n] : 0.f;
+                rb[j] = ld1_if(n < p.N && k < k_end, Bp + (long long)k * p.ldb + n, Bp);
             }
         } else {  // B_CONV: row k is a pixel, column n = (tap, c)
             const int n = n0 + b_row;
@@ -165,136 +185,185 @@ __global__ __launch_bounds__(NT) void gemm_bf16s_kernel(GemmParams p) {
                 const uint32_t b = fdiv(q, p.fdH);
                 const int y = (int)q - (int)b * p.H;
                 const int yy = y + b_dy, xx = x + b_dx;
-                rb[j] = (n < p.N && k < k_end && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W)
-                            ? Bp[(long long)(k + b_dy * p.W + b_dx) * p.Cin + b_c]
-                            : 0.f;
+                rb[j] = ld1_if(n < p.N && k < k_end && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W,
+                               Bp + (long long)(k + b_dy * p.W + b_dx) * p.Cin + b_c, Bp);
             }
         }
     };
 
-    auto store_tiles = [&]() {
-        split_store<NPL>(ra, As + a_kg * R1 + a_row);
-        split_store<NPL>(rb, Bs + b_kg * R1 + b_row);
+    auto store_tiles = [&](uint4* __restrict__ As, uint4* __restrict__ Bs) {
+#pragma unroll
+        for (int ps = 0; ps < APASS; ++ps) split_store<NPL, PA>(ra[ps], As + a_kg * RA1 + a_row + ps * 128);
+        split_store<NPL, PB>(rb, Bs + b_kg * RB1 + b_row);
     };
 
-    v16f acc[2];
+    v16f acc[2][TN];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int a_slot = wm * 64 + (lane & 31);
-    const int b_slot = wn * 32 + (lane & 31);
+    const int b_slot = wn * WN + (lane & 31);
+
+    auto compute_step = [&](const uint4* __restrict__ As, const uint4* __restrict__ Bs, int ks) {
+        bf16x8 a[NPL][2], b[NPL][TN];
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) {
+            const int sa = pl * PA + (2 * ks + khalf) * RA1, sb = pl * PB + (2 * ks + khalf) * RB1;
+            a[pl][0] = __builtin_bit_cast(bf16x8, As[sa + a_slot]);
+            a[pl][1] = __builtin_bit_cast(bf16x8, As[sa + a_slot + 32]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[pl][j] = __builtin_bit_cast(bf16x8, Bs[sb + b_slot + 32 * j]);
+        }
+        // Term-major order: consecutive MFMAs hit DIFFERENT accumulators, so no MFMA waits on the
+        // result of the one issued just before it (dependent-accumulator latency > issue interval).
+        // Smallest terms first: mm, hl, lh (3 planes only), then hm, mh, hh.
+        constexpr int NTERM = (NPL == 3) ? 6 : 3;
+        constexpr int TA[6] = {1, 0, 2, 0, 1, 0};
+        constexpr int TB[6] = {1, 2, 0, 1, 0, 0};
+#pragma unroll
+        for (int t = 6 - NTERM; t < 6; ++t)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[TA[t] < NPL ? TA[t] : 0][i], b[TB[t] < NPL ? TB[t] : 0][j],
+                                                                        acc[i][j], 0, 0, 0);
+    };
 
     if (k_begin < k_end) {
         load_tiles(k_begin);
-        store_tiles();
+        store_tiles(smem4, smem4 + NPL * PA);
         __syncthreads();
+        int cur = 0;
         for (int k0 = k_begin; k0 < k_end; k0 += BK) {
             const bool more = (k0 + BK) < k_end;
             if (more) load_tiles(k0 + BK);
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                bf16x8 a[NPL][2], b[NPL];
-#pragma unroll
-                for (int pl = 0; pl < NPL; ++pl) {
-                    const int s = pl * PLANE + (2 * ks + khalf) * R1;
-                    a[pl][0] = __builtin_bit_cast(bf16x8, As[s + a_slot]);
-                    a[pl][1] = __builtin_bit_cast(bf16x8, As[s + a_slot + 32]);
-                    b[pl] = __builtin_bit_cast(bf16x8, Bs[s + b_slot]);
+            const uint4* As = smem4 + (STAGES == 2 ? cur * STAGE : 0);
+            const uint4* Bs = As + NPL * PA;
+            compute_step(As, Bs, 0);
+            if (STAGES == 2) {
+                if (more) {  // next tile -> the other stage, in the shadow of the second k-step
+                    uint4* nA = smem4 + (cur ^ 1) * STAGE;
+                    store_tiles(nA, nA + NPL * PA);
                 }
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    if (NPL == 3) {  // smallest terms first
-                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[1], acc[i], 0, 0, 0);
-                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[NPL - 1], acc[i], 0, 0, 0);
-                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[NPL - 1][i], b[0], acc[i], 0, 0, 0);
-                    }
-                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[1], acc[i], 0, 0, 0);
-                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[0], acc[i], 0, 0, 0);
-                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[0], acc[i], 0, 0, 0);
-                }
-            }
-            __syncthreads();
-            if (more) {
-                store_tiles();
+                compute_step(As, Bs, 1);
                 __syncthreads();
+                cur ^= 1;
+            } else {
+                compute_step(As, Bs, 1);
+                __syncthreads();
+                if (more) {
+                    store_tiles(smem4, smem4 + NPL * PA);
+                    __syncthreads();
+                }
             }
         }
     }
 
     // ---- epilogue (same contract as gemm.hip) -----------------------------------------
     const int row_base = m0 + wm * 64 + 4 * khalf;
-    const int col = n0 + wn * 32 + (lane & 31);
-    const float bv = (bias != nullptr && col < p.N) ? bias[col] : 0.f;
+    const int col_base = n0 + wn * WN + (lane & 31);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        float oldv[16];
-        if (p.accumulate) {
+    for (int j = 0; j < TN; ++j) {
+        const int col = col_base + 32 * j;
+        const float bv = (bias != nullptr && col < p.N) ? bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            float oldv[16];
+            if (p.accumulate) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = row_base + i * 32 + (r & 3) + 8 * (r >> 2);
+                    oldv[r] = (row < p.M && col < p.N) ? C[(long long)row * p.ldc + col] : 0.f;
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = row_base + i * 32 + (r & 3) + 8 * (r >> 2);
-                oldv[r] = (row < p.M && col < p.N) ? C[(long long)row * p.ldc + col] : 0.f;
+                float v = p.alpha * acc[i][j][r] + bv;
+                if (p.accumulate) v += oldv[r];
+                if (row < p.M && col < p.N) C[(long long)row * p.ldc + col] = v;
+                acc[i][j][r] = v;
             }
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = row_base + i * 32 + (r & 3) + 8 * (r >> 2);
-            float v = p.alpha * acc[i][r] + bv;
-            if (p.accumulate) v += oldv[r];
-            if (row < p.M && col < p.N) C[(long long)row * p.ldc + col] = v;
-            acc[i][r] = v;
         }
     }
 
     if (p.stats != nullptr) {
+        // BatchNorm partials are defined per 128-row group: a BM=256 tile emits two
+        constexpr int WAVES_M = 8 / WAVES_N;  // 2 or 4
+        constexpr int GROUPS = BM / 128;      // row groups of 128 = pairs of wave rows
         __syncthreads();
-        float* red = reinterpret_cast<float*>(smem4);  // [2][BN]
-        const int cnt = min(BM, p.M - m0);
+        float* red = reinterpret_cast<float*>(smem4);  // [WAVES_M][BN]
+        const int grp = wm >> 1;                       // wave rows 2g, 2g+1 form group g
+        const int rows_left = p.M - (m0 + grp * 128);
+        const int cnt = rows_left < 128 ? (rows_left > 0 ? rows_left : 1) : 128;
         const float inv = 1.f / (float)cnt;
-        const int cl = wn * 32 + (lane & 31);
-        float s = 0.f;
+        float mean[TN];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < TN; ++j) {
+            float s = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = row_base + i * 32 + (r & 3) + 8 * (r >> 2);
-                if (row < p.M) s += acc[i][r];
-            }
-        s += __shfl_xor(s, 32, 64);
-        if (khalf == 0) red[wm * BN + cl] = s;
-        __syncthreads();
-        const float mean = (red[cl] + red[BN + cl]) * inv;
-        __syncthreads();
-        s = 0.f;
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = row_base + i * 32 + (r & 3) + 8 * (r >> 2);
-                const float d = acc[i][r] - mean;
-                if (row < p.M) s += d * d;
-            }
-        s += __shfl_xor(s, 32, 64);
-        if (khalf == 0) red[wm * BN + cl] = s;
-        __syncthreads();
-        if (wm == 0 && khalf == 0 && col < p.N) {
-            float* dst = p.stats + ((long long)mb * p.N + col) * 2;
-            dst[0] = mean;
-            dst[1] = red[cl] + red[BN + cl];
+                for (int r = 0; r < 16; ++r) {
+                    const int row = row_base + i * 32 + (r & 3) + 8 * (r >> 2);
+                    if (row < p.M) s += acc[i][j][r];
+                }
+            s += __shfl_xor(s, 32, 64);
+            if (khalf == 0) red[wm * BN + wn * WN + 32 * j + (lane & 31)] = s;
         }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int cl = wn * WN + 32 * j + (lane & 31);
+            mean[j] = (red[(2 * grp) * BN + cl] + red[(2 * grp + 1) * BN + cl]) * inv;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = row_base + i * 32 + (r & 3) + 8 * (r >> 2);
+                    const float d = acc[i][j][r] - mean[j];
+                    if (row < p.M) s += d * d;
+                }
+            s += __shfl_xor(s, 32, 64);
+            if (khalf == 0) red[wm * BN + wn * WN + 32 * j + (lane & 31)] = s;
+        }
+        __syncthreads();
+        if ((wm & 1) == 0 && khalf == 0 && rows_left > 0) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int cl = wn * WN + 32 * j + (lane & 31);
+                const int col = n0 + cl;
+                if (col < p.N) {
+                    float* dst = p.stats + ((long long)(mb * GROUPS + grp) * p.N + col) * 2;
+                    dst[0] = mean[j];
+                    dst[1] = red[(2 * grp) * BN + cl] + red[(2 * grp + 1) * BN + cl];
+                }
+            }
+        }
+        (void)WAVES_M;
     }
 }
 
-template <int AMODE, int BMODE, int NPL>
+template <int AMODE, int BMODE, int NPL, int BM>
 static int launch_bf16(GemmParams& p, hipStream_t stream) {
-    p.mblocks = (p.M + T_ROWS - 1) / T_ROWS;
-    p.nblocks = (p.N + T_ROWS - 1) / T_ROWS;
+    p.mblocks = (p.M + BM - 1) / BM;
+    p.nblocks = (p.N + BN_T - 1) / BN_T;
     dim3 grid((unsigned)(p.mblocks * p.nblocks), 1, (unsigned)(p.batch * p.splits));
-    constexpr size_t lds = (size_t)2 * NPL * PLANE * sizeof(uint4);
+    constexpr int STAGES = (BM == 256) ? 2 : 1;
+    constexpr size_t lds = (size_t)STAGES * NPL * (plane_slots(BM) + plane_slots(BN_T)) * sizeof(uint4);
     static bool attr_done = false;
     if (!attr_done && lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16s_kernel<AMODE, BMODE, NPL>,
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16s_kernel<AMODE, BMODE, NPL, BM>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) {
             set_error("trid_gemm_f32(split): cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
@@ -302,17 +371,28 @@ static int launch_bf16(GemmParams& p, hipStream_t stream) {
         }
         attr_done = true;
     }
-    hipLaunchKernelGGL((gemm_bf16s_kernel<AMODE, BMODE, NPL>), grid, dim3(NT), lds, stream, p);
+    hipLaunchKernelGGL((gemm_bf16s_kernel<AMODE, BMODE, NPL, BM>), grid, dim3(NT), lds, stream, p);
     return check_launch("trid_gemm_f32(split)");
+}
+
+template <int AMODE, int BMODE, int NPL>
+static int pick_tile(GemmParams& p, hipStream_t stream) {
+    // 256-row tiles when there are enough of them to fill the chip (1 workgroup per CU)
+    static const int force = getenv("TRID_SPLIT_BM") ? atoi(getenv("TRID_SPLIT_BM")) : 0;
+    const long long blocks256 = (long long)((p.M + 255) / 256) * ((p.N + BN_T - 1) / BN_T) * p.batch * p.splits;
+    const bool big = force == 256;  // measured: 2 workgroups/CU of 128-row tiles beat 1 workgroup of 256 rows
+    (void)blocks256;
+    if (big) return launch_bf16<AMODE, BMODE, NPL, 256>(p, stream);
+    return launch_bf16<AMODE, BMODE, NPL, 128>(p, stream);
 }
 
 template <int NPL>
 static int dispatch_modes(GemmParams& p, int am, int bm, hipStream_t stream) {
-    if (am == A_KC && bm == B_KC) return launch_bf16<A_KC, B_KC, NPL>(p, stream);
-    if (am == A_CONV && bm == B_KC) return launch_bf16<A_CONV, B_KC, NPL>(p, stream);
-    if (am == A_KC && bm == B_NC) return launch_bf16<A_KC, B_NC, NPL>(p, stream);
-    if (am == A_MC && bm == B_NC) return launch_bf16<A_MC, B_NC, NPL>(p, stream);
-    if (am == A_MC && bm == B_CONV) return launch_bf16<A_MC, B_CONV, NPL>(p, stream);
+    if (am == A_KC && bm == B_KC) return pick_tile<A_KC, B_KC, NPL>(p, stream);
+    if (am == A_CONV && bm == B_KC) return pick_tile<A_CONV, B_KC, NPL>(p, stream);
+    if (am == A_KC && bm == B_NC) return pick_tile<A_KC, B_NC, NPL>(p, stream);
+    if (am == A_MC && bm == B_NC) return pick_tile<A_MC, B_NC, NPL>(p, stream);
+    if (am == A_MC && bm == B_CONV) return pick_tile<A_MC, B_CONV, NPL>(p, stream);
     return TRID_E_UNSUPPORTED;
 }
 
