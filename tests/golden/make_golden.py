@@ -408,8 +408,26 @@ def gen_rank(seed=7):
     np.savez_compressed(os.path.join(HERE, "rank.npz"), **out)
 
 
+def gen_ingest(seed=13):
+    """resize_pos_embed / state_filter (m_resnet.py:220-243): CLIP 7x7 grid -> 24x8 / 6x2."""
+    print("[ingest]")
+    out = {}
+    pe = OF.randn("ingest:pos", (50, 64), seed)
+    for tag, gs in (("a", (24, 8)), ("b", (6, 2))):
+        out["pos_" + tag] = ref_mr.resize_pos_embed(pe, gs).numpy()
+    sd = {"visual.conv1.weight": OF.randn("ingest:w", (4, 3, 3, 3), seed), "visual.attnpool.positional_embedding": pe,
+          "token_embedding.weight": OF.randn("ingest:t", (5, 4), seed)}
+    flt = ref_mr.state_filter(sd, (6, 2))
+    out["filter_keys"] = np.array(sorted(flt.keys()))
+    out["filter_pos"] = flt["attnpool.positional_embedding"].numpy()
+    out["pos_in"] = pe.numpy()
+    np.savez_compressed(os.path.join(HERE, "ingest.npz"), **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["losses", "rank", "text", "tiny", "head", "rn50", "rn101"]
+    which = sys.argv[1:] or ["losses", "rank", "text", "tiny", "head", "rn50", "rn101", "ingest"]
+    if "ingest" in which:
+        gen_ingest()
     if "losses" in which:
         gen_losses()
     if "rank" in which:

@@ -185,3 +185,20 @@ def test_lr_schedule_values():
         opt.step()
         sch.step()
     assert np.allclose(lrs, [0.1, 0.55, 1.0, 1.0, 0.1, 0.1, 0.1, 0.01, 0.01])
+
+
+def test_clip_checkpoint_ingestion_matches_reference(golden_dir):
+    """state_filter / resize_pos_embed (host-side checkpoint ingestion, m_resnet.py:220-243)
+    against vectors captured from the reference functions."""
+    import oracle.fill as OF
+    from textreid_amd.backbones.m_resnet import resize_pos_embed, state_filter
+
+    g = np.load(os.path.join(golden_dir, "ingest.npz"))
+    pe = torch.from_numpy(g["pos_in"])
+    assert np.allclose(resize_pos_embed(pe, (24, 8)).numpy(), g["pos_a"], atol=1e-6)
+    assert np.allclose(resize_pos_embed(pe, (6, 2)).numpy(), g["pos_b"], atol=1e-6)
+    sd = {"visual.conv1.weight": OF.randn("ingest:w", (4, 3, 3, 3), 13), "visual.attnpool.positional_embedding": pe,
+          "token_embedding.weight": OF.randn("ingest:t", (5, 4), 13)}
+    flt = state_filter(sd, (6, 2))
+    assert sorted(flt.keys()) == list(g["filter_keys"])
+    assert np.allclose(flt["attnpool.positional_embedding"].numpy(), g["filter_pos"], atol=1e-6)

@@ -227,3 +227,90 @@ def test_moco_head_three_steps(gpu, golden_dir):
     print({k: "%.1e/%.0e" % v for k, v in errs.items()})
     bad = {k: v for k, v in errs.items() if not v[0] <= v[1]}
     assert not bad, bad
+
+
+def test_full_size_step_vs_oracle(gpu):
+    """configs[0]/[1] shapes (CLIP-RN50 + BiGRU, 384x128, 64-token captions padded to 105) at a
+    batch the CPU oracle finishes in seconds: the three losses, embedding-layer / projection /
+    GRU gradients, queue push and EMA against the oracle on the same seeded inputs."""
+    import bench
+    from textreid_amd.caption import CaptionBatch
+    from textreid_amd.config import moco_cfg
+    from textreid_amd.model import build_model
+
+    B, K, vocab = 16, 64, 3000
+    torch.manual_seed(0)
+    cfg = moco_cfg("m_resnet50", K=K)
+    table = torch.randn(vocab, 512) * 0.02
+    model = build_model(cfg, vocab_dict=table)
+    head = model.embed_model
+    sd = head.state_dict()
+    filled = OF.fill_state(sd, 21, "full.")
+    st = {k: v.clone() for k, v in filled.items()}
+    OH.init_queues(st, 21)
+    for k in ("t_queue", "v_queue", "id_queue", "queue_ptr"):
+        filled[k] = st[k].clone()
+    head.load_state_dict(filled)
+    model.to(gpu).train()
+    images, tokens, lengths, ids = bench.synth_batch(B, 0, "cpu", 5, vocab=vocab)
+    lengths = torch.tensor([64, 40, 64, 9, 33, 64, 12, 64, 50, 64, 21, 64, 64, 7, 64, 30])
+    for i, n in enumerate(lengths.tolist()):
+        tokens[i, n:] = 0
+    ld = model(images.to(gpu), CaptionBatch(tokens.to(gpu), lengths.to(gpu), ids.to(gpu)))
+    sum(ld.values()).backward()
+    for k in OH.trainable_names(st):
+        st[k].requires_grad_(True)
+    key0 = st["v_encoder_k.layer3.2.conv2.weight"].clone()
+    old = OH.train_forward(st, OV.RN50, table, images, tokens, lengths, ids, m=0.999, epsilon=0.1)
+    sum(old.values()).backward()
+    errs = {k: rel(ld[k], old[k]) for k in old}
+    named = dict(head.named_parameters())
+    for k in ("v_embed_layer.weight", "t_embed_layer.bias", "loss_evaluator.projection", "t_encoder_q.gru.weight_hh_l0_reverse",
+              "v_encoder_q.attnpool.c_proj.weight"):
+        errs["grad:" + k] = rel(named[k].grad, st[k].grad)
+    sd2 = head.state_dict()
+    errs["v_queue"] = rel(sd2["v_queue"], st["v_queue"])
+    errs["t_queue"] = rel(sd2["t_queue"], st["t_queue"])
+    assert torch.equal(sd2["id_queue"].cpu(), st["id_queue"]) and int(sd2["queue_ptr"]) == int(st["queue_ptr"]) == B % K
+    errs["ema"] = rel(sd2["v_encoder_k.layer3.2.conv2.weight"], st["v_encoder_k.layer3.2.conv2.weight"])
+    assert not torch.equal(st["v_encoder_k.layer3.2.conv2.weight"], key0)
+    print({k: "%.1e" % v for k, v in errs.items()})
+    bad = {k: v for k, v in errs.items() if not v < TOL}
+    assert not bad, bad
+
+
+def test_full_batch_properties(gpu):
+    """B=128, K=8192 (the benchmarked configuration): size-independent invariants."""
+    import bench
+    from textreid_amd.caption import CaptionBatch
+    from textreid_amd.config import moco_cfg
+    from textreid_amd.model import build_model
+
+    B, K = 128, 8192
+    torch.manual_seed(0)
+    cfg = moco_cfg("m_resnet50", K=K)
+    model = build_model(cfg, vocab_dict=torch.randn(49408, 512) * 0.02).to(gpu).train()
+    head = model.embed_model
+    q0 = head.v_encoder_q.layer4[2].conv3.weight.detach().clone()
+    k0 = head.v_encoder_k.layer4[2].conv3.weight.detach().clone()
+    rm0 = head.v_encoder_k.bn1.running_mean.clone()
+    vq0 = head.v_queue.clone()
+    images, tokens, lengths, ids = bench.synth_batch(B, 0, gpu, 1)
+    ld = model(images, CaptionBatch(tokens, lengths, ids, max_len=64))
+    sum(ld.values()).backward()
+    assert all(torch.isfinite(v) for v in ld.values())
+    # InfoNCE with a fresh queue (ids -1: no column filtered) is ~2*log(1+K) at random init scale
+    assert 0.0 < float(ld["infonce_loss"]) < 2 * (torch.log(torch.tensor(1.0 + K)) + 30)
+    # momentum update is exact and touches parameters only
+    assert torch.equal(head.v_encoder_k.layer4[2].conv3.weight, k0 * 0.999 + q0 * (1.0 - 0.999))
+    assert not torch.equal(head.v_encoder_k.bn1.running_mean, rm0)  # key BN runs in train mode (own stats)
+    # enqueue: first B columns replaced by unit-norm keys, the rest untouched, pointer advanced
+    assert int(head.queue_ptr) == B and torch.equal(head.id_queue[0, :B], ids) and bool((head.id_queue[0, B:] == -1).all())
+    assert torch.equal(head.v_queue[:, B:], vq0[:, B:])
+    assert torch.allclose(head.v_queue[:, :B].norm(dim=0), torch.ones(B, device=gpu), atol=1e-5)
+    # every trainable parameter received a finite gradient; key encoders none
+    for n, p in head.named_parameters():
+        if p.requires_grad:
+            assert p.grad is not None and bool(torch.isfinite(p.grad).all()), n
+        else:
+            assert p.grad is None, n
