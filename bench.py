@@ -111,11 +111,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = local % max(torch.cuda.device_count(), 1)  # (debug: several ranks may share one GPU under gloo)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", init_method="env://")
+        dist.init_process_group(backend=os.environ.get("TRID_DIST_BACKEND", "nccl"), init_method="env://")
 
     from textreid_amd import ops
     from textreid_amd.caption import CaptionBatch
@@ -142,7 +143,7 @@ def main():
 
     def step(i):
         images, tokens, lengths, ids = batches[i % len(batches)]
-        cb = CaptionBatch(tokens, lengths, ids + (i // len(batches)) * len(batches) * (B // 4) * world, max_len=64)
+        cb = CaptionBatch(tokens, lengths, (ids + (i // len(batches)) * len(batches) * (B // 4) * world) % 11003, max_len=64)
         loss_dict = model(images, cb)
         losses = sum(loss_dict.values())
         opt.zero_grad()
@@ -176,7 +177,12 @@ def main():
     prof, ops.PROFILE = ops.PROFILE, None
     tmax = torch.tensor([dt], device=device)
     if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        if dist.get_backend() == "gloo":
+            tc = tmax.cpu()
+            dist.all_reduce(tc, op=dist.ReduceOp.MAX)
+            tmax = tc
+        else:
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     loss_val = float(last.item())
 

@@ -1,0 +1,100 @@
+"""Worker for tests/test_dp_gpu.py: W ranks (gloo, possibly sharing one GPU) run the HIP
+train step on their shard; rank 0 checks losses and reduced gradients against the CPU oracle's
+single-process global-batch computation with per-shard BatchNorm."""
+import os
+import sys
+import types
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import oracle.fill as OF  # noqa: E402
+import oracle.head as OH  # noqa: E402
+import oracle.visual as OV  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
+
+
+def main():
+    dist.init_process_group(os.environ.get("TRID_DIST_BACKEND", "gloo"), init_method="env://")
+    W, r = dist.get_world_size(), dist.get_rank()
+    dev = torch.device("cuda", r % torch.cuda.device_count())
+    torch.cuda.set_device(dev)
+    from textreid_amd.backbones.gru import GRU
+    from textreid_amd.backbones.m_resnet import ModifiedResNet
+    from textreid_amd.caption import CaptionBatch
+    from textreid_amd.embeddings.moco_head.head import MoCoHead
+    from textreid_amd.parallel import GradReducer
+
+    spec, hidden, embed, vocab, C, K, NC, Bl, seed = OV.TINY, 64, 64, 200, 32, 32, 53, 4, 9
+    ns = types.SimpleNamespace
+    table = OF.randn("vocab_table_dp", (vocab, embed), seed, 0.5)
+    vis = ModifiedResNet(list(spec.layers), spec.output_dim, spec.heads, spec.last_stride, (spec.height, spec.in_width), spec.width)
+    txt = GRU(hidden, embed, embed, 1, 0.0, True, "clip_vit", "./", vocab_dict=table)
+    cfg = ns(MODEL=ns(EMBEDDING=ns(FEATURE_SIZE=C, EPSILON=0.1), MOCO=ns(K=K, M=0.9, FC=False), NUM_CLASSES=NC))
+    head = MoCoHead(cfg, vis, txt)
+    filled = OF.fill_state(head.state_dict(), seed, "dp.")
+    st = {k: v.clone() for k, v in filled.items()}
+    OH.init_queues(st, seed)
+    for k in ("t_queue", "v_queue", "id_queue", "queue_ptr"):
+        filled[k] = st[k].clone()
+    head.load_state_dict(filled)
+    head.to(dev).train()
+    Bg = Bl * W
+    x = OF.randn("img:dp", (Bg, 3, spec.height, spec.in_width), seed)
+    tok = OF.randint("tok:dp", 1, vocab, (Bg, 105), seed)
+    ln = OF.randint("len:dp", 3, 30, (Bg,), seed)
+    for i, n in enumerate(ln.tolist()):
+        tok[i, n:] = 0
+    ids = torch.arange(Bg) // 2
+    sl = slice(r * Bl, (r + 1) * Bl)
+    ld = head(x[sl].to(dev), CaptionBatch(tok[sl].to(dev), ln[sl].to(dev), ids[sl].to(dev)))
+    sum(ld.values()).backward()
+    pre = [p for n, p in head.named_parameters() if p.requires_grad and "loss_evaluator" not in n][::-1]
+    red = GradReducer(bucket_mb=1)
+    red.reduce(pre)
+    red.wait()
+    torch.cuda.synchronize()
+    if r == 0:
+        for k in OH.trainable_names(st):
+            st[k].requires_grad_(True)
+        # oracle: per-shard encoders (own BN statistics), global losses
+        vq, tq, vk, tk = [], [], [], []
+        with torch.no_grad():
+            OH.momentum_update(st, 0.9)
+        for w in range(W):
+            s2 = slice(w * Bl, (w + 1) * Bl)
+            vf, tf = OH.encode(st, "q", spec, table, x[s2], tok[s2], ln[s2], True)
+            ve, te = OH.embed_pair(st, vf, tf)
+            vq.append(ve)
+            tq.append(te)
+            with torch.no_grad():
+                vkf, tkf = OH.encode(st, "k", spec, table, x[s2], tok[s2], ln[s2], True)
+                a, b = OH.embed_pair(st, vkf, tkf)
+                vk.append(F.normalize(a, dim=1))
+                tk.append(F.normalize(b, dim=1))
+        v_embed, t_embed = torch.cat(vq), torch.cat(tq)
+        old = OH.losses_from_embeddings(st, v_embed, t_embed, F.normalize(v_embed, dim=1), F.normalize(t_embed, dim=1),
+                                        torch.cat(vk), torch.cat(tk), ids, 0.1)
+        sum(old.values()).backward()
+        rel = lambda a, b: float((a.detach().double().cpu() - b.detach().double().cpu()).abs().max() / (b.detach().double().abs().max() + 1e-30))
+        errs = {k: rel(ld[k], old[k]) for k in old}
+        named = dict(head.named_parameters())
+        for k in ("v_embed_layer.weight", "t_embed_layer.weight", "loss_evaluator.projection", "t_encoder_q.gru.weight_ih_l0",
+                  "v_encoder_q.attnpool.c_proj.weight", "v_encoder_q.layer4.0.conv3.weight"):
+            errs["grad:" + k] = rel(named[k].grad, st[k].grad)
+        OH.enqueue(st, torch.cat(vk), torch.cat(tk), ids)
+        sd = head.state_dict()
+        errs["v_queue"] = rel(sd["v_queue"], st["v_queue"])
+        assert int(sd["queue_ptr"]) == int(st["queue_ptr"]) and torch.equal(sd["id_queue"].cpu(), st["id_queue"])
+        print("DP_ERRS", {k: "%.1e" % v for k, v in errs.items()})
+        bad = {k: v for k, v in errs.items() if not v < 1e-3}
+        assert not bad, bad
+        print("DP_OK")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -24,17 +24,44 @@ def rank():
     return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
 
 
+def _backend():
+    return dist.get_backend() if dist.is_available() and dist.is_initialized() else None
+
+
+def all_gather_rows(x):
+    """[n, ...] per rank -> [W*n, ...] (rank-major).  RCCL: one all_gather_into_tensor on the
+    current stream; gloo (CPU tests / single-GPU debugging): list all_gather staged through host
+    memory for device tensors."""
+    W = world_size()
+    x = x.contiguous()
+    out = torch.empty((W * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+    if _backend() == "gloo" and x.is_cuda:
+        parts = [torch.empty(x.shape, dtype=x.dtype) for _ in range(W)]
+        dist.all_gather(parts, x.cpu())
+        out.copy_(torch.cat(parts, dim=0))
+    else:
+        dist.all_gather_into_tensor(out, x)
+    return out
+
+
+def all_reduce_sum_(t):
+    """In-place SUM all-reduce (async handle or None)."""
+    if _backend() == "gloo" and t.is_cuda:
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM)
+        t.copy_(h)
+        return None
+    return dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True)
+
+
 class _GatherRows(torch.autograd.Function):
     """all_gather along dim 0; backward returns the local rows of the gradient
     (no collective, no scaling: the loss is evaluated in full on every rank)."""
 
     @staticmethod
     def forward(ctx, x):
-        W = world_size()
         ctx.rows = x.shape[0]
-        out = torch.empty((W * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
-        dist.all_gather_into_tensor(out, x.contiguous())
-        return out
+        return all_gather_rows(x)
 
     @staticmethod
     def backward(ctx, g):
@@ -85,12 +112,13 @@ class GradReducer:
 
     def _launch(self, bucket):
         flat = torch.cat([p.grad.reshape(-1) for p in bucket])
-        work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
+        work = all_reduce_sum_(flat)
         self._pending.append((work, flat, bucket))
 
     def wait(self):
         for work, flat, bucket in self._pending:
-            work.wait()
+            if work is not None:
+                work.wait()
             off = 0
             for p in bucket:
                 n = p.numel()
