@@ -93,6 +93,34 @@ def _bn_coeffs(bn, partials, M, training):
     return ops.bn_eval_coeffs(bn.weight, bn.bias, bn.running_mean, bn.running_var)
 
 
+class _WgradStream:
+    """Weight-gradient GEMMs are off the critical path of backward (nothing downstream in the
+    chain consumes them), so they run on a side HIP stream underneath the dgrad GEMMs and the
+    HBM-bound BatchNorm-backward passes of the main stream."""
+
+    def __init__(self, device):
+        self.main = torch.cuda.current_stream(device)
+        self.side = _WgradStream._streams.setdefault(device, torch.cuda.Stream(device=device))
+        self.side.wait_stream(self.main)
+
+    _streams = {}
+
+    def run(self, fn, *tensors):
+        """fn(*tensors) on the side stream, after everything enqueued so far on main."""
+        ev = torch.cuda.Event()
+        ev.record(self.main)
+        self.side.wait_event(ev)
+        for t in tensors:
+            t.record_stream(self.side)  # keep the operands alive for the side stream
+        with torch.cuda.stream(self.side):
+            out = fn(*tensors)
+        out.record_stream(self.main)
+        return out
+
+    def join(self):
+        self.main.wait_stream(self.side)
+
+
 class _EncoderFn(torch.autograd.Function):
     """forward(images, module, *params) -> [B, out_dim]; grads for every parameter."""
 
@@ -321,6 +349,7 @@ class ModifiedResNet(nn.Module):
     def _run_backward(self, S, gout):
         G = {}
         B = S["B"]
+        ws = _WgradStream(gout.device)
         g = self._attnpool_backward(S["attn"], gout, G)
         S["attn"] = None
         blocks = list(self.blocks())
@@ -338,25 +367,25 @@ class ModifiedResNet(nn.Module):
                 G[id(blk.downsample[2].weight)], G[id(blk.downsample[2].bias)] = dg, db
             wc = blk.conv3.weight.view(blk.conv3.out_channels, -1)
             dab = ops.matmul_nn(dyc.view(-1, dyc.shape[-1]), wc).view(ab.shape)
-            G[id(blk.conv3.weight)] = ops.conv1x1_wgrad(dyc, ab).view_as(blk.conv3.weight)
+            G[id(blk.conv3.weight)] = ws.run(ops.conv1x1_wgrad, dyc, ab).view_as(blk.conv3.weight)
             dyb, dg, db, _ = ops.bn_bwd(dab, yb, stb, None, 1, pooled=stride > 1)
             G[id(blk.bn2.weight)], G[id(blk.bn2.bias)] = dg, db
             planes = blk.conv2.out_channels
             wbt = ops.weight_transpose(_w3x3(blk.conv2), planes, 9, planes, flip=True)
             daa = ops.conv3x3(dyb, wbt)
-            G[id(blk.conv2.weight)] = _g3x3(ops.conv3x3_wgrad(dyb, aa), planes, planes)
+            G[id(blk.conv2.weight)] = _g3x3(ws.run(ops.conv3x3_wgrad, dyb, aa), planes, planes)
             dya, dg, db, _ = ops.bn_bwd(daa, ya, sta, None, 1)
             G[id(blk.bn1.weight)], G[id(blk.bn1.bias)] = dg, db
             wa = blk.conv1.weight.view(blk.conv1.out_channels, -1)
             if has_down:
                 wd = blk.downsample[1].weight.view(blk.downsample[1].out_channels, -1)
                 dxd = ops.matmul_nn(dyd.view(-1, dyd.shape[-1]), wd).view(xd.shape)
-                G[id(blk.downsample[1].weight)] = ops.conv1x1_wgrad(dyd, xd).view_as(blk.downsample[1].weight)
+                G[id(blk.downsample[1].weight)] = ws.run(ops.conv1x1_wgrad, dyd, xd).view_as(blk.downsample[1].weight)
                 dx = ops.avgpool2_bwd(dxd) if stride > 1 else dxd
             else:
                 dx = dres
             ops.matmul_nn(dya.view(-1, dya.shape[-1]), wa, out=dx.view(-1, dx.shape[-1]), accumulate=True)
-            G[id(blk.conv1.weight)] = ops.conv1x1_wgrad(dya, x).view_as(blk.conv1.weight)
+            G[id(blk.conv1.weight)] = ws.run(ops.conv1x1_wgrad, dya, x).view_as(blk.conv1.weight)
             g = dx
         S["blocks"] = None
         # ---- stem
@@ -366,18 +395,19 @@ class ModifiedResNet(nn.Module):
         c3o, c3i = self.conv3.out_channels, self.conv3.in_channels
         w3t = ops.weight_transpose(_w3x3(self.conv3), c3o, 9, c3i, flip=True)
         da2 = ops.conv3x3(dy3, w3t)
-        G[id(self.conv3.weight)] = _g3x3(ops.conv3x3_wgrad(dy3, a2), c3o, c3i)
+        G[id(self.conv3.weight)] = _g3x3(ws.run(ops.conv3x3_wgrad, dy3, a2), c3o, c3i)
         dy2, dg, db, _ = ops.bn_bwd(da2, y2, st2, None, 1)
         G[id(self.bn2.weight)], G[id(self.bn2.bias)] = dg, db
         c2o, c2i = self.conv2.out_channels, self.conv2.in_channels
         w2t = ops.weight_transpose(_w3x3(self.conv2), c2o, 9, c2i, flip=True)
         da1 = ops.conv3x3(dy2, w2t)
-        G[id(self.conv2.weight)] = _g3x3(ops.conv3x3_wgrad(dy2, a1), c2o, c2i)
+        G[id(self.conv2.weight)] = _g3x3(ws.run(ops.conv3x3_wgrad, dy2, a1), c2o, c2i)
         dy1, dg, db, _ = ops.bn_bwd(da1, y1, st1, None, 1)
         G[id(self.bn1.weight)], G[id(self.bn1.bias)] = dg, db
-        dw1 = ops.conv1x1_wgrad(dy1, col)  # [32, 28]
+        dw1 = ws.run(ops.conv1x1_wgrad, dy1, col)  # [32, 28]
         c1 = self.conv1.weight
         G[id(c1)] = dw1[:, : c1[0].numel()].reshape(c1.shape)
+        ws.join()
         return [G.get(id(p)) for p in self.parameters()]
 
 
