@@ -354,20 +354,48 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void gemm_kernel(GemmParams
 }
 
 // ---- split-K slab reduction: C[i] = sum_s slab[s][i] (+ C[i]) ---------------------
-__global__ void slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ C, long long n4,
-                                   int splits, long long sSplit, int accumulate) {
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
-         i += (long long)gridDim.x * blockDim.x) {
-        float4 s = reinterpret_cast<const float4*>(slab)[i];
-        for (int k = 1; k < splits; ++k) {
-            float4 t = reinterpret_cast<const float4*>(slab + (long long)k * sSplit)[i];
-            s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+// One workgroup = 64 float4 columns x 4 split lanes: the (possibly several hundred) slabs are
+// walked by 4 waves in parallel with 4 independent loads in flight each, then folded in LDS
+// in a fixed order (deterministic).
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ C,
+                                                          long long n4, int splits, long long sSplit, int accumulate) {
+    __shared__ float4 red[4][64];
+    const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    for (long long base = (long long)blockIdx.x * 64; base < n4; base += (long long)gridDim.x * 64) {
+        const long long i = base + cl;
+        float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+        if (i < n4) {
+            int k = sl;
+            for (; k + 12 < splits; k += 16) {
+                const float4 t0 = reinterpret_cast<const float4*>(slab + (long long)k * sSplit)[i];
+                const float4 t1 = reinterpret_cast<const float4*>(slab + (long long)(k + 4) * sSplit)[i];
+                const float4 t2 = reinterpret_cast<const float4*>(slab + (long long)(k + 8) * sSplit)[i];
+                const float4 t3 = reinterpret_cast<const float4*>(slab + (long long)(k + 12) * sSplit)[i];
+                a0.x += t0.x; a0.y += t0.y; a0.z += t0.z; a0.w += t0.w;
+                a1.x += t1.x; a1.y += t1.y; a1.z += t1.z; a1.w += t1.w;
+                a2.x += t2.x; a2.y += t2.y; a2.z += t2.z; a2.w += t2.w;
+                a3.x += t3.x; a3.y += t3.y; a3.z += t3.z; a3.w += t3.w;
+            }
+            for (; k < splits; k += 4) {
+                const float4 t0 = reinterpret_cast<const float4*>(slab + (long long)k * sSplit)[i];
+                a0.x += t0.x; a0.y += t0.y; a0.z += t0.z; a0.w += t0.w;
+            }
         }
-        if (accumulate) {
-            float4 t = reinterpret_cast<float4*>(C)[i];
-            s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+        a0.x += a1.x + (a2.x + a3.x); a0.y += a1.y + (a2.y + a3.y);
+        a0.z += a1.z + (a2.z + a3.z); a0.w += a1.w + (a2.w + a3.w);
+        red[sl][cl] = a0;
+        __syncthreads();
+        if (sl == 0 && i < n4) {
+            float4 s = red[0][cl];
+            const float4 u = red[1][cl], v = red[2][cl], w = red[3][cl];
+            s.x += u.x + (v.x + w.x); s.y += u.y + (v.y + w.y); s.z += u.z + (v.z + w.z); s.w += u.w + (v.w + w.w);
+            if (accumulate) {
+                const float4 t = reinterpret_cast<float4*>(C)[i];
+                s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+            }
+            reinterpret_cast<float4*>(C)[i] = s;
         }
-        reinterpret_cast<float4*>(C)[i] = s;
+        __syncthreads();
     }
 }
 
@@ -484,6 +512,6 @@ extern "C" int trid_slab_reduce_f32(const float* slab, float* C, long long n, in
     TRID_REQUIRE(slab && C && n > 0 && splits >= 1, "trid_slab_reduce_f32: bad arguments");
     TRID_REQUIRE(n % 4 == 0 && strideSplit % 4 == 0 && aligned16(slab) && aligned16(C), "trid_slab_reduce_f32: needs 16-byte alignment and n%%4==0");
     const long long n4 = n / 4;
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid_for(n4, 256, 2048)), dim3(256), 0, stream, slab, C, n4, splits, strideSplit, accumulate);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid_for(n4, 64, 4096)), dim3(256), 0, stream, slab, C, n4, splits, strideSplit, accumulate);
     return check_launch("trid_slab_reduce_f32");
 }
