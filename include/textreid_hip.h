@@ -262,6 +262,11 @@ int trid_argsort_rows_desc_f32(const float* sim, int ld, int Q, int G, int64_t* 
 int trid_rank_metrics(const int64_t* indices, const int64_t* q_pids, const int64_t* g_pids, int Q, int R,
                       int32_t* first_hit, float* ap, const int64_t* topk, int ntopk, float* cmc, void* stream);
 
+/* k-reciprocal re-rank term (evaluation.py:40-65): out[i,j] = alpha*jaccard(qnn[i,:k], gnn[j,:k]) + base[i,j]
+ * (base may be NULL); qnn [Q,k], gnn [G,k] top-k neighbour indices, k <= 8 */
+int trid_jaccard_add_f32(const int64_t* qnn, const int64_t* gnn, const float* base, long long ldb, float* out, int Q,
+                         int G, int k, float alpha, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -33,3 +33,13 @@ def rank(sim, q_pids, g_pids, topk=(1, 5, 10), get_mAP=True):
     prec = cum / ranks[None] * matches
     AP = prec.sum(1) / num_rel
     return cmc, AP.mean() * 100, indices
+
+
+def k_reciprocal(q_feats, g_feats, neighbor_num=5, alpha=0.05):
+    """evaluation.py:53-65 (+ jaccard_mat :44-50): alpha * Jaccard similarity of the top-k
+    neighbour sets (in the gallery) of every query i and every gallery item j.  float64 as the
+    reference (its numpy matrix is float64)."""
+    qg_nn = torch.argsort(q_feats @ g_feats.t(), dim=1, descending=True)[:, :neighbor_num]
+    gg_nn = torch.argsort(g_feats @ g_feats.t(), dim=1, descending=True)[:, :neighbor_num]
+    eq = (qg_nn[:, None, :, None] == gg_nn[None, :, None, :]).sum(dim=(2, 3)).double()  # |A n B|
+    return alpha * eq / (2 * neighbor_num - eq)

@@ -405,6 +405,20 @@ def gen_rank(seed=7):
     s_ref = torch.matmul(F.normalize(te, p=2, dim=1), F.normalize(ie, p=2, dim=1).t())
     check("similarity", OE.similarity(te, ie), s_ref)
     out.update(te=te.numpy(), ie=ie.numpy(), sim_ti=s_ref.numpy())
+    # k-reciprocal re-rank (evaluation.py:40-65,122-124) and the re-ranked metrics (:144-163)
+    tn, im = F.normalize(te, p=2, dim=1), F.normalize(ie, p=2, dim=1)
+    rtn = ref_eval.k_reciprocal(im, tn)
+    rvn = ref_eval.k_reciprocal(tn, im)
+    check("k_reciprocal rtn", OE.k_reciprocal(im, tn), rtn, 1e-12)
+    check("k_reciprocal rvn", OE.k_reciprocal(tn, im), rvn, 1e-12)
+    tp = OF.randint("rank:tp", 0, 9, (40,), seed)
+    ip = OF.randint("rank:ip", 0, 9, (25,), seed)
+    topk = torch.tensor([1, 5, 10])
+    re_t2i_cmc, re_t2i_map, re_idx = ref_eval.rank(rvn + s_ref, tp, ip, topk, get_mAP=True)
+    re_i2t_cmc, re_i2t_map, _ = ref_eval.rank(rtn + s_ref.t(), ip, tp, topk, get_mAP=True)
+    out.update(rtn=rtn.numpy(), rvn=rvn.numpy(), tp=tp.numpy(), ip=ip.numpy(), re_t2i_cmc=re_t2i_cmc.numpy(),
+               re_t2i_map=re_t2i_map.numpy(), re_i2t_cmc=re_i2t_cmc.numpy(), re_i2t_map=re_i2t_map.numpy(),
+               re_t2i_idx=re_idx.numpy())
     np.savez_compressed(os.path.join(HERE, "rank.npz"), **out)
 
 

@@ -176,3 +176,55 @@ def test_train_step_is_deterministic(gpu):
             losses.append([float(v) for v in ld.values()])
         outs.append(losses)
     assert outs[0] == outs[1]
+
+
+def test_k_reciprocal_rerank_matches_reference_golden(gpu, golden_dir):
+    """evaluation.py:40-65,122-124,144-163: Jaccard re-rank matrices and re-ranked CMC/mAP."""
+    from textreid_amd.evaluation import k_reciprocal, l2_normalize_rows, rank
+
+    g = load(golden_dir, "rank.npz")
+    te, ie = torch.from_numpy(g["te"]).to(gpu), torch.from_numpy(g["ie"]).to(gpu)
+    tn, im = l2_normalize_rows(te), l2_normalize_rows(ie)
+    rtn = k_reciprocal(im, tn)
+    rvn = k_reciprocal(tn, im)
+    assert np.allclose(rtn.cpu().numpy(), g["rtn"], atol=1e-7) and np.allclose(rvn.cpu().numpy(), g["rvn"], atol=1e-7)
+    sim = torch.from_numpy(g["sim_ti"]).to(gpu)
+    tp, ip = torch.from_numpy(g["tp"]).to(gpu), torch.from_numpy(g["ip"]).to(gpu)
+    cmc, mAP, idx = rank(k_reciprocal(tn, im, base=sim), tp, ip, (1, 5, 10), get_mAP=True)
+    assert np.allclose(cmc.cpu().numpy(), g["re_t2i_cmc"], atol=1e-4) and abs(float(mAP) - float(g["re_t2i_map"])) < 1e-3
+    cmc, mAP, _ = rank(k_reciprocal(im, tn, base=sim.t().contiguous()), ip, tp, (1, 5, 10), get_mAP=True)
+    assert np.allclose(cmc.cpu().numpy(), g["re_i2t_cmc"], atol=1e-4) and abs(float(mAP) - float(g["re_i2t_map"])) < 1e-3
+
+
+def test_evaluation_entry_point(gpu, tmp_path):
+    """evaluation(dataset, predictions, ...) with duplicate images (get_unique) vs the oracle."""
+    from textreid_amd.evaluation import evaluation
+
+    N, C = 60, 32
+    img = OF.randn("ev:img", (20, C), 2)
+    image_ids = [i // 3 for i in range(N)]  # 3 captions per image
+    pids = [i // 6 for i in range(N)]       # 2 images per identity
+
+    class DS:
+        def get_id_info(self, idx):
+            return image_ids[idx], pids[idx]
+
+    txt = OF.randn("ev:txt", (N, C), 2)
+    preds = {i: [img[image_ids[i]].to(gpu), txt[i].to(gpu)] for i in range(N)}
+    top1 = evaluation(DS(), preds, str(tmp_path), [1, 5, 10], save_data=True, rerank=True)
+    res = evaluation.last_results
+    keep = torch.tensor([i * 3 for i in range(20)])
+    sim = OE.similarity(txt, img)
+    tpid, ipid = torch.tensor(pids), torch.tensor(pids)[keep]
+    cmc, mAP, _ = OE.rank(sim, tpid, ipid, (1, 5, 10), True)
+    assert np.allclose(res["t2i"][0].cpu().numpy(), cmc.numpy(), atol=1e-4) and abs(float(res["t2i"][1]) - float(mAP)) < 1e-3
+    assert abs(float(top1) - float(cmc[0])) < 1e-4
+    import torch.nn.functional as F
+
+    rvn = OE.k_reciprocal(F.normalize(txt, dim=1), F.normalize(img, dim=1))
+    cmc2, mAP2, _ = OE.rank(rvn + sim, tpid, ipid, (1, 5, 10), True)
+    assert np.allclose(res["re-t2i"][0].cpu().numpy(), cmc2.numpy(), atol=1e-4) and abs(float(res["re-t2i"][1]) - float(mAP2)) < 1e-3
+    assert os.path.exists(os.path.join(str(tmp_path), "inference_data.npz"))
+    evaluation(DS(), preds, str(tmp_path), [1, 5, 10], save_data=False, rerank=False)
+    cmc3, _ = OE.rank(sim, tpid, ipid, (1, 5, 10), False)
+    assert np.allclose(evaluation.last_results["t2i"][0].cpu().numpy(), cmc3.numpy(), atol=1e-4)

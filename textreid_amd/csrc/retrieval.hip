@@ -145,6 +145,29 @@ __global__ __launch_bounds__(256) void cmc_kernel(const int32_t* __restrict__ fi
     }
 }
 
+// k-reciprocal re-rank term (evaluation.py:40-65): out[i,j] = alpha * |A_i n B_j| / |A_i u B_j| (+ base[i,j])
+// for the top-k neighbour index sets A_i = qnn[i,:], B_j = gnn[j,:] (k <= 8, indices unique per row).
+__global__ __launch_bounds__(256) void jaccard_add_kernel(const long long* __restrict__ qnn,
+                                                          const long long* __restrict__ gnn,
+                                                          const float* __restrict__ base, long long ldb,
+                                                          float* __restrict__ out, int Q, int G, int k, float alpha) {
+    const int i = blockIdx.y;
+    long long a[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) a[t] = t < k ? qnn[(long long)i * k + t] : -1 - t;
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < G; j += gridDim.x * blockDim.x) {
+        int inter = 0;
+        for (int u = 0; u < k; ++u) {
+            const long long b = gnn[(long long)j * k + u];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) inter += (a[t] == b) ? 1 : 0;
+        }
+        float v = alpha * (float)inter / (float)(2 * k - inter);
+        if (base != nullptr) v += base[(long long)i * ldb + j];
+        out[(long long)i * G + j] = v;
+    }
+}
+
 }  // namespace trid
 
 using namespace trid;
@@ -235,4 +258,14 @@ extern "C" int trid_rank_metrics(const int64_t* indices, const int64_t* q_pids, 
                        q_pids, g_pids, Q, R, first_hit, ap);
     hipLaunchKernelGGL(cmc_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, first_hit, Q, topk, ntopk, cmc);
     return check_launch("trid_rank_metrics");
+}
+
+extern "C" int trid_jaccard_add_f32(const int64_t* qnn, const int64_t* gnn, const float* base, long long ldb, float* out,
+                                    int Q, int G, int k, float alpha, void* stream) {
+    TRID_REQUIRE(qnn && gnn && out && Q > 0 && G > 0 && k >= 1 && k <= 8, "trid_jaccard_add_f32: bad arguments (k<=8)");
+    TRID_REQUIRE(base == nullptr || ldb >= G, "trid_jaccard_add_f32: bad base stride");
+    dim3 grid((G + 255) / 256 > 64 ? 64 : (G + 255) / 256, Q);
+    hipLaunchKernelGGL(jaccard_add_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const long long*)qnn,
+                       (const long long*)gnn, base, ldb, out, Q, G, k, alpha);
+    return check_launch("trid_jaccard_add_f32");
 }

@@ -2,8 +2,8 @@
 
 Surface of the reference ``lib/data/metrics/evaluation.py``: ``rank(similarity,
 q_pids, g_pids, topk, get_mAP)`` (:11-37) and ``evaluation(dataset, predictions,
-output_folder, topk, save_data, rerank)`` (:76-173, ``rerank=False`` path; the
-k-reciprocal re-rank :40-65 is the "next" row f3).  ``similarity_topk`` is the
+output_folder, topk, save_data, rerank)`` (:76-173) incl. the k-reciprocal / Jaccard re-rank
+(:40-65, row f3).  ``similarity_topk`` is the
 fused form for large galleries (config 5): the [Q,G] matrix is never kept, only
 per-query top-k (value, index) pairs; with ``world_size > 1`` the gallery is
 sharded by rows and the per-shard top-k lists are merged after one all-gather.
@@ -99,6 +99,31 @@ def similarity_topk(text_embed, image_embed, k=10, normalize=True):
     return vals, torch.gather(cand_i, 1, sel)
 
 
+def _topk_neighbours(q, g, k):
+    """indices [Q,k] of the k largest q @ g.T per row (fused similarity + top-k, no [Q,G] kept)."""
+    Q, C = q.shape
+    G = g.shape[0]
+    vals = torch.empty(Q, k, dtype=torch.float32, device=q.device)
+    idx = torch.empty(Q, k, dtype=torch.int64, device=q.device)
+    ws = ops.empty((ops.L.load().trid_topk_ws_floats(Q, G, k),), q)
+    call("trid_sim_topk_f32", _p(q), _p(g), _p(vals), _p(idx), Q, G, C, k, 0, _p(ws), stream())
+    return idx
+
+
+def k_reciprocal(q_feats, g_feats, neighbor_num=5, alpha=0.05, base=None):
+    """alpha * Jaccard(top-k neighbours of query i, top-k neighbours of gallery j) (+ base):
+    the reference's k_reciprocal/jaccard_mat (evaluation.py:40-65; there an O(Q*G) pure-Python
+    double loop) as two fused top-k launches and one set-intersection kernel."""
+    q, g = q_feats.contiguous(), g_feats.contiguous()
+    qnn = _topk_neighbours(q, g, neighbor_num)
+    gnn = _topk_neighbours(g, g, neighbor_num)
+    Q, G = q.shape[0], g.shape[0]
+    out = torch.empty(Q, G, dtype=torch.float32, device=q.device)
+    b = base.contiguous() if base is not None else None
+    call("trid_jaccard_add_f32", _p(qnn), _p(gnn), _p(b), G, _p(out), Q, G, neighbor_num, float(alpha), stream())
+    return out
+
+
 def get_unique(image_ids):
     keep = {}
     for i, image_id in enumerate(image_ids):
@@ -106,9 +131,7 @@ def get_unique(image_ids):
     return torch.tensor(list(keep.values()))
 
 
-def evaluation(dataset, predictions, output_folder, topk, save_data=True, rerank=False):
-    if rerank:
-        raise NotImplementedError("k-reciprocal re-rank (evaluation.py:40-65) is not on the accelerated path yet")
+def evaluation(dataset, predictions, output_folder, topk, save_data=True, rerank=True):
     logger = logging.getLogger("PersonSearch.inference")
     image_ids, pids, image_global, text_global = [], [], [], []
     for idx, prediction in predictions.items():
@@ -123,13 +146,27 @@ def evaluation(dataset, predictions, output_folder, topk, save_data=True, rerank
     image_global = torch.stack(image_global, dim=0)
     text_global = torch.stack(text_global, dim=0)
     keep = get_unique(image_ids).to(dev)
-    image_global = image_global[keep]
+    image_global = l2_normalize_rows(image_global[keep])
     image_pid = image_pid[keep]
-    sim = similarity(text_global, image_global)
-    if save_data:
+    text_global = l2_normalize_rows(text_global)
+    sim = ops.linear(text_global, image_global)  # [texts, images]
+    sim_t = sim.t().contiguous()
+    results = {}
+    if rerank:
+        re_i2t = k_reciprocal(image_global, text_global, base=sim_t)  # rtn_mat + similarity.t()
+        re_t2i = k_reciprocal(text_global, image_global, base=sim)    # rvn_mat + similarity
+        results["i2t"] = rank(sim_t, image_pid, text_pid, topk, get_mAP=True)[:2]
+        results["t2i"] = rank(sim, text_pid, image_pid, topk, get_mAP=True)[:2]
+        results["re-i2t"] = rank(re_i2t, image_pid, text_pid, topk, get_mAP=True)[:2]
+        results["re-t2i"] = rank(re_t2i, text_pid, image_pid, topk, get_mAP=True)[:2]
+        for k, (cmc, mAP) in results.items():
+            logger.info("%-7s topk %s cmc %s mAP %.3f", k, list(topk), [round(float(c), 3) for c in cmc], float(mAP))
+    else:
+        results["t2i"] = (rank(sim, text_pid, image_pid, topk, get_mAP=False)[0], None)
+        results["i2t"] = (rank(sim_t, image_pid, text_pid, topk, get_mAP=False)[0], None)
+        logger.info("topk %s  t2i %s  i2t %s", list(topk), results["t2i"][0].tolist(), results["i2t"][0].tolist())
+    if save_data and output_folder:
         np.savez(os.path.join(output_folder, "inference_data.npz"), image_pid=image_pid.cpu().numpy(),
                  text_pid=text_pid.cpu().numpy(), similarity=sim.cpu().numpy())
-    t2i_cmc, _ = rank(sim, text_pid, image_pid, topk, get_mAP=False)
-    i2t_cmc, _ = rank(sim.t().contiguous(), image_pid, text_pid, topk, get_mAP=False)
-    logger.info("topk %s  t2i %s  i2t %s", list(topk), t2i_cmc.tolist(), i2t_cmc.tolist())
-    return t2i_cmc[0]
+    evaluation.last_results = results
+    return results["t2i"][0][0]
