@@ -228,3 +228,51 @@ def test_evaluation_entry_point(gpu, tmp_path):
     evaluation(DS(), preds, str(tmp_path), [1, 5, 10], save_data=False, rerank=False)
     cmc3, _ = OE.rank(sim, tpid, ipid, (1, 5, 10), False)
     assert np.allclose(evaluation.last_results["t2i"][0].cpu().numpy(), cmc3.numpy(), atol=1e-4)
+
+
+def test_inference_dedupes_image_encodes(gpu):
+    """engine.inference: each distinct image is encoded once (row f2); predictions equal the
+    encode-per-caption path of the reference (inference.py:14-26)."""
+    import types
+
+    from textreid_amd.backbones.gru import GRU
+    from textreid_amd.backbones.m_resnet import ModifiedResNet
+    from textreid_amd.caption import CaptionBatch
+    from textreid_amd.embeddings.moco_head.head import MoCoHead
+    from textreid_amd.engine.inference import compute_on_dataset
+
+    ns = types.SimpleNamespace
+    table = OF.randn("inf:tab", (50, 64), 0, 0.5)
+    vis = ModifiedResNet([1, 1, 1, 1], 64, 4, 1, (96, 32), 16)
+    txt = GRU(64, 64, 64, 1, 0.0, True, "clip_vit", "./", vocab_dict=table)
+    cfg = ns(MODEL=ns(EMBEDDING=ns(FEATURE_SIZE=32, EPSILON=0.1), MOCO=ns(K=32, M=0.9, FC=False), NUM_CLASSES=53))
+    model = ns(embed_model=MoCoHead(cfg, vis, txt).to(gpu))
+    model.eval = lambda: model.embed_model.eval()
+    N = 12
+    imgs = OF.randn("inf:img", (4, 3, 96, 32), 0)
+    image_ids = [i // 3 for i in range(N)]
+    tok = OF.randint("inf:tok", 1, 50, (N, 105), 0)
+    ln = OF.randint("inf:len", 2, 20, (N,), 0)
+
+    class DS:
+        def get_id_info(self, idx):
+            return image_ids[idx], image_ids[idx] // 2
+
+        def __len__(self):
+            return N
+
+    class Loader:
+        dataset = DS()
+
+        def __iter__(self):
+            for s in range(0, N, 4):
+                idx = list(range(s, s + 4))
+                yield imgs[[image_ids[i] for i in idx]], CaptionBatch(tok[idx], ln[idx]), idx
+
+    a = compute_on_dataset(model, Loader(), gpu, dedupe=True)
+    assert compute_on_dataset.last_stats == {"images_encoded": 4, "samples": N}
+    b = compute_on_dataset(model, Loader(), gpu, dedupe=False)
+    assert compute_on_dataset.last_stats["images_encoded"] == N
+    for i in range(N):
+        # eval-mode BatchNorm is per-sample independent: identical up to GEMM tile-edge effects
+        assert torch.allclose(a[i][0], b[i][0], rtol=1e-5, atol=1e-6) and torch.equal(a[i][1], b[i][1])

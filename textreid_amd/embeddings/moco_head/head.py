@@ -189,5 +189,17 @@ class MoCoHead(nn.Module):
         return [v_embed, t_embed]
 
 
+    @torch.no_grad()
+    def encode_images(self, images):
+        """eval-mode image embeddings [N,C] (head.py:114,178)."""
+        return losses.linear(self.v_encoder_q(images), self.v_embed_layer.weight, self.v_embed_layer.bias)
+
+    @torch.no_grad()
+    def encode_captions(self, captions):
+        """eval-mode caption embeddings [N,C] (head.py:115,179)."""
+        return losses.linear(self.t_encoder_q(CaptionBatch.from_list(captions)), self.t_embed_layer.weight,
+                             self.t_embed_layer.bias)
+
+
 def build_moco_head(cfg, visual_model, textual_model):
     return MoCoHead(cfg, visual_model, textual_model)

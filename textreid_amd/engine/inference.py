@@ -12,16 +12,43 @@ from ..evaluation import evaluation
 from ..parallel import rank, world_size
 
 
-def compute_on_dataset(model, data_loader, device):
+def compute_on_dataset(model, data_loader, device, dedupe=True):
+    """Eval encode.  The reference encodes the image once per CAPTION although only unique images
+    are kept afterwards (inference.py:17-25, evaluation.py:113-115: 6156 image forwards for 3074
+    images on CUHK-PEDES).  With ``dedupe`` each distinct image id is encoded once and its
+    embedding reused (row f2); results are identical."""
     model.eval()
-    results = {}
-    for images, captions, image_ids in data_loader:
-        images = images.to(device)
+    head = model.embed_model
+    dataset = getattr(data_loader, "dataset", None)
+    can_dedupe = dedupe and dataset is not None and hasattr(dataset, "get_id_info")
+    results, cache = {}, {}
+    stats = {"images_encoded": 0, "samples": 0}
+    for images, captions, idxs in data_loader:
+        idxs = [int(i) for i in idxs]
         captions = captions.to(device) if hasattr(captions, "to") else [c.to(device) for c in captions]
         with torch.no_grad():
-            v, t = model(images, captions)
-        for i, img_id in enumerate(image_ids):
-            results[int(img_id)] = [v[i], t[i]]
+            t = head.encode_captions(captions)
+            if can_dedupe:
+                iids = [dataset.get_id_info(i)[0] for i in idxs]
+                todo = {}
+                for j, iid in enumerate(iids):
+                    if iid not in cache and iid not in todo:
+                        todo[iid] = j
+                if todo:
+                    sel = torch.tensor(list(todo.values()))
+                    emb = head.encode_images(images[sel].to(device))
+                    for r, iid in enumerate(todo):
+                        cache[iid] = emb[r]
+                    stats["images_encoded"] += len(todo)
+                v = [cache[iid] for iid in iids]
+            else:
+                emb = head.encode_images(images.to(device))
+                v = [emb[j] for j in range(len(idxs))]
+                stats["images_encoded"] += len(idxs)
+        for j, i in enumerate(idxs):
+            results[i] = [v[j], t[j]]
+        stats["samples"] += len(idxs)
+    compute_on_dataset.last_stats = stats
     return results
 
 
