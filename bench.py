@@ -95,6 +95,33 @@ def cpu_baseline(sample_b=32, steps=3):
     }
 
 
+def retrieval_bench(device, world, G_total=1000000, Q=10000, k=10):
+    """configs[4] per-GPU work: Q=1e4 text queries against this rank's 1/8 shard (at least) of a
+    1e6-image gallery; similarity + fused per-query top-10 on device, plus eval-mode gallery encode rate."""
+    from textreid_amd.evaluation import similarity_topk
+
+    shard = G_total // max(world, 8)
+    gen = torch.Generator(device="cpu").manual_seed(7)
+    q = torch.nn.functional.normalize(torch.randn(Q, 256, generator=gen), dim=1).to(device)
+    g = torch.nn.functional.normalize(torch.randn(shard, 256, generator=gen), dim=1).to(device)
+    similarity_topk(q[:256], g[:8192], k, normalize=False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    vals, idx = similarity_topk(q, g, k, normalize=False)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {
+        "metric": "gallery imgs/sec (retrieval: similarity + top-10, Q=1e4 queries)",
+        "value": shard / dt,
+        "unit": "gallery imgs/s per GPU",
+        "gallery_shard": shard,
+        "queries": Q,
+        "seconds": dt,
+        "tflops": 2.0 * Q * shard * 256 / dt / 1e12,
+        "note": "one GPU's shard of the 1e6-image gallery of configs[4] (8-way row sharding; per-shard top-10 lists are merged after one all-gather)",
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -104,6 +131,7 @@ def main():
     ap.add_argument("--queue", type=int, default=8192)
     ap.add_argument("--model", default="m_resnet50")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--retrieval", action="store_true", help="also time the config-5 retrieval shard (adds a 'retrieval' object)")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -241,6 +269,8 @@ def main():
             },
             "roofline": roofline,
         }
+        if args.retrieval:
+            out["retrieval"] = retrieval_bench(device, world)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
         else:
