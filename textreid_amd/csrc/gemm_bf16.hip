@@ -177,16 +177,33 @@ __global__ __launch_bounds__(NT) void gemm_bf16s_kernel(GemmParams p) {
             }
         } else {  // B_CONV: row k is a pixel, column n = (tap, c)
             const int n = n0 + b_row;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int k = k0 + 8 * b_kg + j;
-                const uint32_t q = fdiv((uint32_t)k, p.fdW);
-                const int x = k - (int)q * p.W;
+            const int kbase = k0 + 8 * b_kg;  // multiple of 8
+            if ((p.W & 7) == 0) {
+                // the 8 consecutive pixels of a k-group never leave their image row when W % 8 == 0:
+                // one (y, x) decomposition per k-group instead of eight
+                const uint32_t q = fdiv((uint32_t)kbase, p.fdW);
+                const int x0 = kbase - (int)q * p.W;
                 const uint32_t b = fdiv(q, p.fdH);
-                const int y = (int)q - (int)b * p.H;
-                const int yy = y + b_dy, xx = x + b_dx;
-                rb[j] = ld1_if(n < p.N && k < k_end && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W,
-                               Bp + (long long)(k + b_dy * p.W + b_dx) * p.Cin + b_c, Bp);
+                const int yy = (int)q - (int)b * p.H + b_dy;
+                const bool row_ok = n < p.N && yy >= 0 && yy < p.H;
+                const float* src = Bp + (long long)(kbase + b_dy * p.W + b_dx) * p.Cin + b_c;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int xx = x0 + j + b_dx;
+                    rb[j] = ld1_if(row_ok && (kbase + j) < k_end && xx >= 0 && xx < p.W, src + (long long)j * p.Cin, Bp);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int k = kbase + j;
+                    const uint32_t q = fdiv((uint32_t)k, p.fdW);
+                    const int x = k - (int)q * p.W;
+                    const uint32_t b = fdiv(q, p.fdH);
+                    const int y = (int)q - (int)b * p.H;
+                    const int yy = y + b_dy, xx = x + b_dx;
+                    rb[j] = ld1_if(n < p.N && k < k_end && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W,
+                                   Bp + (long long)(k + b_dy * p.W + b_dx) * p.Cin + b_c, Bp);
+                }
             }
         }
     };

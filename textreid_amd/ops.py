@@ -135,8 +135,13 @@ def matmul_nn(a, b, out=None, alpha=1.0, accumulate=False):
     return out
 
 
-def _wgrad_splits(tiles, K):
-    return max(1, min(int(math.ceil(1024.0 / max(tiles, 1))), K // 512))
+def _wgrad_splits(tiles, K, slots=512):
+    """Split-K factor for a weight-gradient GEMM: fill the chip with whole waves of workgroups
+    (`slots` = 256 CUs x 2 resident workgroups): the largest split count whose grid is at most
+    two full waves, never leaving a nearly-empty tail wave, with >= 512 reduction rows per split."""
+    tiles = max(tiles, 1)
+    cap = max(1, K // 512)
+    return max(1, min(cap, (2 * slots) // tiles))
 
 
 def matmul_tn(a, b, out=None, alpha=1.0):
