@@ -24,6 +24,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int BN_T = 128;             // tile width
 constexpr int NT = 512;               // 8 waves
+#ifndef TRID_SPLIT_WAVES_PER_SIMD
+#define TRID_SPLIT_WAVES_PER_SIMD 0
+#endif
 // LDS image of one operand tile with R rows: 16-byte slots, slot = kgroup*(R+1) + row, one image per plane
 __host__ __device__ constexpr int plane_slots(int R) { return 4 * (R + 1); }
 
@@ -70,7 +73,7 @@ __device__ __forceinline__ float ld1_if(bool ok, const float* __restrict__ p, co
 // BM = 256: 4x2 waves (64x64 per wave), two LDS stages (one barrier per K-tile), 1 workgroup per CU:
 //           25 % less LDS write traffic and half the LDS reads per MFMA.
 template <int AMODE, int BMODE, int NPL, int BM>
-__global__ __launch_bounds__(NT) void gemm_bf16s_kernel(GemmParams p) {
+__global__ __launch_bounds__(NT, (BM == 128 && TRID_SPLIT_WAVES_PER_SIMD > 0) ? TRID_SPLIT_WAVES_PER_SIMD : 1) void gemm_bf16s_kernel(GemmParams p) {
     constexpr int BN = BN_T;
     constexpr int WAVES_N = (BM == 256) ? 2 : 4;
     constexpr int WN = BN / WAVES_N;  // 64 or 32
@@ -251,14 +254,24 @@ __global__ __launch_bounds__(NT) void gemm_bf16s_kernel(GemmParams p) {
                                                                         acc[i][j], 0, 0, 0);
     };
 
+    // 3x3 implicit GEMM: walk K channel-group-major (all 9 taps of a 32-channel slab back to
+    // back) instead of tap-major, so the nine shifted re-reads of one activation slab are adjacent
+    // in time and hit L1/L2 instead of going back to the Infinity Cache / HBM.
+    const bool permute = (AMODE == A_CONV) && (BMODE == B_KC) && (p.Cin % BK == 0) && p.splits == 1;
+    auto tile_k = [&](int k0) {
+        if (!permute) return k0;
+        const int kt = k0 / BK;
+        return (kt % 9) * p.Cin + (kt / 9) * BK;
+    };
+
     if (k_begin < k_end) {
-        load_tiles(k_begin);
+        load_tiles(tile_k(k_begin));
         store_tiles(smem4, smem4 + NPL * PA);
         __syncthreads();
         int cur = 0;
         for (int k0 = k_begin; k0 < k_end; k0 += BK) {
             const bool more = (k0 + BK) < k_end;
-            if (more) load_tiles(k0 + BK);
+            if (more) load_tiles(tile_k(k0 + BK));
             const uint4* As = smem4 + (STAGES == 2 ? cur * STAGE : 0);
             const uint4* Bs = As + NPL * PA;
             compute_step(As, Bs, 0);
