@@ -27,8 +27,18 @@ constexpr int NT = 512;               // 8 waves
 #ifndef TRID_SPLIT_WAVES_PER_SIMD
 #define TRID_SPLIT_WAVES_PER_SIMD 0
 #endif
-// LDS image of one operand tile with R rows: 16-byte slots, slot = kgroup*(R+1) + row, one image per plane
-__host__ __device__ constexpr int plane_slots(int R) { return 4 * (R + 1); }
+// LDS image of one operand tile with R rows: 16-byte slots (8 consecutive k of one row), one image per plane.
+//   K-contiguous operands:  slot = kgroup*(R+1) + row                      (loader lane = one slot)
+//   M/N-contiguous operands (R = 128): slot = kgroup*144 + (row%4)*36 + row/4
+//     -> a lane that loaded a float4 ALONG the rows writes its 4 rows to 4 slot runs that are
+//        consecutive across lanes, and MFMA fragment reads (32 consecutive rows per half-wave) stay
+//        conflict-free for ds_read_b128's 16-lane groups ((row%4)*4 + row/4 is distinct mod 16).
+__host__ __device__ constexpr int plane_slots(int R) { return 4 * (R + 1) > 4 * 144 ? 4 * (R + 1) : 4 * 144; }
+template <bool KCONTIG, int R>
+__device__ __forceinline__ int slot_of(int kg, int row) {
+    if (KCONTIG) return kg * (R + 1) + row;
+    return kg * 144 + (row & 3) * 36 + (row >> 2);
+}
 
 // two fp32 -> one dword of two bf16 (round-to-nearest-even); `lo` lands in bits 0..15
 __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
@@ -59,6 +69,33 @@ __device__ __forceinline__ void split_store(const float (&v)[8], uint4* __restri
     for (int pl = 0; pl < NPL; ++pl) dst[pl * PLANE] = make_uint4(w[pl][0], w[pl][1], w[pl][2], w[pl][3]);
 }
 
+// Wide loader store: this lane holds w[kk] = float4 along 4 consecutive rows for k = 4kq+kk.  Each row's
+// 4 k-values become half a slot (8 bytes) per plane in the swizzled M/N-contiguous image.
+template <int NPL, int PLANE>
+__device__ __forceinline__ void split_store_wide(const float4 (&w)[4], uint4* __restrict__ base, int mq, int kq) {
+    const int kg = kq >> 1, half = kq & 1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float r0, r1, r2, r3;
+        if (j == 0) { r0 = w[0].x; r1 = w[1].x; r2 = w[2].x; r3 = w[3].x; }
+        else if (j == 1) { r0 = w[0].y; r1 = w[1].y; r2 = w[2].y; r3 = w[3].y; }
+        else if (j == 2) { r0 = w[0].z; r1 = w[1].z; r2 = w[2].z; r3 = w[3].z; }
+        else { r0 = w[0].w; r1 = w[1].w; r2 = w[2].w; r3 = w[3].w; }
+        uint2* dst = reinterpret_cast<uint2*>(base + slot_of<false, 128>(kg, 4 * mq + j)) + half;
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) {
+            const unsigned h0 = cvt_pk_bf16(r0, r1), h1 = cvt_pk_bf16(r2, r3);
+            dst[pl * PLANE * 2] = make_uint2(h0, h1);
+            if (pl + 1 < NPL) {
+                r0 -= __builtin_bit_cast(float, h0 << 16);
+                r1 -= __builtin_bit_cast(float, h0 & 0xffff0000u);
+                r2 -= __builtin_bit_cast(float, h1 << 16);
+                r3 -= __builtin_bit_cast(float, h1 & 0xffff0000u);
+            }
+        }
+    }
+}
+
 // predicated loads without divergent branches: read from a always-valid address, then select
 __device__ __forceinline__ float4 ld4_if(bool ok, const float* __restrict__ p, const float* __restrict__ safe) {
     const float4 v = *reinterpret_cast<const float4*>(ok ? p : safe);
@@ -80,7 +117,10 @@ __global__ __launch_bounds__(NT, (BM == 128 && TRID_SPLIT_WAVES_PER_SIMD > 0) ? 
     constexpr int TN = WN / 32;       // 2 or 1
     constexpr int STAGES = (BM == 256) ? 2 : 1;
     constexpr int PA = plane_slots(BM), PB = plane_slots(BN);
-    constexpr int RA1 = BM + 1, RB1 = BN + 1;
+    // M/N-contiguous operands are loaded WIDE (float4 along the rows, 4 consecutive k per lane) and
+    // transposed through registers into the swizzled LDS image (128-row tiles only)
+    constexpr bool A_WIDE = (AMODE == A_MC) && BM == 128;
+    constexpr bool B_WIDE = (BMODE != B_KC);
     constexpr int STAGE = NPL * (PA + PB);  // slots per stage
     constexpr int APASS = BM / 128;         // loader passes over the A rows
     extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
@@ -105,11 +145,14 @@ __global__ __launch_bounds__(NT, (BM == 128 && TRID_SPLIT_WAVES_PER_SIMD > 0) ? 
     float* __restrict__ C = p.C + (long long)bz * p.sC + (long long)sz * p.sSplit;
     const float* __restrict__ bias = p.bias ? p.bias + (long long)bz * p.sBias : nullptr;
 
-    // loader lanes: K-contiguous operands -> (kg = tid&3, row = tid>>2); M/N-contiguous -> (row = tid&127, kg = tid>>7)
+    // loader lanes.  K-contiguous operands: all 512 threads, (kg = tid&3, row = tid>>2), one 8-k slot each.
+    // Wide (M/N-contiguous) operands: 256 threads per operand (A: waves 0-3, B: waves 4-7),
+    // (mq = t&31 -> rows 4mq..4mq+3, kq = t>>5 -> k 4kq..4kq+3), four float4 loads each.
     constexpr bool A_K = (AMODE != A_MC);
-    constexpr bool B_K = (BMODE == B_KC);
     const int a_kg = A_K ? (tid & 3) : (tid >> 7), a_row = A_K ? (tid >> 2) : (tid & 127);
-    const int b_kg = B_K ? (tid & 3) : (tid >> 7), b_row = B_K ? (tid >> 2) : (tid & 127);
+    const int b_kg = tid & 3, b_row = tid >> 2;  // B_KC only
+    const int w_mq = tid & 31, w_kq = (tid & 255) >> 5;
+    const bool a_wide_lane = tid < 256, b_wide_lane = tid >= 256;
 
     int a_y[APASS], a_x[APASS];
     if (AMODE == A_CONV) {
@@ -124,7 +167,7 @@ __global__ __launch_bounds__(NT, (BM == 128 && TRID_SPLIT_WAVES_PER_SIMD > 0) ? 
     }
     int b_dy = 0, b_dx = 0, b_c = 0;
     if (BMODE == B_CONV) {
-        const int j = n0 + b_row;
+        const int j = n0 + 4 * w_mq;
         const uint32_t tap = fdiv((uint32_t)j, p.fdC);
         b_c = j - (int)tap * p.Cin;
         b_dy = (int)tap / 3 - 1;
@@ -132,6 +175,7 @@ __global__ __launch_bounds__(NT, (BM == 128 && TRID_SPLIT_WAVES_PER_SIMD > 0) ? 
     }
 
     float ra[APASS][8], rb[8];
+    float4 wa[4], wb[4];
 
     auto load_tiles = [&](int k0) {
         // ---- A ----
@@ -156,12 +200,20 @@ __global__ __launch_bounds__(NT, (BM == 128 && TRID_SPLIT_WAVES_PER_SIMD > 0) ? 
                 const float4 u = ld4_if(ok, src, A), v = ld4_if(ok, src + 4, A);
                 ra[ps][0] = u.x; ra[ps][1] = u.y; ra[ps][2] = u.z; ra[ps][3] = u.w;
                 ra[ps][4] = v.x; ra[ps][5] = v.y; ra[ps][6] = v.z; ra[ps][7] = v.w;
-            } else {  // A_MC: A[k*lda + m], lanes along m
+            } else if (!A_WIDE) {  // A_MC, narrow fallback (256-row tiles): A[k*lda + m], lanes along m
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int k = k0 + 8 * a_kg + j;
                     ra[ps][j] = ld1_if(m < p.M && k < k_end, A + (long long)k * p.lda + m, A);
                 }
+            }
+        }
+        if (A_WIDE && a_wide_lane) {  // A_MC wide: float4 along m for 4 consecutive k
+            const int m = m0 + 4 * w_mq;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = k0 + 4 * w_kq + j;
+                wa[j] = ld4_if(m < p.M && k < k_end, A + (long long)k * p.lda + m, A);
             }
         }
         // ---- B ----
@@ -172,49 +224,61 @@ __global__ __launch_bounds__(NT, (BM == 128 && TRID_SPLIT_WAVES_PER_SIMD > 0) ? 
             const float4 u = ld4_if(ok, src, Bp), v = ld4_if(ok, src + 4, Bp);
             rb[0] = u.x; rb[1] = u.y; rb[2] = u.z; rb[3] = u.w; rb[4] = v.x; rb[5] = v.y; rb[6] = v.z; rb[7] = v.w;
         } else if (BMODE == B_NC) {
-            const int n = n0 + b_row;
+            if (b_wide_lane) {
+                const int n = n0 + 4 * w_mq;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int k = k0 + 8 * b_kg + j;
-                rb[j] = ld1_if(n < p.N && k < k_end, Bp + (long long)k * p.ldb + n, Bp);
-            }
-        } else {  // B_CONV: row k is a pixel, column n = (tap, c)
-            const int n = n0 + b_row;
-            const int kbase = k0 + 8 * b_kg;  // multiple of 8
-            if ((p.W & 7) == 0) {
-                // the 8 consecutive pixels of a k-group never leave their image row when W % 8 == 0:
-                // one (y, x) decomposition per k-group instead of eight
-                const uint32_t q = fdiv((uint32_t)kbase, p.fdW);
-                const int x0 = kbase - (int)q * p.W;
-                const uint32_t b = fdiv(q, p.fdH);
-                const int yy = (int)q - (int)b * p.H + b_dy;
-                const bool row_ok = n < p.N && yy >= 0 && yy < p.H;
-                const float* src = Bp + (long long)(kbase + b_dy * p.W + b_dx) * p.Cin + b_c;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int xx = x0 + j + b_dx;
-                    rb[j] = ld1_if(row_ok && (kbase + j) < k_end && xx >= 0 && xx < p.W, src + (long long)j * p.Cin, Bp);
+                for (int j = 0; j < 4; ++j) {
+                    const int k = k0 + 4 * w_kq + j;
+                    wb[j] = ld4_if(n < p.N && k < k_end, Bp + (long long)k * p.ldb + n, Bp);
                 }
-            } else {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int k = kbase + j;
-                    const uint32_t q = fdiv((uint32_t)k, p.fdW);
-                    const int x = k - (int)q * p.W;
+            }
+        } else {  // B_CONV: row k is a pixel, 4 consecutive columns n = (tap, c..c+3)
+            if (b_wide_lane) {
+                const int n = n0 + 4 * w_mq;
+                const int kbase = k0 + 4 * w_kq;  // multiple of 4
+                if ((p.W & 3) == 0) {
+                    // 4 consecutive pixels stay in one image row when W % 4 == 0: one decomposition
+                    const uint32_t q = fdiv((uint32_t)kbase, p.fdW);
+                    const int x0 = kbase - (int)q * p.W;
                     const uint32_t b = fdiv(q, p.fdH);
-                    const int y = (int)q - (int)b * p.H;
-                    const int yy = y + b_dy, xx = x + b_dx;
-                    rb[j] = ld1_if(n < p.N && k < k_end && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W,
-                                   Bp + (long long)(k + b_dy * p.W + b_dx) * p.Cin + b_c, Bp);
+                    const int yy = (int)q - (int)b * p.H + b_dy;
+                    const bool row_ok = n < p.N && yy >= 0 && yy < p.H;
+                    const float* src = Bp + (long long)(kbase + b_dy * p.W + b_dx) * p.Cin + b_c;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int xx = x0 + j + b_dx;
+                        wb[j] = ld4_if(row_ok && (kbase + j) < k_end && xx >= 0 && xx < p.W, src + (long long)j * p.Cin, Bp);
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int k = kbase + j;
+                        const uint32_t q = fdiv((uint32_t)k, p.fdW);
+                        const int x = k - (int)q * p.W;
+                        const uint32_t b = fdiv(q, p.fdH);
+                        const int y = (int)q - (int)b * p.H;
+                        const int yy = y + b_dy, xx = x + b_dx;
+                        wb[j] = ld4_if(n < p.N && k < k_end && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W,
+                                       Bp + (long long)(k + b_dy * p.W + b_dx) * p.Cin + b_c, Bp);
+                    }
                 }
             }
         }
     };
 
     auto store_tiles = [&](uint4* __restrict__ As, uint4* __restrict__ Bs) {
+        if (A_WIDE) {
+            if (a_wide_lane) split_store_wide<NPL, PA>(wa, As, w_mq, w_kq);
+        } else {
 #pragma unroll
-        for (int ps = 0; ps < APASS; ++ps) split_store<NPL, PA>(ra[ps], As + a_kg * RA1 + a_row + ps * 128);
-        split_store<NPL, PB>(rb, Bs + b_kg * RB1 + b_row);
+            for (int ps = 0; ps < APASS; ++ps)
+                split_store<NPL, PA>(ra[ps], As + slot_of<true, BM>(a_kg, a_row + ps * 128));
+        }
+        if (B_WIDE) {
+            if (b_wide_lane) split_store_wide<NPL, PB>(wb, Bs, w_mq, w_kq);
+        } else {
+            split_store<NPL, PB>(rb, Bs + slot_of<true, BN>(b_kg, b_row));
+        }
     };
 
     v16f acc[2][TN];
@@ -232,11 +296,12 @@ __global__ __launch_bounds__(NT, (BM == 128 && TRID_SPLIT_WAVES_PER_SIMD > 0) ? 
         bf16x8 a[NPL][2], b[NPL][TN];
 #pragma unroll
         for (int pl = 0; pl < NPL; ++pl) {
-            const int sa = pl * PA + (2 * ks + khalf) * RA1, sb = pl * PB + (2 * ks + khalf) * RB1;
-            a[pl][0] = __builtin_bit_cast(bf16x8, As[sa + a_slot]);
-            a[pl][1] = __builtin_bit_cast(bf16x8, As[sa + a_slot + 32]);
+            const int kg = 2 * ks + khalf;
+            a[pl][0] = __builtin_bit_cast(bf16x8, As[pl * PA + slot_of<!A_WIDE, BM>(kg, a_slot)]);
+            a[pl][1] = __builtin_bit_cast(bf16x8, As[pl * PA + slot_of<!A_WIDE, BM>(kg, a_slot + 32)]);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[pl][j] = __builtin_bit_cast(bf16x8, Bs[sb + b_slot + 32 * j]);
+            for (int j = 0; j < TN; ++j)
+                b[pl][j] = __builtin_bit_cast(bf16x8, Bs[pl * PB + slot_of<!B_WIDE, BN>(kg, b_slot + 32 * j)]);
         }
         // Term-major order: consecutive MFMAs hit DIFFERENT accumulators, so no MFMA waits on the
         // result of the one issued just before it (dependent-accumulator latency > issue interval).
