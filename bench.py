@@ -219,6 +219,24 @@ def main():
     nlaunch = len(prof["events"])
     achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
 
+    # the same kernel alone on the GPU (no side-stream work sharing the CUs): the 3x3 layers of layer2-4
+    iso_fl, iso_ms = 0.0, 0.0
+    for (Hh, Ww, Cc) in ((96, 32, 128), (48, 16, 128), (48, 16, 256), (24, 8, 256), (24, 8, 512)):
+        xx = torch.randn(B, Hh, Ww, Cc, device=device)
+        ww = torch.randn(Cc, 9 * Cc, device=device)
+        ops.conv3x3(xx, ww, stats=True)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            ops.conv3x3(xx, ww, stats=True)
+        e1.record()
+        torch.cuda.synchronize()
+        iso_ms += e0.elapsed_time(e1) / 3
+        iso_fl += 2.0 * B * Hh * Ww * Cc * 9 * Cc
+        del xx, ww
+    achieved_isolated = iso_fl / (iso_ms * 1e-3) / 1e12
+
     prec = ops.GEMM_PRECISION
     if prec in (3, 6):
         # the dominant kernel executes `prec` bf16 MFMA products per fp32 multiply-add
@@ -239,6 +257,9 @@ def main():
         "unit": "TFLOP/s",
         "frac": achieved / peak,
         "traffic": None,
+        "achieved_isolated": achieved_isolated,
+        "frac_isolated": achieved_isolated / peak,
+        "note": "achieved/frac: events around every launch of this kernel during the timed steps, while the text / key-encoder / weight-gradient streams share the CUs; *_isolated: the same kernel on the five layer2-4 3x3 shapes with the GPU to itself",
         "peak_note": peak_note,
         "launches": nlaunch,
         "avg_launch_ms": ms / max(nlaunch, 1),
