@@ -12,43 +12,53 @@ to learn the batch-max length (the reference syncs at gru.py:74).
 import torch
 
 
-class Caption(object):
+def _as_rows(text, dtype, device):
+    """Token input in any reference-accepted form -> list of 1-D tensors."""
+    if isinstance(text, torch.Tensor):
+        t = text.to(dtype)
+        return [t] if t.dim() == 1 else list(t.reshape(-1, t.shape[-1]))
+    if len(text) and not isinstance(text[0], (list, tuple, torch.Tensor)):
+        text = [text]
+    return [torch.as_tensor(row, dtype=dtype, device=device) for row in text]
+
+
+class Caption:
+    """One caption record: ``text`` is the zero-padded (or truncated) token row(s) [n, max_length],
+    ``length`` the unpadded token count(s); free-form per-sample fields (``id``, ``image_id`` ...)
+    ride along in ``extra_fields``.  A raw ``str`` caption is kept as is (word count as length)."""
+
+    __slots__ = ("text", "length", "max_length", "padded", "dtype", "extra_fields")
+
     def __init__(self, text, length=None, max_length=None, padded=False, dtype=torch.int64):
+        self.dtype, self.padded, self.extra_fields = dtype, True, {}
+        if isinstance(text, str):
+            self.text, self.max_length = text, max_length
+            self.length = len(text.split()) if length is None else length
+            return
         device = text.device if isinstance(text, torch.Tensor) else torch.device("cpu")
-        if isinstance(text, list):
-            text = [torch.as_tensor(line, dtype=dtype, device=device) for line in text]
-            if length is None:
-                length = torch.stack([torch.tensor(line.size(0), dtype=torch.int64, device=device) for line in text])
-            if max_length is None:
-                max_length = max(line.size(-1) for line in text)
-        elif not isinstance(text, str):
-            text = torch.as_tensor(text, dtype=dtype, device=device)
-            if length is None:
-                length = torch.tensor(text.size(-1), dtype=torch.int64, device=device)
-            if max_length is None:
-                max_length = text.size(-1)
-        elif length is None:
-            length = len(text.split())
-        if not padded and not isinstance(text, str):
-            text = self.pad(text, max_length, device)
-        self.text = text
+        if padded:  # already a padded tensor (the .to() path): adopt it
+            self.text = torch.as_tensor(text, dtype=dtype, device=device)
+            self.length = length
+            self.max_length = self.text.shape[-1] if max_length is None else max_length
+            return
+        rows = _as_rows(text, dtype, device)
+        counts = [int(r.numel()) for r in rows]
+        single = isinstance(text, torch.Tensor) and text.dim() == 1
+        if length is None:
+            length = torch.tensor(counts[0] if single else counts, dtype=torch.int64, device=device)
         self.length = length
-        self.max_length = max_length
-        self.padded = True
-        self.dtype = dtype
-        self.extra_fields = {}
+        self.max_length = max(counts) if max_length is None else max_length
+        self.text = self.pad(rows, self.max_length, device)
 
     @staticmethod
-    def pad(text, max_length, device):
-        rows = []
-        for line in text:
-            n = line.size(0)
-            if n < max_length:
-                rows.append(torch.cat((line, torch.zeros(max_length - n, dtype=torch.int64, device=device))))
-            else:
-                rows.append(line[:max_length])
-        return torch.stack(rows)
+    def pad(rows, max_length, device):
+        out = torch.zeros(len(rows), max_length, dtype=torch.int64, device=device)
+        for i, row in enumerate(rows):
+            n = min(int(row.numel()), max_length)
+            out[i, :n] = row[:n]
+        return out
 
+    # -- per-sample side data ------------------------------------------------------------
     def add_field(self, field, field_data):
         self.extra_fields[field] = field_data
 
@@ -59,25 +69,24 @@ class Caption(object):
         return field in self.extra_fields
 
     def fields(self):
-        return list(self.extra_fields.keys())
+        return list(self.extra_fields)
 
     def to(self, device):
-        cap = Caption(self.text, self.length, self.max_length, self.padded, self.dtype)
-        if not isinstance(self.text, str):
-            cap.text = cap.text.to(device)
-            cap.length = cap.length.to(device)
-        for k, v in self.extra_fields.items():
-            cap.add_field(k, v.to(device) if hasattr(v, "to") else v)
-        return cap
+        if isinstance(self.text, str):
+            moved = Caption(self.text, self.length, self.max_length, dtype=self.dtype)
+        else:
+            moved = Caption(self.text.to(device), self.length.to(device), self.max_length, padded=True, dtype=self.dtype)
+        moved.extra_fields = {k: (v.to(device) if hasattr(v, "to") else v) for k, v in self.extra_fields.items()}
+        return moved
 
     def __len__(self):
         return len(self.text)
 
     def __repr__(self):
-        return "Caption(length={}, max_length={}, padded={})".format(self.length, self.max_length, self.padded)
+        return f"Caption(length={self.length}, max_length={self.max_length}, fields={self.fields()})"
 
 
-class CaptionBatch(object):
+class CaptionBatch:
     """tokens [B,L] i64, lengths [B] i64, ids [B] i64 (or None), max_len: host int."""
 
     def __init__(self, tokens, lengths, ids=None, max_len=None):
