@@ -187,7 +187,7 @@ def main():
         torch.cuda.synchronize()
         log("warmup step %d done" % i)
     # live roofline of the dominant kernel: 3x3 implicit-GEMM conv, 128x128 tiles
-    split = ops.GEMM_PRECISION in (3, 6)
+    split = ops.GEMM_PRECISION in (1, 3, 6)
     dom = (ops.A_CONV, ops.B_KC, 128, 128, split)
     ops.PROFILE = {"match": lambda key: key == dom, "events": []}
     if world > 1:
@@ -241,9 +241,14 @@ def main():
     if prec in (3, 6):
         # the dominant kernel executes `prec` bf16 MFMA products per fp32 multiply-add
         peak = BF16_MFMA_PEAK_TFLOPS / prec
-        kname = "trid::gemm_bf16s_kernel<A_CONV,B_KC,%d planes> (3x3 implicit-GEMM conv fwd+dgrad; fp32 operands split into bf16 planes, %d bf16 MFMA 32x32x16 products per multiply-add, fp32 accumulate)" % (prec // 2, prec)
+        kname = "trid::gemm_pp_kernel<A_CONV,%d planes> / trid::gemm_bf16s_kernel<A_CONV,B_KC,%d planes> (3x3 implicit-GEMM conv fwd+dgrad, 256x128 role-alternating tiles where the grid fills the chip, 128x128 otherwise; fp32 operands split into bf16 planes, %d bf16 MFMA 32x32x16 products per multiply-add, fp32 accumulate)" % (prec // 2, prec // 2, prec)
         peak_note = "dense bf16 MFMA peak 2500 TFLOP/s / %d products = fp32-equivalent peak" % prec
         arith = "fp32 operands and accumulation; products evaluated as %d bf16 MFMA terms of a %d-way bf16 split (dropped terms <= 2^-%d)" % (prec, prec // 2, 26 if prec == 6 else 17)
+    elif prec == 1:
+        peak = BF16_MFMA_PEAK_TFLOPS
+        kname = "trid::gemm_bf16s_kernel<A_CONV,B_KC,1 plane> (3x3 implicit-GEMM conv fwd+dgrad; fp32 tensors in HBM, operands rounded to bf16 while staged into LDS, one bf16 MFMA 32x32x16 per product, fp32 accumulate)"
+        peak_note = "dense bf16 MFMA peak"
+        arith = "bf16 operands (rounded on the fly), fp32 accumulation, fp32 tensors / BatchNorm / losses / optimizer (bf16-autocast arithmetic); NOT the configs[1] fp32 line"
     else:
         peak = F32_MFMA_PEAK_TFLOPS
         kname = "trid::gemm_kernel<A_CONV,B_KC,128,128,2,4> (3x3 implicit-GEMM conv fwd+dgrad, fp32 MFMA 32x32x2)"
@@ -277,11 +282,11 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "bf16" if prec == 1 else "f32",
             "data": "synthetic",
             "config": {
-                "workload": "configs[1]: CLIP-%s + GRU, bs%d/GPU, 384x128 images, 64-token captions, MoCo queue %d, fp32, %dxMI355X; random-init weights, synthetic inputs resident in HBM" % (
-                    "RN50" if args.model == "m_resnet50" else "RN101", B, args.queue, world),
+                "workload": "configs[1]: CLIP-%s + GRU, bs%d/GPU, 384x128 images, 64-token captions, MoCo queue %d, %s, %dxMI355X; random-init weights, synthetic inputs resident in HBM" % (
+                    "RN50" if args.model == "m_resnet50" else "RN101", B, args.queue, "bf16 MFMA (TRID_GEMM_PRECISION=1)" if prec == 1 else "fp32", world),
                 "global_batch": B * world,
                 "parallelism": "dp%d" % world,
                 "optimizer": "Adam (fused multi-tensor)",

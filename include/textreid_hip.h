@@ -72,8 +72,9 @@ typedef struct trid_gemm_desc {
     int32_t H, W, Cin;  /* conv gather geometry */
     int32_t precision;  /* 0: exact fp32-input MFMA; 6 / 3: fp32 operands split on the fly into 3 / 2 bf16
                          * planes, 6 / 3 bf16 MFMAs per product, fp32 accumulate (6 is fp32-class, dropped
-                         * terms <= 2^-26; 3 drops ~2^-17).  Shapes the split kernel does not cover fall
-                         * back to 0. */
+                         * terms <= 2^-26; 3 drops ~2^-17); 1: operands rounded to bf16, one MFMA per
+                         * product, fp32 accumulate (bf16-autocast arithmetic).  Shapes the split kernel
+                         * does not cover fall back to 0. */
 } trid_gemm_desc;
 
 int trid_gemm_f32(const trid_gemm_desc* d, void* stream);
@@ -246,10 +247,12 @@ int trid_enqueue_f32(float* v_queue, float* t_queue, int64_t* id_queue, int64_t*
  * ------------------------------------------------------------------------- */
 /* sim = q @ g.T for q [Q,C], g [G,C] (both L2-normalised by the caller), fused
  * per-row top-k (k <= 16) sorted descending, ties -> lower index first.
- * out_val [Q,k] f32, out_idx [Q,k] i64 (+ idx_offset).  ws floats >= trid_topk_ws_floats(Q,G,k). */
+ * out_val [Q,k] f32, out_idx [Q,k] i64 (+ idx_offset).  ws floats >= trid_topk_ws_floats(Q,G,k).
+ * precision: arithmetic of the similarity GEMM, as trid_gemm_desc.precision (6: split bf16, fp32-class;
+ * 0: exact fp32-input MFMA). */
 long long trid_topk_ws_floats(int Q, int G, int k);
 int trid_sim_topk_f32(const float* q, const float* g, float* out_val, int64_t* out_idx, int Q, int G, int C,
-                      int k, long long idx_offset, float* ws, void* stream);
+                      int k, long long idx_offset, int precision, float* ws, void* stream);
 
 /* per-row top-k of a given similarity matrix (rank(get_mAP=False), evaluation.py:17-19) */
 int trid_topk_rows_f32(const float* sim, int ld, int Q, int G, int k, float* out_val, int64_t* out_idx,

@@ -66,6 +66,33 @@ def test_fused_similarity_topk(gpu, Q, G, k):
     assert torch.allclose(vals.cpu(), rv, atol=2e-6)
 
 
+@pytest.mark.parametrize("G,k", [(10, 10), (63, 5), (257, 10), (4099, 16), (20000, 10)])
+def test_topk_rows_adversarial_orders_and_ties(gpu, G, k):
+    """Row top-k kernel on the orders a threshold filter is weakest on: ascending (every element
+    is admitted), descending, constant (pure ties -> lowest indices), few distinct values, -inf."""
+    from textreid_amd.evaluation import call, _p, stream
+
+    gen = torch.Generator().manual_seed(G)
+    rows = [
+        torch.arange(G, dtype=torch.float32),                      # ascending
+        -torch.arange(G, dtype=torch.float32),                     # descending
+        torch.full((G,), 0.25),                                    # constant
+        torch.randint(0, 3, (G,), generator=gen).float(),          # heavy ties
+        torch.randn(G, generator=gen),
+        torch.where(torch.rand(G, generator=gen) < 0.5, torch.tensor(-float("inf")), torch.randn(G, generator=gen)),
+    ]
+    sim = torch.stack(rows).to(gpu)
+    Q = sim.shape[0]
+    vals = torch.empty(Q, k, device=gpu)
+    idx = torch.empty(Q, k, dtype=torch.int64, device=gpu)
+    call("trid_topk_rows_f32", _p(sim), G, Q, G, k, _p(vals), _p(idx), stream())
+    # expected: stable descending sort = (value desc, index asc)
+    order = torch.sort(sim.cpu(), dim=1, descending=True, stable=True)
+    assert torch.equal(vals.cpu(), order.values[:, :k])
+    finite = torch.isfinite(order.values[:, :k])
+    assert torch.equal(idx.cpu()[finite], order.indices[:, :k][finite])
+
+
 def test_topk_full_size_properties(gpu):
     """Config-5-shaped shard at reduced Q: top-k is sorted, indices valid and
     unique, and every returned value equals the recomputed dot product."""

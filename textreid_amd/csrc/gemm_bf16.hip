@@ -6,6 +6,8 @@
 // and a product a*b is evaluated as the sum of the significant plane products:
 //     NPL = 3 ("bf16x6"): hh + hm + mh + hl + lh + mm   (dropped terms <= 2^-26 |ab|: fp32-class)
 //     NPL = 2 ("bf16x3"): hh + hm + mh                  (dropped terms ~ 2^-17 |ab|)
+//     NPL = 1 ("bf16")  : hh                            (operands rounded to bf16, fp32 accumulate:
+//                                                        the arithmetic of a bf16 autocast run)
 // all accumulated in the MFMA's fp32 accumulator, small terms first.  Same loader modes,
 // epilogues (alpha / bias / accumulate / split-K / BatchNorm partials) and C ABI as gemm.hip.
 //
@@ -16,96 +18,15 @@
 
 #include <stdlib.h>
 
-#include "gemm_common.h"
+#include "split_common.h"
 
 namespace trid {
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int BN_T = 128;             // tile width
 constexpr int NT = 512;               // 8 waves
 #ifndef TRID_SPLIT_WAVES_PER_SIMD
 #define TRID_SPLIT_WAVES_PER_SIMD 0
 #endif
-// LDS image of one operand tile with R rows: 16-byte slots (8 consecutive k of one row), one image per plane.
-//   K-contiguous operands:  slot = kgroup*(R+1) + row                      (loader lane = one slot)
-//   M/N-contiguous operands (R = 128): slot = kgroup*144 + (row%4)*36 + row/4
-//     -> a lane that loaded a float4 ALONG the rows writes its 4 rows to 4 slot runs that are
-//        consecutive across lanes, and MFMA fragment reads (32 consecutive rows per half-wave) stay
-//        conflict-free for ds_read_b128's 16-lane groups ((row%4)*4 + row/4 is distinct mod 16).
-__host__ __device__ constexpr int plane_slots(int R) { return 4 * (R + 1) > 4 * 144 ? 4 * (R + 1) : 4 * 144; }
-template <bool KCONTIG, int R>
-__device__ __forceinline__ int slot_of(int kg, int row) {
-    if (KCONTIG) return kg * (R + 1) + row;
-    return kg * 144 + (row & 3) * 36 + (row >> 2);
-}
-
-// two fp32 -> one dword of two bf16 (round-to-nearest-even); `lo` lands in bits 0..15
-__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
-    unsigned r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-    return r;
-}
-
-template <int NPL, int PLANE>
-__device__ __forceinline__ void split_store(const float (&v)[8], uint4* __restrict__ dst) {
-    // dst: plane 0 slot; planes are PLANE slots apart.  Per pair of values: one packed convert
-    // per plane, residuals formed exactly in fp32 (x - float(bf16(x)) is representable).
-    unsigned w[NPL][4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        float r0 = v[2 * q], r1 = v[2 * q + 1];
-#pragma unroll
-        for (int pl = 0; pl < NPL; ++pl) {
-            const unsigned h = cvt_pk_bf16(r0, r1);
-            w[pl][q] = h;
-            if (pl + 1 < NPL) {
-                r0 -= __builtin_bit_cast(float, h << 16);
-                r1 -= __builtin_bit_cast(float, h & 0xffff0000u);
-            }
-        }
-    }
-#pragma unroll
-    for (int pl = 0; pl < NPL; ++pl) dst[pl * PLANE] = make_uint4(w[pl][0], w[pl][1], w[pl][2], w[pl][3]);
-}
-
-// Wide loader store: this lane holds w[kk] = float4 along 4 consecutive rows for k = 4kq+kk.  Each row's
-// 4 k-values become half a slot (8 bytes) per plane in the swizzled M/N-contiguous image.
-template <int NPL, int PLANE>
-__device__ __forceinline__ void split_store_wide(const float4 (&w)[4], uint4* __restrict__ base, int mq, int kq) {
-    const int kg = kq >> 1, half = kq & 1;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        float r0, r1, r2, r3;
-        if (j == 0) { r0 = w[0].x; r1 = w[1].x; r2 = w[2].x; r3 = w[3].x; }
-        else if (j == 1) { r0 = w[0].y; r1 = w[1].y; r2 = w[2].y; r3 = w[3].y; }
-        else if (j == 2) { r0 = w[0].z; r1 = w[1].z; r2 = w[2].z; r3 = w[3].z; }
-        else { r0 = w[0].w; r1 = w[1].w; r2 = w[2].w; r3 = w[3].w; }
-        uint2* dst = reinterpret_cast<uint2*>(base + slot_of<false, 128>(kg, 4 * mq + j)) + half;
-#pragma unroll
-        for (int pl = 0; pl < NPL; ++pl) {
-            const unsigned h0 = cvt_pk_bf16(r0, r1), h1 = cvt_pk_bf16(r2, r3);
-            dst[pl * PLANE * 2] = make_uint2(h0, h1);
-            if (pl + 1 < NPL) {
-                r0 -= __builtin_bit_cast(float, h0 << 16);
-                r1 -= __builtin_bit_cast(float, h0 & 0xffff0000u);
-                r2 -= __builtin_bit_cast(float, h1 << 16);
-                r3 -= __builtin_bit_cast(float, h1 & 0xffff0000u);
-            }
-        }
-    }
-}
-
-// predicated loads without divergent branches: read from a always-valid address, then select
-__device__ __forceinline__ float4 ld4_if(bool ok, const float* __restrict__ p, const float* __restrict__ safe) {
-    const float4 v = *reinterpret_cast<const float4*>(ok ? p : safe);
-    return ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
-}
-__device__ __forceinline__ float ld1_if(bool ok, const float* __restrict__ p, const float* __restrict__ safe) {
-    const float v = *(ok ? p : safe);
-    return ok ? v : 0.f;
-}
-
 // BM = 128: 2x4 waves (64x32 per wave), one LDS stage, 2 workgroups per CU.
 // BM = 256: 4x2 waves (64x64 per wave), two LDS stages (one barrier per K-tile), 1 workgroup per CU:
 //           25 % less LDS write traffic and half the LDS reads per MFMA.
@@ -306,7 +227,7 @@ __global__ __launch_bounds__(NT, (BM == 128 && TRID_SPLIT_WAVES_PER_SIMD > 0) ? 
         // Term-major order: consecutive MFMAs hit DIFFERENT accumulators, so no MFMA waits on the
         // result of the one issued just before it (dependent-accumulator latency > issue interval).
         // Smallest terms first: mm, hl, lh (3 planes only), then hm, mh, hh.
-        constexpr int NTERM = (NPL == 3) ? 6 : 3;
+        constexpr int NTERM = (NPL == 3) ? 6 : (NPL == 2) ? 3 : 1;
         constexpr int TA[6] = {1, 0, 2, 0, 1, 0};
         constexpr int TB[6] = {1, 2, 0, 1, 0, 0};
 #pragma unroll
@@ -493,6 +414,7 @@ static int dispatch_modes(GemmParams& p, int am, int bm, hipStream_t stream) {
 
 int gemm_bf16_dispatch(GemmParams& p, int a_mode, int b_mode, int precision, hipStream_t stream) {
     if (precision == 6) return dispatch_modes<3>(p, a_mode, b_mode, stream);
+    if (precision == 1) return dispatch_modes<1>(p, a_mode, b_mode, stream);
     return dispatch_modes<2>(p, a_mode, b_mode, stream);
 }
 

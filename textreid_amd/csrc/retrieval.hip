@@ -11,56 +11,84 @@ namespace trid {
 
 constexpr int TOPK_MAX = 16;
 
+// Running top-k of one similarity row per wave.  The k best (value, index) pairs live one per
+// lane (lane i = i-th best, sorted by value descending, ties lower index first); the k-th value
+// is the wave-uniform admission threshold.  The row is streamed with UNROLL independent float4
+// loads per lane in flight and tested against the threshold with one ballot per batch, so after
+// the first few hundred elements the kernel is a pure HBM stream; the rare survivors
+// (~k ln(G/k) per row for unordered data) are inserted one at a time with a ballot-popcount
+// position and a one-lane shuffle shift.  Exact for any input order (sorted-ascending rows
+// degrade to one insertion per element, never to a wrong answer).
 template <int KK>
 __global__ __launch_bounds__(256) void topk_merge_rows_kernel(const float* __restrict__ sim, int ld, int Q, int Gc,
                                                               long long col_offset, float* __restrict__ best_val,
                                                               long long* __restrict__ best_idx, int first) {
+    constexpr int UNROLL = 8;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= Q) return;
-    float v[KK];
-    long long id[KK];
+    float lv = -INFINITY;
+    long long li = -1;
+    if (!first && lane < KK) {
+        lv = best_val[(long long)row * KK + lane];
+        li = best_idx[(long long)row * KK + lane];
+    }
+    float t = __shfl(lv, KK - 1, 64);
+    long long ti = __shfl(li, KK - 1, 64);
+
+    auto offer = [&](float cv, long long ci) {  // wave-uniform candidate
+        if (!(cv > t || (cv == t && (ti < 0 || ci < ti)))) return;
+        const bool ahead = lane < KK && (lv > cv || (lv == cv && li >= 0 && li < ci));
+        const int pos = __popcll(__ballot(ahead));
+        const float uv = __shfl_up(lv, 1, 64);
+        const long long ui = __shfl_up(li, 1, 64);
+        if (lane > pos) { lv = uv; li = ui; }
+        if (lane == pos) { lv = cv; li = ci; }
+        if (lane >= KK) { lv = -INFINITY; li = -1; }
+        t = __shfl(lv, KK - 1, 64);
+        ti = __shfl(li, KK - 1, 64);
+    };
+
+    const float* r = sim + (long long)row * ld;
+    const bool vec_ok = ((reinterpret_cast<uintptr_t>(r) & 15) == 0);
+    for (int base = 0; base < Gc; base += 256 * UNROLL) {
+        float4 x[UNROLL];
 #pragma unroll
-    for (int i = 0; i < KK; ++i) { v[i] = -INFINITY; id[i] = -1; }
-    auto insert = [&](float x, long long xi) {
-        // keep v sorted descending; ties -> lower index first
-        if (x > v[KK - 1] || (x == v[KK - 1] && xi >= 0 && (id[KK - 1] < 0 || xi < id[KK - 1]))) {
-            v[KK - 1] = x; id[KK - 1] = xi;
+        for (int u = 0; u < UNROLL; ++u) {
+            const int j = base + u * 256 + lane * 4;
+            if (vec_ok && j + 3 < Gc) {
+                x[u] = *reinterpret_cast<const float4*>(r + j);
+            } else {
+                x[u].x = j < Gc ? r[j] : -INFINITY;
+                x[u].y = j + 1 < Gc ? r[j + 1] : -INFINITY;
+                x[u].z = j + 2 < Gc ? r[j + 2] : -INFINITY;
+                x[u].w = j + 3 < Gc ? r[j + 3] : -INFINITY;
+            }
+        }
+        bool hit = false;
 #pragma unroll
-            for (int i = KK - 1; i > 0; --i) {
-                const bool sw = v[i] > v[i - 1] || (v[i] == v[i - 1] && id[i] >= 0 && (id[i - 1] < 0 || id[i] < id[i - 1]));
-                if (sw) {
-                    const float tv = v[i]; v[i] = v[i - 1]; v[i - 1] = tv;
-                    const long long ti = id[i]; id[i] = id[i - 1]; id[i - 1] = ti;
+        for (int u = 0; u < UNROLL; ++u) hit = hit || x[u].x >= t || x[u].y >= t || x[u].z >= t || x[u].w >= t;
+        if (__ballot(hit) == 0ull) continue;
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const int j0 = base + u * 256;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float xc = c == 0 ? x[u].x : c == 1 ? x[u].y : c == 2 ? x[u].z : x[u].w;
+                // padding lanes carry -inf: admitted only while the list still has empty slots, and
+                // then they are indistinguishable from the empty slots themselves
+                unsigned long long bal = __ballot(xc >= t && (j0 + lane * 4 + c) < Gc);
+                while (bal) {
+                    const int src = __ffsll((long long)bal) - 1;
+                    bal &= bal - 1;
+                    offer(__shfl(xc, src, 64), col_offset + j0 + src * 4 + c);
                 }
             }
         }
-    };
-    const float* r = sim + (long long)row * ld;
-    for (int j = lane; j < Gc; j += 64) insert(r[j], col_offset + j);
-    if (!first && lane < KK) insert(best_val[(long long)row * KK + lane], best_idx[(long long)row * KK + lane]);
-    // tournament: KK rounds, each picks the wave-wide best head and pops it
-    for (int round = 0; round < KK; ++round) {
-        float bv = v[0];
-        long long bi = id[0];
-        int bl = lane;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const float ov = __shfl_xor(bv, o, 64);
-            const long long oi = __shfl_xor(bi, o, 64);
-            const int ol = __shfl_xor(bl, o, 64);
-            const bool take = ov > bv || (ov == bv && ((oi >= 0 && (bi < 0 || oi < bi)) || (oi == bi && ol < bl)));
-            if (take) { bv = ov; bi = oi; bl = ol; }
-        }
-        if (lane == 0) {
-            best_val[(long long)row * KK + round] = bv;
-            best_idx[(long long)row * KK + round] = bi;
-        }
-        if (lane == bl) {
-#pragma unroll
-            for (int i = 0; i < KK - 1; ++i) { v[i] = v[i + 1]; id[i] = id[i + 1]; }
-            v[KK - 1] = -INFINITY; id[KK - 1] = -1;
-        }
+    }
+    if (lane < KK) {
+        best_val[(long long)row * KK + lane] = lv;
+        best_idx[(long long)row * KK + lane] = li;
     }
 }
 
@@ -180,7 +208,7 @@ extern "C" long long trid_topk_ws_floats(int Q, int G, int k) {
 }
 
 extern "C" int trid_sim_topk_f32(const float* q, const float* g, float* out_val, int64_t* out_idx, int Q, int G, int C,
-                                 int k, long long idx_offset, float* ws, void* stream) {
+                                 int k, long long idx_offset, int precision, float* ws, void* stream) {
     TRID_REQUIRE(q && g && out_val && out_idx && ws, "trid_sim_topk_f32: null pointer");
     TRID_REQUIRE(Q > 0 && G > 0 && C > 0 && C % 4 == 0, "trid_sim_topk_f32: bad shape (C%%4)");
     TRID_REQUIRE(k >= 1 && k <= TOPK_MAX && k <= G, "trid_sim_topk_f32: k must be in [1,%d] and <= G", TOPK_MAX);
@@ -194,6 +222,7 @@ extern "C" int trid_sim_topk_f32(const float* q, const float* g, float* out_val,
         d.lda = C; d.ldb = C; d.ldc = Gc;
         d.batch = 1; d.splits = 1; d.alpha = 1.f;
         d.a_mode = TRID_A_KC; d.b_mode = TRID_B_KC;
+        d.precision = precision;
         int rc = trid_gemm_f32(&d, stream);
         if (rc) return rc;
         const dim3 grid((Q + 3) / 4), block(256);

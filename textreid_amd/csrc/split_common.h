@@ -1,0 +1,91 @@
+// Helpers shared by the split-precision GEMM kernels (gemm_bf16.hip, gemm_pp.hip): fp32 -> bf16
+// plane splitting while staging into LDS, LDS slot maps, branch-free predicated loads.
+#pragma once
+#include "gemm_common.h"
+
+namespace trid {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// LDS image of one operand tile with R rows: 16-byte slots (8 consecutive k of one row), one image per plane.
+//   K-contiguous operands:  slot = kgroup*(R+1) + row                      (loader lane = one slot)
+//   M/N-contiguous operands (R = 128): slot = kgroup*144 + (row%4)*36 + row/4
+//     -> a lane that loaded a float4 ALONG the rows writes its 4 rows to 4 slot runs that are
+//        consecutive across lanes, and MFMA fragment reads (32 consecutive rows per half-wave) stay
+//        conflict-free for ds_read_b128's 16-lane groups ((row%4)*4 + row/4 is distinct mod 16).
+__host__ __device__ constexpr int plane_slots(int R) { return 4 * (R + 1) > 4 * 144 ? 4 * (R + 1) : 4 * 144; }
+template <bool KCONTIG, int R>
+__device__ __forceinline__ int slot_of(int kg, int row) {
+    if (KCONTIG) return kg * (R + 1) + row;
+    return kg * 144 + (row & 3) * 36 + (row >> 2);
+}
+
+// two fp32 -> one dword of two bf16 (round-to-nearest-even); `lo` lands in bits 0..15
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+
+template <int NPL, int PLANE>
+__device__ __forceinline__ void split_store(const float (&v)[8], uint4* __restrict__ dst) {
+    // dst: plane 0 slot; planes are PLANE slots apart.  Per pair of values: one packed convert
+    // per plane, residuals formed exactly in fp32 (x - float(bf16(x)) is representable).
+    unsigned w[NPL][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float r0 = v[2 * q], r1 = v[2 * q + 1];
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) {
+            const unsigned h = cvt_pk_bf16(r0, r1);
+            w[pl][q] = h;
+#ifndef TRID_EXP_NOSPLIT
+            if (pl + 1 < NPL) {
+                r0 -= __builtin_bit_cast(float, h << 16);
+                r1 -= __builtin_bit_cast(float, h & 0xffff0000u);
+            }
+#endif
+        }
+    }
+#pragma unroll
+    for (int pl = 0; pl < NPL; ++pl) dst[pl * PLANE] = make_uint4(w[pl][0], w[pl][1], w[pl][2], w[pl][3]);
+}
+
+// Wide loader store: this lane holds w[kk] = float4 along 4 consecutive rows for k = 4kq+kk.  Each row's
+// 4 k-values become half a slot (8 bytes) per plane in the swizzled M/N-contiguous image.
+template <int NPL, int PLANE>
+__device__ __forceinline__ void split_store_wide(const float4 (&w)[4], uint4* __restrict__ base, int mq, int kq) {
+    const int kg = kq >> 1, half = kq & 1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float r0, r1, r2, r3;
+        if (j == 0) { r0 = w[0].x; r1 = w[1].x; r2 = w[2].x; r3 = w[3].x; }
+        else if (j == 1) { r0 = w[0].y; r1 = w[1].y; r2 = w[2].y; r3 = w[3].y; }
+        else if (j == 2) { r0 = w[0].z; r1 = w[1].z; r2 = w[2].z; r3 = w[3].z; }
+        else { r0 = w[0].w; r1 = w[1].w; r2 = w[2].w; r3 = w[3].w; }
+        uint2* dst = reinterpret_cast<uint2*>(base + slot_of<false, 128>(kg, 4 * mq + j)) + half;
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) {
+            const unsigned h0 = cvt_pk_bf16(r0, r1), h1 = cvt_pk_bf16(r2, r3);
+            dst[pl * PLANE * 2] = make_uint2(h0, h1);
+            if (pl + 1 < NPL) {
+                r0 -= __builtin_bit_cast(float, h0 << 16);
+                r1 -= __builtin_bit_cast(float, h0 & 0xffff0000u);
+                r2 -= __builtin_bit_cast(float, h1 << 16);
+                r3 -= __builtin_bit_cast(float, h1 & 0xffff0000u);
+            }
+        }
+    }
+}
+
+// predicated loads without divergent branches: read from a always-valid address, then select
+__device__ __forceinline__ float4 ld4_if(bool ok, const float* __restrict__ p, const float* __restrict__ safe) {
+    const float4 v = *reinterpret_cast<const float4*>(ok ? p : safe);
+    return ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+__device__ __forceinline__ float ld1_if(bool ok, const float* __restrict__ p, const float* __restrict__ safe) {
+    const float v = *(ok ? p : safe);
+    return ok ? v : 0.f;
+}
+
+}  // namespace trid

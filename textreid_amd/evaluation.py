@@ -83,7 +83,7 @@ def similarity_topk(text_embed, image_embed, k=10, normalize=True):
         sizes = [torch.zeros(1, dtype=torch.int64, device=q.device) for _ in range(W)]
         dist.all_gather(sizes, torch.tensor([G], dtype=torch.int64, device=q.device))
         offset = int(sum(int(s) for s in sizes[: dist_rank()]))
-    call("trid_sim_topk_f32", _p(q), _p(g), _p(vals), _p(idx), Q, G, C, k, offset, _p(ws), stream())
+    call("trid_sim_topk_f32", _p(q), _p(g), _p(vals), _p(idx), Q, G, C, k, offset, ops.GEMM_PRECISION, _p(ws), stream())
     if W == 1:
         return vals, idx
     import torch.distributed as dist
@@ -106,7 +106,7 @@ def _topk_neighbours(q, g, k):
     vals = torch.empty(Q, k, dtype=torch.float32, device=q.device)
     idx = torch.empty(Q, k, dtype=torch.int64, device=q.device)
     ws = ops.empty((ops.L.load().trid_topk_ws_floats(Q, G, k),), q)
-    call("trid_sim_topk_f32", _p(q), _p(g), _p(vals), _p(idx), Q, G, C, k, 0, _p(ws), stream())
+    call("trid_sim_topk_f32", _p(q), _p(g), _p(vals), _p(idx), Q, G, C, k, 0, ops.GEMM_PRECISION, _p(ws), stream())
     return idx
 
 

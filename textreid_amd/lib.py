@@ -10,7 +10,7 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtextreid_hip.so")
+LIB_PATH = os.environ.get("TRID_LIB_PATH") or os.path.join(_HERE, "libtextreid_hip.so")  # override: kernel experiments
 
 TRID_A_KC, TRID_A_MC, TRID_A_CONV = 0, 1, 2
 TRID_B_KC, TRID_B_NC, TRID_B_CONV = 0, 1, 2

@@ -40,7 +40,7 @@ PROFILE = None
 
 def _uses_split(M, N, K, a_mode, conv):
     """Mirror of the split-kernel eligibility test in trid_gemm_f32()."""
-    return (GEMM_PRECISION in (3, 6) and K % 8 == 0 and K >= 32 and M >= 96 and N >= 96
+    return (GEMM_PRECISION in (1, 3, 6) and K % 8 == 0 and K >= 32 and M >= 96 and N >= 96
             and (a_mode != A_CONV or conv[2] % 8 == 0))
 
 

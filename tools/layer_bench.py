@@ -16,15 +16,22 @@ def t(fn, reps=5):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps
 rows = []
+FILT = os.environ.get("TRID_LB_FILTER", "")
 def conv1(name, P, Ci, Co, count=1, acc=False):
+    if FILT and not any(f in name for f in FILT.split(",")): return
     M = B * P
     x, w, dy = rnd(M, Ci), rnd(Co, Ci), rnd(M, Co)
     dx = torch.empty(M, Ci, device=dev)
     fl = 2.0 * M * Ci * Co
     rows.append((name + " fwd", count, t(lambda: ops.conv1x1(x, w, stats=True)), fl))
-    rows.append((name + " dgrad", count, t(lambda: ops.matmul_nn(dy, w, out=dx, accumulate=acc)), fl))
+    if os.environ.get("TRID_DGRAD_T"):  # data gradient against a pre-transposed weight copy (K-contiguous B)
+        wT = w.t().contiguous()
+        rows.append((name + " dgrad", count, t(lambda: ops.linear(dy, wT, out=dx, accumulate=acc)), fl))
+    else:
+        rows.append((name + " dgrad", count, t(lambda: ops.matmul_nn(dy, w, out=dx, accumulate=acc)), fl))
     rows.append((name + " wgrad", count, t(lambda: ops.conv1x1_wgrad(dy, x)), fl))
 def conv3(name, H, W, Ci, Co, count=1):
+    if FILT and not any(f in name for f in FILT.split(",")): return
     x, w, dy = rnd(B, H, W, Ci), rnd(Co, 9 * Ci), rnd(B, H, W, Co)
     wt = rnd(Ci, 9 * Co)
     fl = 2.0 * B * H * W * Ci * Co * 9
