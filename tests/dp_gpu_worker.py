@@ -92,6 +92,21 @@ def main():
         bad = {k: v for k, v in errs.items() if not v < 1e-3}
         assert not bad, bad
         print("DP_OK")
+    # ---- sharded retrieval: every rank scores its own (unevenly sized) gallery shard, lists are merged
+    from textreid_amd.evaluation import similarity_topk
+
+    sizes = [700 + 300 * w for w in range(W)]
+    qe = OF.randn("dp:q", (33, 64), seed)
+    ge = OF.randn("dp:g", (sum(sizes), 64), seed)
+    lo = sum(sizes[:r])
+    vals, idx = similarity_topk(qe.to(dev), ge[lo:lo + sizes[r]].to(dev), 10)
+    torch.cuda.synchronize()
+    sim = F.normalize(qe, dim=1) @ F.normalize(ge, dim=1).t()
+    rv, ri = torch.topk(sim, 10, dim=1)
+    assert torch.equal(idx.cpu(), ri), "sharded top-k indices differ from the dense top-k"
+    assert torch.allclose(vals.cpu(), rv, atol=2e-6)
+    if r == 0:
+        print("DP_RETRIEVAL_OK")
     dist.barrier()
     dist.destroy_process_group()
 

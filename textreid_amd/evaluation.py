@@ -78,20 +78,16 @@ def similarity_topk(text_embed, image_embed, k=10, normalize=True):
     ws = ops.empty((ops.L.load().trid_topk_ws_floats(Q, G, k),), q)
     offset = 0
     if W > 1:
-        import torch.distributed as dist
+        from .parallel import all_gather_rows
 
-        sizes = [torch.zeros(1, dtype=torch.int64, device=q.device) for _ in range(W)]
-        dist.all_gather(sizes, torch.tensor([G], dtype=torch.int64, device=q.device))
-        offset = int(sum(int(s) for s in sizes[: dist_rank()]))
+        sizes = all_gather_rows(torch.tensor([G], dtype=torch.int64, device=q.device))
+        offset = int(sizes[: dist_rank()].sum())
     call("trid_sim_topk_f32", _p(q), _p(g), _p(vals), _p(idx), Q, G, C, k, offset, ops.GEMM_PRECISION, _p(ws), stream())
     if W == 1:
         return vals, idx
-    import torch.distributed as dist
-
-    av = torch.empty(W, Q, k, dtype=torch.float32, device=q.device)
-    ai = torch.empty(W, Q, k, dtype=torch.int64, device=q.device)
-    dist.all_gather_into_tensor(av, vals)
-    dist.all_gather_into_tensor(ai, idx)
+    # per-shard lists -> every rank: [W*Q, k] rank-major, then one row top-k over the W*k candidates
+    av = all_gather_rows(vals).view(W, Q, k)
+    ai = all_gather_rows(idx).view(W, Q, k)
     cand_v = av.permute(1, 0, 2).reshape(Q, W * k).contiguous()
     cand_i = ai.permute(1, 0, 2).reshape(Q, W * k).contiguous()
     sel = torch.empty(Q, k, dtype=torch.int64, device=q.device)
