@@ -489,20 +489,13 @@ extern "C" int trid_gemm_f32(const trid_gemm_desc* d, void* stream_) {
 
     int rc;
     const int am = d->a_mode, bm = d->b_mode;
+    // the split kernels address operands with 31-bit byte offsets (buffer loads): < 2 GB per operand and batch
+    const long long a_elems = am == A_KC ? (long long)(d->M + 256) * d->lda
+                            : am == A_MC ? (long long)d->K * d->lda : (long long)(d->M + 256 + 2 * d->W + 2) * d->Cin;
+    const long long b_elems = bm == B_KC ? (long long)(d->N + 128) * d->ldb : bm == B_NC ? (long long)d->K * d->ldb : 0;
+    const bool small_enough = a_elems < (1ll << 29) && b_elems < (1ll << 29);
     if ((d->precision == 1 || d->precision == 3 || d->precision == 6) && d->K % 8 == 0 && d->K >= 32 && d->M >= 96 && d->N >= 96 &&
-        (am != A_CONV || d->Cin % 8 == 0)) {
-        static const int pp_mode = getenv("TRID_PP") ? atoi(getenv("TRID_PP")) : 2;  // 0 off, 1 always, 2 auto
-        // ping-pong kernel: K-contiguous operands, 31-bit byte offsets (< 2 GB per operand), 3x3 only in channel-group-major order
-        const bool pp_ok = (long long)(d->M + 256 + 2 * d->W + 2) * (am == A_CONV ? d->Cin : d->lda) < (1ll << 29) &&
-                           (long long)(d->N + 128) * d->ldb < (1ll << 29) &&
-                           (am != A_CONV || (d->Cin % BK == 0 && d->splits == 1));
-        // pp_mode 1: every eligible shape; 2 (auto): where the 256x128 grid fills the chip and K is long
-        const long long tiles256 = (long long)((d->M + 255) / 256) * ((d->N + 127) / 128) * d->batch * d->splits;
-        const bool pp_auto = tiles256 >= 256 && d->K >= 256;
-        if ((pp_mode == 1 || (pp_mode == 2 && pp_auto)) && d->M >= 256 && pp_ok) {
-            rc = gemm_pp_dispatch(p, am, bm, d->precision, stream);
-            if (rc != TRID_E_UNSUPPORTED) return rc;
-        }
+        (am != A_CONV || d->Cin % 8 == 0) && small_enough) {
         rc = gemm_bf16_dispatch(p, am, bm, d->precision, stream);
         if (rc != TRID_E_UNSUPPORTED) return rc;
     }

@@ -16,8 +16,6 @@
 // row, slot = kgroup*(128+1) + row, one image per plane -> every MFMA operand fetch is one
 // conflict-free ds_read_b128 per plane.
 
-#include <stdlib.h>
-
 #include "split_common.h"
 
 namespace trid {
@@ -69,23 +67,53 @@ __global__ __launch_bounds__(NT, (BM == 128 && TRID_SPLIT_WAVES_PER_SIMD > 0) ? 
     // loader lanes.  K-contiguous operands: all 512 threads, (kg = tid&3, row = tid>>2), one 8-k slot each.
     // Wide (M/N-contiguous) operands: 256 threads per operand (A: waves 0-3, B: waves 4-7),
     // (mq = t&31 -> rows 4mq..4mq+3, kq = t>>5 -> k 4kq..4kq+3), four float4 loads each.
+    //
+    // Loads are raw BUFFER loads wherever the address splits into a loop-invariant per-lane byte offset
+    // and a per-tile scalar offset (everything except the B_CONV gather and 3x3 inputs whose channel
+    // count is not a multiple of the K-tile): no per-tile 64-bit address arithmetic, no branches around
+    // the loads.  Out-of-range rows read as zero in hardware (voffset >= num_records - soffset); padding
+    // taps, a ragged last K-tile and lanes beyond M/N set bit 31 of the offset instead.
     constexpr bool A_K = (AMODE != A_MC);
     const int a_kg = A_K ? (tid & 3) : (tid >> 7), a_row = A_K ? (tid >> 2) : (tid & 127);
     const int b_kg = tid & 3, b_row = tid >> 2;  // B_KC only
     const int w_mq = tid & 31, w_kq = (tid & 255) >> 5;
     const bool a_wide_lane = tid < 256, b_wide_lane = tid >= 256;
+    constexpr unsigned OOB = 0x80000000u;
+    // channel-group-major K order of the 3x3 implicit GEMM (see tile_k below): tap is uniform per tile
+    const bool permute = (AMODE == A_CONV) && (BMODE == B_KC) && (p.Cin % BK == 0) && p.splits == 1;
+
+    const long long a_ld = (AMODE == A_CONV) ? p.Cin : p.lda;
+    const long long a_rows = (AMODE == A_KC) ? p.M : (AMODE == A_MC) ? p.K : (long long)p.M + 2 * p.W + 2;
+    const float* a_base = (AMODE == A_CONV) ? A - (long long)(p.W + 1) * p.Cin : A;  // tap offsets stay >= 0
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a_base, 0, (unsigned)(a_rows * a_ld * 4), 0x00020000);
+    const long long b_rows = (BMODE == B_KC) ? p.N : p.K;
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)Bp, 0, (unsigned)(b_rows * p.ldb * 4), 0x00020000);
 
     int a_y[APASS], a_x[APASS];
-    if (AMODE == A_CONV) {
+    unsigned voA[APASS], amask[APASS];
 #pragma unroll
-        for (int ps = 0; ps < APASS; ++ps) {
-            const int m = m0 + a_row + ps * 128;
+    for (int ps = 0; ps < APASS; ++ps) {
+        const int m = m0 + a_row + ps * 128;
+        voA[ps] = (unsigned)(((long long)m * a_ld + 8 * a_kg) * 4);
+        amask[ps] = 0x1ffu;
+        if (AMODE == A_CONV) {
             const uint32_t q = fdiv((uint32_t)m, p.fdW);
             a_x[ps] = m - (int)q * p.W;
             const uint32_t b = fdiv(q, p.fdH);
             a_y[ps] = (int)q - (int)b * p.H;
+            unsigned mk = 0;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int yy = a_y[ps] + t / 3 - 1, xx = a_x[ps] + t % 3 - 1;
+                if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) mk |= 1u << t;
+            }
+            amask[ps] = m < p.M ? mk : 0u;
         }
     }
+    // wide lanes: rows are k, lanes run along m / n; a lane beyond M / N is dead for the whole kernel
+    const unsigned voAw = (m0 + 4 * w_mq < p.M) ? (unsigned)(((long long)(4 * w_kq) * p.lda + m0 + 4 * w_mq) * 4) : OOB;
+    const unsigned voBw = (n0 + 4 * w_mq < p.N) ? (unsigned)(((long long)(4 * w_kq) * p.ldb + n0 + 4 * w_mq) * 4) : OOB;
+    const unsigned voB = (unsigned)(((long long)(n0 + b_row) * p.ldb + 8 * b_kg) * 4);
     int b_dy = 0, b_dx = 0, b_c = 0;
     if (BMODE == B_CONV) {
         const int j = n0 + 4 * w_mq;
@@ -98,19 +126,35 @@ __global__ __launch_bounds__(NT, (BM == 128 && TRID_SPLIT_WAVES_PER_SIMD > 0) ? 
     float ra[APASS][8], rb[8];
     float4 wa[4], wb[4];
 
+    auto ldb4 = [](const __amdgpu_buffer_rsrc_t& rs, unsigned vo, unsigned so) {
+        return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, so, 0));
+    };
+
+    // k0: K offset of the tile (already permuted for the 3x3 fast path)
     auto load_tiles = [&](int k0) {
         // ---- A ----
+        if (AMODE == A_KC || (AMODE == A_CONV && permute)) {
+            unsigned so, kill = 0;
+            int tap = 0;
+            if (AMODE == A_CONV) {
+                tap = k0 / p.Cin;  // uniform: a tile never straddles taps when Cin % BK == 0
+                so = (unsigned)((((tap / 3) * p.W + (tap % 3)) * p.Cin + (k0 - tap * p.Cin)) * 4);
+            } else {
+                so = (unsigned)(k0 * 4);
+                kill = (k0 + 8 * a_kg < k_end) ? 0u : OOB;
+            }
 #pragma unroll
-        for (int ps = 0; ps < APASS; ++ps) {
-            const int m = m0 + a_row + ps * 128;
-            if (AMODE == A_KC) {
-                const int k = k0 + 8 * a_kg;
-                const bool ok = m < p.M && k < k_end;
-                const float* src = A + (long long)m * p.lda + k;
-                const float4 u = ld4_if(ok, src, A), v = ld4_if(ok, src + 4, A);
+            for (int ps = 0; ps < APASS; ++ps) {
+                unsigned vo = voA[ps] | kill;
+                if (AMODE == A_CONV) vo = ((amask[ps] >> tap) & 1u) ? vo : OOB;
+                const float4 u = ldb4(rsA, vo, so), v = ldb4(rsA, vo + 16, so);
                 ra[ps][0] = u.x; ra[ps][1] = u.y; ra[ps][2] = u.z; ra[ps][3] = u.w;
                 ra[ps][4] = v.x; ra[ps][5] = v.y; ra[ps][6] = v.z; ra[ps][7] = v.w;
-            } else if (AMODE == A_CONV) {
+            }
+        } else if (AMODE == A_CONV) {  // general 3x3 gather (channel counts that are not a multiple of the K-tile)
+#pragma unroll
+            for (int ps = 0; ps < APASS; ++ps) {
+                const int m = m0 + a_row + ps * 128;
                 const int k = k0 + 8 * a_kg;
                 const uint32_t tap = fdiv((uint32_t)k, p.fdC);
                 const int c = k - (int)tap * p.Cin;
@@ -121,7 +165,11 @@ __global__ __launch_bounds__(NT, (BM == 128 && TRID_SPLIT_WAVES_PER_SIMD > 0) ? 
                 const float4 u = ld4_if(ok, src, A), v = ld4_if(ok, src + 4, A);
                 ra[ps][0] = u.x; ra[ps][1] = u.y; ra[ps][2] = u.z; ra[ps][3] = u.w;
                 ra[ps][4] = v.x; ra[ps][5] = v.y; ra[ps][6] = v.z; ra[ps][7] = v.w;
-            } else if (!A_WIDE) {  // A_MC, narrow fallback (256-row tiles): A[k*lda + m], lanes along m
+            }
+        } else if (!A_WIDE) {  // A_MC, narrow fallback (256-row tiles): A[k*lda + m], lanes along m
+#pragma unroll
+            for (int ps = 0; ps < APASS; ++ps) {
+                const int m = m0 + a_row + ps * 128;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int k = k0 + 8 * a_kg + j;
@@ -129,29 +177,20 @@ __global__ __launch_bounds__(NT, (BM == 128 && TRID_SPLIT_WAVES_PER_SIMD > 0) ? 
                 }
             }
         }
-        if (A_WIDE && a_wide_lane) {  // A_MC wide: float4 along m for 4 consecutive k
-            const int m = m0 + 4 * w_mq;
+        if (A_WIDE && a_wide_lane) {  // A_MC wide: float4 along m for 4 consecutive k (rows k >= K read as zero)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int k = k0 + 4 * w_kq + j;
-                wa[j] = ld4_if(m < p.M && k < k_end, A + (long long)k * p.lda + m, A);
-            }
+            for (int j = 0; j < 4; ++j) wa[j] = ldb4(rsA, voAw, (unsigned)((long long)(k0 + j) * p.lda * 4));
         }
         // ---- B ----
         if (BMODE == B_KC) {
-            const int n = n0 + b_row, k = k0 + 8 * b_kg;
-            const bool ok = n < p.N && k < k_end;
-            const float* src = Bp + (long long)n * p.ldb + k;
-            const float4 u = ld4_if(ok, src, Bp), v = ld4_if(ok, src + 4, Bp);
+            const unsigned vo = voB | ((k0 + 8 * b_kg < k_end) ? 0u : OOB);
+            const unsigned so = (unsigned)(k0 * 4);
+            const float4 u = ldb4(rsB, vo, so), v = ldb4(rsB, vo + 16, so);
             rb[0] = u.x; rb[1] = u.y; rb[2] = u.z; rb[3] = u.w; rb[4] = v.x; rb[5] = v.y; rb[6] = v.z; rb[7] = v.w;
         } else if (BMODE == B_NC) {
             if (b_wide_lane) {
-                const int n = n0 + 4 * w_mq;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int k = k0 + 4 * w_kq + j;
-                    wb[j] = ld4_if(n < p.N && k < k_end, Bp + (long long)k * p.ldb + n, Bp);
-                }
+                for (int j = 0; j < 4; ++j) wb[j] = ldb4(rsB, voBw, (unsigned)((long long)(k0 + j) * p.ldb * 4));
             }
         } else {  // B_CONV: row k is a pixel, 4 consecutive columns n = (tap, c..c+3)
             if (b_wide_lane) {
@@ -243,7 +282,6 @@ __global__ __launch_bounds__(NT, (BM == 128 && TRID_SPLIT_WAVES_PER_SIMD > 0) ? 
     // 3x3 implicit GEMM: walk K channel-group-major (all 9 taps of a 32-channel slab back to
     // back) instead of tap-major, so the nine shifted re-reads of one activation slab are adjacent
     // in time and hit L1/L2 instead of going back to the Infinity Cache / HBM.
-    const bool permute = (AMODE == A_CONV) && (BMODE == B_KC) && (p.Cin % BK == 0) && p.splits == 1;
     auto tile_k = [&](int k0) {
         if (!permute) return k0;
         const int kt = k0 / BK;
@@ -393,12 +431,9 @@ static int launch_bf16(GemmParams& p, hipStream_t stream) {
 
 template <int AMODE, int BMODE, int NPL>
 static int pick_tile(GemmParams& p, hipStream_t stream) {
-    // 256-row tiles when there are enough of them to fill the chip (1 workgroup per CU)
-    static const int force = getenv("TRID_SPLIT_BM") ? atoi(getenv("TRID_SPLIT_BM")) : 0;
-    const long long blocks256 = (long long)((p.M + 255) / 256) * ((p.N + BN_T - 1) / BN_T) * p.batch * p.splits;
-    const bool big = force == 256;  // measured: 2 workgroups/CU of 128-row tiles beat 1 workgroup of 256 rows
-    (void)blocks256;
-    if (big) return launch_bf16<AMODE, BMODE, NPL, 256>(p, stream);
+    // 128x128 tiles, two workgroups per CU.  (A 256x128 double-buffered variant - BM = 256 in the kernel
+    // template, one workgroup per CU - and a role-alternating 256x128 schedule were both measured
+    // 3-4 % slower on the same box and are not instantiated)
     return launch_bf16<AMODE, BMODE, NPL, 128>(p, stream);
 }
 

@@ -34,7 +34,5 @@ constexpr int BK = 32;
 // split-precision variants (gemm_bf16.hip): fp32 operands split on the fly into 2 or 3
 // bf16 planes, 3 or 6 bf16 MFMAs per product, fp32 accumulation
 int gemm_bf16_dispatch(GemmParams& p, int a_mode, int b_mode, int precision, hipStream_t stream);
-// role-alternating 256x128 variant for K-contiguous operands (gemm_pp.hip); TRID_E_UNSUPPORTED otherwise
-int gemm_pp_dispatch(GemmParams& p, int a_mode, int b_mode, int precision, hipStream_t stream);
 
 }  // namespace trid
