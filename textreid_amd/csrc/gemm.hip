@@ -494,8 +494,8 @@ extern "C" int trid_gemm_f32(const trid_gemm_desc* d, void* stream_) {
                             : am == A_MC ? (long long)d->K * d->lda : (long long)(d->M + 256 + 2 * d->W + 2) * d->Cin;
     const long long b_elems = bm == B_KC ? (long long)(d->N + 128) * d->ldb : bm == B_NC ? (long long)d->K * d->ldb : 0;
     const bool small_enough = a_elems < (1ll << 29) && b_elems < (1ll << 29);
-    if ((d->precision == 1 || d->precision == 3 || d->precision == 6) && d->K % 8 == 0 && d->K >= 32 && d->M >= 96 && d->N >= 96 &&
-        (am != A_CONV || d->Cin % 8 == 0) && small_enough) {
+    if ((d->precision == 1 || d->precision == 3 || d->precision == 6) && d->K % 8 == 0 && d->K >= 32 && d->M >= 64 && d->N >= 64 &&
+        (d->M >= 96 || d->N >= 96) && (am != A_CONV || d->Cin % 8 == 0) && small_enough) {
         rc = gemm_bf16_dispatch(p, am, bm, d->precision, stream);
         if (rc != TRID_E_UNSUPPORTED) return rc;
     }

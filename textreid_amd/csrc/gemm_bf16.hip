@@ -12,7 +12,7 @@
 // epilogues (alpha / bias / accumulate / split-K / BatchNorm partials) and C ABI as gemm.hip.
 //
 // Tile 128x128x32, 8 waves (2x4, 64x32 per wave), single LDS stage + register prefetch;
-// 3 workgroups per CU at NPL=3.  LDS image: 16-byte slots holding 8 consecutive k of one
+// 2 workgroups per CU.  LDS image: 16-byte slots holding 8 consecutive k of one
 // row, slot = kgroup*(128+1) + row, one image per plane -> every MFMA operand fetch is one
 // conflict-free ds_read_b128 per plane.
 
@@ -20,28 +20,26 @@
 
 namespace trid {
 
-constexpr int BN_T = 128;             // tile width
+constexpr int BM_T = 128;             // tile height
 constexpr int NT = 512;               // 8 waves
 #ifndef TRID_SPLIT_WAVES_PER_SIMD
 #define TRID_SPLIT_WAVES_PER_SIMD 0
 #endif
-// BM = 128: 2x4 waves (64x32 per wave), one LDS stage, 2 workgroups per CU.
-// BM = 256: 4x2 waves (64x64 per wave), two LDS stages (one barrier per K-tile), 1 workgroup per CU:
-//           25 % less LDS write traffic and half the LDS reads per MFMA.
-template <int AMODE, int BMODE, int NPL, int BM>
-__global__ __launch_bounds__(NT, (BM == 128 && TRID_SPLIT_WAVES_PER_SIMD > 0) ? TRID_SPLIT_WAVES_PER_SIMD : 1) void gemm_bf16s_kernel(GemmParams p) {
-    constexpr int BN = BN_T;
-    constexpr int WAVES_N = (BM == 256) ? 2 : 4;
-    constexpr int WN = BN / WAVES_N;  // 64 or 32
-    constexpr int TN = WN / 32;       // 2 or 1
-    constexpr int STAGES = (BM == 256) ? 2 : 1;
+// Tile 128 x BN x 32, one LDS stage + register prefetch, 2 workgroups per CU.
+//   BN = 128: 2 x 4 waves, 64 x 32 per wave;   BN = 64 (outputs with <= 64 columns: stem, layer1):
+//   4 x 2 waves, 32 x 32 per wave - half the MFMA work per tile for the same A staging, still ahead
+//   of the fp32-input MFMA kernel whose peak is 16x lower.
+template <int AMODE, int BMODE, int NPL, int BN>
+__global__ __launch_bounds__(NT, (TRID_SPLIT_WAVES_PER_SIMD > 0) ? TRID_SPLIT_WAVES_PER_SIMD : 1) void gemm_bf16s_kernel(GemmParams p) {
+    constexpr int BM = BM_T;
+    constexpr int WAVES_N = BN / 32;           // 4 or 2
+    constexpr int WAVES_M = 8 / WAVES_N;       // 2 or 4
+    constexpr int TM = BM / (32 * WAVES_M);    // 32-row MFMA tiles per wave: 2 or 1
     constexpr int PA = plane_slots(BM), PB = plane_slots(BN);
     // M/N-contiguous operands are loaded WIDE (float4 along the rows, 4 consecutive k per lane) and
-    // transposed through registers into the swizzled LDS image (128-row tiles only)
-    constexpr bool A_WIDE = (AMODE == A_MC) && BM == 128;
+    // transposed through registers into the swizzled LDS image
+    constexpr bool A_WIDE = (AMODE == A_MC);
     constexpr bool B_WIDE = (BMODE != B_KC);
-    constexpr int STAGE = NPL * (PA + PB);  // slots per stage
-    constexpr int APASS = BM / 128;         // loader passes over the A rows
     extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
 
     const int tid = threadIdx.x;
@@ -89,6 +87,7 @@ __global__ __launch_bounds__(NT, (BM == 128 && TRID_SPLIT_WAVES_PER_SIMD > 0) ? 
     const long long b_rows = (BMODE == B_KC) ? p.N : p.K;
     const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)Bp, 0, (unsigned)(b_rows * p.ldb * 4), 0x00020000);
 
+    constexpr int APASS = 1;  // one loader pass covers the 128 A rows
     int a_y[APASS], a_x[APASS];
     unsigned voA[APASS], amask[APASS];
 #pragma unroll
@@ -112,8 +111,8 @@ __global__ __launch_bounds__(NT, (BM == 128 && TRID_SPLIT_WAVES_PER_SIMD > 0) ? 
     }
     // wide lanes: rows are k, lanes run along m / n; a lane beyond M / N is dead for the whole kernel
     const unsigned voAw = (m0 + 4 * w_mq < p.M) ? (unsigned)(((long long)(4 * w_kq) * p.lda + m0 + 4 * w_mq) * 4) : OOB;
-    const unsigned voBw = (n0 + 4 * w_mq < p.N) ? (unsigned)(((long long)(4 * w_kq) * p.ldb + n0 + 4 * w_mq) * 4) : OOB;
-    const unsigned voB = (unsigned)(((long long)(n0 + b_row) * p.ldb + 8 * b_kg) * 4);
+    const unsigned voBw = (4 * w_mq < BN && n0 + 4 * w_mq < p.N) ? (unsigned)(((long long)(4 * w_kq) * p.ldb + n0 + 4 * w_mq) * 4) : OOB;
+    const unsigned voB = b_row < BN ? (unsigned)(((long long)(n0 + b_row) * p.ldb + 8 * b_kg) * 4) : OOB;
     int b_dy = 0, b_dx = 0, b_c = 0;
     if (BMODE == B_CONV) {
         const int j = n0 + 4 * w_mq;
@@ -166,16 +165,6 @@ __global__ __launch_bounds__(NT, (BM == 128 && TRID_SPLIT_WAVES_PER_SIMD > 0) ? 
                 ra[ps][0] = u.x; ra[ps][1] = u.y; ra[ps][2] = u.z; ra[ps][3] = u.w;
                 ra[ps][4] = v.x; ra[ps][5] = v.y; ra[ps][6] = v.z; ra[ps][7] = v.w;
             }
-        } else if (!A_WIDE) {  // A_MC, narrow fallback (256-row tiles): A[k*lda + m], lanes along m
-#pragma unroll
-            for (int ps = 0; ps < APASS; ++ps) {
-                const int m = m0 + a_row + ps * 128;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int k = k0 + 8 * a_kg + j;
-                    ra[ps][j] = ld1_if(m < p.M && k < k_end, A + (long long)k * p.lda + m, A);
-                }
-            }
         }
         if (A_WIDE && a_wide_lane) {  // A_MC wide: float4 along m for 4 consecutive k (rows k >= K read as zero)
 #pragma unroll
@@ -202,7 +191,7 @@ __global__ __launch_bounds__(NT, (BM == 128 && TRID_SPLIT_WAVES_PER_SIMD > 0) ? 
                     const int x0 = kbase - (int)q * p.W;
                     const uint32_t b = fdiv(q, p.fdH);
                     const int yy = (int)q - (int)b * p.H + b_dy;
-                    const bool row_ok = n < p.N && yy >= 0 && yy < p.H;
+                    const bool row_ok = 4 * w_mq < BN && n < p.N && yy >= 0 && yy < p.H;
                     const float* src = Bp + (long long)(kbase + b_dy * p.W + b_dx) * p.Cin + b_c;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
@@ -218,7 +207,7 @@ __global__ __launch_bounds__(NT, (BM == 128 && TRID_SPLIT_WAVES_PER_SIMD > 0) ? 
                         const uint32_t b = fdiv(q, p.fdH);
                         const int y = (int)q - (int)b * p.H;
                         const int yy = y + b_dy, xx = x + b_dx;
-                        wb[j] = ld4_if(n < p.N && k < k_end && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W,
+                        wb[j] = ld4_if(4 * w_mq < BN && n < p.N && k < k_end && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W,
                                        Bp + (long long)(k + b_dy * p.W + b_dx) * p.Cin + b_c, Bp);
                     }
                 }
@@ -230,53 +219,45 @@ __global__ __launch_bounds__(NT, (BM == 128 && TRID_SPLIT_WAVES_PER_SIMD > 0) ? 
         if (A_WIDE) {
             if (a_wide_lane) split_store_wide<NPL, PA>(wa, As, w_mq, w_kq);
         } else {
-#pragma unroll
-            for (int ps = 0; ps < APASS; ++ps)
-                split_store<NPL, PA>(ra[ps], As + slot_of<true, BM>(a_kg, a_row + ps * 128));
+            split_store<NPL, PA>(ra[0], As + slot_of<true, BM>(a_kg, a_row));
         }
         if (B_WIDE) {
-            if (b_wide_lane) split_store_wide<NPL, PB>(wb, Bs, w_mq, w_kq);
-        } else {
+            if (b_wide_lane && 4 * w_mq < BN) split_store_wide<NPL, PB>(wb, Bs, w_mq, w_kq);
+        } else if (b_row < BN) {
             split_store<NPL, PB>(rb, Bs + slot_of<true, BN>(b_kg, b_row));
         }
     };
 
-    v16f acc[2][TN];
+    v16f acc[TM];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
-    const int a_slot = wm * 64 + (lane & 31);
-    const int b_slot = wn * WN + (lane & 31);
+    const int a_slot = wm * (32 * TM) + (lane & 31);
+    const int b_slot = wn * 32 + (lane & 31);
 
     auto compute_step = [&](const uint4* __restrict__ As, const uint4* __restrict__ Bs, int ks) {
-        bf16x8 a[NPL][2], b[NPL][TN];
+        bf16x8 a[NPL][TM], b[NPL];
 #pragma unroll
         for (int pl = 0; pl < NPL; ++pl) {
             const int kg = 2 * ks + khalf;
-            a[pl][0] = __builtin_bit_cast(bf16x8, As[pl * PA + slot_of<!A_WIDE, BM>(kg, a_slot)]);
-            a[pl][1] = __builtin_bit_cast(bf16x8, As[pl * PA + slot_of<!A_WIDE, BM>(kg, a_slot + 32)]);
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
-                b[pl][j] = __builtin_bit_cast(bf16x8, Bs[pl * PB + slot_of<!B_WIDE, BN>(kg, b_slot + 32 * j)]);
+            for (int i = 0; i < TM; ++i)
+                a[pl][i] = __builtin_bit_cast(bf16x8, As[pl * PA + slot_of<!A_WIDE, BM>(kg, a_slot + 32 * i)]);
+            b[pl] = __builtin_bit_cast(bf16x8, Bs[pl * PB + slot_of<!B_WIDE, BN>(kg, b_slot)]);
         }
-        // Term-major order: consecutive MFMAs hit DIFFERENT accumulators, so no MFMA waits on the
-        // result of the one issued just before it (dependent-accumulator latency > issue interval).
-        // Smallest terms first: mm, hl, lh (3 planes only), then hm, mh, hh.
+        // Term-major order: consecutive MFMAs hit DIFFERENT accumulators where the wave has two, so no
+        // MFMA waits on the result of the one issued just before it.  Smallest terms first: mm, hl, lh
+        // (3 planes only), then hm, mh, hh.
         constexpr int NTERM = (NPL == 3) ? 6 : (NPL == 2) ? 3 : 1;
         constexpr int TA[6] = {1, 0, 2, 0, 1, 0};
         constexpr int TB[6] = {1, 2, 0, 1, 0, 0};
 #pragma unroll
         for (int t = 6 - NTERM; t < 6; ++t)
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[TA[t] < NPL ? TA[t] : 0][i], b[TB[t] < NPL ? TB[t] : 0][j],
-                                                                        acc[i][j], 0, 0, 0);
+            for (int i = 0; i < TM; ++i)
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[TA[t] < NPL ? TA[t] : 0][i], b[TB[t] < NPL ? TB[t] : 0], acc[i], 0, 0, 0);
     };
 
     // 3x3 implicit GEMM: walk K channel-group-major (all 9 taps of a 32-channel slab back to
@@ -292,132 +273,99 @@ __global__ __launch_bounds__(NT, (BM == 128 && TRID_SPLIT_WAVES_PER_SIMD > 0) ? 
         load_tiles(tile_k(k_begin));
         store_tiles(smem4, smem4 + NPL * PA);
         __syncthreads();
-        int cur = 0;
         for (int k0 = k_begin; k0 < k_end; k0 += BK) {
             const bool more = (k0 + BK) < k_end;
             if (more) load_tiles(tile_k(k0 + BK));
-            const uint4* As = smem4 + (STAGES == 2 ? cur * STAGE : 0);
+            const uint4* As = smem4;
             const uint4* Bs = As + NPL * PA;
             compute_step(As, Bs, 0);
-            if (STAGES == 2) {
-                if (more) {  // next tile -> the other stage, in the shadow of the second k-step
-                    uint4* nA = smem4 + (cur ^ 1) * STAGE;
-                    store_tiles(nA, nA + NPL * PA);
-                }
-                compute_step(As, Bs, 1);
+            compute_step(As, Bs, 1);
+            __syncthreads();
+            if (more) {
+                store_tiles(smem4, smem4 + NPL * PA);
                 __syncthreads();
-                cur ^= 1;
-            } else {
-                compute_step(As, Bs, 1);
-                __syncthreads();
-                if (more) {
-                    store_tiles(smem4, smem4 + NPL * PA);
-                    __syncthreads();
-                }
             }
         }
     }
 
     // ---- epilogue (same contract as gemm.hip) -----------------------------------------
-    const int row_base = m0 + wm * 64 + 4 * khalf;
-    const int col_base = n0 + wn * WN + (lane & 31);
+    const int row_base = m0 + wm * (32 * TM) + 4 * khalf;
+    const int col = n0 + wn * 32 + (lane & 31);
+    const float bv = (bias != nullptr && col < p.N) ? bias[col] : 0.f;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int col = col_base + 32 * j;
-        const float bv = (bias != nullptr && col < p.N) ? bias[col] : 0.f;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            float oldv[16];
-            if (p.accumulate) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = row_base + i * 32 + (r & 3) + 8 * (r >> 2);
-                    oldv[r] = (row < p.M && col < p.N) ? C[(long long)row * p.ldc + col] : 0.f;
-                }
-            }
+    for (int i = 0; i < TM; ++i) {
+        float oldv[16];
+        if (p.accumulate) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = row_base + i * 32 + (r & 3) + 8 * (r >> 2);
-                float v = p.alpha * acc[i][j][r] + bv;
-                if (p.accumulate) v += oldv[r];
-                if (row < p.M && col < p.N) C[(long long)row * p.ldc + col] = v;
-                acc[i][j][r] = v;
+                oldv[r] = (row < p.M && col < p.N) ? C[(long long)row * p.ldc + col] : 0.f;
             }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = row_base + i * 32 + (r & 3) + 8 * (r >> 2);
+            float v = p.alpha * acc[i][r] + bv;
+            if (p.accumulate) v += oldv[r];
+            if (row < p.M && col < p.N) C[(long long)row * p.ldc + col] = v;
+            acc[i][r] = v;
         }
     }
 
     if (p.stats != nullptr) {
-        // BatchNorm partials are defined per 128-row group: a BM=256 tile emits two
-        constexpr int WAVES_M = 8 / WAVES_N;  // 2 or 4
-        constexpr int GROUPS = BM / 128;      // row groups of 128 = pairs of wave rows
+        // BatchNorm partials of this 128-row tile: column (mean, M2) over the rows < M
         __syncthreads();
         float* red = reinterpret_cast<float*>(smem4);  // [WAVES_M][BN]
-        const int grp = wm >> 1;                       // wave rows 2g, 2g+1 form group g
-        const int rows_left = p.M - (m0 + grp * 128);
-        const int cnt = rows_left < 128 ? (rows_left > 0 ? rows_left : 1) : 128;
+        const int rows_left = p.M - m0;
+        const int cnt = rows_left < 128 ? rows_left : 128;
         const float inv = 1.f / (float)cnt;
-        float mean[TN];
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            float s = 0.f;
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = row_base + i * 32 + (r & 3) + 8 * (r >> 2);
-                    if (row < p.M) s += acc[i][j][r];
-                }
+        const int cl = wn * 32 + (lane & 31);
+        auto column_total = [&](float s) {  // sum over the tile's 128 rows of a per-lane partial
             s += __shfl_xor(s, 32, 64);
-            if (khalf == 0) red[wm * BN + wn * WN + 32 * j + (lane & 31)] = s;
-        }
-        __syncthreads();
+            if (khalf == 0) red[wm * BN + cl] = s;
+            __syncthreads();
+            float t = 0.f;
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int cl = wn * WN + 32 * j + (lane & 31);
-            mean[j] = (red[(2 * grp) * BN + cl] + red[(2 * grp + 1) * BN + cl]) * inv;
-        }
-        __syncthreads();
+            for (int w = 0; w < WAVES_M; ++w) t += red[w * BN + cl];
+            __syncthreads();
+            return t;
+        };
+        float s = 0.f;
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            float s = 0.f;
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = row_base + i * 32 + (r & 3) + 8 * (r >> 2);
-                    const float d = acc[i][j][r] - mean[j];
-                    if (row < p.M) s += d * d;
-                }
-            s += __shfl_xor(s, 32, 64);
-            if (khalf == 0) red[wm * BN + wn * WN + 32 * j + (lane & 31)] = s;
-        }
-        __syncthreads();
-        if ((wm & 1) == 0 && khalf == 0 && rows_left > 0) {
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int cl = wn * WN + 32 * j + (lane & 31);
-                const int col = n0 + cl;
-                if (col < p.N) {
-                    float* dst = p.stats + ((long long)(mb * GROUPS + grp) * p.N + col) * 2;
-                    dst[0] = mean[j];
-                    dst[1] = red[(2 * grp) * BN + cl] + red[(2 * grp + 1) * BN + cl];
-                }
+            for (int r = 0; r < 16; ++r) {
+                const int row = row_base + i * 32 + (r & 3) + 8 * (r >> 2);
+                if (row < p.M) s += acc[i][r];
             }
+        const float mean = column_total(s) * inv;
+        s = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row_base + i * 32 + (r & 3) + 8 * (r >> 2);
+                const float d = acc[i][r] - mean;
+                if (row < p.M) s += d * d;
+            }
+        const float m2 = column_total(s);
+        if (wm == 0 && khalf == 0 && col < p.N) {
+            float* dst = p.stats + ((long long)mb * p.N + col) * 2;
+            dst[0] = mean;
+            dst[1] = m2;
         }
-        (void)WAVES_M;
     }
 }
 
-template <int AMODE, int BMODE, int NPL, int BM>
+template <int AMODE, int BMODE, int NPL, int BN>
 static int launch_bf16(GemmParams& p, hipStream_t stream) {
-    p.mblocks = (p.M + BM - 1) / BM;
-    p.nblocks = (p.N + BN_T - 1) / BN_T;
+    p.mblocks = (p.M + BM_T - 1) / BM_T;
+    p.nblocks = (p.N + BN - 1) / BN;
     dim3 grid((unsigned)(p.mblocks * p.nblocks), 1, (unsigned)(p.batch * p.splits));
-    constexpr int STAGES = (BM == 256) ? 2 : 1;
-    constexpr size_t lds = (size_t)STAGES * NPL * (plane_slots(BM) + plane_slots(BN_T)) * sizeof(uint4);
+    constexpr size_t lds = (size_t)NPL * (plane_slots(BM_T) + plane_slots(BN)) * sizeof(uint4);
     static bool attr_done = false;
     if (!attr_done && lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16s_kernel<AMODE, BMODE, NPL, BM>,
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16s_kernel<AMODE, BMODE, NPL, BN>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) {
             set_error("trid_gemm_f32(split): cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
@@ -425,15 +373,16 @@ static int launch_bf16(GemmParams& p, hipStream_t stream) {
         }
         attr_done = true;
     }
-    hipLaunchKernelGGL((gemm_bf16s_kernel<AMODE, BMODE, NPL, BM>), grid, dim3(NT), lds, stream, p);
+    hipLaunchKernelGGL((gemm_bf16s_kernel<AMODE, BMODE, NPL, BN>), grid, dim3(NT), lds, stream, p);
     return check_launch("trid_gemm_f32(split)");
 }
 
 template <int AMODE, int BMODE, int NPL>
 static int pick_tile(GemmParams& p, hipStream_t stream) {
-    // 128x128 tiles, two workgroups per CU.  (A 256x128 double-buffered variant - BM = 256 in the kernel
-    // template, one workgroup per CU - and a role-alternating 256x128 schedule were both measured
-    // 3-4 % slower on the same box and are not instantiated)
+    // 128-row tiles, two workgroups per CU; 64 columns when the output is that narrow.  (A 256x128
+    // double-buffered tile with one workgroup per CU and a role-alternating 256x128 schedule were both
+    // measured 3-4 % slower on the same box)
+    if (p.N <= 64) return launch_bf16<AMODE, BMODE, NPL, 64>(p, stream);
     return launch_bf16<AMODE, BMODE, NPL, 128>(p, stream);
 }
 

@@ -40,7 +40,7 @@ PROFILE = None
 
 def _uses_split(M, N, K, a_mode, conv):
     """Mirror of the split-kernel eligibility test in trid_gemm_f32()."""
-    return (GEMM_PRECISION in (1, 3, 6) and K % 8 == 0 and K >= 32 and M >= 96 and N >= 96
+    return (GEMM_PRECISION in (1, 3, 6) and K % 8 == 0 and K >= 32 and M >= 64 and N >= 64 and (M >= 96 or N >= 96)
             and (a_mode != A_CONV or conv[2] % 8 == 0))
 
 
@@ -94,7 +94,7 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, a_mode=A_KC, b_mode=B_KC, alpha=1.0, a
     prof = PROFILE
     if prof is not None:
         split = _uses_split(M, N, K, a_mode, conv)
-        key = (a_mode, b_mode) + ((128, 128) if split else _gemm_tile(M, N, stats is not None)) + (split,)
+        key = (a_mode, b_mode) + ((128, 64 if N <= 64 else 128) if split else _gemm_tile(M, N, stats is not None)) + (split,)
         if prof["match"](key):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
