@@ -95,6 +95,30 @@ def cpu_baseline(sample_b=32, steps=3):
     }
 
 
+def encode_bench(model, images, tokens, lengths, reps=5):
+    """Eval-mode encode rates (test_net.py path: running-stat BatchNorm, no key encoders): gallery images/s
+    and query captions/s of ONE GPU at the training batch size."""
+    from textreid_amd.caption import CaptionBatch
+
+    head = model.embed_model
+    was_training = model.training
+    model.eval()
+    cb = CaptionBatch(tokens, lengths, max_len=64)
+    out = {}
+    with torch.no_grad():
+        for name, fn in (("gallery_encode_imgs_per_s", lambda: head.encode_images(images)),
+                         ("query_encode_captions_per_s", lambda: head.encode_captions(cb))):
+            fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize()
+            out[name] = reps * images.shape[0] / (time.perf_counter() - t0)
+    model.train(was_training)
+    return out
+
+
 def retrieval_bench(device, world, rank, G_total=1000000, Q=10000, k=10):
     """configs[4]: Q=1e4 text queries against a 1e6-image gallery whose rows are sharded over the ranks
     (1/8 per GPU; a single GPU times one such shard): similarity + per-query top-10 on device; with
@@ -291,6 +315,7 @@ def main():
     retr = None
     if not args.no_retrieval:
         retr = retrieval_bench(device, world, rank)
+        retr.update(encode_bench(model, batches[0][0], batches[0][1], batches[0][2]))
         log("retrieval: %.1f M gallery imgs/s" % (retr["value"] / 1e6))
     if rank == 0:
         out = {

@@ -22,20 +22,23 @@ namespace trid {
 
 constexpr int BM_T = 128;             // tile height
 constexpr int NT = 512;               // 8 waves
-#ifndef TRID_SPLIT_WAVES_PER_SIMD
-#define TRID_SPLIT_WAVES_PER_SIMD 0
+#ifndef TRID_NARROW_WAVES
+#define TRID_NARROW_WAVES 6  // 64-column K-contiguous tiles: 40 KB of LDS -> 3 workgroups per CU if the kernel fits 80 VGPRs
 #endif
 // Tile 128 x BN x 32, one LDS stage + register prefetch, 2 workgroups per CU.
 //   BN = 128: 2 x 4 waves, 64 x 32 per wave;   BN = 64 (outputs with <= 64 columns: stem, layer1):
 //   4 x 2 waves, 32 x 32 per wave - half the MFMA work per tile for the same A staging, still ahead
 //   of the fp32-input MFMA kernel whose peak is 16x lower.
+// B image: the swizzled wide layout needs 576 slots; a K-contiguous 64-row image only 4 x 65
+__host__ __device__ constexpr int b_plane_slots(int bmode, int bn) { return (bmode == B_KC && bn == 64) ? 4 * (64 + 1) : plane_slots(bn); }
+
 template <int AMODE, int BMODE, int NPL, int BN>
-__global__ __launch_bounds__(NT, (TRID_SPLIT_WAVES_PER_SIMD > 0) ? TRID_SPLIT_WAVES_PER_SIMD : 1) void gemm_bf16s_kernel(GemmParams p) {
+__global__ __launch_bounds__(NT, (BN == 64 && BMODE == B_KC && TRID_NARROW_WAVES > 0) ? TRID_NARROW_WAVES : 1) void gemm_bf16s_kernel(GemmParams p) {
     constexpr int BM = BM_T;
     constexpr int WAVES_N = BN / 32;           // 4 or 2
     constexpr int WAVES_M = 8 / WAVES_N;       // 2 or 4
     constexpr int TM = BM / (32 * WAVES_M);    // 32-row MFMA tiles per wave: 2 or 1
-    constexpr int PA = plane_slots(BM), PB = plane_slots(BN);
+    constexpr int PA = plane_slots(BM), PB = b_plane_slots(BMODE, BN);
     // M/N-contiguous operands are loaded WIDE (float4 along the rows, 4 consecutive k per lane) and
     // transposed through registers into the swizzled LDS image
     constexpr bool A_WIDE = (AMODE == A_MC);
@@ -362,7 +365,7 @@ static int launch_bf16(GemmParams& p, hipStream_t stream) {
     p.mblocks = (p.M + BM_T - 1) / BM_T;
     p.nblocks = (p.N + BN - 1) / BN;
     dim3 grid((unsigned)(p.mblocks * p.nblocks), 1, (unsigned)(p.batch * p.splits));
-    constexpr size_t lds = (size_t)NPL * (plane_slots(BM_T) + plane_slots(BN)) * sizeof(uint4);
+    constexpr size_t lds = (size_t)NPL * (plane_slots(BM_T) + b_plane_slots(BMODE, BN)) * sizeof(uint4);
     static bool attr_done = false;
     if (!attr_done && lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16s_kernel<AMODE, BMODE, NPL, BN>,
