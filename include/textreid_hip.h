@@ -248,6 +248,9 @@ int trid_enqueue_f32(float* v_queue, float* t_queue, int64_t* id_queue, int64_t*
 /* sim = q @ g.T for q [Q,C], g [G,C] (both L2-normalised by the caller), fused
  * per-row top-k (k <= 16) sorted descending, ties -> lower index first.
  * out_val [Q,k] f32, out_idx [Q,k] i64 (+ idx_offset).  ws floats >= trid_topk_ws_floats(Q,G,k).
+ * The first 8192 gallery rows go through a [Q, 8192] similarity panel and a streaming row scan; the rest
+ * through ONE GEMM whose epilogue keeps only elements that reach the row's current k-th value (exact for
+ * any input order: list overflow falls back to panel passes on device, without a host round trip).
  * precision: arithmetic of the similarity GEMM, as trid_gemm_desc.precision (6: split bf16, fp32-class;
  * 0: exact fp32-input MFMA). */
 long long trid_topk_ws_floats(int Q, int G, int k);

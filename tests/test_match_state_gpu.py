@@ -93,6 +93,29 @@ def test_topk_rows_adversarial_orders_and_ties(gpu, G, k):
     assert torch.equal(idx.cpu()[finite], order.indices[:, :k][finite])
 
 
+def test_fused_similarity_topk_overflow_fallback(gpu):
+    """Gallery ordered so that every later column beats the thresholds set by the first chunk: the
+    admission-filter candidate lists overflow and the gated dense passes must produce the exact answer.
+    Mixed with rows that do not overflow (random) and heavy ties."""
+    from textreid_amd.evaluation import similarity_topk
+
+    G, Q, C = 8192 * 2 + 1234, 96, 64
+    gen = torch.Generator().manual_seed(3)
+    gal = torch.zeros(G, C)
+    gal[:, 0] = torch.arange(G, dtype=torch.float32) * 1e-4      # ascending along the gallery
+    gal[:, 1] = torch.randn(G, generator=gen)
+    gal[:, 2] = torch.randint(0, 2, (G,), generator=gen).float()  # two-valued -> ties
+    q = torch.zeros(Q, C)
+    q[:32, 0] = 1.0            # rows 0-31: similarity ascending with the index (worst case)
+    q[32:64, 1] = 1.0          # rows 32-63: random order
+    q[64:, 2] = 1.0            # rows 64-95: ties everywhere -> lowest indices win
+    vals, idx = similarity_topk(q.to(gpu), gal.to(gpu), 10, normalize=False)
+    sim = q @ gal.t()
+    order = torch.sort(sim, dim=1, descending=True, stable=True)
+    assert torch.equal(vals.cpu(), order.values[:, :10])
+    assert torch.equal(idx.cpu(), order.indices[:, :10])
+
+
 def test_topk_full_size_properties(gpu):
     """Config-5-shaped shard at reduced Q: top-k is sorted, indices valid and
     unique, and every returned value equals the recomputed dot product."""

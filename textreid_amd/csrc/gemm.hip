@@ -45,6 +45,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void gemm_kernel(GemmParams
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int STAGE = BK * LDA + BK * LDB;
 
+    if (p.gate != nullptr && *p.gate == 0) return;  // predicated launch (retrieval overflow fallback)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -449,11 +450,12 @@ static int dispatch_tile(GemmParams& p, hipStream_t stream) {
 
 using namespace trid;
 
-extern "C" int trid_gemm_f32(const trid_gemm_desc* d, void* stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
+extern "C" int trid_gemm_f32(const trid_gemm_desc* d, void* stream) { return trid_gemm_launch(d, nullptr, nullptr, (hipStream_t)stream); }
+
+int trid_gemm_launch(const trid_gemm_desc* d, const GemmFilter* filt, const int* gate, hipStream_t stream) {
     TRID_REQUIRE(d != nullptr, "trid_gemm_f32: null descriptor");
     TRID_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "trid_gemm_f32: empty problem M=%d N=%d K=%d", d->M, d->N, d->K);
-    TRID_REQUIRE(d->A && d->B && d->C, "trid_gemm_f32: null operand");
+    TRID_REQUIRE(d->A && d->B && (d->C || filt), "trid_gemm_f32: null operand");
     TRID_REQUIRE(aligned16(d->A) && aligned16(d->B) && aligned16(d->C), "trid_gemm_f32: operands must be 16-byte aligned");
     TRID_REQUIRE(d->a_mode >= 0 && d->a_mode <= 2 && d->b_mode >= 0 && d->b_mode <= 2, "trid_gemm_f32: bad loader mode");
     TRID_REQUIRE(d->batch >= 1 && d->splits >= 1, "trid_gemm_f32: batch/splits must be >= 1");
@@ -467,6 +469,8 @@ extern "C" int trid_gemm_f32(const trid_gemm_desc* d, void* stream_) {
     p.alpha = d->alpha; p.accumulate = d->accumulate;
     p.bias = d->bias; p.sBias = d->strideBias; p.stats = d->stats;
     p.H = d->H; p.W = d->W; p.Cin = d->Cin;
+    if (filt) p.filt = *filt;
+    p.gate = gate;
     // contiguous-direction alignment (float4 loads)
     if (d->a_mode == A_KC) TRID_REQUIRE(d->K % 4 == 0 && d->lda % 4 == 0, "A_KC needs K%%4==0 and lda%%4==0 (K=%d lda=%lld)", d->K, d->lda);
     if (d->a_mode == A_MC) TRID_REQUIRE(d->M % 4 == 0 && d->lda % 4 == 0, "A_MC needs M%%4==0 and lda%%4==0 (M=%d)", d->M);
@@ -499,6 +503,7 @@ extern "C" int trid_gemm_f32(const trid_gemm_desc* d, void* stream_) {
         rc = gemm_bf16_dispatch(p, am, bm, d->precision, stream);
         if (rc != TRID_E_UNSUPPORTED) return rc;
     }
+    if (filt) return TRID_E_UNSUPPORTED;  // the filter epilogue exists in the split kernel only
     if (am == A_KC && bm == B_KC) rc = dispatch_tile<A_KC, B_KC>(p, stream);
     else if (am == A_CONV && bm == B_KC) rc = dispatch_tile<A_CONV, B_KC>(p, stream);
     else if (am == A_KC && bm == B_NC) rc = dispatch_tile<A_KC, B_NC>(p, stream);

@@ -45,6 +45,7 @@ __global__ __launch_bounds__(NT, (BN == 64 && BMODE == B_KC && TRID_NARROW_WAVES
     constexpr bool B_WIDE = (BMODE != B_KC);
     extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
 
+    if (p.gate != nullptr && *p.gate == 0) return;  // predicated launch (retrieval overflow fallback)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -294,6 +295,33 @@ __global__ __launch_bounds__(NT, (BN == 64 && BMODE == B_KC && TRID_NARROW_WAVES
     // ---- epilogue (same contract as gemm.hip) -----------------------------------------
     const int row_base = m0 + wm * (32 * TM) + 4 * khalf;
     const int col = n0 + wn * 32 + (lane & 31);
+    if (p.filt.thr != nullptr) {
+        // top-k admission filter: nothing is stored but the (rare) elements that reach the row's threshold
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            float thr[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row_base + i * 32 + (r & 3) + 8 * (r >> 2);
+                thr[r] = (row < p.M && col < p.N) ? p.filt.thr[(long long)row * p.filt.thr_stride] : INFINITY;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = p.alpha * acc[i][r];
+                if (v >= thr[r]) {
+                    const int row = row_base + i * 32 + (r & 3) + 8 * (r >> 2);
+                    const int slot = atomicAdd(p.filt.cnt + row, 1);
+                    if (slot < p.filt.cap) {
+                        float2* dst = reinterpret_cast<float2*>(p.filt.cand) + (long long)row * p.filt.cap + slot;
+                        *dst = make_float2(v, __int_as_float(col + p.filt.col0));
+                    } else {
+                        *p.filt.overflow = 1;
+                    }
+                }
+            }
+        }
+        return;
+    }
     const float bv = (bias != nullptr && col < p.N) ? bias[col] : 0.f;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {

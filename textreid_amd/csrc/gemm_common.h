@@ -9,6 +9,19 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 enum { A_KC = 0, A_MC = 1, A_CONV = 2 };
 enum { B_KC = 0, B_NC = 1, B_CONV = 2 };
 
+// Top-k admission filter epilogue (retrieval.hip; split kernel only): instead of storing C, every element
+// >= thr[row * thr_stride] is appended to the row's candidate list (value, column) through an atomic
+// per-row counter; `overflow` is raised when a list is full.
+struct GemmFilter {
+    const float* thr;
+    int thr_stride;
+    int* cnt;        // [M]
+    float* cand;     // [M][cap][2]: value, column (int bits)
+    int cap;
+    int col0;        // added to the column index
+    int* overflow;
+};
+
 struct GemmParams {
     const float* A;
     const float* B;
@@ -27,6 +40,8 @@ struct GemmParams {
     int H, W, Cin;      // conv geometry (A_CONV: M=Bimg*H*W,K=9*Cin; B_CONV: K=Bimg*H*W,N=9*Cin)
     FastDiv fdW, fdH, fdC;
     int mblocks, nblocks;
+    GemmFilter filt;   // filt.thr == nullptr: normal epilogue
+    const int* gate;   // optional device flag: the whole launch is a no-op when *gate == 0
 };
 
 constexpr int BK = 32;
@@ -34,5 +49,13 @@ constexpr int BK = 32;
 // split-precision variants (gemm_bf16.hip): fp32 operands split on the fly into 2 or 3
 // bf16 planes, 3 or 6 bf16 MFMAs per product, fp32 accumulation
 int gemm_bf16_dispatch(GemmParams& p, int a_mode, int b_mode, int precision, hipStream_t stream);
+
+}  // namespace trid
+
+// trid_gemm_f32 plus the internal extras (either may be null).  With a filter the call returns
+// TRID_E_UNSUPPORTED when the shape / precision does not run on the split kernel.
+int trid_gemm_launch(const trid_gemm_desc* d, const trid::GemmFilter* filt, const int* gate, hipStream_t stream);
+
+namespace trid {
 
 }  // namespace trid

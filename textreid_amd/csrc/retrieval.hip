@@ -5,38 +5,30 @@
 // into the running per-row top-k (one wave per query row, register insertion sort +
 // shuffle tournament), so only Q*k (value, index) pairs ever leave the device.
 
-#include "common.h"
+#include "gemm_common.h"
 
 namespace trid {
 
 constexpr int TOPK_MAX = 16;
 
-// Running top-k of one similarity row per wave.  The k best (value, index) pairs live one per
-// lane (lane i = i-th best, sorted by value descending, ties lower index first); the k-th value
-// is the wave-uniform admission threshold.  The row is streamed with UNROLL independent float4
-// loads per lane in flight and tested against the threshold with one ballot per batch, so after
-// the first few hundred elements the kernel is a pure HBM stream; the rare survivors
-// (~k ln(G/k) per row for unordered data) are inserted one at a time with a ballot-popcount
-// position and a one-lane shuffle shift.  Exact for any input order (sorted-ascending rows
-// degrade to one insertion per element, never to a wrong answer).
+// Running top-k of one similarity row, held by one wave.  The k best (value, index) pairs live one per
+// lane (lane i = i-th best, sorted by value descending, ties lower index first); the k-th value is the
+// wave-uniform admission threshold.  Survivors are inserted one at a time with a ballot-popcount
+// position and a one-lane shuffle shift.
 template <int KK>
-__global__ __launch_bounds__(256) void topk_merge_rows_kernel(const float* __restrict__ sim, int ld, int Q, int Gc,
-                                                              long long col_offset, float* __restrict__ best_val,
-                                                              long long* __restrict__ best_idx, int first) {
-    constexpr int UNROLL = 8;
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= Q) return;
-    float lv = -INFINITY;
-    long long li = -1;
-    if (!first && lane < KK) {
-        lv = best_val[(long long)row * KK + lane];
-        li = best_idx[(long long)row * KK + lane];
+struct WaveTopk {
+    float lv, t;
+    long long li, ti;
+    int lane;
+    __device__ __forceinline__ void init(int lane_, const float* __restrict__ val, const long long* __restrict__ idx) {
+        lane = lane_;
+        lv = -INFINITY;
+        li = -1;
+        if (val != nullptr && lane < KK) { lv = val[lane]; li = idx[lane]; }
+        t = __shfl(lv, KK - 1, 64);
+        ti = __shfl(li, KK - 1, 64);
     }
-    float t = __shfl(lv, KK - 1, 64);
-    long long ti = __shfl(li, KK - 1, 64);
-
-    auto offer = [&](float cv, long long ci) {  // wave-uniform candidate
+    __device__ __forceinline__ void offer(float cv, long long ci) {  // wave-uniform candidate
         if (!(cv > t || (cv == t && (ti < 0 || ci < ti)))) return;
         const bool ahead = lane < KK && (lv > cv || (lv == cv && li >= 0 && li < ci));
         const int pos = __popcll(__ballot(ahead));
@@ -47,7 +39,37 @@ __global__ __launch_bounds__(256) void topk_merge_rows_kernel(const float* __res
         if (lane >= KK) { lv = -INFINITY; li = -1; }
         t = __shfl(lv, KK - 1, 64);
         ti = __shfl(li, KK - 1, 64);
-    };
+    }
+    // every lane's candidate (xc, ci) with ok set is offered, in lane order
+    __device__ __forceinline__ void offer_lanes(bool ok, float xc, long long ci) {
+        unsigned long long bal = __ballot(ok && xc >= t);
+        while (bal) {
+            const int src = __ffsll((long long)bal) - 1;
+            bal &= bal - 1;
+            offer(__shfl(xc, src, 64), __shfl(ci, src, 64));
+        }
+    }
+    __device__ __forceinline__ void store(float* __restrict__ val, long long* __restrict__ idx) const {
+        if (lane < KK) { val[lane] = lv; idx[lane] = li; }
+    }
+};
+
+// Dense row scan: the row is streamed with UNROLL independent float4 loads per lane in flight and tested
+// against the threshold with one ballot per batch, so after the first few hundred elements the kernel is
+// a pure HBM stream (~k ln(G/k) survivors per row for unordered data).  Exact for any input order
+// (sorted-ascending rows degrade to one insertion per element, never to a wrong answer).
+template <int KK>
+__global__ __launch_bounds__(256) void topk_merge_rows_kernel(const float* __restrict__ sim, int ld, int Q, int Gc,
+                                                              long long col_offset, float* __restrict__ best_val,
+                                                              long long* __restrict__ best_idx, int first,
+                                                              const int* __restrict__ gate) {
+    if (gate != nullptr && *gate == 0) return;
+    constexpr int UNROLL = 8;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= Q) return;
+    WaveTopk<KK> L;
+    L.init(lane, first ? nullptr : best_val + (long long)row * KK, best_idx + (long long)row * KK);
 
     const float* r = sim + (long long)row * ld;
     const bool vec_ok = ((reinterpret_cast<uintptr_t>(r) & 15) == 0);
@@ -67,29 +89,44 @@ __global__ __launch_bounds__(256) void topk_merge_rows_kernel(const float* __res
         }
         bool hit = false;
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) hit = hit || x[u].x >= t || x[u].y >= t || x[u].z >= t || x[u].w >= t;
+        for (int u = 0; u < UNROLL; ++u) hit = hit || x[u].x >= L.t || x[u].y >= L.t || x[u].z >= L.t || x[u].w >= L.t;
         if (__ballot(hit) == 0ull) continue;
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
-            const int j0 = base + u * 256;
+            const int j0 = base + u * 256 + lane * 4;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const float xc = c == 0 ? x[u].x : c == 1 ? x[u].y : c == 2 ? x[u].z : x[u].w;
-                // padding lanes carry -inf: admitted only while the list still has empty slots, and
-                // then they are indistinguishable from the empty slots themselves
-                unsigned long long bal = __ballot(xc >= t && (j0 + lane * 4 + c) < Gc);
-                while (bal) {
-                    const int src = __ffsll((long long)bal) - 1;
-                    bal &= bal - 1;
-                    offer(__shfl(xc, src, 64), col_offset + j0 + src * 4 + c);
-                }
+                // padding lanes carry -inf and are excluded by index
+                L.offer_lanes(j0 + c < Gc, xc, col_offset + j0 + c);
             }
         }
     }
-    if (lane < KK) {
-        best_val[(long long)row * KK + lane] = lv;
-        best_idx[(long long)row * KK + lane] = li;
+    L.store(best_val + (long long)row * KK, best_idx + (long long)row * KK);
+}
+
+// Candidate lists written by the GEMM's admission-filter epilogue (value, column) -> running top-k.
+// A no-op when any list overflowed (*overflow != 0): the caller's gated dense passes redo the work.
+template <int KK>
+__global__ __launch_bounds__(256) void topk_merge_cands_kernel(const float2* __restrict__ cand, const int* __restrict__ cnt,
+                                                               int cap, int Q, long long idx_offset,
+                                                               float* __restrict__ best_val, long long* __restrict__ best_idx,
+                                                               const int* __restrict__ overflow) {
+    if (*overflow != 0) return;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= Q) return;
+    const int n = cnt[row];
+    if (n == 0) return;
+    WaveTopk<KK> L;
+    L.init(lane, best_val + (long long)row * KK, best_idx + (long long)row * KK);
+    const float2* c = cand + (long long)row * cap;
+    for (int base = 0; base < n; base += 64) {
+        const bool ok = base + lane < n;
+        const float2 pr = ok ? c[base + lane] : make_float2(-INFINITY, 0.f);
+        L.offer_lanes(ok, pr.x, idx_offset + __float_as_int(pr.y));
     }
+    L.store(best_val + (long long)row * KK, best_idx + (long long)row * KK);
 }
 
 // Full descending argsort of each row (evaluation.py:14): one workgroup per row,
@@ -202,19 +239,55 @@ using namespace trid;
 
 static int topk_chunk_cols(int G) { return G < 8192 ? ((G + 3) / 4 * 4) : 8192; }
 
+// workspace: [Q x Gc similarity panel | later reused as Q candidate lists of Gc/2 (value, column) pairs]
+//            [Q list counters][1 overflow flag]
 extern "C" long long trid_topk_ws_floats(int Q, int G, int k) {
     (void)k;
-    return (long long)Q * topk_chunk_cols(G);
+    return (long long)Q * topk_chunk_cols(G) + Q + 4;
 }
 
+template <int KK>
+static void launch_scan(const float* ws, int ld, int Q, int n, long long off, float* out_val, int64_t* out_idx, int first,
+                        const int* gate, hipStream_t stream) {
+    hipLaunchKernelGGL(topk_merge_rows_kernel<KK>, dim3((Q + 3) / 4), dim3(256), 0, stream, ws, ld, Q, n, off, out_val,
+                       (long long*)out_idx, first, gate);
+}
+template <int KK>
+static void launch_cands(const float* cand, const int* cnt, int cap, int Q, long long off, float* out_val, int64_t* out_idx,
+                         const int* overflow, hipStream_t stream) {
+    hipLaunchKernelGGL(topk_merge_cands_kernel<KK>, dim3((Q + 3) / 4), dim3(256), 0, stream, (const float2*)cand, cnt, cap, Q,
+                       off, out_val, (long long*)out_idx, overflow);
+}
+#define TRID_TOPK_SWITCH(k, CALL)                                                                                  \
+    switch (k) {                                                                                                   \
+        case 1: CALL(1); break; case 2: CALL(2); break; case 3: CALL(3); break; case 4: CALL(4); break;            \
+        case 5: CALL(5); break; case 6: CALL(6); break; case 7: CALL(7); break; case 8: CALL(8); break;            \
+        case 9: CALL(9); break; case 10: CALL(10); break; case 11: CALL(11); break; case 12: CALL(12); break;      \
+        case 13: CALL(13); break; case 14: CALL(14); break; case 15: CALL(15); break; case 16: CALL(16); break;    \
+    }
+
+// Similarity + per-query top-k of Q queries against G gallery rows.
+//   1. the first Gc columns: GEMM -> [Q, Gc] panel -> streaming row scan -> sorted lists, whose k-th
+//      value is every row's admission threshold;
+//   2. all remaining columns in ONE GEMM whose epilogue stores nothing but the elements that reach the
+//      row's threshold (~k (G-Gc)/Gc per row for unordered data) into per-row candidate lists;
+//   3. the lists are merged into the running top-k.
+// If a list overflows (adversarially ordered gallery) step 3 does nothing and the gated dense passes of
+// step 4 (panel GEMM + scan per chunk, each a no-op unless the overflow flag is set) redo columns >= Gc,
+// so the result is exact for any input.  Shapes / precisions the split kernel does not cover run the
+// dense passes unconditionally.
 extern "C" int trid_sim_topk_f32(const float* q, const float* g, float* out_val, int64_t* out_idx, int Q, int G, int C,
-                                 int k, long long idx_offset, int precision, float* ws, void* stream) {
+                                 int k, long long idx_offset, int precision, float* ws, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
     TRID_REQUIRE(q && g && out_val && out_idx && ws, "trid_sim_topk_f32: null pointer");
     TRID_REQUIRE(Q > 0 && G > 0 && C > 0 && C % 4 == 0, "trid_sim_topk_f32: bad shape (C%%4)");
     TRID_REQUIRE(k >= 1 && k <= TOPK_MAX && k <= G, "trid_sim_topk_f32: k must be in [1,%d] and <= G", TOPK_MAX);
     const int Gc = topk_chunk_cols(G);
-    for (int c0 = 0; c0 < G; c0 += Gc) {
-        const int n = (G - c0) < Gc ? (G - c0) : Gc;
+    int* cnt = reinterpret_cast<int*>(ws + (long long)Q * Gc);
+    int* overflow = cnt + Q;
+    const int cap = Gc / 2;
+
+    auto panel_gemm = [&](int c0, int n, const int* gate) {
         trid_gemm_desc d;
         memset(&d, 0, sizeof(d));
         d.A = q; d.B = g + (long long)c0 * C; d.C = ws;
@@ -223,23 +296,53 @@ extern "C" int trid_sim_topk_f32(const float* q, const float* g, float* out_val,
         d.batch = 1; d.splits = 1; d.alpha = 1.f;
         d.a_mode = TRID_A_KC; d.b_mode = TRID_B_KC;
         d.precision = precision;
-        int rc = trid_gemm_f32(&d, stream);
+        return trid_gemm_launch(&d, nullptr, gate, stream);
+    };
+    auto dense_pass = [&](int c0, const int* gate) {
+        const int n = (G - c0) < Gc ? (G - c0) : Gc;
+        int rc = panel_gemm(c0, n, gate);
         if (rc) return rc;
-        const dim3 grid((Q + 3) / 4), block(256);
         const int first = c0 == 0;
         const long long off = idx_offset + c0;
-#define TRID_TOPK_CASE(KK)                                                                                          \
-    case KK:                                                                                                        \
-        hipLaunchKernelGGL(topk_merge_rows_kernel<KK>, grid, block, 0, (hipStream_t)stream, ws, Gc, Q, n, off, out_val, \
-                           (long long*)out_idx, first);                                                             \
-        break;
-        switch (k) {
-            TRID_TOPK_CASE(1) TRID_TOPK_CASE(2) TRID_TOPK_CASE(3) TRID_TOPK_CASE(4) TRID_TOPK_CASE(5) TRID_TOPK_CASE(6)
-            TRID_TOPK_CASE(7) TRID_TOPK_CASE(8) TRID_TOPK_CASE(9) TRID_TOPK_CASE(10) TRID_TOPK_CASE(11) TRID_TOPK_CASE(12)
-            TRID_TOPK_CASE(13) TRID_TOPK_CASE(14) TRID_TOPK_CASE(15) TRID_TOPK_CASE(16)
+#define TRID_CALL(KK) launch_scan<KK>(ws, Gc, Q, n, off, out_val, out_idx, first, gate, stream)
+        TRID_TOPK_SWITCH(k, TRID_CALL)
+#undef TRID_CALL
+        return check_launch("trid_sim_topk_f32");
+    };
+
+    int rc = dense_pass(0, nullptr);
+    if (rc || G <= Gc) return rc;
+
+    bool fused = false;
+    {
+        hipError_t e = hipMemsetAsync(cnt, 0, (size_t)(Q + 1) * sizeof(int), stream);
+        if (e != hipSuccess) { set_error("trid_sim_topk_f32: memset failed: %s", hipGetErrorString(e)); return (int)e; }
+        trid_gemm_desc d;
+        memset(&d, 0, sizeof(d));
+        d.A = q; d.B = g + (long long)Gc * C; d.C = nullptr;
+        d.M = Q; d.N = G - Gc; d.K = C;
+        d.lda = C; d.ldb = C; d.ldc = 0;
+        d.batch = 1; d.splits = 1; d.alpha = 1.f;
+        d.a_mode = TRID_A_KC; d.b_mode = TRID_B_KC;
+        d.precision = precision;
+        GemmFilter f;
+        f.thr = out_val + (k - 1); f.thr_stride = k;
+        f.cnt = cnt; f.cand = ws; f.cap = cap; f.col0 = Gc; f.overflow = overflow;
+        rc = trid_gemm_launch(&d, &f, nullptr, stream);
+        if (rc == TRID_OK) {
+            fused = true;
+#define TRID_CALL(KK) launch_cands<KK>(ws, cnt, cap, Q, idx_offset, out_val, out_idx, overflow, stream)
+            TRID_TOPK_SWITCH(k, TRID_CALL)
+#undef TRID_CALL
+            rc = check_launch("trid_sim_topk_f32");
+            if (rc) return rc;
+        } else if (rc != TRID_E_UNSUPPORTED) {
+            return rc;
         }
-#undef TRID_TOPK_CASE
-        rc = check_launch("trid_sim_topk_f32");
+    }
+    // dense passes over the remaining chunks: unconditional without the fused path, gated on overflow with it
+    for (int c0 = Gc; c0 < G; c0 += Gc) {
+        rc = dense_pass(c0, fused ? overflow : nullptr);
         if (rc) return rc;
     }
     return TRID_OK;
@@ -249,18 +352,9 @@ extern "C" int trid_topk_rows_f32(const float* sim, int ld, int Q, int G, int k,
                                   void* stream) {
     TRID_REQUIRE(sim && out_val && out_idx && Q > 0 && G > 0 && ld >= G, "trid_topk_rows_f32: bad arguments");
     TRID_REQUIRE(k >= 1 && k <= TOPK_MAX && k <= G, "trid_topk_rows_f32: k must be in [1,%d] and <= G", TOPK_MAX);
-    const dim3 grid((Q + 3) / 4), block(256);
-#define TRID_TOPK_CASE(KK)                                                                                         \
-    case KK:                                                                                                       \
-        hipLaunchKernelGGL(topk_merge_rows_kernel<KK>, grid, block, 0, (hipStream_t)stream, sim, ld, Q, G, 0LL, out_val, \
-                           (long long*)out_idx, 1);                                                                \
-        break;
-    switch (k) {
-        TRID_TOPK_CASE(1) TRID_TOPK_CASE(2) TRID_TOPK_CASE(3) TRID_TOPK_CASE(4) TRID_TOPK_CASE(5) TRID_TOPK_CASE(6)
-        TRID_TOPK_CASE(7) TRID_TOPK_CASE(8) TRID_TOPK_CASE(9) TRID_TOPK_CASE(10) TRID_TOPK_CASE(11) TRID_TOPK_CASE(12)
-        TRID_TOPK_CASE(13) TRID_TOPK_CASE(14) TRID_TOPK_CASE(15) TRID_TOPK_CASE(16)
-    }
-#undef TRID_TOPK_CASE
+#define TRID_CALL(KK) launch_scan<KK>(sim, ld, Q, G, 0LL, out_val, out_idx, 1, nullptr, (hipStream_t)stream)
+    TRID_TOPK_SWITCH(k, TRID_CALL)
+#undef TRID_CALL
     return check_launch("trid_topk_rows_f32");
 }
 
