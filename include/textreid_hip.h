@@ -75,6 +75,9 @@ typedef struct trid_gemm_desc {
                          * terms <= 2^-26; 3 drops ~2^-17); 1: operands rounded to bf16, one MFMA per
                          * product, fp32 accumulate (bf16-autocast arithmetic).  Shapes the split kernel
                          * does not cover fall back to 0. */
+    const float* residual; /* NULL, or [M][ldres] added after bias (eval: identity / folded downsample branch) */
+    int64_t ldres;
+    int32_t relu;          /* != 0: C = max(C, 0) last (eval: BatchNorm folded into weights + bias, ReLU here) */
 } trid_gemm_desc;
 
 int trid_gemm_f32(const trid_gemm_desc* d, void* stream);

@@ -88,6 +88,27 @@ def test_visual_encoder(gpu, golden_dir, tag, spec):
     assert not bad, bad
 
 
+def test_eval_bn_folding_matches_unfolded(gpu):
+    """eval-mode BatchNorm folded into the conv weights (ReLU / residual in the GEMM epilogue)
+    gives the unfolded eval path's output up to fp32 rounding of the folded weights."""
+    from textreid_amd.backbones.m_resnet import ModifiedResNet
+
+    spec = OV.RN50
+    m = ModifiedResNet(list(spec.layers), spec.output_dim, spec.heads, spec.last_stride, (spec.height, spec.in_width), spec.width)
+    fill_module(m, 5).to(gpu).train()
+    x = OF.randn("img:fold", (4, 3, spec.height, spec.in_width), 5).to(gpu)
+    with torch.no_grad():
+        for _ in range(10):  # warm running statistics
+            m(x)
+        m.eval()
+        m.fold_eval_bn = False
+        ref = m(x)
+        m.fold_eval_bn = True
+        out = m(x)
+    # folding rounds w*scale once more per layer; 50 random-weight layers amplify that to ~5e-5
+    assert rel(out, ref) < 2e-4, rel(out, ref)
+
+
 def test_text_encoder(gpu, golden_dir):
     from textreid_amd.backbones.gru import GRU
     from textreid_amd.caption import CaptionBatch

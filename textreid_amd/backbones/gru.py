@@ -30,8 +30,8 @@ def load_vocab_dict(root, use_onehot):
 
 class _GRUFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, mod, tokens, lengths, lmax, w_ih_f, w_hh_f, w_ih_r, w_hh_r):
-        save = any(ctx.needs_input_grad)
+    def forward(ctx, mod, tokens, lengths, lmax, save, w_ih_f, w_hh_f, w_ih_r, w_hh_r):
+        # `save` comes from the caller: ctx.needs_input_grad ignores torch.no_grad()
         B = tokens.shape[0]
         H = w_hh_f.shape[1]
         E = w_ih_f.shape[1]
@@ -99,7 +99,7 @@ class _GRUFn(torch.autograd.Function):
             ops.gemm(dGi, x, slab, 3 * H, E, KK, 6 * H, E, E, a_mode=ops.A_MC, b_mode=ops.B_NC, batch=2,
                      strideA=3 * H, strideB=0, strideC=3 * H * E, splits=splits, strideSplit=n)
             ops.call("trid_slab_reduce_f32", ops._p(slab), ops._p(dwih), n, splits, n, 0, st)
-        return None, None, None, None, dwih[0], dwhh[0], dwih[1], dwhh[1]
+        return None, None, None, None, None, dwih[0], dwhh[0], dwih[1], dwhh[1]
 
 
 class GRU(nn.Module):
@@ -127,8 +127,9 @@ class GRU(nn.Module):
         if self.vocab_dict.device != cb.tokens.device:
             self.vocab_dict = self.vocab_dict.to(cb.tokens.device)
         g = self.gru
-        return _GRUFn.apply(self, cb.tokens.contiguous(), cb.lengths.contiguous(), cb.max_len, g.weight_ih_l0,
-                            g.weight_hh_l0, g.weight_ih_l0_reverse, g.weight_hh_l0_reverse)
+        ws = (g.weight_ih_l0, g.weight_hh_l0, g.weight_ih_l0_reverse, g.weight_hh_l0_reverse)
+        save = torch.is_grad_enabled() and any(w.requires_grad for w in ws)
+        return _GRUFn.apply(self, cb.tokens.contiguous(), cb.lengths.contiguous(), cb.max_len, save, *ws)
 
 
 def build_gru(cfg, bidirectional, vocab_dict=None):

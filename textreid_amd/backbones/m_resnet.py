@@ -122,12 +122,16 @@ class _WgradStream:
 
 
 class _EncoderFn(torch.autograd.Function):
-    """forward(images, module, *params) -> [B, out_dim]; grads for every parameter."""
+    """forward(images, module, save, *params) -> [B, out_dim]; grads for every parameter.
+    `save` (activations kept for backward) is decided by the caller: inside forward() grad mode is
+    always off and ctx.needs_input_grad ignores torch.no_grad()."""
 
     @staticmethod
-    def forward(ctx, images, mod, *params):
-        save = any(ctx.needs_input_grad[2:])
-        out, saved = mod._run_forward(images, save)
+    def forward(ctx, images, mod, save, *params):
+        if not mod.training and not save and mod.fold_eval_bn and getattr(mod, "_debug_taps", None) is None:
+            out, saved = mod._run_forward_folded(images), None
+        else:
+            out, saved = mod._run_forward(images, save)
         ctx.mod = mod
         ctx.saved = saved
         return out
@@ -139,7 +143,7 @@ class _EncoderFn(torch.autograd.Function):
         if saved is None:
             raise RuntimeError("backward through an encoder forward that did not save activations")
         grads = mod._run_backward(saved, gout.contiguous())
-        return (None, None) + tuple(grads)
+        return (None, None, None) + tuple(grads)
 
 
 class ModifiedResNet(nn.Module):
@@ -147,6 +151,7 @@ class ModifiedResNet(nn.Module):
         super().__init__()
         self.output_dim = output_dim
         self.out_channels = output_dim
+        self.fold_eval_bn = True  # eval + no_grad: BatchNorm folded into the conv weights, ReLU/residual in the GEMM epilogue
         self.input_resolution = input_resolution
         self.conv1 = nn.Conv2d(3, width // 2, kernel_size=3, stride=2, padding=1, bias=False)
         self.bn1 = nn.BatchNorm2d(width // 2)
@@ -191,7 +196,47 @@ class ModifiedResNet(nn.Module):
             raise RuntimeError("textreid_amd.ModifiedResNet runs on the HIP kernel library only (CUDA tensors); no CPU fallback")
         x = x.type(self.conv1.weight.dtype).contiguous()
         params = list(self.parameters())
-        return _EncoderFn.apply(x, self, *params)
+        save = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        return _EncoderFn.apply(x, self, save, *params)
+
+    def _run_forward_folded(self, images):
+        """Eval mode (test_net.py / inference.py:14-26): BatchNorm uses running statistics, so it is
+        folded into the conv weights (w * gamma*invstd, bias = beta - mean*gamma*invstd) and the
+        ReLU / residual add run in the GEMM epilogue - no elementwise pass except the 2x2 average
+        pools.  Same values as the unfolded eval path up to fp32 rounding of the folded weights."""
+        B = images.shape[0]
+        col, Ho, Wo = ops.stem_im2col(images)
+        c1 = self.conv1.weight
+        w1p = torch.zeros(c1.shape[0], col.shape[1], device=c1.device, dtype=c1.dtype)
+        w1p[:, : c1[0].numel()] = c1.detach().reshape(c1.shape[0], -1)
+
+        def folded(w2d, bn):
+            return ops.fold_bn(w2d, _bn_coeffs(bn, None, 0, False))
+
+        w, b = folded(w1p, self.bn1)
+        a1 = ops.conv1x1(col, w, bias=b, relu=True).view(B, Ho, Wo, -1)
+        w, b = folded(_w3x3(self.conv2), self.bn2)
+        a2 = ops.conv3x3(a1, w, bias=b, relu=True)
+        w, b = folded(_w3x3(self.conv3), self.bn3)
+        x = ops.bn_apply_pool2(ops.conv3x3(a2, w, bias=b, relu=True), None)
+        for blk in self.blocks():
+            stride = blk.stride
+            w, b = folded(blk.conv1.weight.view(blk.conv1.out_channels, -1), blk.bn1)
+            aa = ops.conv1x1(x, w, bias=b, relu=True)
+            w, b = folded(_w3x3(blk.conv2), blk.bn2)
+            ab = ops.conv3x3(aa, w, bias=b, relu=True)
+            if stride > 1:
+                ab = ops.bn_apply_pool2(ab, None)
+            if blk.downsample is not None:
+                xd = ops.bn_apply_pool2(x, None) if stride > 1 else x
+                w, b = folded(blk.downsample[1].weight.view(blk.downsample[1].out_channels, -1), blk.downsample[2])
+                ident = ops.conv1x1(xd, w, bias=b)
+            else:
+                ident = x
+            w, b = folded(blk.conv3.weight.view(blk.conv3.out_channels, -1), blk.bn3)
+            x = ops.conv1x1(ab, w, bias=b, relu=True, residual=ident)
+        feat, _ = self._attnpool_forward(x, False)
+        return feat
 
     def _run_forward(self, images, save):
         training = self.training

@@ -285,6 +285,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void gemm_kernel(GemmParams
                 const int row = row_base + i * 32 + (r & 3) + 8 * (r >> 2);
                 float v = p.alpha * acc[i][j][r] + bv;
                 if (p.accumulate) v += oldv[r];
+                if (p.res != nullptr && row < p.M && col < p.N) v += p.res[(long long)row * p.ldres + col];
+                if (p.relu) v = fmaxf(v, 0.f);
                 if (row < p.M && col < p.N) C[(long long)row * p.ldc + col] = v;
                 acc[i][j][r] = v;
             }
@@ -468,6 +470,7 @@ int trid_gemm_launch(const trid_gemm_desc* d, const GemmFilter* filt, const int*
     p.batch = d->batch; p.splits = d->splits;
     p.alpha = d->alpha; p.accumulate = d->accumulate;
     p.bias = d->bias; p.sBias = d->strideBias; p.stats = d->stats;
+    p.res = d->residual; p.ldres = d->ldres; p.relu = d->relu;
     p.H = d->H; p.W = d->W; p.Cin = d->Cin;
     if (filt) p.filt = *filt;
     p.gate = gate;
@@ -485,7 +488,8 @@ int trid_gemm_launch(const trid_gemm_desc* d, const GemmFilter* filt, const int*
         p.fdC = make_fastdiv((uint32_t)d->Cin);
     }
     TRID_REQUIRE(!(d->stats && (d->splits != 1 || d->batch != 1)), "stats epilogue needs splits==1, batch==1");
-    TRID_REQUIRE(!(d->splits > 1 && (d->accumulate || d->bias)), "split-K writes raw slabs: no bias/accumulate");
+    TRID_REQUIRE(!(d->splits > 1 && (d->accumulate || d->bias || d->residual || d->relu)), "split-K writes raw slabs: no bias/accumulate/residual/relu");
+    TRID_REQUIRE(!(d->residual && d->batch != 1), "residual epilogue needs batch==1");
     int kc = (d->K + d->splits - 1) / d->splits;
     kc = (kc + BK - 1) / BK * BK;
     p.k_chunk = kc;

@@ -338,6 +338,8 @@ __global__ __launch_bounds__(NT, (BN == 64 && BMODE == B_KC && TRID_NARROW_WAVES
             const int row = row_base + i * 32 + (r & 3) + 8 * (r >> 2);
             float v = p.alpha * acc[i][r] + bv;
             if (p.accumulate) v += oldv[r];
+            if (p.res != nullptr && row < p.M && col < p.N) v += p.res[(long long)row * p.ldres + col];
+            if (p.relu) v = fmaxf(v, 0.f);
             if (row < p.M && col < p.N) C[(long long)row * p.ldc + col] = v;
             acc[i][r] = v;
         }

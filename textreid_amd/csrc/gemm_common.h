@@ -37,6 +37,9 @@ struct GemmParams {
     const float* bias;  // [N] or null
     long long sBias;
     float* stats;       // [mblocks][N][2] (mean, M2) or null
+    const float* res;   // [M][ldres] added after bias, or null
+    long long ldres;
+    int relu;           // clamp at zero last
     int H, W, Cin;      // conv geometry (A_CONV: M=Bimg*H*W,K=9*Cin; B_CONV: K=Bimg*H*W,N=9*Cin)
     FastDiv fdW, fdH, fdC;
     int mblocks, nblocks;

@@ -44,6 +44,9 @@ class GemmDesc(ctypes.Structure):
         ("W", ctypes.c_int32),
         ("Cin", ctypes.c_int32),
         ("precision", ctypes.c_int32),
+        ("residual", ctypes.c_void_p),
+        ("ldres", ctypes.c_int64),
+        ("relu", ctypes.c_int32),
     ]
 
 

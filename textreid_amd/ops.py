@@ -72,7 +72,7 @@ def empty(shape, like=None, dtype=torch.float32, device=None):
 # --------------------------------------------------------------------------- GEMM
 def gemm(A, B, C, M, N, K, lda, ldb, ldc, a_mode=A_KC, b_mode=B_KC, alpha=1.0, accumulate=False, bias=None,
          stats=None, batch=1, strideA=0, strideB=0, strideC=0, splits=1, strideSplit=0, conv=None, a_off=0, b_off=0,
-         c_off=0, strideBias=0, bias_off=0):
+         c_off=0, strideBias=0, bias_off=0, residual=None, ldres=0, relu=False):
     """Raw descriptor call.  a_off/b_off/c_off are element offsets into A/B/C."""
     d = GemmDesc()
     d.A = _p(A) + 4 * a_off
@@ -91,6 +91,9 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, a_mode=A_KC, b_mode=B_KC, alpha=1.0, a
     if conv is not None:
         d.H, d.W, d.Cin = conv
     d.precision = GEMM_PRECISION
+    d.residual = _p(residual)
+    d.ldres = ldres
+    d.relu = 1 if relu else 0
     prof = PROFILE
     if prof is not None:
         split = _uses_split(M, N, K, a_mode, conv)
@@ -166,26 +169,33 @@ def stats_buffer(M, N, like):
     return empty(((M + STATS_ROWS - 1) // STATS_ROWS, N, 2), like)
 
 
-def conv1x1(x, w, stats=False):
-    """x [B,H,W,C] NHWC (or [M,C]), w [N,C] -> y [.., N]; optional BN partials."""
+def conv1x1(x, w, stats=False, bias=None, relu=False, residual=None):
+    """x [B,H,W,C] NHWC (or [M,C]), w [N,C] -> y [.., N]; optional BN partials (training) or the
+    fused eval epilogue: + bias[N] (+ residual [.., N]) then ReLU."""
     C = x.shape[-1]
     M = x.numel() // C
     N = w.shape[0]
     y = empty(x.shape[:-1] + (N,), x)
     st = stats_buffer(M, N, x) if stats else None
-    gemm(x, w, y, M, N, C, C, w.stride(0), N, stats=st)
+    gemm(x, w, y, M, N, C, C, w.stride(0), N, stats=st, bias=bias, relu=relu, residual=residual, ldres=N)
     return (y, st) if stats else y
 
 
-def conv3x3(x, w, stats=False):
+def conv3x3(x, w, stats=False, bias=None, relu=False):
     """x [B,H,W,C] NHWC, w [N, 9*C] (tap-major, channel-minor = OHWI) -> y [B,H,W,N]."""
     Bi, H, W, C = x.shape
     N = w.shape[0]
     M = Bi * H * W
     y = empty((Bi, H, W, N), x)
     st = stats_buffer(M, N, x) if stats else None
-    gemm(x, w, y, M, N, 9 * C, C, 9 * C, N, a_mode=A_CONV, stats=st, conv=(H, W, C))
+    gemm(x, w, y, M, N, 9 * C, C, 9 * C, N, a_mode=A_CONV, stats=st, conv=(H, W, C), bias=bias, relu=relu)
     return (y, st) if stats else y
+
+
+def fold_bn(w2d, st):
+    """Eval-mode BatchNorm folded into the preceding conv: (w * scale[:,None], shift) so that
+    relu(bn(conv(x, w))) == relu(conv(x, w') + shift), one GEMM with a bias + ReLU epilogue."""
+    return rowscale_add(st.scale, w2d), st.shift
 
 
 def conv1x1_wgrad(dy, x):
