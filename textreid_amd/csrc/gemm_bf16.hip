@@ -51,6 +51,9 @@ __global__ __launch_bounds__(NT, (BN == 64 && BMODE == B_KC && TRID_NARROW_WAVES
     const int wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int khalf = lane >> 5;
+    // the second-dispatched half of the workgroup loses the age-based issue arbitration on every
+    // segment (its 24 MFMAs take 2000 cycles against 1150 for waves 0-3 in a cycle trace): static priority
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
 
     const uint32_t nwg = (uint32_t)p.mblocks * (uint32_t)p.nblocks;
     const uint32_t lid = xcd_remap(blockIdx.x, nwg);
