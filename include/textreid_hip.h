@@ -110,10 +110,12 @@ int trid_bn_finalize_f32(const float* partials, int nparts, int rows_per_part, l
 /* eval mode: scale/shift from running statistics */
 int trid_bn_eval_coeffs_f32(const float* gamma, const float* beta, const float* running_mean,
                             const float* running_var, float eps, float* scale, float* shift, int C, void* stream);
-/* out = act( y*scale[c]+shift[c] + (res ? (rscale ? res*rscale[c]+rshift[c] : res) : 0) ) */
+/* out = act( y*scale[c]+shift[c] + (res ? (rscale ? res*rscale[c]+rshift[c] : res) : 0) ).
+ * relu_mask (optional, M*C/8 bytes): 1 bit per element, set where the pre-activation value is > 0, for
+ * trid_bn_bwd_* mask_mode 3.  Element quad i = (row*C + c)/4 -> 64-bit words (i/64)*4 + (c%4), bit i%64. */
 int trid_bn_apply_f32(const float* y, const float* scale, const float* shift, const float* res,
                       const float* rscale, const float* rshift, float* out, long long M, int C, int relu,
-                      void* stream);
+                      uint64_t* relu_mask, void* stream);
 /* out[b,y/2,x/2,c] = mean over 2x2 of act(y*scale+shift)   (scale==NULL: plain pooling of y) */
 int trid_bn_apply_pool2_f32(const float* y, const float* scale, const float* shift, float* out, int B, int H,
                             int W, int C, int relu, void* stream);
@@ -121,7 +123,7 @@ int trid_bn_apply_pool2_f32(const float* y, const float* scale, const float* shi
 int trid_avgpool2_bwd_f32(const float* g, float* dx, int B, int H, int W, int C, int accumulate, void* stream);
 
 /* BatchNorm backward.  g is dL/d(out).  mask_mode: 0 none, 1 recompute
- * (y*scale+shift > 0), 2 from `act` (> 0).  pooled != 0: g has shape
+ * (y*scale+shift > 0), 2 from `act` (> 0), 3 from the bit mask of trid_bn_apply_f32 passed as `act`.  pooled != 0: g has shape
  * [B,H/2,W/2,C] and the effective gradient is 0.25*g[b,y/2,x/2,c] (AvgPool2d(2)
  * after the activation).  Step 1 reduces dbeta = sum gm, dgamma = sum gm*xhat
  * (workspace: ws floats >= trid_bn_bwd_ws_floats(C)); step 2 writes

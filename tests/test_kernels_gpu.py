@@ -173,15 +173,18 @@ def test_bn_fwd_bwd(ops, C, mode):
         o = ops.bn_apply(yd, st, relu=(mode == "relu"))
         dy, dg, db, _ = ops.bn_bwd(god, yd, st, None, 1 if mode == "relu" else 0)
     elif mode == "res":
-        o = ops.bn_apply(yd, st, relu=True, res=dev(nhwc(res)))
+        o, bits = ops.bn_apply(yd, st, relu=True, res=dev(nhwc(res)), want_mask=True)
         dy, dg, db, dres = ops.bn_bwd(god, yd, st, None, 2, act=o, want_dres=True)
         assert rel(dres.permute(0, 3, 1, 2), rr.grad) < 1e-5
+        # the 1-bit mask written by bn_apply (mode 3) selects exactly what `act > 0` (mode 2) selects
+        dy3, dg3, db3, dres3 = ops.bn_bwd(god, yd, st, None, 3, act=bits, want_dres=True)
+        assert torch.equal(dy3, dy) and torch.equal(dres3, dres) and torch.equal(dg3, dg) and torch.equal(db3, db)
     elif mode == "res_bn":
         rd = dev(nhwc(res))
         r2, rp = ops.conv1x1(rd, dev(eye), stats=True)
         st2 = ops.bn_finalize(rp, B * H * W, dev(g2), dev(b2), None, None)
-        o = ops.bn_apply(yd, st, relu=True, res=rd, res_st=st2)
-        dy, dg, db, _ = ops.bn_bwd(god, yd, st, None, 2, act=o)
+        o, bits = ops.bn_apply(yd, st, relu=True, res=rd, res_st=st2, want_mask=True)
+        dy, dg, db, _ = ops.bn_bwd(god, yd, st, None, 3, act=bits)
         dyr, _, _, _ = ops.bn_bwd(god, rd, st2, None, 2, act=o)
         assert rel(dyr.permute(0, 3, 1, 2), rr.grad) < 2e-5
     else:

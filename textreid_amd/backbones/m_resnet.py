@@ -285,11 +285,12 @@ class ModifiedResNet(nn.Module):
                 wd = blk.downsample[1].weight.view(blk.downsample[1].out_channels, -1)
                 yd, pd = ops.conv1x1(xd, wd, stats=True) if training else (ops.conv1x1(xd, wd), None)
                 std = _bn_coeffs(blk.downsample[2], pd, Mc, training)
-                out = ops.bn_apply(yc, stc, relu=True, res=yd, res_st=std)
+                out = ops.bn_apply(yc, stc, relu=True, res=yd, res_st=std, want_mask=save)
             else:
-                out = ops.bn_apply(yc, stc, relu=True, res=x)
+                out = ops.bn_apply(yc, stc, relu=True, res=x, want_mask=save)
             if save:
-                S["blocks"].append((x, ya, sta, aa, yb, stb, ab, yc, stc, xd, yd, std, out))
+                out, rmask = out  # 1-bit ReLU mask of the block output for the backward pass
+                S["blocks"].append((x, ya, sta, aa, yb, stb, ab, yc, stc, xd, yd, std, rmask))
             x = out
             if getattr(self, "_debug_taps", None) is not None:
                 self._debug_taps[len(self._debug_taps)] = out
@@ -400,15 +401,15 @@ class ModifiedResNet(nn.Module):
         blocks = list(self.blocks())
         dbg = getattr(self, "_debug_grads", None)
         for blk, rec in zip(reversed(blocks), reversed(S["blocks"])):
-            x, ya, sta, aa, yb, stb, ab, yc, stc, xd, yd, std, out = rec
+            x, ya, sta, aa, yb, stb, ab, yc, stc, xd, yd, std, rmask = rec
             if dbg is not None:
                 dbg.append(g)
             stride = blk.stride
             has_down = blk.downsample is not None
-            dyc, dg, db, dres = ops.bn_bwd(g, yc, stc, None, 2, act=out, want_dres=not has_down)
+            dyc, dg, db, dres = ops.bn_bwd(g, yc, stc, None, 3, act=rmask, want_dres=not has_down)
             G[id(blk.bn3.weight)], G[id(blk.bn3.bias)] = dg, db
             if has_down:
-                dyd, dg, db, _ = ops.bn_bwd(g, yd, std, None, 2, act=out)
+                dyd, dg, db, _ = ops.bn_bwd(g, yd, std, None, 3, act=rmask)
                 G[id(blk.downsample[2].weight)], G[id(blk.downsample[2].bias)] = dg, db
             wc = blk.conv3.weight.view(blk.conv3.out_channels, -1)
             dab = ops.matmul_nn(dyc.view(-1, dyc.shape[-1]), wc).view(ab.shape)

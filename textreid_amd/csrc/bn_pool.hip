@@ -127,7 +127,8 @@ __device__ __forceinline__ float4 relu4(float4 v) {
 __global__ void bn_apply_kernel(const float4* __restrict__ y, const float4* __restrict__ scale,
                                 const float4* __restrict__ shift, const float4* __restrict__ res,
                                 const float4* __restrict__ rscale, const float4* __restrict__ rshift,
-                                float4* __restrict__ out, long long total4, int CQ, int relu) {
+                                float4* __restrict__ out, long long total4, int CQ, int relu,
+                                unsigned long long* __restrict__ mask) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4;
          i += (long long)gridDim.x * blockDim.x) {
         const int cq = (int)(i % CQ);
@@ -136,6 +137,16 @@ __global__ void bn_apply_kernel(const float4* __restrict__ y, const float4* __re
             float4 r = res[i];
             if (rscale != nullptr) r = affine4(r, rscale[cq], rshift[cq]);
             v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+        }
+        if (mask != nullptr) {
+            // 1 bit per element for the backward pass (instead of re-reading the output twice):
+            // quad i -> words (i/64)*4 + c, bit i%64; a wave covers 64 consecutive quads
+            const unsigned long long bx = __ballot(v.x > 0.f), by = __ballot(v.y > 0.f);
+            const unsigned long long bz = __ballot(v.z > 0.f), bw = __ballot(v.w > 0.f);
+            if ((threadIdx.x & 63) == 0) {
+                unsigned long long* m = mask + (i >> 6) * 4;
+                m[0] = bx; m[1] = by; m[2] = bz; m[3] = bw;
+            }
         }
         if (relu) v = relu4(v);
         out[i] = v;
@@ -231,6 +242,11 @@ __device__ __forceinline__ void bn_bwd_elem(const BnBwdArgs& a, long long i, int
         const float4 z = a.act[i];
         g.x = z.x > 0.f ? g.x : 0.f; g.y = z.y > 0.f ? g.y : 0.f;
         g.z = z.z > 0.f ? g.z : 0.f; g.w = z.w > 0.f ? g.w : 0.f;
+    } else if (a.mask_mode == 3) {  // bit mask written by bn_apply
+        const unsigned long long* m = reinterpret_cast<const unsigned long long*>(a.act) + (i >> 6) * 4;
+        const int bit = (int)(i & 63);
+        g.x = ((m[0] >> bit) & 1ull) ? g.x : 0.f; g.y = ((m[1] >> bit) & 1ull) ? g.y : 0.f;
+        g.z = ((m[2] >> bit) & 1ull) ? g.z : 0.f; g.w = ((m[3] >> bit) & 1ull) ? g.w : 0.f;
     }
     gm = g;
 }
@@ -377,14 +393,15 @@ extern "C" int trid_bn_eval_coeffs_f32(const float* gamma, const float* beta, co
 
 extern "C" int trid_bn_apply_f32(const float* y, const float* scale, const float* shift, const float* res,
                                  const float* rscale, const float* rshift, float* out, long long M, int C, int relu,
-                                 void* stream) {
+                                 uint64_t* relu_mask, void* stream) {
     TRID_REQUIRE(y && scale && shift && out && M > 0 && C > 0 && C % 4 == 0, "trid_bn_apply_f32: bad arguments (C%%4)");
     TRID_REQUIRE((rscale == nullptr) == (rshift == nullptr), "trid_bn_apply_f32: rscale/rshift both or none");
     TRID_REQUIRE(aligned16(y) && aligned16(out) && aligned16(scale) && aligned16(shift) && (!res || aligned16(res)), "trid_bn_apply_f32: 16-byte alignment");
     const long long total4 = M * (C / 4);
     hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(total4, 256 * 4)), dim3(256), 0, (hipStream_t)stream,
                        (const float4*)y, (const float4*)scale, (const float4*)shift, (const float4*)res,
-                       (const float4*)rscale, (const float4*)rshift, (float4*)out, total4, C / 4, relu);
+                       (const float4*)rscale, (const float4*)rshift, (float4*)out, total4, C / 4, relu,
+                       (unsigned long long*)relu_mask);
     return check_launch("trid_bn_apply_f32");
 }
 
@@ -421,7 +438,7 @@ static int bn_bwd_fill(BnBwdArgs& a, const float* g, const float* y, const float
     TRID_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "bn_bwd: bad shape");
     const int CQ = C / 4;
     TRID_REQUIRE(256 % CQ == 0 || CQ % 256 == 0, "bn_bwd: C/4 must divide 256 or be a multiple of 256 (C=%d)", C);
-    TRID_REQUIRE(mask_mode >= 0 && mask_mode <= 2 && (mask_mode != 2 || act), "bn_bwd: bad mask mode");
+    TRID_REQUIRE(mask_mode >= 0 && mask_mode <= 3 && (mask_mode < 2 || act), "bn_bwd: bad mask mode");
     TRID_REQUIRE(!pooled || (H % 2 == 0 && W % 2 == 0), "bn_bwd: pooled needs even H,W");
     TRID_REQUIRE((long long)B * H * W < (1LL << 31), "bn_bwd: too many pixels");
     a.g = (const float4*)g; a.y = (const float4*)y; a.act = (const float4*)act;

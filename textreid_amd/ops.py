@@ -265,14 +265,17 @@ def bn_eval_coeffs(gamma, beta, running_mean, running_var, eps=BN_EPS):
     return st
 
 
-def bn_apply(y, st, relu=True, res=None, res_st=None, out=None):
+def bn_apply(y, st, relu=True, res=None, res_st=None, out=None, want_mask=False):
+    """out = act(bn(y) (+ res | bn(res))).  want_mask: also return the 1-bit-per-element ReLU mask
+    (int64 words) the backward pass uses instead of re-reading `out` (bn_bwd mask_mode 3)."""
     C = y.shape[-1]
     M = y.numel() // C
     if out is None:
         out = torch.empty_like(y)
+    mask = torch.empty(((M * C // 4 + 63) // 64) * 4, dtype=torch.int64, device=y.device) if want_mask else None
     call("trid_bn_apply_f32", _p(y), _p(st.scale), _p(st.shift), _p(res), _p(res_st.scale) if res_st else None,
-         _p(res_st.shift) if res_st else None, _p(out), M, C, 1 if relu else 0, stream())
-    return out
+         _p(res_st.shift) if res_st else None, _p(out), M, C, 1 if relu else 0, _p(mask), stream())
+    return (out, mask) if want_mask else out
 
 
 def bn_apply_pool2(y, st, relu=True):
