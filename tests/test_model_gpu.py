@@ -300,6 +300,44 @@ def test_full_size_step_vs_oracle(gpu):
     assert not bad, bad
 
 
+def test_bf16_arithmetic_mode_tracks_fp32(gpu):
+    """configs[3]'s bf16: TRID_GEMM_PRECISION=1 rounds GEMM operands to bf16 (fp32 accumulate, fp32 tensors).
+    Outside the fp32 parity contract by construction; the bound written here is what bf16 operand rounding
+    (2^-9 relative) leaves of a default-initialised (well-conditioned) RN50 + BiGRU step: the three losses
+    within 5 %, eval embeddings within 5e-2 of the fp32-class path on the same weights and batch
+    (measured: losses 0.6-2.4 %, eval embeddings 2e-3 - 5e-3)."""
+    import bench
+    from textreid_amd import ops
+    from textreid_amd.caption import CaptionBatch
+    from textreid_amd.config import moco_cfg
+    from textreid_amd.model import build_model
+
+    B, K = 16, 64
+    torch.manual_seed(0)
+    model = build_model(moco_cfg("m_resnet50", K=K), vocab_dict=torch.randn(3000, 512) * 0.02).to(gpu)
+    images, tokens, lengths, ids = bench.synth_batch(B, 0, gpu, 5, vocab=3000)
+    cb = CaptionBatch(tokens, lengths, ids, max_len=64)
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+    out = {}
+    old = ops.GEMM_PRECISION
+    try:
+        for prec in (6, 1):
+            ops.GEMM_PRECISION = prec
+            model.load_state_dict(state)
+            model.train()
+            ld = model(images, cb)
+            model.eval()
+            with torch.no_grad():
+                ev, et = model(images, cb)
+            out[prec] = ({k: float(v) for k, v in ld.items()}, ev.clone(), et.clone())
+    finally:
+        ops.GEMM_PRECISION = old
+    for k in out[6][0]:
+        assert abs(out[1][0][k] - out[6][0][k]) <= 5e-2 * abs(out[6][0][k]), (k, out[1][0][k], out[6][0][k])
+    print({k: (out[1][0][k], out[6][0][k]) for k in out[6][0]}, rel(out[1][1], out[6][1]), rel(out[1][2], out[6][2]))
+    assert rel(out[1][1], out[6][1]) < 5e-2 and rel(out[1][2], out[6][2]) < 5e-2, (rel(out[1][1], out[6][1]), rel(out[1][2], out[6][2]))
+
+
 def test_full_batch_properties(gpu):
     """B=128, K=8192 (the benchmarked configuration): size-independent invariants."""
     import bench
