@@ -284,7 +284,7 @@ def main():
         # the dominant kernel executes `prec` bf16 MFMA products per fp32 multiply-add
         peak = BF16_MFMA_PEAK_TFLOPS / prec
         kname = "trid::gemm_bf16s_kernel<A_CONV,B_KC,%d planes> (3x3 implicit-GEMM conv fwd+dgrad; fp32 operands split into bf16 planes, %d bf16 MFMA 32x32x16 products per multiply-add, fp32 accumulate)" % (prec // 2, prec)
-        peak_note = "dense bf16 MFMA peak 2500 TFLOP/s / %d products = fp32-equivalent peak" % prec
+        peak_note = "dense bf16 MFMA peak 2500 TFLOP/s / %d products = fp32-equivalent peak (a 1 s pure-MFMA loop with random bf16 operands sustains 1858 TFLOP/s on this box: power-limited ~1.8 GHz, profiles/r01i_mfma_bf16_sustained.txt)" % prec
         arith = "fp32 operands and accumulation; products evaluated as %d bf16 MFMA terms of a %d-way bf16 split (dropped terms <= 2^-%d)" % (prec, prec // 2, 26 if prec == 6 else 17)
     elif prec == 1:
         peak = BF16_MFMA_PEAK_TFLOPS
