@@ -296,6 +296,19 @@ def main():
         kname = "trid::gemm_kernel<A_CONV,B_KC,128,128,2,4> (3x3 implicit-GEMM conv fwd+dgrad, fp32 MFMA 32x32x2)"
         peak_note = "fp32-input MFMA dense peak"
         arith = "exact fp32-input MFMA"
+    # HBM-side bytes per launch of the dominant kernel from the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
+    # passes of this same command (profiles/r01j_pmc_hbm_traffic.txt, gfx950 2x FETCH_SIZE correction applied)
+    traffic, traffic_note = None, None
+    try:
+        here = os.path.dirname(os.path.abspath(__file__))
+        for line in open(os.path.join(here, "profiles", "r01j_pmc_hbm_traffic.txt")):
+            f = line.split()
+            if prec == 6 and len(f) > 5 and "gemm_bf16s_kernel<2," in line and line.rstrip().endswith("0, 3, 128>(trid::GemmParams)"):
+                traffic = (float(f[2]) + float(f[3])) * 1e6
+                traffic_note = "PMC passes of profiles/r01j (not re-measured in this run): read %s MB + write %s MB per launch; algorithmic input + output of these layers ~ 115 MB" % (f[2], f[3])
+                break
+    except OSError:
+        pass
     roofline = {
         "bound": "mfma",
         "kernel": kname,
@@ -303,7 +316,8 @@ def main():
         "peak": peak,
         "unit": "TFLOP/s",
         "frac": achieved / peak,
-        "traffic": None,
+        "traffic": traffic,
+        "traffic_note": traffic_note,
         "achieved_isolated": achieved_isolated,
         "frac_isolated": achieved_isolated / peak,
         "note": "achieved/frac: events around every launch of this kernel during the timed steps, while the text / key-encoder / weight-gradient streams share the CUs; *_isolated: the same kernel on the five layer2-4 3x3 shapes with the GPU to itself",
