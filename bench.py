@@ -203,6 +203,9 @@ def main():
     log("model built")
     opt = make_optimizer(cfg, model)
     reducer = GradReducer()
+    if world > 1 and os.environ.get("TRID_DP_OVERLAP", "1") != "0":
+        # image-encoder gradients are all-reduced per residual layer from inside its backward (overlap)
+        model.embed_model.v_encoder_q.grad_sync = reducer
     pre_gather = [p for n, p in model.named_parameters() if p.requires_grad and "loss_evaluator" not in n]
     pre_gather.reverse()
     B = args.batch

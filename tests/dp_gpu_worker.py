@@ -49,10 +49,12 @@ def main():
         tok[i, n:] = 0
     ids = torch.arange(Bg) // 2
     sl = slice(r * Bl, (r + 1) * Bl)
+    red = GradReducer(bucket_mb=1)
+    if os.environ.get("TRID_DP_OVERLAP", "1") != "0":  # staged all-reduce from inside the encoder's backward
+        head.v_encoder_q.grad_sync = red
     ld = head(x[sl].to(dev), CaptionBatch(tok[sl].to(dev), ln[sl].to(dev), ids[sl].to(dev)))
     sum(ld.values()).backward()
     pre = [p for n, p in head.named_parameters() if p.requires_grad and "loss_evaluator" not in n][::-1]
-    red = GradReducer(bucket_mb=1)
     red.reduce(pre)
     red.wait()
     torch.cuda.synchronize()
@@ -82,7 +84,8 @@ def main():
         errs = {k: rel(ld[k], old[k]) for k in old}
         named = dict(head.named_parameters())
         for k in ("v_embed_layer.weight", "t_embed_layer.weight", "loss_evaluator.projection", "t_encoder_q.gru.weight_ih_l0",
-                  "v_encoder_q.attnpool.c_proj.weight", "v_encoder_q.layer4.0.conv3.weight"):
+                  "v_encoder_q.attnpool.c_proj.weight", "v_encoder_q.layer4.0.conv3.weight",
+                  "v_encoder_q.layer3.0.conv2.weight", "v_encoder_q.layer1.0.bn2.bias", "v_encoder_q.conv1.weight"):
             errs["grad:" + k] = rel(named[k].grad, st[k].grad)
         OH.enqueue(st, torch.cat(vk), torch.cat(tk), ids)
         sd = head.state_dict()

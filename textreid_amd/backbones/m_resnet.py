@@ -152,6 +152,7 @@ class ModifiedResNet(nn.Module):
         self.output_dim = output_dim
         self.out_channels = output_dim
         self.fold_eval_bn = True  # eval + no_grad: BatchNorm folded into the conv weights, ReLU/residual in the GEMM epilogue
+        self.grad_sync = None     # data parallel: a parallel.GradReducer; backward stages gradients into it per residual layer
         self.input_resolution = input_resolution
         self.conv1 = nn.Conv2d(3, width // 2, kernel_size=3, stride=2, padding=1, bias=False)
         self.bn1 = nn.BatchNorm2d(width // 2)
@@ -399,6 +400,20 @@ class ModifiedResNet(nn.Module):
         g = self._attnpool_backward(S["attn"], gout, G)
         S["attn"] = None
         blocks = list(self.blocks())
+        sync = self.grad_sync
+        staged = set()
+
+        def stage_ready():
+            """Data parallel: everything in G that has not been handed over yet is final - start its
+            all-reduce now (after the weight-gradient stream has caught up), under the rest of backward."""
+            if sync is None:
+                return
+            ws.join()
+            ps = [p for p in self.parameters() if id(p) in G and id(p) not in staged and G[id(p)] is not None]
+            staged.update(id(p) for p in ps)
+            sync.stage(ps, [G[id(p)] for p in ps])
+
+        first_of_layer = {id(layer[0]) for layer in (self.layer1, self.layer2, self.layer3, self.layer4)}
         dbg = getattr(self, "_debug_grads", None)
         for blk, rec in zip(reversed(blocks), reversed(S["blocks"])):
             x, ya, sta, aa, yb, stb, ab, yc, stc, xd, yd, std, rmask = rec
@@ -433,6 +448,8 @@ class ModifiedResNet(nn.Module):
             ops.matmul_nn(dya.view(-1, dya.shape[-1]), wa, out=dx.view(-1, dx.shape[-1]), accumulate=True)
             G[id(blk.conv1.weight)] = ws.run(ops.conv1x1_wgrad, dya, x).view_as(blk.conv1.weight)
             g = dx
+            if id(blk) in first_of_layer:  # a whole residual layer (and, the first time, the attention pool) is done
+                stage_ready()
         S["blocks"] = None
         # ---- stem
         col, y1, st1, a1, y2, st2, a2, y3, st3 = S["stem"]
@@ -454,6 +471,9 @@ class ModifiedResNet(nn.Module):
         c1 = self.conv1.weight
         G[id(c1)] = dw1[:, : c1[0].numel()].reshape(c1.shape)
         ws.join()
+        if sync is not None:
+            stage_ready()  # the stem
+            G.update(sync.finish_stages())
         return [G.get(id(p)) for p in self.parameters()]
 
 

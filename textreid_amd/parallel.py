@@ -81,7 +81,11 @@ def gather_embeddings(v_embed, t_embed, v_key, t_key, ids):
 
 
 class GradReducer:
-    """Bucketed SUM all-reduce of parameter gradients on a side stream.
+    """Bucketed SUM all-reduce of parameter gradients (RCCL runs collectives on its own stream).
+
+    Two entry points: `stage()/finish_stages()` are called from INSIDE the image encoder's backward
+    (ModifiedResNet.grad_sync) so that most of the 150 MB of conv gradients is reduced underneath the
+    remaining backward; `reduce()/wait()` after backward picks up everything that was not staged.
 
     ``reduce(params)`` flattens the gradients of ``params`` into ~bucket_mb
     buckets in the given order (call it with parameters in reverse execution
@@ -94,13 +98,58 @@ class GradReducer:
     def __init__(self, bucket_mb=64):
         self.bucket_elems = int(bucket_mb * (1 << 20) // 4)
         self._pending = []
+        self._stages = []
+        self._staged = set()
+
+    # ---- in-backward staging: the image encoder's backward hands over each residual stage's gradients
+    # as soon as they are final, so their all-reduce runs under the backward of the earlier stages
+    def stage(self, params, grads):
+        """Start the SUM all-reduce of `grads` (gradients of `params`, same order).  No-op at world size 1."""
+        if world_size() == 1 or not grads:
+            return
+        flats, layouts = [], []
+        for g in grads:
+            if g.is_contiguous():
+                flats.append(g.view(-1))
+                layouts.append(("c", g.shape))
+            elif g.dim() == 4 and g.is_contiguous(memory_format=torch.channels_last):
+                flats.append(g.permute(0, 2, 3, 1).reshape(-1))  # storage order, no copy
+                layouts.append(("cl", g.shape))
+            else:
+                flats.append(g.contiguous().view(-1))
+                layouts.append(("c", g.shape))
+        flat = torch.cat(flats)
+        work = all_reduce_sum_(flat)
+        self._stages.append((work, flat, list(params), layouts))
+
+    def finish_stages(self):
+        """Join every staged all-reduce; {id(param): reduced gradient} in each gradient's original layout."""
+        out = {}
+        for work, flat, params, layouts in self._stages:
+            if work is not None:
+                work.wait()
+            off = 0
+            for p, (kind, shape) in zip(params, layouts):
+                n = 1
+                for d in shape:
+                    n *= d
+                piece = flat[off : off + n]
+                if kind == "cl":
+                    N, C, H, W = shape
+                    out[id(p)] = piece.view(N, H, W, C).permute(0, 3, 1, 2)
+                else:
+                    out[id(p)] = piece.view(shape)
+                self._staged.add(id(p))
+                off += n
+        self._stages = []
+        return out
 
     def reduce(self, params):
         if world_size() == 1:
             return
         bucket, n = [], 0
         for p in params:
-            if p.grad is None:
+            if p.grad is None or id(p) in self._staged:  # staged gradients were reduced inside backward
                 continue
             bucket.append(p)
             n += p.numel()
@@ -125,3 +174,4 @@ class GradReducer:
                 p.grad.copy_(flat[off : off + n].view_as(p.grad))
                 off += n
         self._pending = []
+        self._staged = set()
