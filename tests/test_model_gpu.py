@@ -338,6 +338,52 @@ def test_bf16_arithmetic_mode_tracks_fp32(gpu):
     assert rel(out[1][1], out[6][1]) < 5e-2 and rel(out[1][2], out[6][2]) < 5e-2, (rel(out[1][1], out[6][1]), rel(out[1][2], out[6][2]))
 
 
+@pytest.mark.parametrize("B", [1, 3, 6])
+def test_head_step_odd_batch_sizes(gpu, B):
+    """Edge batch sizes (1, odd, not a multiple of 4) through the whole MoCo step against the oracle:
+    losses, a conv / BN / GRU gradient, queue state."""
+    from textreid_amd.backbones.gru import GRU
+    from textreid_amd.backbones.m_resnet import ModifiedResNet
+    from textreid_amd.caption import CaptionBatch
+    from textreid_amd.embeddings.moco_head.head import MoCoHead
+
+    spec, hidden, embed, vocab, C, K, NC, seed = OV.TINY, 64, 64, 200, 32, 12, 53, 40 + B
+    ns = types.SimpleNamespace
+    table = OF.randn("vocab_table_odd", (vocab, embed), seed, 0.5)
+    vis = ModifiedResNet(list(spec.layers), spec.output_dim, spec.heads, spec.last_stride, (spec.height, spec.in_width), spec.width)
+    txt = GRU(hidden, embed, embed, 1, 0.0, True, "clip_vit", "./", vocab_dict=table)
+    cfg = ns(MODEL=ns(EMBEDDING=ns(FEATURE_SIZE=C, EPSILON=0.1), MOCO=ns(K=K, M=0.9, FC=False), NUM_CLASSES=NC))
+    head = MoCoHead(cfg, vis, txt)
+    filled = OF.fill_state(head.state_dict(), seed, "odd.")
+    st = {k: v.clone() for k, v in filled.items()}
+    OH.init_queues(st, seed)
+    for k in ("t_queue", "v_queue", "id_queue", "queue_ptr"):
+        filled[k] = st[k].clone()
+    head.load_state_dict(filled)
+    head.to(gpu).train()
+    x = OF.randn("img:odd", (B, 3, spec.height, spec.in_width), seed)
+    tok = OF.randint("tok:odd", 1, vocab, (B, 105), seed)
+    ln = OF.randint("len:odd", 1, 40, (B,), seed)
+    for i, n in enumerate(ln.tolist()):
+        tok[i, n:] = 0
+    ids = torch.arange(B) // 2
+    ld = head(x.to(gpu), CaptionBatch(tok.to(gpu), ln.to(gpu), ids.to(gpu)))
+    sum(ld.values()).backward()
+    for k in OH.trainable_names(st):
+        st[k].requires_grad_(True)
+    old = OH.train_forward(st, spec, table, x, tok, ln, ids, m=0.9, epsilon=0.1)
+    sum(old.values()).backward()
+    errs = {k: rel(ld[k], old[k]) for k in old}
+    named = dict(head.named_parameters())
+    for k in ("v_encoder_q.layer2.0.conv2.weight", "v_encoder_q.bn1.weight", "t_encoder_q.gru.weight_hh_l0", "v_embed_layer.bias"):
+        errs["grad:" + k] = rel(named[k].grad, st[k].grad)
+    sd = head.state_dict()
+    errs["v_queue"] = rel(sd["v_queue"], st["v_queue"])
+    assert int(sd["queue_ptr"]) == int(st["queue_ptr"]) == B % K and torch.equal(sd["id_queue"].cpu(), st["id_queue"])
+    bad = {k: v for k, v in errs.items() if not v < TOL}
+    assert not bad, bad
+
+
 def test_full_batch_properties(gpu):
     """B=128, K=8192 (the benchmarked configuration): size-independent invariants."""
     import bench

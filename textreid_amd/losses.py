@@ -79,20 +79,25 @@ class _GlobalAlignFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, v, t, labels, alpha, beta, scale_pos, scale_neg):
         B, C = v.shape
-        if B % 4:
-            raise RuntimeError("global_align_loss kernel needs a batch that is a multiple of 4 (got %d)" % B)
         vn, inv_v = ops.l2norm_rows(v.detach().contiguous())
         tn, inv_t = ops.l2norm_rows(t.detach().contiguous())
-        S = ops.linear(vn, tn)  # [B,B] cosine
+        Bp = (B + 3) // 4 * 4
+        if Bp != B:  # the [B,B] matrix is a GEMM operand later (leading dimension % 4): zero-pad the batch
+            vp, tp = torch.zeros(Bp, C, device=v.device), torch.zeros(Bp, C, device=v.device)
+            vp[:B].copy_(vn)
+            tp[:B].copy_(tn)
+        else:
+            vp, tp = vn, tn
+        S = ops.linear(vp, tp)  # [Bp,Bp] cosine (padding rows / columns are zero and stay zero)
         rows = ops.empty((B,), v)
-        call("trid_global_align_rows_f32", _p(S), _p(labels.long().contiguous()), _p(rows), B, B, float(alpha),
+        call("trid_global_align_rows_f32", _p(S), _p(labels.long().contiguous()), _p(rows), B, Bp, float(alpha),
              float(beta), float(scale_pos), float(scale_neg), 1.0, stream())
         loss = ops.empty((1,), v)
         ops.sum_to(rows, loss, 1.0)
-        dvn = ops.matmul_nn(S, tn)
-        dtn = ops.matmul_tn(S, vn)
-        dv = ops.l2norm_rows_bwd(dvn, vn, inv_v)
-        dt = ops.l2norm_rows_bwd(dtn, tn, inv_t)
+        dvn = ops.matmul_nn(S, tp)[:B]
+        dtn = ops.matmul_tn(S, vp)[:B]
+        dv = ops.l2norm_rows_bwd(dvn.contiguous(), vn, inv_v)
+        dt = ops.l2norm_rows_bwd(dtn.contiguous(), tn, inv_t)
         ctx.saved = (dv, dt)
         return loss[0]
 
