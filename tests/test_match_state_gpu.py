@@ -12,6 +12,8 @@ pytestmark = pytest.mark.gpu
 
 import oracle.evaluation as OE  # noqa: E402
 import oracle.fill as OF  # noqa: E402
+import oracle.head as OH  # noqa: E402
+import oracle.visual as OV  # noqa: E402
 
 
 @pytest.fixture(scope="module")
@@ -19,6 +21,12 @@ def gpu():
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     return torch.device("cuda")
+
+
+def rel(a, b):
+    a = torch.as_tensor(a).detach().double().cpu()
+    b = torch.as_tensor(b).detach().double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
 
 
 def load(golden_dir, name):
@@ -91,6 +99,19 @@ def test_topk_rows_adversarial_orders_and_ties(gpu, G, k):
     assert torch.equal(vals.cpu(), order.values[:, :k])
     finite = torch.isfinite(order.values[:, :k])
     assert torch.equal(idx.cpu()[finite], order.indices[:, :k][finite])
+
+
+@pytest.mark.parametrize("Q,G,k", [(1, 100, 10), (5, 8192, 10), (5, 8193, 3), (70, 8192 + 64, 10), (130, 8192 * 3 + 5, 16), (64, 8192 + 63, 1)])
+def test_fused_similarity_topk_shape_edges(gpu, Q, G, k):
+    """Chunk boundaries of the retrieval path: exactly one panel, one column past it, a filtered tail narrower
+    than a GEMM tile, fewer queries than a tile (falls back to panel passes), k = 1 and k = 16."""
+    from textreid_amd.evaluation import similarity_topk
+
+    te, ie = OF.randn("tke:q%d" % Q, (Q, 64), 2), OF.randn("tke:g%d" % G, (G, 64), 2)
+    vals, idx = similarity_topk(te.to(gpu), ie.to(gpu), k)
+    rv, ri = torch.topk(OE.similarity(te, ie), k, dim=1)
+    assert torch.equal(idx.cpu(), ri)
+    assert torch.allclose(vals.cpu(), rv, atol=2e-6)
 
 
 def test_fused_similarity_topk_overflow_fallback(gpu):
@@ -200,6 +221,49 @@ def test_ema_and_enqueue(gpu):
     assert head.state_dict()["v_queue"].shape == (32, 64)
     with pytest.raises(AssertionError):
         head._dequeue_and_enqueue(torch.randn(24, 32, device=gpu), torch.randn(24, 32, device=gpu), torch.arange(24, device=gpu))
+
+
+def test_queue_wraparound_and_all_positive_ids(gpu):
+    """K = 2B: the ring pointer wraps on the second step and the third overwrites the first slab; every sample
+    of a step shares ONE id (all pairs positive) and later steps hit those ids in the queue (columns masked
+    out of the InfoNCE negatives).  Losses and queue state against the oracle for 3 steps."""
+    from textreid_amd.backbones.gru import GRU
+    from textreid_amd.backbones.m_resnet import ModifiedResNet
+    from textreid_amd.caption import CaptionBatch
+    from textreid_amd.embeddings.moco_head.head import MoCoHead
+    import types
+
+    spec, hidden, embed, vocab, C, B, NC, seed = OV.TINY, 64, 64, 200, 32, 4, 53, 77
+    K = 2 * B
+    ns = types.SimpleNamespace
+    table = OF.randn("vocab_table_wrap", (vocab, embed), seed, 0.5)
+    vis = ModifiedResNet(list(spec.layers), spec.output_dim, spec.heads, spec.last_stride, (spec.height, spec.in_width), spec.width)
+    txt = GRU(hidden, embed, embed, 1, 0.0, True, "clip_vit", "./", vocab_dict=table)
+    cfg = ns(MODEL=ns(EMBEDDING=ns(FEATURE_SIZE=C, EPSILON=0.1), MOCO=ns(K=K, M=0.9, FC=False), NUM_CLASSES=NC))
+    head = MoCoHead(cfg, vis, txt)
+    filled = OF.fill_state(head.state_dict(), seed, "wrap.")
+    st = {k: v.clone() for k, v in filled.items()}
+    OH.init_queues(st, seed)
+    for k in ("t_queue", "v_queue", "id_queue", "queue_ptr"):
+        filled[k] = st[k].clone()
+    head.load_state_dict(filled)
+    head.to(gpu).train()
+    for step, id_value in enumerate((7, 7, 9)):  # step 1 finds step 0's ids in the queue; step 2 wraps
+        x = OF.randn("img:wrap%d" % step, (B, 3, spec.height, spec.in_width), seed)
+        tok = OF.randint("tok:wrap%d" % step, 1, vocab, (B, 105), seed)
+        ln = OF.randint("len:wrap%d" % step, 2, 50, (B,), seed)
+        for i, n in enumerate(ln.tolist()):
+            tok[i, n:] = 0
+        ids = torch.full((B,), id_value, dtype=torch.int64)
+        ld = head(x.to(gpu), CaptionBatch(tok.to(gpu), ln.to(gpu), ids.to(gpu)))
+        with torch.no_grad():
+            old = OH.train_forward(st, spec, table, x, tok, ln, ids, m=0.9, epsilon=0.1)
+        for k in old:
+            assert rel(ld[k], old[k]) < 1e-3, (step, k, float(ld[k]), float(old[k]))
+        sd = head.state_dict()
+        assert int(sd["queue_ptr"]) == int(st["queue_ptr"]) == ((step + 1) * B) % K
+        assert torch.equal(sd["id_queue"].cpu(), st["id_queue"])
+        assert rel(sd["v_queue"], st["v_queue"]) < 1e-3 and rel(sd["t_queue"], st["t_queue"]) < 1e-3
 
 
 def test_train_step_is_deterministic(gpu):

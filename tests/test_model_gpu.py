@@ -88,6 +88,41 @@ def test_visual_encoder(gpu, golden_dir, tag, spec):
     assert not bad, bad
 
 
+@pytest.mark.parametrize("spec", [
+    OV.VisualSpec(layers=(1, 2, 1, 1), width=16, heads=4, output_dim=64, last_stride=2, height=64, in_width=64),   # CLIP default stride, square
+    OV.VisualSpec(layers=(2, 1, 1, 2), width=32, heads=8, output_dim=128, last_stride=1, height=128, in_width=64),  # 2:1 ReID crop
+], ids=["stride2-64x64", "stride1-128x64"])
+def test_visual_encoder_other_geometries(gpu, spec):
+    """Resolutions / strides / depths other than the benchmarked one (RES5_STRIDE 2, square inputs, more than
+    one block per layer) against the oracle: train forward, input-independent gradients, eval."""
+    from textreid_amd.backbones.m_resnet import ModifiedResNet
+
+    seed, B = 17, 3
+    m = ModifiedResNet(list(spec.layers), spec.output_dim, spec.heads, spec.last_stride, (spec.height, spec.in_width), spec.width)
+    fill_module(m, seed).to(gpu).train()
+    x = OF.randn("img:geo", (B, 3, spec.height, spec.in_width), seed)
+    st = {k: (torch.zeros((), dtype=torch.int64) if k.endswith("num_batches_tracked") else OF.fill(k, s_, seed))
+          for k, s_ in OV.state_shapes(spec).items()}
+    for k in st:
+        if OV.is_param(k):
+            st[k].requires_grad_(True)
+    yo = OV.visual_forward(st, x, spec, True)
+    y = m(x.to(gpu))
+    assert rel(y, yo) < TOL, rel(y, yo)
+    w = OF.randn("gout:geo", tuple(y.shape), seed)
+    (yo * w).sum().backward()
+    (y * w.to(gpu)).sum().backward()
+    named = dict(m.named_parameters())
+    errs = {k: rel(named[k].grad, st[k].grad) for k in ("conv1.weight", "layer1.0.conv2.weight", "layer2.0.downsample.1.weight",
+                                                         "layer4.0.bn3.weight", "attnpool.positional_embedding", "attnpool.c_proj.bias")}
+    bad = {k: v for k, v in errs.items() if not v < TOL}
+    assert not bad, bad
+    with torch.no_grad():
+        m.eval()
+        ye = m(x.to(gpu))
+    assert rel(ye, OV.visual_forward(st, x, spec, False)) < TOL
+
+
 def test_eval_bn_folding_matches_unfolded(gpu):
     """eval-mode BatchNorm folded into the conv weights (ReLU / residual in the GEMM epilogue)
     gives the unfolded eval path's output up to fp32 rounding of the folded weights."""
