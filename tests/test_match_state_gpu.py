@@ -390,3 +390,71 @@ def test_inference_dedupes_image_encodes(gpu):
     for i in range(N):
         # eval-mode BatchNorm is per-sample independent: identical up to GEMM tile-edge effects
         assert torch.allclose(a[i][0], b[i][0], rtol=1e-5, atol=1e-6) and torch.equal(a[i][1], b[i][1])
+
+
+def test_do_train_config0_plumbing(gpu, tmp_path):
+    """BASELINE configs[0] on the GPU box: moco_gru_cliprn50 at bs128, K=2048, 256 synthetic 384x128 images +
+    64-token captions, ONE epoch (2 steps) of engine.trainer.do_train + the per-epoch evaluation through
+    engine.inference, as train_net.py drives them (trainer.py:38-139).  Plumbing: losses finite and
+    decreasing-ish, queue pointer / ids advanced by exactly two batches, LR schedule stepped, R@1 returned."""
+    import bench
+    from textreid_amd.caption import CaptionBatch
+    from textreid_amd.config import moco_cfg
+    from textreid_amd.engine.trainer import do_train
+    from textreid_amd.model import build_model
+    from textreid_amd.solver import make_lr_scheduler, make_optimizer
+
+    B, K, N = 128, 2048, 256
+    torch.manual_seed(0)
+    cfg = moco_cfg("m_resnet50", K=K)
+    model = build_model(cfg, vocab_dict=torch.randn(49408, 512) * 0.02).to(gpu)
+    opt = make_optimizer(cfg, model)
+    sched = make_lr_scheduler(cfg, opt)
+    batches = [bench.synth_batch(B, s, "cpu", 3) for s in range(N // B)]
+
+    class TrainLoader:
+        def __len__(self):
+            return len(batches)
+
+        def __iter__(self):
+            for im, tk, ln, ids in batches:
+                yield im, CaptionBatch(tk, ln, ids, max_len=64), None
+
+    vn = 32
+    vim, vtk, vln, vids = bench.synth_batch(vn, 9, "cpu", 4)
+
+    class ValDS:
+        def get_id_info(self, idx):
+            return idx // 2, int(vids[idx])
+
+        def __len__(self):
+            return vn
+
+    class ValLoader:
+        dataset = ValDS()
+
+        def __iter__(self):
+            for s in range(0, vn, 16):
+                idx = list(range(s, s + 16))
+                yield vim[[i // 2 * 2 for i in idx]], CaptionBatch(vtk[idx], vln[idx]), idx
+
+    seen = []
+
+    class Meters:
+        def update(self, **kw):
+            seen.append(kw)
+
+        def __str__(self):
+            return str(seen[-1])
+
+    lr0 = opt.param_groups[0]["lr"]
+    args = {"max_epoch": 1, "epoch": 0, "iteration": 0}
+    do_train(model, TrainLoader(), [ValLoader()], opt, sched, None, Meters(), gpu, checkpoint_period=10, evaluate_period=1,
+             arguments=args, log_period=1)
+    head = model.embed_model
+    assert args["iteration"] == 2 and args["epoch"] == 1 and len(seen) == 2
+    assert all(np.isfinite(v) for kw in seen for v in kw.values())
+    assert int(head.queue_ptr) == (2 * B) % K
+    assert torch.equal(head.id_queue[0, : 2 * B].cpu(), torch.cat([batches[0][3], batches[1][3]]))
+    assert opt.param_groups[0]["lr"] != lr0 or sched.last_epoch == 1
+

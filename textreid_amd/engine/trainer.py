@@ -34,6 +34,8 @@ def do_train(model, data_loader, data_loader_val, optimizer, scheduler, checkpoi
     max_epoch, epoch, iteration = arguments["max_epoch"], arguments["epoch"], arguments["iteration"]
     reducer = GradReducer()
     pre_gather = [p for n, p in model.named_parameters() if p.requires_grad and "loss_evaluator" not in n][::-1]
+    if world_size() > 1 and hasattr(getattr(model, "embed_model", None), "v_encoder_q"):
+        model.embed_model.v_encoder_q.grad_sync = reducer  # conv gradients all-reduced from inside backward
     best_top1 = 0.0
     start = time.time()
     while epoch < max_epoch:
