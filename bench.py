@@ -308,7 +308,7 @@ def main():
             f = line.split()
             if prec == 6 and len(f) > 5 and "gemm_bf16s_kernel<2," in line and line.rstrip().endswith("0, 3, 128>(trid::GemmParams)"):
                 traffic = (float(f[2]) + float(f[3])) * 1e6
-                traffic_note = "PMC passes of profiles/r01j (not re-measured in this run): read %s MB + write %s MB per launch; algorithmic input + output of these layers ~ 115 MB" % (f[2], f[3])
+                traffic_note = "PMC passes of profiles/r01j (not re-measured in this run): read %s MB + write %s MB per launch; algorithmic input + weights + output of these layers ~ 58 + 9 + 58 MB (each of the 8 XCD L2s fetches its own copy of the filter)" % (f[2], f[3])
                 break
     except OSError:
         pass
