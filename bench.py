@@ -95,6 +95,36 @@ def cpu_baseline(sample_b=32, steps=3):
     }
 
 
+def queue_similarity_bench(device, B=128, C=256, K=8192, reps=20):
+    """The batch x queue similarity / masked-InfoNCE block on its own (head.py:148-170 + losses.py:206-217):
+    hit mask, two [B,C]x[C,K] similarity GEMMs, the row kernel that emits loss and dL/dS in place, two
+    [B,K]x[K,C] gradient GEMMs.  Algorithmic HBM bytes = both queues + ids + queries + gradients
+    (17.4 MB at K=8192); no [B,K] matrix is written to HBM beyond the in-place logits (L2/MALL)."""
+    from textreid_amd import losses
+
+    g = torch.Generator(device="cpu").manual_seed(11)
+    nrm = lambda t: torch.nn.functional.normalize(t, dim=1).to(device)
+    vq, tq, vk, tk = (nrm(torch.randn(B, C, generator=g)) for _ in range(4))
+    tqueue, vqueue = nrm(torch.randn(K, C, generator=g)), nrm(torch.randn(K, C, generator=g))
+    ids = torch.arange(B, device=device) // 4
+    idq = torch.randint(0, 11003, (1, K), generator=g).to(device)
+    fn = lambda: losses.queue_infonce_loss(vq, tq, vk, tk, ids, tqueue, vqueue, idq)
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    nbytes = 2 * C * K * 4 + 8 * K + 4 * B * C * 4 + 2 * B * C * 4
+    flops = 2 * 2 * 2.0 * B * C * K  # similarity + gradient GEMMs, both modalities
+    return {"K": K, "ms": ms, "algorithmic_MB": nbytes / 1e6, "achieved_GB_per_s": nbytes / ms / 1e6,
+            "achieved_TFLOP_per_s": flops / ms / 1e9,
+            "note": "9 small launches per modality (similarity GEMM, segment-parallel InfoNCE passes, split-K gradient GEMM ...): launch-latency-bound at K=8192; HBM roofline would be %.1f us" % (nbytes / 8e12 * 1e6)}
+
+
 def encode_bench(model, images, tokens, lengths, reps=5):
     """Eval-mode encode rates (test_net.py path: running-stat BatchNorm, no key encoders): gallery images/s
     and query captions/s of ONE GPU at the training batch size."""
@@ -334,6 +364,7 @@ def main():
         retr = retrieval_bench(device, world, rank)
         retr.update(encode_bench(model, batches[0][0], batches[0][1], batches[0][2]))
         log("retrieval: %.1f M gallery imgs/s" % (retr["value"] / 1e6))
+    qsim = [queue_similarity_bench(device, B=B, K=k) for k in sorted({args.queue, 65536})]
     if rank == 0:
         out = {
             "metric": "image-text pairs/sec (train), CLIP-RN50 + BiGRU MoCo step, bs128/GPU",
@@ -360,6 +391,7 @@ def main():
             "roofline": roofline,
         }
         out["retrieval"] = retr
+        out["queue_similarity"] = qsim
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
         else:

@@ -195,9 +195,11 @@ int trid_queue_hit_mask(const int64_t* id_queue, const int64_t* ids, uint8_t* fl
 /* InfoNCE over [pos | masked negs]/T with label 0 (losses.py:206-217).
  * S: [B, ldS] similarity of queries vs the K queue rows (raw dot products), in
  * place becomes dL/dS (already scaled by gscale/(B*T)); pos[b] = <q_b, key_b>;
- * outputs loss_rows[b] = lse - pos/T and dpos[b]. */
+ * outputs loss_rows[b] = lse - pos/T and dpos[b].  Rows are cut into 4096-column segments (one workgroup
+ * each, two passes) so that long queues fill the chip; ws floats >= trid_infonce_ws_floats(B, K). */
+long long trid_infonce_ws_floats(int B, int K);
 int trid_infonce_rows_f32(float* S, const float* pos, const uint8_t* hit, float* loss_rows, float* dpos, int B,
-                          int K, int ldS, float invT, float gscale, void* stream);
+                          int K, int ldS, float invT, float gscale, float* ws, void* stream);
 /* rowdot[b] = <x_b, y_b> */
 int trid_rowdot_f32(const float* x, const float* y, float* out, long long rows, int C, void* stream);
 /* dx[b,:] (+)= s[b]*y[b,:] */

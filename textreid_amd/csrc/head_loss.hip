@@ -77,26 +77,99 @@ __global__ void queue_hit_mask_kernel(const int64_t* __restrict__ id_queue, cons
     flag[k] = hit ? 1 : 0;
 }
 
-// one workgroup per query row
-__global__ __launch_bounds__(256) void infonce_rows_kernel(float* __restrict__ S, const float* __restrict__ pos,
-                                                           const uint8_t* __restrict__ hit,
-                                                           float* __restrict__ loss_rows, float* __restrict__ dpos,
-                                                           int K, int ldS, float invT, float gs) {
+// InfoNCE over one query row's masked queue logits, split over the row so that long queues fill the chip:
+// a row of K logits is cut into segments of INFONCE_SEG columns, one workgroup each.
+//   pass 1 (infonce_partial_kernel): per segment, max and sum of exp over the unmasked columns;
+//   pass 2 (infonce_finish_kernel) : every workgroup folds the row's segment partials (fixed order, so the
+//          result does not depend on scheduling) with the positive logit into the row's log-sum-exp,
+//          then rewrites its segment in place as dL/dS; segment 0 also emits the row loss and dL/dpos.
+// float4 accesses throughout (K and ldS multiples of 4 take the vector path).
+constexpr int INFONCE_SEG = 4096;
+
+__global__ __launch_bounds__(256) void infonce_partial_kernel(const float* __restrict__ S, const uint8_t* __restrict__ hit,
+                                                              float2* __restrict__ part, int K, int ldS, float invT) {
     __shared__ float red[8];
-    const int b = blockIdx.x;
+    const int b = blockIdx.x, seg = blockIdx.y, nseg = gridDim.y;
+    const float* r = S + (long long)b * ldS;
+    const int k0 = seg * INFONCE_SEG, k1 = min(K, k0 + INFONCE_SEG);
+    const bool vec = ((ldS & 3) == 0) && ((reinterpret_cast<uintptr_t>(S) & 15) == 0);
+    float m = -INFINITY;
+    if (vec) {
+        for (int k = k0 + 4 * threadIdx.x; k < k1; k += 1024) {
+            const float4 v = *reinterpret_cast<const float4*>(r + k);
+            const uchar4 h = *reinterpret_cast<const uchar4*>(hit + k);  // k % 4 == 0; tail handled below
+            if (k + 3 < k1) {
+                if (!h.x) m = fmaxf(m, v.x * invT);
+                if (!h.y) m = fmaxf(m, v.y * invT);
+                if (!h.z) m = fmaxf(m, v.z * invT);
+                if (!h.w) m = fmaxf(m, v.w * invT);
+            } else {
+                for (int t = k; t < k1; ++t) if (!hit[t]) m = fmaxf(m, r[t] * invT);
+            }
+        }
+    } else {
+        for (int k = k0 + threadIdx.x; k < k1; k += 256) if (!hit[k]) m = fmaxf(m, r[k] * invT);
+    }
+    m = block_max(m, red);
+    float l = 0.f;
+    if (m > -INFINITY) {
+        if (vec) {
+            for (int k = k0 + 4 * threadIdx.x; k < k1; k += 1024) {
+                const float4 v = *reinterpret_cast<const float4*>(r + k);
+                const uchar4 h = *reinterpret_cast<const uchar4*>(hit + k);
+                if (k + 3 < k1) {
+                    if (!h.x) l += expf(v.x * invT - m);
+                    if (!h.y) l += expf(v.y * invT - m);
+                    if (!h.z) l += expf(v.z * invT - m);
+                    if (!h.w) l += expf(v.w * invT - m);
+                } else {
+                    for (int t = k; t < k1; ++t) if (!hit[t]) l += expf(r[t] * invT - m);
+                }
+            }
+        } else {
+            for (int k = k0 + threadIdx.x; k < k1; k += 256) if (!hit[k]) l += expf(r[k] * invT - m);
+        }
+    }
+    l = block_sum(l, red);
+    if (threadIdx.x == 0) part[(long long)b * nseg + seg] = make_float2(m, l);
+}
+
+__global__ __launch_bounds__(256) void infonce_finish_kernel(float* __restrict__ S, const float* __restrict__ pos,
+                                                             const uint8_t* __restrict__ hit,
+                                                             const float2* __restrict__ part,
+                                                             float* __restrict__ loss_rows, float* __restrict__ dpos,
+                                                             int K, int ldS, float invT, float gs) {
+    const int b = blockIdx.x, seg = blockIdx.y, nseg = gridDim.y;
     float* r = S + (long long)b * ldS;
     const float p = pos[b] * invT;
     float m = p;
-    for (int k = threadIdx.x; k < K; k += 256)
-        if (!hit[k]) m = fmaxf(m, r[k] * invT);
-    m = block_max(m, red);
-    float l = 0.f;
-    for (int k = threadIdx.x; k < K; k += 256)
-        if (!hit[k]) l += expf(r[k] * invT - m);
-    l = block_sum(l, red) + expf(p - m);
+    for (int s2 = 0; s2 < nseg; ++s2) m = fmaxf(m, part[(long long)b * nseg + s2].x);
+    float l = expf(p - m);
+    for (int s2 = 0; s2 < nseg; ++s2) {
+        const float2 q = part[(long long)b * nseg + s2];
+        if (q.x > -INFINITY) l += q.y * expf(q.x - m);
+    }
     const float lse = m + logf(l);
-    for (int k = threadIdx.x; k < K; k += 256) r[k] = hit[k] ? 0.f : expf(r[k] * invT - lse) * gs;
-    if (threadIdx.x == 0) {
+    const int k0 = seg * INFONCE_SEG, k1 = min(K, k0 + INFONCE_SEG);
+    const bool vec = ((ldS & 3) == 0) && ((reinterpret_cast<uintptr_t>(S) & 15) == 0);
+    if (vec) {
+        for (int k = k0 + 4 * threadIdx.x; k < k1; k += 1024) {
+            if (k + 3 < k1) {
+                float4 v = *reinterpret_cast<const float4*>(r + k);
+                const uchar4 h = *reinterpret_cast<const uchar4*>(hit + k);
+                v.x = h.x ? 0.f : expf(v.x * invT - lse) * gs;
+                v.y = h.y ? 0.f : expf(v.y * invT - lse) * gs;
+                v.z = h.z ? 0.f : expf(v.z * invT - lse) * gs;
+                v.w = h.w ? 0.f : expf(v.w * invT - lse) * gs;
+                *reinterpret_cast<float4*>(r + k) = v;
+            } else {
+                for (int t = k; t < k1; ++t) r[t] = hit[t] ? 0.f : expf(r[t] * invT - lse) * gs;
+            }
+        }
+    } else {
+        for (int k = k0 + threadIdx.x; k < k1; k += 256) r[k] = hit[k] ? 0.f : expf(r[k] * invT - lse) * gs;
+    }
+    if (seg == 0 && threadIdx.x == 0) {
         loss_rows[b] = lse - p;
         dpos[b] = (expf(p - lse) - 1.f) * gs;
     }
@@ -298,11 +371,16 @@ extern "C" int trid_queue_hit_mask(const int64_t* id_queue, const int64_t* ids, 
     return check_launch("trid_queue_hit_mask");
 }
 
+extern "C" long long trid_infonce_ws_floats(int B, int K) { return 2LL * B * ((K + INFONCE_SEG - 1) / INFONCE_SEG); }
+
 extern "C" int trid_infonce_rows_f32(float* S, const float* pos, const uint8_t* hit, float* loss_rows, float* dpos,
-                                     int B, int K, int ldS, float invT, float gscale, void* stream) {
-    TRID_REQUIRE(S && pos && hit && loss_rows && dpos && B > 0 && K > 0 && ldS >= K, "trid_infonce_rows_f32: bad arguments");
-    hipLaunchKernelGGL(infonce_rows_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, S, pos, hit, loss_rows, dpos, K,
-                       ldS, invT, gscale * invT / (float)B);
+                                     int B, int K, int ldS, float invT, float gscale, float* ws, void* stream) {
+    TRID_REQUIRE(S && pos && hit && loss_rows && dpos && ws && B > 0 && K > 0 && ldS >= K, "trid_infonce_rows_f32: bad arguments");
+    TRID_REQUIRE((reinterpret_cast<uintptr_t>(hit) & 3) == 0 && (reinterpret_cast<uintptr_t>(ws) & 7) == 0, "trid_infonce_rows_f32: hit must be 4-byte and ws 8-byte aligned");
+    const int nseg = (K + INFONCE_SEG - 1) / INFONCE_SEG;
+    hipLaunchKernelGGL(infonce_partial_kernel, dim3(B, nseg), dim3(256), 0, (hipStream_t)stream, S, hit, (float2*)ws, K, ldS, invT);
+    hipLaunchKernelGGL(infonce_finish_kernel, dim3(B, nseg), dim3(256), 0, (hipStream_t)stream, S, pos, hit, (const float2*)ws,
+                       loss_rows, dpos, K, ldS, invT, gscale * invT / (float)B);
     return check_launch("trid_infonce_rows_f32");
 }
 

@@ -127,8 +127,9 @@ class _InfoNCEFn(torch.autograd.Function):
             hit = torch.zeros(K, dtype=torch.uint8, device=S.device)
             rows = ops.empty((B,), S)
             dpos = ops.empty((B,), S)
+            ws = ops.empty((ops.L.load().trid_infonce_ws_floats(B, K),), S)
             call("trid_infonce_rows_f32", _p(S), _p(pos.detach().reshape(-1).contiguous()), _p(hit), _p(rows), _p(dpos),
-                 B, K, K, 1.0 / T, 1.0, stream())
+                 B, K, K, 1.0 / T, 1.0, _p(ws), stream())
             ops.sum_to(rows, loss, 1.0 / B, accumulate=i > 0)
             outs += [dpos.view(B, 1), S]
         ctx.saved = outs
@@ -164,7 +165,8 @@ class _QueueInfoNCEFn(torch.autograd.Function):
             pos = ops.rowdot(q, key)
             rows = ops.empty((B,), q)
             dpos = ops.empty((B,), q)
-            call("trid_infonce_rows_f32", _p(S), _p(pos), _p(hit), _p(rows), _p(dpos), B, K, K, 1.0 / T, 1.0, stream())
+            ws = ops.empty((ops.L.load().trid_infonce_ws_floats(B, K),), q)
+            call("trid_infonce_rows_f32", _p(S), _p(pos), _p(hit), _p(rows), _p(dpos), B, K, K, 1.0 / T, 1.0, _p(ws), stream())
             ops.sum_to(rows, loss, 1.0 / B, accumulate=i > 0)
             dq = ops.matmul_nn(S, queue)
             ops.rowscale_add(dpos, key, dq, accumulate=True)
