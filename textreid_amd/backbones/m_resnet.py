@@ -85,10 +85,15 @@ def _g3x3(dw, N, C):
     return dw.view(N, 3, 3, C).permute(0, 3, 1, 2)
 
 
-def _bn_coeffs(bn, partials, M, training):
+def _bn_coeffs(bn, partials, M, training, counters=None):
+    """Per-layer BatchNorm coefficients.  Training also advances `num_batches_tracked`; with `counters`
+    (a list) the increment is deferred so the caller can bump all 55 counters in one launch."""
     if training:
         st = ops.bn_finalize(partials, M, bn.weight, bn.bias, bn.running_mean, bn.running_var)
-        bn.num_batches_tracked += 1
+        if counters is None:
+            bn.num_batches_tracked += 1
+        else:
+            counters.append(bn.num_batches_tracked)
         return st
     return ops.bn_eval_coeffs(bn.weight, bn.bias, bn.running_mean, bn.running_var)
 
@@ -249,16 +254,17 @@ class ModifiedResNet(nn.Module):
         w1p = torch.zeros(c1.shape[0], col.shape[1], device=c1.device, dtype=c1.dtype)
         w1p[:, : c1[0].numel()] = c1.detach().reshape(c1.shape[0], -1)
         y1, p1 = ops.conv1x1(col, w1p, stats=True) if training else (ops.conv1x1(col, w1p), None)
-        st1 = _bn_coeffs(self.bn1, p1, y1.shape[0], training)
+        nbt = []  # num_batches_tracked buffers, incremented together at the end of the pass
+        st1 = _bn_coeffs(self.bn1, p1, y1.shape[0], training, nbt)
         y1 = y1.view(B, Ho, Wo, -1)
         a1 = ops.bn_apply(y1, st1, relu=True)
         w2 = _w3x3(self.conv2)
         y2, p2 = ops.conv3x3(a1, w2, stats=True) if training else (ops.conv3x3(a1, w2), None)
-        st2 = _bn_coeffs(self.bn2, p2, B * Ho * Wo, training)
+        st2 = _bn_coeffs(self.bn2, p2, B * Ho * Wo, training, nbt)
         a2 = ops.bn_apply(y2, st2, relu=True)
         w3 = _w3x3(self.conv3)
         y3, p3 = ops.conv3x3(a2, w3, stats=True) if training else (ops.conv3x3(a2, w3), None)
-        st3 = _bn_coeffs(self.bn3, p3, B * Ho * Wo, training)
+        st3 = _bn_coeffs(self.bn3, p3, B * Ho * Wo, training, nbt)
         x = ops.bn_apply_pool2(y3, st3, relu=True)
         if save:
             S["stem"] = (col, y1, st1, a1, y2, st2, a2, y3, st3)
@@ -270,22 +276,22 @@ class ModifiedResNet(nn.Module):
             wa = blk.conv1.weight.view(blk.conv1.out_channels, -1)
             ya, pa = ops.conv1x1(x, wa, stats=True) if training else (ops.conv1x1(x, wa), None)
             Ma = ya.numel() // ya.shape[-1]
-            sta = _bn_coeffs(blk.bn1, pa, Ma, training)
+            sta = _bn_coeffs(blk.bn1, pa, Ma, training, nbt)
             aa = ops.bn_apply(ya, sta, relu=True)
             wb = _w3x3(blk.conv2)
             yb, pb = ops.conv3x3(aa, wb, stats=True) if training else (ops.conv3x3(aa, wb), None)
-            stb = _bn_coeffs(blk.bn2, pb, Ma, training)
+            stb = _bn_coeffs(blk.bn2, pb, Ma, training, nbt)
             ab = ops.bn_apply_pool2(yb, stb, relu=True) if stride > 1 else ops.bn_apply(yb, stb, relu=True)
             wc = blk.conv3.weight.view(blk.conv3.out_channels, -1)
             yc, pc = ops.conv1x1(ab, wc, stats=True) if training else (ops.conv1x1(ab, wc), None)
             Mc = yc.numel() // yc.shape[-1]
-            stc = _bn_coeffs(blk.bn3, pc, Mc, training)
+            stc = _bn_coeffs(blk.bn3, pc, Mc, training, nbt)
             xd = yd = std = None
             if blk.downsample is not None:
                 xd = ops.bn_apply_pool2(x, None) if stride > 1 else x
                 wd = blk.downsample[1].weight.view(blk.downsample[1].out_channels, -1)
                 yd, pd = ops.conv1x1(xd, wd, stats=True) if training else (ops.conv1x1(xd, wd), None)
-                std = _bn_coeffs(blk.downsample[2], pd, Mc, training)
+                std = _bn_coeffs(blk.downsample[2], pd, Mc, training, nbt)
                 out = ops.bn_apply(yc, stc, relu=True, res=yd, res_st=std, want_mask=save)
             else:
                 out = ops.bn_apply(yc, stc, relu=True, res=x, want_mask=save)
@@ -295,6 +301,8 @@ class ModifiedResNet(nn.Module):
             x = out
             if getattr(self, "_debug_taps", None) is not None:
                 self._debug_taps[len(self._debug_taps)] = out
+        if nbt:
+            torch._foreach_add_(nbt, 1)  # one launch instead of one per BatchNorm layer
         # ---- attention pool (m_resnet.py:103-135), token-0 query only
         feat, asave = self._attnpool_forward(x, save)
         if save:
