@@ -255,3 +255,27 @@ def test_gemm_arithmetic_modes(ops, prec, tol):
         assert rel(ops.linear(dev(big), dev(small)), big @ small.t()) < tol
     finally:
         ops.GEMM_PRECISION = old
+
+
+def test_abi_argument_errors_are_reported_not_fatal(ops):
+    """C-ABI contract: bad arguments return a negative TRID_E_* code with a thread-local message
+    (surfaced as RuntimeError by the binding) and leave the device usable - no abort, no sticky HIP error."""
+    x, w = dev(R("ex", 64, 36)), dev(R("ew", 48, 36))
+    out = ops.empty((64, 48), x)
+    with pytest.raises(RuntimeError, match="K%4"):  # K-contiguous operands need K % 4 == 0
+        ops.gemm(x[:, :35], w[:, :35], out, 64, 48, 35, 36, 36, 48)
+    with pytest.raises(RuntimeError, match="16-byte"):  # operand base alignment
+        ops.gemm(x, w, out, 64, 44, 36, 36, 36, 48, c_off=1)
+    with pytest.raises(RuntimeError, match="split-K"):  # split-K slabs take no bias
+        ops.gemm(x, w, ops.empty((2, 64, 48), x), 64, 48, 36, 36, 36, 48, splits=2, strideSplit=64 * 48, bias=dev(R("eb", 48)))
+    with pytest.raises(RuntimeError, match="k must be"):
+        from textreid_amd.evaluation import similarity_topk
+
+        similarity_topk(dev(R("eq", 4, 64)), dev(R("eg", 40, 64)), k=17)
+    with pytest.raises(RuntimeError, match="bn_bwd"):  # channel count the BN-backward tiling does not cover
+        y = dev(R("ey", 1, 2, 2, 24))
+        st = ops.BNState(24, y)
+        ops.bn_bwd(y, y, st, None, 1)
+    # the library is still healthy afterwards
+    assert rel(ops.linear(x, w), x.cpu() @ w.cpu().t()) < 2e-5
+
