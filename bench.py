@@ -122,7 +122,7 @@ def queue_similarity_bench(device, B=128, C=256, K=8192, reps=20):
     flops = 2 * 2 * 2.0 * B * C * K  # similarity + gradient GEMMs, both modalities
     return {"K": K, "ms": ms, "algorithmic_MB": nbytes / 1e6, "achieved_GB_per_s": nbytes / ms / 1e6,
             "achieved_TFLOP_per_s": flops / ms / 1e9,
-            "note": "9 small launches per modality (similarity GEMM, segment-parallel InfoNCE passes, split-K gradient GEMM ...): launch-latency-bound at K=8192; HBM roofline would be %.1f us" % (nbytes / 8e12 * 1e6)}
+            "note": "5 small launches per modality (similarity GEMM, two segment-parallel InfoNCE passes, split-K gradient GEMM + slab reduce): launch-latency-bound at K=8192; HBM roofline would be %.1f us" % (nbytes / 8e12 * 1e6)}
 
 
 def encode_bench(model, images, tokens, lengths, reps=5):

@@ -200,6 +200,11 @@ int trid_queue_hit_mask(const int64_t* id_queue, const int64_t* ids, uint8_t* fl
 long long trid_infonce_ws_floats(int B, int K);
 int trid_infonce_rows_f32(float* S, const float* pos, const uint8_t* hit, float* loss_rows, float* dpos, int B,
                           int K, int ldS, float invT, float gscale, float* ws, void* stream);
+/* Same, for the fused queue path (head.py:159-170): the positive logit <q_b, key_b> is formed inside (q, key
+ * [B, C]) and dq0[b,:] = dL/dpos[b] * key[b,:] is written, onto which the caller accumulates dL/dS @ queue. */
+int trid_infonce_queue_rows_f32(float* S, const float* q, const float* key, const uint8_t* hit, float* loss_rows,
+                                float* dq0, int B, int K, int ldS, int C, float invT, float gscale, float* ws,
+                                void* stream);
 /* rowdot[b] = <x_b, y_b> */
 int trid_rowdot_f32(const float* x, const float* y, float* out, long long rows, int C, void* stream);
 /* dx[b,:] (+)= s[b]*y[b,:] */

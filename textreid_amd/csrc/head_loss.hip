@@ -134,14 +134,28 @@ __global__ __launch_bounds__(256) void infonce_partial_kernel(const float* __res
     if (threadIdx.x == 0) part[(long long)b * nseg + seg] = make_float2(m, l);
 }
 
+// `pos` may be null: then the positive logit <q_b, key_b> is computed here from q / key [B, C] (saves a
+// launch), and segment 0 also writes dq0[b, :] = dL/dpos * key_b, the positive-pair term of dL/dq that the
+// gradient GEMM then accumulates onto.
 __global__ __launch_bounds__(256) void infonce_finish_kernel(float* __restrict__ S, const float* __restrict__ pos,
                                                              const uint8_t* __restrict__ hit,
                                                              const float2* __restrict__ part,
                                                              float* __restrict__ loss_rows, float* __restrict__ dpos,
-                                                             int K, int ldS, float invT, float gs) {
+                                                             int K, int ldS, float invT, float gs,
+                                                             const float* __restrict__ q, const float* __restrict__ key,
+                                                             float* __restrict__ dq0, int C) {
+    __shared__ float red[8];
     const int b = blockIdx.x, seg = blockIdx.y, nseg = gridDim.y;
     float* r = S + (long long)b * ldS;
-    const float p = pos[b] * invT;
+    float praw;
+    if (pos != nullptr) {
+        praw = pos[b];
+    } else {
+        float d = 0.f;
+        for (int c = threadIdx.x; c < C; c += 256) d = fmaf(q[(long long)b * C + c], key[(long long)b * C + c], d);
+        praw = block_sum(d, red);
+    }
+    const float p = praw * invT;
     float m = p;
     for (int s2 = 0; s2 < nseg; ++s2) m = fmaxf(m, part[(long long)b * nseg + s2].x);
     float l = expf(p - m);
@@ -169,9 +183,14 @@ __global__ __launch_bounds__(256) void infonce_finish_kernel(float* __restrict__
     } else {
         for (int k = k0 + threadIdx.x; k < k1; k += 256) r[k] = hit[k] ? 0.f : expf(r[k] * invT - lse) * gs;
     }
-    if (seg == 0 && threadIdx.x == 0) {
-        loss_rows[b] = lse - p;
-        dpos[b] = (expf(p - lse) - 1.f) * gs;
+    if (seg == 0) {
+        const float dp = (expf(p - lse) - 1.f) * gs;
+        if (threadIdx.x == 0) {
+            loss_rows[b] = lse - p;
+            if (dpos != nullptr) dpos[b] = dp;
+        }
+        if (dq0 != nullptr)
+            for (int c = threadIdx.x; c < C; c += 256) dq0[(long long)b * C + c] = dp * key[(long long)b * C + c];
     }
 }
 
@@ -380,8 +399,23 @@ extern "C" int trid_infonce_rows_f32(float* S, const float* pos, const uint8_t* 
     const int nseg = (K + INFONCE_SEG - 1) / INFONCE_SEG;
     hipLaunchKernelGGL(infonce_partial_kernel, dim3(B, nseg), dim3(256), 0, (hipStream_t)stream, S, hit, (float2*)ws, K, ldS, invT);
     hipLaunchKernelGGL(infonce_finish_kernel, dim3(B, nseg), dim3(256), 0, (hipStream_t)stream, S, pos, hit, (const float2*)ws,
-                       loss_rows, dpos, K, ldS, invT, gscale * invT / (float)B);
+                       loss_rows, dpos, K, ldS, invT, gscale * invT / (float)B, (const float*)nullptr, (const float*)nullptr,
+                       (float*)nullptr, 0);
     return check_launch("trid_infonce_rows_f32");
+}
+
+extern "C" int trid_infonce_queue_rows_f32(float* S, const float* q, const float* key, const uint8_t* hit, float* loss_rows,
+                                           float* dq0, int B, int K, int ldS, int C, float invT, float gscale, float* ws,
+                                           void* stream) {
+    TRID_REQUIRE(S && q && key && hit && loss_rows && dq0 && ws && B > 0 && K > 0 && C > 0 && ldS >= K,
+                 "trid_infonce_queue_rows_f32: bad arguments");
+    TRID_REQUIRE((reinterpret_cast<uintptr_t>(hit) & 3) == 0 && (reinterpret_cast<uintptr_t>(ws) & 7) == 0,
+                 "trid_infonce_queue_rows_f32: hit must be 4-byte and ws 8-byte aligned");
+    const int nseg = (K + INFONCE_SEG - 1) / INFONCE_SEG;
+    hipLaunchKernelGGL(infonce_partial_kernel, dim3(B, nseg), dim3(256), 0, (hipStream_t)stream, S, hit, (float2*)ws, K, ldS, invT);
+    hipLaunchKernelGGL(infonce_finish_kernel, dim3(B, nseg), dim3(256), 0, (hipStream_t)stream, S, (const float*)nullptr, hit,
+                       (const float2*)ws, loss_rows, (float*)nullptr, K, ldS, invT, gscale * invT / (float)B, q, key, dq0, C);
+    return check_launch("trid_infonce_queue_rows_f32");
 }
 
 extern "C" int trid_rowdot_f32(const float* x, const float* y, float* out, long long rows, int C, void* stream) {

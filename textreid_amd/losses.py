@@ -157,20 +157,20 @@ class _QueueInfoNCEFn(torch.autograd.Function):
         hit = torch.empty(K, dtype=torch.uint8, device=v_q.device)
         call("trid_queue_hit_mask", _p(id_queue), _p(ids.long().contiguous()), _p(hit), K, B, stream())
         loss = ops.empty((1,), v_q)
+        rows = ops.empty((2, B), v_q)  # per-row losses of both modalities, summed by one launch
         grads = []
         for i, (q, key, queue) in enumerate(((v_q, t_k, t_queue), (t_q, v_k, v_queue))):
             q = q.detach().contiguous()
             key = key.detach().contiguous()
             S = ops.linear(q, queue)  # [B,K] raw dot products
-            pos = ops.rowdot(q, key)
-            rows = ops.empty((B,), q)
-            dpos = ops.empty((B,), q)
+            dq = ops.empty((B, C), q)
             ws = ops.empty((ops.L.load().trid_infonce_ws_floats(B, K),), q)
-            call("trid_infonce_rows_f32", _p(S), _p(pos), _p(hit), _p(rows), _p(dpos), B, K, K, 1.0 / T, 1.0, _p(ws), stream())
-            ops.sum_to(rows, loss, 1.0 / B, accumulate=i > 0)
-            dq = ops.matmul_nn(S, queue)
-            ops.rowscale_add(dpos, key, dq, accumulate=True)
+            # loss rows, dL/dS in place, and dq = dL/dpos * key (the positive-pair term)
+            call("trid_infonce_queue_rows_f32", _p(S), _p(q), _p(key), _p(hit), _p(rows[i]), _p(dq), B, K, K, C, 1.0 / T, 1.0,
+                 _p(ws), stream())
+            ops.matmul_nn(S, queue, out=dq, accumulate=True)
             grads.append(dq)
+        ops.sum_to(rows.view(-1), loss, 1.0 / B)
         ctx.saved = grads
         return loss[0]
 
