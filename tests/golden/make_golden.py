@@ -35,6 +35,7 @@ torch.Tensor.cuda = lambda self, *a, **k: self  # shim (i)
 torch.set_num_threads(8)
 
 import oracle.fill as OF  # noqa: E402
+from oracle.fill import digest, digest_err, grad_floor, strided_sample  # noqa: E402
 import oracle.head as OH  # noqa: E402
 import oracle.text as OT  # noqa: E402
 import oracle.visual as OV  # noqa: E402
@@ -184,6 +185,93 @@ def gen_visual(tag, spec, B, seed, grads=()):
     np.savez_compressed(os.path.join(HERE, "visual_%s.npz" % tag), **f32(out))
 
 
+# conv filters whose gradient is stored as a strided sample (in addition to the digest of EVERY gradient):
+# stem, first / middle / last residual layers, 1x1 and 3x3, plain and downsample paths
+FULL_CONV_GRADS = ("conv1.weight", "conv3.weight", "layer1.0.conv2.weight", "layer1.0.downsample.0.weight",
+                   "layer2.0.conv2.weight", "layer2.3.conv1.weight", "layer3.0.conv3.weight", "layer3.2.conv2.weight",
+                   "layer4.0.downsample.0.weight", "layer4.2.conv2.weight", "layer4.2.conv3.weight")
+
+
+def gen_visual_full(tag, spec, B, seed):
+    """Full-size encoder fixture under the ``margin`` fill style (oracle/fill.py): the reference's fp32
+    result is within 1e-4 of an fp64 evaluation for EVERY stored quantity (asserted below), so the GPU
+    test holds a flat 1e-3 on all of them.  Stored: train output, a digest of every parameter gradient,
+    strided samples of 11 filter gradients, a digest of every stage's activation (G2 of SURVEY 8 c2),
+    a digest of every BatchNorm running statistic, eval output cold and after WARM more train passes."""
+    print("[visual %s, margin style, B=%d]" % (tag, B))
+    m = ref_visual(spec)
+    m.load_state_dict(OF.fill_state(m.state_dict(), seed, style="margin"))
+    x = OF.randn("img:" + tag, (B, 3, spec.height, spec.in_width), seed)
+    acts = {}
+    hooks = [m.avgpool.register_forward_hook(lambda mod, i, o: acts.__setitem__("stem", o.detach()))]
+    for li in range(1, 5):
+        for bi, blk in enumerate(getattr(m, "layer%d" % li)):
+            hooks.append(blk.register_forward_hook(lambda mod, i, o, k="layer%d.%d" % (li, bi): acts.__setitem__(k, o.detach())))
+    m.train()
+    y = m(x)
+    for h in hooks:
+        h.remove()
+    w_out = OF.randn("gout:" + tag, tuple(y.shape), seed)
+    (y * w_out).sum().backward()
+    out = {"out_train": y.detach().numpy(), "spec": np.array(list(spec.layers) + [spec.width, spec.heads, spec.output_dim, spec.height, spec.in_width, B, seed])}
+    named = dict(m.named_parameters())
+    for k, p in named.items():
+        out["gdig:" + k] = digest("grad:" + k, p.grad)
+    for k in FULL_CONV_GRADS:
+        out["grad:" + k] = strided_sample(named[k].grad).numpy()
+    for k, a in acts.items():
+        out["adig:" + k] = digest("act:" + k, a)
+    for k, v in m.state_dict().items():
+        if k.endswith(("running_mean", "running_var")):
+            out["rdig:" + k] = digest("run:" + k, v)
+    m.eval()
+    with torch.no_grad():
+        out["out_eval"] = m(x).numpy()
+    m.train()
+    with torch.no_grad():
+        for _ in range(WARM):
+            m(x)
+        m.eval()
+        out["out_eval_warm"] = m(x).numpy()
+
+    worst = 0.0
+    for dt in (torch.float32, torch.float64):
+        st = {}
+        for k, s in OV.state_shapes(spec).items():
+            st[k] = torch.zeros((), dtype=torch.int64) if k.endswith("num_batches_tracked") else OF.fill(k, s, seed, style="margin").to(dt)
+            if OV.is_param(k) and st[k].dtype.is_floating_point:
+                st[k].requires_grad_(True)
+        xx = x.to(dt)
+        taps = {}
+        yo = OV.visual_forward(st, xx, spec, True, taps)
+        (yo * w_out.to(dt)).sum().backward()
+        run1 = {k: v.detach().clone() for k, v in st.items() if k.endswith(("running_mean", "running_var"))}
+        with torch.no_grad():
+            ye = OV.visual_forward(st, xx, spec, False)
+            for _ in range(WARM):
+                OV.visual_forward(st, xx, spec, True)
+            yw = OV.visual_forward(st, xx, spec, False)
+        errs = {"out_train": rel(yo, y), "out_eval": rel(ye, torch.from_numpy(out["out_eval"])), "out_eval_warm": rel(yw, torch.from_numpy(out["out_eval_warm"]))}
+        gfl = grad_floor([v for k, v in out.items() if k.startswith("gdig:")])
+        for k, p in named.items():
+            errs["grad:" + k] = float((st[k].grad.double() - p.grad.double()).abs().max() / max(float(p.grad.abs().max()), gfl))
+        for k in acts:
+            errs["act:" + k] = rel(taps[k], acts[k])
+        for k, v in run1.items():
+            errs["run:" + k] = digest_err(digest("run:" + k, v), out["rdig:" + k])
+        top = sorted(errs.items(), key=lambda kv: -kv[1])[:4]
+        if dt == torch.float32:
+            print("  oracle fp32 vs reference: worst", [(k, "%.1e" % v) for k, v in top])
+            assert top[0][1] < 1e-4, top
+        else:
+            print("  reference fp32 vs fp64 truth (conditioning): worst", [(k, "%.1e" % v) for k, v in top])
+            assert top[0][1] < 3e-4, ("fixture is not well-conditioned: choose another seed", top)
+            worst = top[0][1]
+            out["truth:out_train"] = yo.detach().numpy()
+    out["conditioning"] = np.array(worst)
+    np.savez_compressed(os.path.join(HERE, "visual_%s.npz" % tag), **f32(out))
+
+
 def gen_text(seed=3):
     print("[text]")
     hidden, embed, vocab, Lpad = 512, 512, 300, 105
@@ -224,9 +312,39 @@ def ns(**kw):
     return types.SimpleNamespace(**kw)
 
 
+HEAD_LR, HEAD_MOMENTUM, HEAD_WD = 0.02, 0.9, 4e-5
+
+
+def head_groups(named):
+    """Parameter groups of the reference's make_optimizer (lib/solver/build.py:6-18): one group per
+    tensor, bias lr x2 and no weight decay."""
+    groups = []
+    for k, p in named:
+        if not p.requires_grad:
+            continue
+        lr, wd = (2 * HEAD_LR, 0.0) if "bias" in k else (HEAD_LR, HEAD_WD)
+        groups.append({"params": [p], "lr": lr, "weight_decay": wd})
+    return groups
+
+
+def head_step_inputs(s, spec, B, vocab, Lpad, seed):
+    x = OF.randn("img:head%d" % s, (B, 3, spec.height, spec.in_width), seed)
+    lens = [int(v) for v in OF.randint("len:head%d" % s, 3, 30, (B,), seed)]
+    tok, ln = synth_tokens("tok:head%d" % s, B, lens, vocab, Lpad, seed)
+    # ids: duplicates inside the batch, and from step 1 on, hits in the queue
+    ids = torch.tensor([10 * s + (i // 2) for i in range(B)], dtype=torch.int64)
+    if s > 0:
+        ids[0] = 10 * (s - 1)  # equals an id already enqueued -> filtered column
+    return x, tok, ln, ids
+
+
 def gen_head(seed=5, steps=3):
-    """Tiny visual encoder + small BiGRU + MoCo head, 3 optimiser steps (Adam via
-    the reference's make_optimizer rule: bias lr x2, wd 0)."""
+    """Tiny visual encoder + small BiGRU + MoCo head, 3 optimiser steps with the reference's
+    make_optimizer rule (SOLVER.OPTIMIZER "SGD", momentum 0.9, bias lr x2 / wd 0; lib/solver/build.py:6-23).
+    SGD, not Adam: Adam's first steps are lr*sign(g), which turns rounding noise on near-zero gradients
+    into full-size parameter differences; the fused Adam kernel has its own test against torch.optim.Adam.
+    ``margin`` fill style (oracle/fill.py) so that every stored quantity of the fp32 reference is within
+    3e-4 of an fp64 evaluation (asserted) and the GPU test can hold a flat 1e-3."""
     print("[head]")
     spec = OV.TINY
     hidden, embed, vocab, Lpad = 64, 64, 200, 105
@@ -240,116 +358,97 @@ def gen_head(seed=5, steps=3):
     sd = head.state_dict()
     shapes = OH.state_shapes(spec, K, C, NC, hidden, embed)
     assert {k: tuple(v.shape) for k, v in sd.items()} == {k: tuple(s) for k, s in shapes.items()}, "head state mismatch"
-    filled = OF.fill_state(sd, seed, "head.")
-    st = {k: v.clone() for k, v in filled.items()}
-    OH.init_queues(st, seed)
+    filled = OF.fill_state(sd, seed, "head.", style="margin")
+    st0 = {k: v.clone() for k, v in filled.items()}
+    OH.init_queues(st0, seed)
     for k in ("t_queue", "v_queue", "id_queue", "queue_ptr"):
-        filled[k] = st[k].clone()
+        filled[k] = st0[k].clone()
     head.load_state_dict(filled)
     head.train()
+    opt = torch.optim.SGD(head_groups(head.named_parameters()), lr=HEAD_LR, momentum=HEAD_MOMENTUM)
 
-    # reference optimiser rule (lib/solver/build.py:6-25)
-    groups = []
-    for k, p in head.named_parameters():
-        if not p.requires_grad:
-            continue
-        lr, wd = 1e-3, 4e-5
-        if "bias" in k:
-            lr, wd = 2e-3, 0.0
-        groups.append({"params": [p], "lr": lr, "weight_decay": wd})
-    opt = torch.optim.Adam(groups, lr=1e-3, betas=(0.9, 0.999), eps=1e-8)
-
-    tr = OH.trainable_names(st)
-    for k in tr:
-        st[k].requires_grad_(True)
-    ogroups = []
-    for k in tr:
-        lr, wd = (2e-3, 0.0) if "bias" in k else (1e-3, 4e-5)
-        ogroups.append({"params": [st[k]], "lr": lr, "weight_decay": wd})
-    oopt = torch.optim.Adam(ogroups, lr=1e-3, betas=(0.9, 0.999), eps=1e-8)
-
-    out = {"dims": np.array([hidden, embed, vocab, Lpad, C, K, NC, B, seed, steps]), "m": np.array(0.9)}
+    out = {"dims": np.array([hidden, embed, vocab, Lpad, C, K, NC, B, seed, steps]), "m": np.array(0.9),
+           "sgd": np.array([HEAD_LR, HEAD_MOMENTUM, HEAD_WD])}
     for s in range(steps):
-        x = OF.randn("img:head%d" % s, (B, 3, spec.height, spec.in_width), seed)
-        lens = [int(v) for v in OF.randint("len:head%d" % s, 3, 30, (B,), seed)]
-        tok, ln = synth_tokens("tok:head%d" % s, B, lens, vocab, Lpad, seed)
-        # ids: duplicates inside the batch, and from step 1 on, hits in the queue
-        ids = torch.tensor([10 * s + (i // 2) for i in range(B)], dtype=torch.int64)
-        if s > 0:
-            ids[0] = 10 * (s - 1)  # equals an id already enqueued -> filtered column
-        caps = make_captions(tok, ln, ids)
-        ld = head(x, caps)
-        loss = sum(ld.values())
+        x, tok, ln, ids = head_step_inputs(s, spec, B, vocab, Lpad, seed)
+        ld = head(x, make_captions(tok, ln, ids))
         opt.zero_grad()
-        loss.backward()
+        sum(ld.values()).backward()
         if s == 0:
-            g0 = {k: p.grad.clone() for k, p in head.named_parameters() if p.grad is not None}
+            for k, p in head.named_parameters():
+                if p.grad is not None:
+                    out["gdig0:" + k] = digest("grad0:" + k, p.grad)
+            for k in ("v_embed_layer.weight", "loss_evaluator.projection", "t_encoder_q.gru.weight_hh_l0", "v_encoder_q.conv1.weight",
+                      "v_encoder_q.layer2.0.conv2.weight", "v_encoder_q.attnpool.q_proj.weight"):
+                out["grad0:" + k] = dict(head.named_parameters())[k].grad.numpy().copy()
         opt.step()
-
-        old = OH.train_forward(st, spec, table, x, tok, ln, ids, m=0.9, epsilon=0.1)
-        oloss = sum(old.values())
-        oopt.zero_grad()
-        oloss.backward()
-        if s == 0:
-            for k in ("v_embed_layer.weight", "loss_evaluator.projection", "t_encoder_q.gru.weight_hh_l0", "v_encoder_q.conv1.weight", "v_encoder_q.attnpool.q_proj.weight"):
-                check("step0 grad " + k, st[k].grad, g0[k], 2e-4)
-                out["grad0:" + k] = g0[k].numpy()
-        oopt.step()
         for k in ld:
-            check("step%d %s" % (s, k), old[k], ld[k], 1e-4)
             out["loss%d:%s" % (s, k)] = ld[k].detach().numpy()
-        out["images%d" % s] = x.numpy()
-        out["tokens%d" % s] = tok.numpy()
-        out["lengths%d" % s] = ln.numpy()
-        out["ids%d" % s] = ids.numpy()
+        out["images%d" % s], out["tokens%d" % s], out["lengths%d" % s], out["ids%d" % s] = x.numpy(), tok.numpy(), ln.numpy(), ids.numpy()
     sd2 = head.state_dict()
+    for k, v in sd2.items():  # the WHOLE state after 3 steps: parameters, key encoders, BN statistics, queues
+        if v.dtype.is_floating_point:
+            out["fdig:" + k] = digest("final:" + k, v)
     for k in ("v_queue", "t_queue", "id_queue", "queue_ptr", "v_encoder_k.conv1.weight", "t_encoder_k.gru.weight_ih_l0", "v_encoder_k.bn1.running_mean", "v_embed_layer.weight"):
-        check("final " + k, st[k].float(), sd2[k].float(), 2e-4)
         out["final:" + k] = sd2[k].numpy()
-    # eval path (head.py:178-183)
-    head.eval()
+    head.eval()  # eval path (head.py:178-183)
     with torch.no_grad():
-        ev = head(x, caps)
-    eo = OH.eval_forward(st, spec, table, x, tok, ln)
-    check("eval v", eo[0], ev[0], 2e-4)
-    check("eval t", eo[1], ev[1], 2e-4)
+        ev = head(x, make_captions(tok, ln, ids))
     out["eval_v"], out["eval_t"] = ev[0].numpy(), ev[1].numpy()
 
-    # fp64 oracle trajectory = "truth" for the noise-aware GPU criterion
-    t64 = head_truth(out, filled, spec, table, (hidden, embed, vocab, Lpad, C, K, NC, B, seed, steps), 0.9)
-    for k, v in t64.items():
-        out["truth:" + k] = v
-        if k in out:
-            print("  noise(ref fp32 vs fp64) %-40s %.1e" % (k, rel(torch.from_numpy(np.asarray(out[k])).double(), torch.from_numpy(v))))
+    # the same trajectory on the oracle: fp32 must reproduce the reference, fp64 measures the conditioning
+    for dt in (torch.float32, torch.float64):
+        res = head_oracle(out, filled, spec, table, dt)
+        errs = {}
+        gfl = grad_floor([v for k, v in out.items() if k.startswith("gdig0:")])
+        for k, v in res.items():
+            ref = out[k]
+            if k.startswith("gdig0:"):
+                errs[k] = digest_err(v, ref, gfl)
+            elif k.startswith("fdig:"):
+                errs[k] = digest_err(v, ref)
+            elif k.startswith("grad0:"):
+                errs[k] = float(np.abs(np.asarray(v, dtype=np.float64) - ref).max() / max(np.abs(ref).max(), gfl))
+            else:
+                errs[k] = rel(torch.as_tensor(v), torch.as_tensor(ref))
+        top = sorted(errs.items(), key=lambda kv: -kv[1])[:4]
+        if dt == torch.float32:
+            print("  oracle fp32 vs reference: worst", [(k, "%.1e" % v) for k, v in top])
+            assert top[0][1] < 1e-4, top
+        else:
+            print("  reference fp32 vs fp64 truth (conditioning): worst", [(k, "%.1e" % v) for k, v in top])
+            assert top[0][1] < 3e-4, ("fixture is not well-conditioned", top)
+            out["conditioning"] = np.array(top[0][1])
     np.savez_compressed(os.path.join(HERE, "head.npz"), **f32(out))
 
 
-def head_truth(out, filled, spec, table, dims, m):
-    hidden, embed, vocab, Lpad, C, K, NC, B, seed, steps = dims
-    dt = torch.float64
+def head_oracle(out, filled, spec, table, dt):
+    """The head fixture's trajectory on the oracle in precision ``dt``; returns the same keys."""
+    hidden, embed, vocab, Lpad, C, K, NC, B, seed, steps = (int(v) for v in out["dims"])
     st = {k: (v.clone().to(dt) if v.dtype.is_floating_point else v.clone()) for k, v in filled.items()}
     tr = OH.trainable_names(st)
-    groups = []
     for k in tr:
         st[k].requires_grad_(True)
-        lr, wd = (2e-3, 0.0) if "bias" in k else (1e-3, 4e-5)
-        groups.append({"params": [st[k]], "lr": lr, "weight_decay": wd})
-    opt = torch.optim.Adam(groups, lr=1e-3, betas=(0.9, 0.999), eps=1e-8)
+    opt = torch.optim.SGD(head_groups([(k, st[k]) for k in tr]), lr=HEAD_LR, momentum=HEAD_MOMENTUM)
     res = {}
     for s in range(steps):
         x, tok, ln, ids = (torch.from_numpy(out["%s%d" % (k, s)]) for k in ("images", "tokens", "lengths", "ids"))
-        ld = OH.train_forward(st, spec, table.to(dt), x.to(dt), tok, ln, ids, m=m, epsilon=0.1)
+        ld = OH.train_forward(st, spec, table.to(dt), x.to(dt), tok, ln, ids, m=0.9, epsilon=0.1)
         opt.zero_grad()
         sum(ld.values()).backward()
         if s == 0:
             for k in out:
-                if k.startswith("grad0:"):
+                if k.startswith("gdig0:"):
+                    res[k] = digest("grad0:" + k[6:], st[k[6:]].grad)
+                elif k.startswith("grad0:"):
                     res[k] = st[k[6:]].grad.numpy().copy()
         opt.step()
         for k in ld:
             res["loss%d:%s" % (s, k)] = ld[k].detach().numpy()
     for k in out:
-        if k.startswith("final:") and st[k[6:]].dtype.is_floating_point:
+        if k.startswith("fdig:"):
+            res[k] = digest("final:" + k[5:], st[k[5:]])
+        elif k.startswith("final:") and st[k[6:]].dtype.is_floating_point:
             res[k] = st[k[6:]].detach().numpy().copy()
     ev = OH.eval_forward(st, spec, table.to(dt), x.to(dt), tok, ln)
     res["eval_v"], res["eval_t"] = ev[0].numpy(), ev[1].numpy()
@@ -453,7 +552,7 @@ if __name__ == "__main__":
     if "head" in which:
         gen_head()
     if "rn50" in which:
-        gen_visual("rn50", OV.RN50, 2, 2, grads=("bn1.weight", "layer4.2.bn3.bias", "attnpool.c_proj.bias"))
+        gen_visual_full("rn50", OV.RN50, 8, 2)
     if "rn101" in which:
-        gen_visual("rn101", OV.RN101, 2, 2, grads=("bn1.weight", "attnpool.c_proj.bias"))
+        gen_visual_full("rn101", OV.RN101, 8, 2)
     print("done")

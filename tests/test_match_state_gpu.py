@@ -157,6 +157,39 @@ def test_topk_full_size_properties(gpu):
     assert bool(((full > kth[:8] + 1e-6).sum(1) <= 9).all())
 
 
+def test_config4_full_gallery_one_gpu(gpu):
+    """configs[4] at full size on ONE GPU: Q = 1e4 text queries x G = 1e6 gallery images (1 GB of fp32
+    embeddings), fused similarity + top-10.  Index-exact against a dense CPU product for 64 spot rows
+    (near-ties, |gap| < 2e-6, may swap: then the VALUES must agree); size-independent properties for
+    all 1e4 rows: sorted, indices valid and distinct, every value equals the recomputed dot product."""
+    from textreid_amd.evaluation import similarity_topk
+
+    Q, G, C, k = 10000, 1000000, 256, 10
+    gen = torch.Generator(device="cpu").manual_seed(7)
+    qc = torch.nn.functional.normalize(torch.randn(Q, C, generator=gen), dim=1)
+    gc = torch.nn.functional.normalize(torch.randn(G, C, generator=gen), dim=1)
+    q, gal = qc.to(gpu), gc.to(gpu)
+    vals, idx = similarity_topk(q, gal, k, normalize=False)
+    assert bool((vals[:, :-1] >= vals[:, 1:]).all())
+    assert int(idx.min()) >= 0 and int(idx.max()) < G
+    srt = torch.sort(idx, dim=1).values
+    assert bool((srt[:, 1:] != srt[:, :-1]).all())  # distinct per row
+    re = torch.empty_like(vals)
+    for r0 in range(0, Q, 1000):  # recomputed dot products, chunked (torch only as checker)
+        re[r0:r0 + 1000] = (q[r0:r0 + 1000, None, :] * gal[idx[r0:r0 + 1000]]).sum(-1)
+    assert torch.allclose(re, vals, atol=2e-6)
+    rows = torch.randperm(Q, generator=gen)[:64]
+    dense = qc[rows] @ gc.t()  # CPU fp32, 64 x 1e6
+    rv, ri = torch.topk(dense, k, dim=1)
+    gv, gi = vals[rows.to(gpu)].cpu(), idx[rows.to(gpu)].cpu()
+    assert torch.allclose(gv, rv, atol=2e-6)
+    diff = gi != ri
+    if bool(diff.any()):  # only near-ties may differ in order
+        assert bool(((gv - rv).abs()[diff] < 2e-6).all())
+        assert bool((dense.gather(1, gi)[diff] - rv[diff]).abs().max() < 2e-6)
+    assert float(diff.float().mean()) < 0.01
+
+
 def test_fused_adam_matches_torch_adam(gpu):
     from textreid_amd.solver import FusedAdam
 

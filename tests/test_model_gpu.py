@@ -38,54 +38,84 @@ def load(golden_dir, name):
     return np.load(os.path.join(golden_dir, name))
 
 
-def noise_aware(errs, name, hip, golden, truth, floor=TOL):
-    """HIP must be as close to the fp64 truth as the reference's own fp32 result is
-    (x3), and within `floor` when the problem is well-conditioned."""
-    ref_noise = rel(golden, truth)
-    errs[name] = (rel(hip, truth), max(floor, 3.0 * ref_noise))
-
-
-def fill_module(mod, seed, prefix=""):
-    mod.load_state_dict(OF.fill_state(mod.state_dict(), seed, prefix))
+def fill_module(mod, seed, prefix="", style="he"):
+    mod.load_state_dict(OF.fill_state(mod.state_dict(), seed, prefix, style=style))
     return mod
 
 
-@pytest.mark.parametrize("tag,spec", [("tiny", OV.TINY), ("rn50", OV.RN50), ("rn101", OV.RN101)])
-def test_visual_encoder(gpu, golden_dir, tag, spec):
+def test_visual_encoder_tiny(gpu, golden_dir):
+    """Tiny encoder, He-style random weights (unstructured ReLU masks): train forward, eleven
+    gradients, BatchNorm statistics, eval cold and warm against the reference-captured vectors, flat 1e-3."""
     from textreid_amd.backbones.m_resnet import ModifiedResNet
 
+    tag, spec = "tiny", OV.TINY
     g = load(golden_dir, "visual_%s.npz" % tag)
     B, seed = int(g["spec"][-2]), int(g["spec"][-1])
     m = ModifiedResNet(list(spec.layers), spec.output_dim, spec.heads, spec.last_stride, (spec.height, spec.in_width), spec.width)
     fill_module(m, seed).to(gpu).train()
     x = OF.randn("img:" + tag, (B, 3, spec.height, spec.in_width), seed).to(gpu)
     y = m(x)
-    errs = {}
-    noise_aware(errs, "out_train", y, g["out_train"], g["truth:out_train"])
+    errs = {"out_train": rel(y, g["out_train"])}
     (y * OF.randn("gout:" + tag, tuple(y.shape), seed).to(gpu)).sum().backward()
     named = dict(m.named_parameters())
     for k in g.files:
         if k.startswith("grad:"):
-            noise_aware(errs, k, named[k[5:]].grad, g[k], g["truth:" + k])
+            errs[k] = rel(named[k[5:]].grad, g[k])
     sd = m.state_dict()
-    errs["bn1.running_mean"] = (rel(sd["bn1.running_mean"], g["bn1_running_mean"]), 1e-5)
-    errs["bn1.running_var"] = (rel(sd["bn1.running_var"], g["bn1_running_var"]), 1e-5)
+    errs["bn1.running_mean"] = rel(sd["bn1.running_mean"], g["bn1_running_mean"])
+    errs["bn1.running_var"] = rel(sd["bn1.running_var"], g["bn1_running_var"])
     last = [k for k in sd if k.endswith("bn3.running_var")][-1]
-    errs["last.running_var"] = (rel(sd[last], g["last_running_var"]), TOL)
+    errs["last.running_var"] = rel(sd[last], g["last_running_var"])
     assert int(sd["bn1.num_batches_tracked"]) == 1
     with torch.no_grad():
         m.eval()
-        # cold running statistics make the random-weight net explode (|act| ~ 1e6 for RN101) and the
-        # saturated attention softmax chaotic: only a loose bound there, the warm check is the tight one
-        errs["out_eval_cold"] = (rel(m(x), g["out_eval"]), TOL if tag == "tiny" else 5e-2)
+        errs["out_eval_cold"] = rel(m(x), g["out_eval"])
         m.train()
         for _ in range(25):
             m(x)
         m.eval()
-        noise_aware(errs, "out_eval_warm", m(x), g["out_eval_warm"], g["truth:out_eval_warm"])
-    print(tag, {k: "%.1e/%.0e" % v for k, v in errs.items()})
-    bad = {k: v for k, v in errs.items() if not v[0] <= v[1]}
+        errs["out_eval_warm"] = rel(m(x), g["out_eval_warm"])
+    print(tag, {k: "%.1e" % v for k, v in errs.items()})
+    bad = {k: v for k, v in errs.items() if not v <= TOL}
     assert not bad, bad
+
+
+@pytest.mark.parametrize("tag,spec", [("rn50", OV.RN50), ("rn101", OV.RN101)])
+def test_visual_encoder_full_size(gpu, golden_dir, tag, spec):
+    """CLIP-RN50 / RN101 at 384x128, B=8, against the reference-captured fixture, FLAT 1e-3 on every
+    quantity: train output, ALL parameter gradients (digest of each + strided samples of 11 filter
+    gradients, trunk included), every stage's activation digest, every BatchNorm running statistic, eval
+    output with cold and with warm running statistics.  The fixture's weights use the `margin` fill style
+    (oracle/fill.py): the reference's own fp32 result is within 1e-4 of fp64 on all of these."""
+    from fixture_check import assert_within, visual_full_errors
+    from textreid_amd.backbones.m_resnet import ModifiedResNet
+
+    g = load(golden_dir, "visual_%s.npz" % tag)
+    B, seed = int(g["spec"][-2]), int(g["spec"][-1])
+    m = ModifiedResNet(list(spec.layers), spec.output_dim, spec.heads, spec.last_stride, (spec.height, spec.in_width), spec.width)
+    fill_module(m, seed, style="margin").to(gpu).train()
+    x = OF.randn("img:" + tag, (B, 3, spec.height, spec.in_width), seed).to(gpu)
+    m._debug_taps = {}
+    y = m(x)
+    taps = {k: v.permute(0, 3, 1, 2) for k, v in m._debug_taps.items()}
+    m._debug_taps = None
+    (y * OF.randn("gout:" + tag, tuple(y.shape), seed).to(gpu)).sum().backward()
+    named = dict(m.named_parameters())
+    sd = m.state_dict()
+    assert int(sd["bn1.num_batches_tracked"]) == 1
+    errs = visual_full_errors(g, y, lambda k: named[k].grad, taps, sd)
+    del taps
+    with torch.no_grad():
+        m.eval()
+        errs["out_eval_cold"] = rel(m(x), g["out_eval"])
+        m.train()
+        for _ in range(25):
+            m(x)
+        m.eval()
+        errs["out_eval_warm"] = rel(m(x), g["out_eval_warm"])
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+    print(tag, len(errs), "quantities; worst:", [(k, "%.1e" % v) for k, v in worst])
+    assert_within(errs, TOL)
 
 
 @pytest.mark.parametrize("spec", [
@@ -222,9 +252,11 @@ def ns(**kw):
 
 
 def test_moco_head_three_steps(gpu, golden_dir):
-    """Tiny encoders + MoCo head, three Adam steps: losses per step, step-0
-    gradients, final queues / pointer / key params / BN stats, eval embeddings
-    -- all against the reference-captured golden vectors."""
+    """Tiny encoders + MoCo head, three optimiser steps (the reference's make_optimizer rule with
+    SOLVER.OPTIMIZER "SGD"): losses per step, EVERY step-0 gradient, the ENTIRE state after the last step
+    (parameters, key encoders, BatchNorm statistics, queues; ids / pointer bit-exact) and the eval
+    embeddings against the reference-captured trajectory, flat 1e-3."""
+    from fixture_check import assert_within, head_errors
     from textreid_amd.backbones.gru import GRU
     from textreid_amd.backbones.m_resnet import ModifiedResNet
     from textreid_amd.caption import CaptionBatch
@@ -232,6 +264,7 @@ def test_moco_head_three_steps(gpu, golden_dir):
 
     g = load(golden_dir, "head.npz")
     hidden, embed, vocab, Lpad, C, K, NC, B, seed, steps = (int(v) for v in g["dims"])
+    lr, mom, wd = (float(v) for v in g["sgd"])
     spec = OV.TINY
     table = OF.randn("vocab_table_head", (vocab, embed), seed, 0.5)
     vis = ModifiedResNet(list(spec.layers), spec.output_dim, spec.heads, spec.last_stride, (spec.height, spec.in_width), spec.width)
@@ -239,20 +272,16 @@ def test_moco_head_three_steps(gpu, golden_dir):
     cfg = ns(MODEL=ns(EMBEDDING=ns(FEATURE_SIZE=C, EPSILON=0.1), MOCO=ns(K=K, M=float(g["m"]), FC=False), NUM_CLASSES=NC))
     head = MoCoHead(cfg, vis, txt)
     sd = head.state_dict()
-    filled = OF.fill_state(sd, seed, "head.")
+    filled = OF.fill_state(sd, seed, "head.", style="margin")
     st = {k: torch.zeros(tuple(s), dtype=torch.int64) if k in ("id_queue", "queue_ptr") else torch.zeros(tuple(s)) for k, s in OH.state_shapes(spec, K, C, NC, hidden, embed).items() if k in ("t_queue", "v_queue", "id_queue", "queue_ptr")}
     OH.init_queues(st, seed)
     filled.update(st)
     head.load_state_dict(filled)
     head.to(gpu).train()
-    groups = []
-    for k, p in head.named_parameters():
-        if not p.requires_grad:
-            continue
-        lr, wd = (2e-3, 0.0) if "bias" in k else (1e-3, 4e-5)
-        groups.append({"params": [p], "lr": lr, "weight_decay": wd})
-    opt = torch.optim.Adam(groups, lr=1e-3, betas=(0.9, 0.999), eps=1e-8)
-    errs = {}
+    groups = [{"params": [p], "lr": 2 * lr if "bias" in k else lr, "weight_decay": 0.0 if "bias" in k else wd}
+              for k, p in head.named_parameters() if p.requires_grad]
+    opt = torch.optim.SGD(groups, lr=lr, momentum=mom)
+    losses, g0 = {}, {}
     for s in range(steps):
         x, tok, ln, ids = (torch.from_numpy(g["%s%d" % (k, s)]).to(gpu) for k in ("images", "tokens", "lengths", "ids"))
         cb = CaptionBatch(tok, ln, ids)
@@ -260,79 +289,115 @@ def test_moco_head_three_steps(gpu, golden_dir):
         opt.zero_grad()
         sum(ld.values()).backward()
         if s == 0:
-            named = dict(head.named_parameters())
-            for k in g.files:
-                if k.startswith("grad0:"):
-                    noise_aware(errs, k, named[k[6:]].grad, g[k], g["truth:" + k])
+            g0 = {k: p.grad.clone() for k, p in head.named_parameters() if p.grad is not None}
         opt.step()
         for k in ld:
-            kk = "loss%d:%s" % (s, k)
-            noise_aware(errs, kk, ld[k], g[kk], g["truth:" + kk])
+            losses["loss%d:%s" % (s, k)] = ld[k].detach()
     sd2 = head.state_dict()
-    for k in g.files:
-        if k.startswith("final:"):
-            if "truth:" + k in g.files:
-                noise_aware(errs, k, sd2[k[6:]].float(), g[k].astype(np.float32), g["truth:" + k])
-            else:  # integer state: ids, pointer -- bit exact
-                errs[k] = (float((sd2[k[6:]].cpu() != torch.from_numpy(g[k])).sum()), 0.0)
     head.eval()
     with torch.no_grad():
         ev = head(x, cb)
-    noise_aware(errs, "eval_v", ev[0], g["eval_v"], g["truth:eval_v"])
-    noise_aware(errs, "eval_t", ev[1], g["eval_t"], g["truth:eval_t"])
-    print({k: "%.1e/%.0e" % v for k, v in errs.items()})
-    bad = {k: v for k, v in errs.items() if not v[0] <= v[1]}
-    assert not bad, bad
+    errs = head_errors(g, losses, lambda k: g0[k], sd2, ev)
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+    print(len(errs), "quantities; worst:", [(k, "%.1e" % v) for k, v in worst])
+    assert_within(errs, TOL)
 
 
-def test_full_size_step_vs_oracle(gpu):
-    """configs[0]/[1] shapes (CLIP-RN50 + BiGRU, 384x128, 64-token captions padded to 105) at a
-    batch the CPU oracle finishes in seconds: the three losses, embedding-layer / projection /
-    GRU gradients, queue push and EMA against the oracle on the same seeded inputs."""
+def _full_step_vs_oracle(gpu, arch, spec, B, K, vocab, seed):
+    """One MoCo train step of the full-size model on the HIP path and on the CPU oracle from the same
+    `margin`-style state and seeded batch.  Returns {name: relative error} over the three losses, EVERY
+    trainable gradient (full tensors, against max(max|ref|, gradient floor)), both queues, every
+    momentum-updated key parameter and every BatchNorm running statistic of all four encoders."""
     import bench
     from textreid_amd.caption import CaptionBatch
     from textreid_amd.config import moco_cfg
     from textreid_amd.model import build_model
 
-    B, K, vocab = 16, 64, 3000
     torch.manual_seed(0)
-    cfg = moco_cfg("m_resnet50", K=K)
+    cfg = moco_cfg(arch, K=K)
     table = torch.randn(vocab, 512) * 0.02
     model = build_model(cfg, vocab_dict=table)
     head = model.embed_model
-    sd = head.state_dict()
-    filled = OF.fill_state(sd, 21, "full.")
+    filled = OF.fill_state(head.state_dict(), seed, "full.", style="margin")
     st = {k: v.clone() for k, v in filled.items()}
-    OH.init_queues(st, 21)
+    OH.init_queues(st, seed)
     for k in ("t_queue", "v_queue", "id_queue", "queue_ptr"):
         filled[k] = st[k].clone()
     head.load_state_dict(filled)
     model.to(gpu).train()
     images, tokens, lengths, ids = bench.synth_batch(B, 0, "cpu", 5, vocab=vocab)
-    lengths = torch.tensor([64, 40, 64, 9, 33, 64, 12, 64, 50, 64, 21, 64, 64, 7, 64, 30])
+    lengths = torch.tensor(([64, 40, 64, 9, 33, 64, 12, 64, 50, 64, 21, 64, 64, 7, 64, 30] * ((B + 15) // 16))[:B])
     for i, n in enumerate(lengths.tolist()):
         tokens[i, n:] = 0
     ld = model(images.to(gpu), CaptionBatch(tokens.to(gpu), lengths.to(gpu), ids.to(gpu)))
     sum(ld.values()).backward()
-    for k in OH.trainable_names(st):
+    tr = OH.trainable_names(st)
+    for k in tr:
         st[k].requires_grad_(True)
     key0 = st["v_encoder_k.layer3.2.conv2.weight"].clone()
-    old = OH.train_forward(st, OV.RN50, table, images, tokens, lengths, ids, m=0.999, epsilon=0.1)
+    old = OH.train_forward(st, spec, table, images, tokens, lengths, ids, m=0.999, epsilon=0.1)
     sum(old.values()).backward()
-    errs = {k: rel(ld[k], old[k]) for k in old}
+    errs = {"loss:" + k: rel(ld[k], old[k]) for k in old}
     named = dict(head.named_parameters())
-    for k in ("v_embed_layer.weight", "t_embed_layer.bias", "loss_evaluator.projection", "t_encoder_q.gru.weight_hh_l0_reverse",
-              "v_encoder_q.attnpool.c_proj.weight"):
-        errs["grad:" + k] = rel(named[k].grad, st[k].grad)
+    gfl = 1e-3 * max(float(st[k].grad.abs().max()) for k in tr)
+    for k in tr:
+        ref = st[k].grad.double()
+        fl = gfl * (10.0 if k.endswith("attnpool.k_proj.bias") else 1.0)  # analytically zero gradient, see fixture_check
+        errs["grad:" + k] = float((named[k].grad.detach().cpu().double() - ref).abs().max() / max(float(ref.abs().max()), fl))
     sd2 = head.state_dict()
-    errs["v_queue"] = rel(sd2["v_queue"], st["v_queue"])
-    errs["t_queue"] = rel(sd2["t_queue"], st["t_queue"])
+    for k, v in st.items():
+        if k.startswith(("v_encoder_k.", "t_encoder_k.")) and v.dtype.is_floating_point or k.endswith(("running_mean", "running_var")) or k in ("v_queue", "t_queue"):
+            errs["state:" + k] = rel(sd2[k], v)
     assert torch.equal(sd2["id_queue"].cpu(), st["id_queue"]) and int(sd2["queue_ptr"]) == int(st["queue_ptr"]) == B % K
-    errs["ema"] = rel(sd2["v_encoder_k.layer3.2.conv2.weight"], st["v_encoder_k.layer3.2.conv2.weight"])
     assert not torch.equal(st["v_encoder_k.layer3.2.conv2.weight"], key0)
-    print({k: "%.1e" % v for k, v in errs.items()})
-    bad = {k: v for k, v in errs.items() if not v < TOL}
-    assert not bad, bad
+    return errs
+
+
+def test_full_size_step_vs_oracle(gpu):
+    """configs[0]/[1] shapes (CLIP-RN50 + BiGRU, 384x128, 64-token captions padded to 105, ragged lengths)
+    at a batch the CPU oracle finishes in seconds: flat 1e-3 on the losses, ALL 183 trainable gradients
+    (trunk conv filters included), queue push, EMA of every key parameter, all BatchNorm statistics."""
+    from fixture_check import assert_within
+
+    errs = _full_step_vs_oracle(gpu, "m_resnet50", OV.RN50, B=16, K=64, vocab=3000, seed=21)
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+    print(len(errs), "quantities; worst:", [(k, "%.1e" % v) for k, v in worst])
+    assert sum(k.startswith("grad:") for k in errs) == 183
+    assert_within(errs, TOL)
+
+
+def test_config3_rn101_k65536_bf16(gpu):
+    """configs[3] on one GPU: CLIP-RN101 + BiGRU, MoCo queue 65536, bf16 arithmetic (TRID_GEMM_PRECISION=1:
+    GEMM operands rounded to bf16, fp32 accumulation and tensors), one train step against the fp32 CPU oracle.
+    This mode is OUTSIDE the fp32 parity contract by construction; the bounds below are what bf16 operand
+    rounding (2^-9 per product, ~100 layers deep) leaves: losses within 2 %, gradients / key parameters /
+    queues within 1e-1 of the tensor maximum (measured: see the printed line; fp32-class default mode: 1e-3).
+    The same step in the default fp32-class arithmetic is held to the flat 1e-3."""
+    from fixture_check import assert_within
+    from textreid_amd import ops
+
+    old = ops.GEMM_PRECISION
+    try:
+        ops.GEMM_PRECISION = 1
+        errs = _full_step_vs_oracle(gpu, "m_resnet101", OV.RN101, B=16, K=65536, vocab=3000, seed=23)
+    finally:
+        ops.GEMM_PRECISION = old
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+    losses = {k: v for k, v in errs.items() if k.startswith("loss:")}
+    print("bf16:", len(errs), "quantities; losses", {k: "%.1e" % v for k, v in losses.items()}, "worst:", [(k, "%.1e" % v) for k, v in worst])
+    assert_within(losses, 2e-2)
+    assert_within({k: v for k, v in errs.items() if not k.startswith("loss:")}, 1e-1)
+
+
+def test_config3_rn101_k65536_fp32_class(gpu):
+    """The configs[3] model and queue size (RN101, K=65536) in the default fp32-class arithmetic: flat 1e-3
+    on losses, all 336 trainable gradients, queues, key parameters, BatchNorm statistics."""
+    from fixture_check import assert_within
+
+    errs = _full_step_vs_oracle(gpu, "m_resnet101", OV.RN101, B=16, K=65536, vocab=3000, seed=23)
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+    print(len(errs), "quantities; worst:", [(k, "%.1e" % v) for k, v in worst])
+    assert_within(errs, TOL)
 
 
 def test_bf16_arithmetic_mode_tracks_fp32(gpu):

@@ -271,6 +271,11 @@ class ModifiedResNet(nn.Module):
         # ---- residual layers (m_resnet.py:54-67)
         if save:
             S["blocks"] = []
+        taps = getattr(self, "_debug_taps", None)  # parity tests: per-stage activations (NHWC), keyed like the oracle's taps
+        if taps is not None:
+            taps["stem"] = x
+            names = {id(blk): "layer%d.%d" % (li + 1, bi) for li, layer in enumerate((self.layer1, self.layer2, self.layer3, self.layer4))
+                     for bi, blk in enumerate(layer)}
         for blk in self.blocks():
             stride = blk.stride
             wa = blk.conv1.weight.view(blk.conv1.out_channels, -1)
@@ -299,8 +304,8 @@ class ModifiedResNet(nn.Module):
                 out, rmask = out  # 1-bit ReLU mask of the block output for the backward pass
                 S["blocks"].append((x, ya, sta, aa, yb, stb, ab, yc, stc, xd, yd, std, rmask))
             x = out
-            if getattr(self, "_debug_taps", None) is not None:
-                self._debug_taps[len(self._debug_taps)] = out
+            if taps is not None:
+                taps[names[id(blk)]] = out
         if nbt:
             torch._foreach_add_(nbt, 1)  # one launch instead of one per BatchNorm layer
         # ---- attention pool (m_resnet.py:103-135), token-0 query only
