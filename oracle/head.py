@@ -93,8 +93,8 @@ def momentum_update(state, m):
         state[kn] = state[kn] * m + state[qn].detach() * (1.0 - m)
 
 
-def encode(state, which, spec, table, images, tokens, lengths, training):
-    v = V.visual_forward(_Sub(state, "v_encoder_" + which), images, spec, training)
+def encode(state, which, spec, table, images, tokens, lengths, training, vtaps=None):
+    v = V.visual_forward(_Sub(state, "v_encoder_" + which), images, spec, training, vtaps)
     t = T.text_forward(sub(state, "t_encoder_" + which), table, tokens, lengths)
     return v, t
 
@@ -147,7 +147,8 @@ def train_forward(state, spec, table, images, tokens, lengths, ids, m=0.999, eps
     reference module mutates itself (BN running stats of all four encoders, key
     parameters, queues, pointer).  Returns the loss dict."""
     id_q = ids.long()
-    v_feat, t_feat = encode(state, "q", spec, table, images, tokens, lengths, True)
+    vtaps = taps.setdefault("visual_q", {}) if taps is not None else None  # per-stage taps + ReLU margin of the query encoder
+    v_feat, t_feat = encode(state, "q", spec, table, images, tokens, lengths, True, vtaps)
     v_embed, t_embed = embed_pair(state, v_feat, t_feat)
     v_q, t_q = F.normalize(v_embed, dim=1), F.normalize(t_embed, dim=1)
     with torch.no_grad():

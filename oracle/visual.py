@@ -97,6 +97,14 @@ def is_param(name):
     return leaf not in ("running_mean", "running_var", "num_batches_tracked")
 
 
+def _relu(x, taps):
+    """F.relu; with a taps dict also tracks the smallest |pre-activation| seen ("relu_min"): the
+    fixtures' ReLU decision margin (tests/golden/make_golden.py keeps it far above fp32 rounding)."""
+    if taps is not None:
+        taps["relu_min"] = min(taps.get("relu_min", float("inf")), float(x.detach().abs().min()))
+    return F.relu(x)
+
+
 def _bn(st, p, x, training):
     # nn.BatchNorm2d: batch stats + running update (momentum 0.1, unbiased var)
     # when training, running stats when not.  m_resnet.py:19,22,27,49,164-170
@@ -109,8 +117,8 @@ def _bn(st, p, x, training):
 
 def bottleneck(st, p, x, stride, has_down, training, taps=None):
     # m_resnet.py:54-67
-    out = F.relu(_bn(st, p + ".bn1", F.conv2d(x, st[p + ".conv1.weight"]), training))
-    out = F.relu(_bn(st, p + ".bn2", F.conv2d(out, st[p + ".conv2.weight"], padding=1), training))
+    out = _relu(_bn(st, p + ".bn1", F.conv2d(x, st[p + ".conv1.weight"]), training), taps)
+    out = _relu(_bn(st, p + ".bn2", F.conv2d(out, st[p + ".conv2.weight"], padding=1), training), taps)
     if stride > 1:
         out = F.avg_pool2d(out, stride)
     out = _bn(st, p + ".bn3", F.conv2d(out, st[p + ".conv3.weight"]), training)
@@ -119,7 +127,7 @@ def bottleneck(st, p, x, stride, has_down, training, taps=None):
         if stride > 1:
             idn = F.avg_pool2d(idn, stride)
         idn = _bn(st, p + ".downsample.1", F.conv2d(idn, st[p + ".downsample.0.weight"]), training)
-    return F.relu(out + idn)
+    return _relu(out + idn, taps)
 
 
 def attention_pool(st, x, heads):
@@ -149,15 +157,15 @@ def visual_forward(st, images, spec, training, taps=None):
     running stats) when training, as nn.BatchNorm2d does.  ``taps`` (dict)
     optionally collects per-stage activations for the parity tests."""
     x = images.to(st["conv1.weight"].dtype)  # m_resnet.py:209
-    x = F.relu(_bn(st, "bn1", F.conv2d(x, st["conv1.weight"], stride=2, padding=1), training))
-    x = F.relu(_bn(st, "bn2", F.conv2d(x, st["conv2.weight"], padding=1), training))
-    x = F.relu(_bn(st, "bn3", F.conv2d(x, st["conv3.weight"], padding=1), training))
+    x = _relu(_bn(st, "bn1", F.conv2d(x, st["conv1.weight"], stride=2, padding=1), training), taps)
+    x = _relu(_bn(st, "bn2", F.conv2d(x, st["conv2.weight"], padding=1), training), taps)
+    x = _relu(_bn(st, "bn3", F.conv2d(x, st["conv3.weight"], padding=1), training), taps)
     x = F.avg_pool2d(x, 2)
     if taps is not None:
         taps["stem"] = x
     for p, inpl, planes, stride in block_plan(spec):
         has_down = stride > 1 or inpl != planes * 4
-        x = bottleneck(st, p, x, stride, has_down, training)
+        x = bottleneck(st, p, x, stride, has_down, training, taps)
         if taps is not None:
             taps[p] = x
     out = attention_pool(st, x, spec.heads)

@@ -279,3 +279,48 @@ def test_abi_argument_errors_are_reported_not_fatal(ops):
     # the library is still healthy afterwards
     assert rel(ops.linear(x, w), x.cpu() @ w.cpu().t()) < 2e-5
 
+
+
+@pytest.mark.parametrize("B,K,wgs,prec", [(128, 8192, 0, 6), (5, 64, 0, 6), (130, 96, 0, 6), (128, 2048, 3, 6), (33, 65536, 0, 6), (128, 8192, 0, 1)])
+def test_fused_queue_infonce(ops, B, K, wgs, prec):
+    """queue_nce.hip - ONE pass over both [K,256] queues: similarity, batch-wide negative filter, InfoNCE and
+    dL/dq - against the oracle's materialised form (head.py:148-170 + losses.py:206-217) evaluated in fp64.
+    Edge cases: fewer queries than a wave tile, a ragged second query block, hits in the queue and duplicate
+    ids in the batch, a workgroup count that does not divide the tiles, K = 65536; bf16-operand mode (prec 1).
+    fp32-class bound: loss 1e-5, gradient 1e-4 of its maximum (measured ~1e-6 / ~3e-6)."""
+    import oracle.head as OH
+    import oracle.losses as OL
+    from textreid_amd import losses as L
+
+    C, T = 256, 0.07
+    nrm = lambda t: F.normalize(t, dim=1)
+    vq, tq, vk, tk = (nrm(R("qn:%s%d" % (n, B), B, C)) for n in ("vq", "tq", "vk", "tk"))
+    tqueue, vqueue = nrm(R("qn:tqueue%d" % K, K, C)), nrm(R("qn:vqueue%d" % K, K, C))
+    vk = nrm(vk + 0.7 * tq)  # realistic positives: the positive logit is not negligible against the negatives
+    tk = nrm(tk + 0.7 * vq)
+    ids = OF.randint("qn:ids", 0, max(2, B // 3), (B,), 0)  # duplicates inside the batch
+    idq = OF.randint("qn:idq", 0, 4 * K, (1, K), 1) + B  # mostly misses ...
+    idq[0, ::7] = ids[0]  # ... plus hits: every 7th column carries an id of the batch -> filtered
+    idq[0, 3] = ids[B - 1]
+    st = {"id_queue": idq, "t_queue": tqueue.t().double(), "v_queue": vqueue.t().double()}
+    a = [x.double().clone().requires_grad_(True) for x in (vq, tq)]
+    vp, vn, tp, tn = OH.contrast_logits(st, a[0], a[1], vk.double(), tk.double(), ids)
+    ref = OL.infonce_loss(vp, vn, tp, tn, T)
+    (ref * 3.0).backward()
+    old = (ops.GEMM_PRECISION, L.QUEUE_NCE_WGS, L.FUSED_QUEUE_NCE)
+    try:
+        ops.GEMM_PRECISION, L.QUEUE_NCE_WGS, L.FUSED_QUEUE_NCE = prec, wgs, True
+        g = [dev(x).requires_grad_(True) for x in (vq, tq)]
+        out = L.queue_infonce_loss(g[0], g[1], dev(vk), dev(tk), dev(ids), dev(tqueue), dev(vqueue), dev(idq), T)
+        (out * 3.0).backward()
+        out2 = L.queue_infonce_loss(dev(vq), dev(tq), dev(vk), dev(tk), dev(ids), dev(tqueue), dev(vqueue), dev(idq), T)
+        L.FUSED_QUEUE_NCE = False  # the GEMM + row-kernel form must agree with the fused one
+        out3 = L.queue_infonce_loss(dev(vq), dev(tq), dev(vk), dev(tk), dev(ids), dev(tqueue), dev(vqueue), dev(idq), T)
+    finally:
+        ops.GEMM_PRECISION, L.QUEUE_NCE_WGS, L.FUSED_QUEUE_NCE = old
+    tol_l, tol_g = (1e-5, 1e-4) if prec == 6 else (2e-3, 2e-2)
+    e = (rel(out, ref), rel(g[0].grad, a[0].grad), rel(g[1].grad, a[1].grad))
+    print("fused queue InfoNCE B=%d K=%d prec=%d: loss %.1e grads %.1e %.1e" % ((B, K, prec) + e))
+    assert e[0] < tol_l and e[1] < tol_g and e[2] < tol_g, e
+    assert torch.equal(out, out2)  # bit-reproducible (fixed-order fold of the partials, no atomics)
+    assert rel(out3, ref) < tol_l

@@ -303,46 +303,61 @@ def test_moco_head_three_steps(gpu, golden_dir):
     assert_within(errs, TOL)
 
 
+def full_step_case(spec, B, K, vocab, seed):
+    """CPU-only construction of a full-size one-step case: (`margin`-style head state, embedding table,
+    images, tokens, lengths, ids).  Shared with tools/pick_fullstep_seed.py, which chose the seeds used
+    below so that the query encoder's smallest |ReLU input| is >= oracle.fill.RELU_MIN."""
+    import bench
+
+    torch.manual_seed(0)
+    table = torch.randn(vocab, 512) * 0.02
+    shapes = OH.state_shapes(spec, K)
+    st = {}
+    for k, s_ in shapes.items():
+        if k.endswith("num_batches_tracked"):
+            st[k] = torch.zeros((), dtype=torch.int64)
+        elif k in ("id_queue", "queue_ptr"):
+            st[k] = torch.zeros(s_, dtype=torch.int64)
+        else:
+            st[k] = OF.fill("full." + k, s_, seed, style="margin")
+    OH.init_queues(st, seed)
+    images, tokens, lengths, ids = bench.synth_batch(B, 0, "cpu", 5, vocab=vocab)
+    lengths = torch.tensor(([64, 40, 64, 9, 33, 64, 12, 64, 50, 64, 21, 64, 64, 7, 64, 30] * ((B + 15) // 16))[:B])
+    for i, n in enumerate(lengths.tolist()):
+        tokens[i, n:] = 0
+    return st, table, images, tokens, lengths, ids
+
+
 def _full_step_vs_oracle(gpu, arch, spec, B, K, vocab, seed):
     """One MoCo train step of the full-size model on the HIP path and on the CPU oracle from the same
     `margin`-style state and seeded batch.  Returns {name: relative error} over the three losses, EVERY
     trainable gradient (full tensors, against max(max|ref|, gradient floor)), both queues, every
     momentum-updated key parameter and every BatchNorm running statistic of all four encoders."""
-    import bench
     from textreid_amd.caption import CaptionBatch
     from textreid_amd.config import moco_cfg
     from textreid_amd.model import build_model
 
-    torch.manual_seed(0)
-    cfg = moco_cfg(arch, K=K)
-    table = torch.randn(vocab, 512) * 0.02
-    model = build_model(cfg, vocab_dict=table)
+    st, table, images, tokens, lengths, ids = full_step_case(spec, B, K, vocab, seed)
+    model = build_model(moco_cfg(arch, K=K), vocab_dict=table)
     head = model.embed_model
-    filled = OF.fill_state(head.state_dict(), seed, "full.", style="margin")
-    st = {k: v.clone() for k, v in filled.items()}
-    OH.init_queues(st, seed)
-    for k in ("t_queue", "v_queue", "id_queue", "queue_ptr"):
-        filled[k] = st[k].clone()
-    head.load_state_dict(filled)
+    head.load_state_dict({k: v.clone() for k, v in st.items()})
     model.to(gpu).train()
-    images, tokens, lengths, ids = bench.synth_batch(B, 0, "cpu", 5, vocab=vocab)
-    lengths = torch.tensor(([64, 40, 64, 9, 33, 64, 12, 64, 50, 64, 21, 64, 64, 7, 64, 30] * ((B + 15) // 16))[:B])
-    for i, n in enumerate(lengths.tolist()):
-        tokens[i, n:] = 0
     ld = model(images.to(gpu), CaptionBatch(tokens.to(gpu), lengths.to(gpu), ids.to(gpu)))
     sum(ld.values()).backward()
     tr = OH.trainable_names(st)
     for k in tr:
         st[k].requires_grad_(True)
     key0 = st["v_encoder_k.layer3.2.conv2.weight"].clone()
-    old = OH.train_forward(st, spec, table, images, tokens, lengths, ids, m=0.999, epsilon=0.1)
+    taps = {}
+    old = OH.train_forward(st, spec, table, images, tokens, lengths, ids, m=0.999, epsilon=0.1, taps=taps)
+    assert taps["visual_q"]["relu_min"] >= 0.5 * OF.RELU_MIN, "case is not well-conditioned (ReLU margin %g): pick another seed" % taps["visual_q"]["relu_min"]
     sum(old.values()).backward()
     errs = {"loss:" + k: rel(ld[k], old[k]) for k in old}
     named = dict(head.named_parameters())
     gfl = 1e-3 * max(float(st[k].grad.abs().max()) for k in tr)
     for k in tr:
         ref = st[k].grad.double()
-        fl = gfl * (10.0 if k.endswith("attnpool.k_proj.bias") else 1.0)  # analytically zero gradient, see fixture_check
+        fl = gfl * (100.0 if k.endswith("attnpool.k_proj.bias") else 1.0)  # analytically zero gradient, see fixture_check
         errs["grad:" + k] = float((named[k].grad.detach().cpu().double() - ref).abs().max() / max(float(ref.abs().max()), fl))
     sd2 = head.state_dict()
     for k, v in st.items():
@@ -359,7 +374,7 @@ def test_full_size_step_vs_oracle(gpu):
     (trunk conv filters included), queue push, EMA of every key parameter, all BatchNorm statistics."""
     from fixture_check import assert_within
 
-    errs = _full_step_vs_oracle(gpu, "m_resnet50", OV.RN50, B=16, K=64, vocab=3000, seed=21)
+    errs = _full_step_vs_oracle(gpu, "m_resnet50", OV.RN50, B=16, K=64, vocab=3000, seed=30)  # seed: tools/pick_fullstep_seed.py
     worst = sorted(errs.items(), key=lambda kv: -kv[1])[:5]
     print(len(errs), "quantities; worst:", [(k, "%.1e" % v) for k, v in worst])
     assert sum(k.startswith("grad:") for k in errs) == 183
@@ -379,7 +394,7 @@ def test_config3_rn101_k65536_bf16(gpu):
     old = ops.GEMM_PRECISION
     try:
         ops.GEMM_PRECISION = 1
-        errs = _full_step_vs_oracle(gpu, "m_resnet101", OV.RN101, B=16, K=65536, vocab=3000, seed=23)
+        errs = _full_step_vs_oracle(gpu, "m_resnet101", OV.RN101, B=16, K=65536, vocab=3000, seed=43)  # seed: tools/pick_fullstep_seed.py
     finally:
         ops.GEMM_PRECISION = old
     worst = sorted(errs.items(), key=lambda kv: -kv[1])[:5]
@@ -394,7 +409,7 @@ def test_config3_rn101_k65536_fp32_class(gpu):
     on losses, all 336 trainable gradients, queues, key parameters, BatchNorm statistics."""
     from fixture_check import assert_within
 
-    errs = _full_step_vs_oracle(gpu, "m_resnet101", OV.RN101, B=16, K=65536, vocab=3000, seed=23)
+    errs = _full_step_vs_oracle(gpu, "m_resnet101", OV.RN101, B=16, K=65536, vocab=3000, seed=43)  # seed: tools/pick_fullstep_seed.py
     worst = sorted(errs.items(), key=lambda kv: -kv[1])[:5]
     print(len(errs), "quantities; worst:", [(k, "%.1e" % v) for k, v in worst])
     assert_within(errs, TOL)

@@ -1,0 +1,340 @@
+// Fused queue similarity + masked InfoNCE, forward AND gradient, in one pass over the MoCo queues.
+//
+// Reference: head.py:148-170 (negative filter, pos / neg logits of both modalities) followed by
+// losses.py:206-217 (cross entropy over [pos | negs] / T with label 0).  The reference clones the
+// queues, gathers the unfiltered columns and materialises [B, |neg|] logits twice; here the
+// [K, C] row-major queues are streamed ONCE, 32 rows at a time, and nothing of size B x K exists:
+//
+//   per 32-row queue tile (coalesced 1 KB rows -> split into bf16 planes -> LDS, two images):
+//     S^T[j, b] = <queue_j, q_b>                 MFMA 32x32x16, A = tile (LDS), B = queries (registers)
+//     P[j, b]   = hit_j ? 0 : exp((S - bound)/T) in the accumulator layout, no shuffles
+//     l[b]     += sum_j P[j, b]                  in-lane adds (+ one half-wave shuffle at the very end)
+//     O[b, :]  += sum_j P[j, b] * queue_j        MFMA again: A = P (registers, as produced), B = tile (LDS)
+//
+// Queries and queue rows are L2-normalised (head.py:128-129,140,145; queue columns are normalised keys),
+// so every logit lies in [-bound/T, bound/T] with bound = 1 and a FIXED shift replaces the running
+// maximum of an online softmax: exp((s - 1)/T) is in [e^-28.6, 1] at T = 0.07 - no rescaling of O, no
+// overflow, no underflow.  Each workgroup owns a contiguous range of queue rows for 128 queries (4 waves
+// x 32) and writes its partial (l, O); a finish kernel folds the partials in a fixed order (bit-
+// reproducible, no atomics), adds the positive pair <q_b, key_b> and emits the per-row loss and dL/dq.
+//
+// Arithmetic: fp32-class.  fp32 operands are split on the fly into three bf16 planes exactly as in
+// gemm_bf16.hip; S uses the six significant plane products (dropped terms <= 2^-26), P (two planes,
+// relative error 2^-17) times the three queue planes uses five.  precision = 1 keeps one plane of
+// everything (bf16-autocast arithmetic, configs[3]).
+
+#include <mutex>
+
+#include "split_common.h"
+
+namespace trid {
+
+constexpr int QC = 256;          // embedding width this kernel is built for (FEATURE_SIZE of the MoCo configs)
+constexpr int QCH = QC / 16;     // 16-wide K chunks of the similarity product
+constexpr int QCT = QC / 32;     // 32-wide column tiles of O
+constexpr int QTILE = 32;        // queue rows per tile
+constexpr int QB = 128;          // queries per workgroup (4 waves x 32)
+constexpr int A1_SLOTS = 2 * QCH * 33;  // [chunk*2 + half][33] 16-byte slots (row j at +j)
+constexpr int A2_SLOTS = 4 * QC;        // [kk*2 + half][c]
+
+struct QnceParams {
+    const float* q[2];       // [B, QC] normalised queries: modality 0 = image queries, 1 = text queries
+    const float* queue[2];   // [K, QC] row-major: modality 0 reads the TEXT queue, 1 the IMAGE queue
+    const uint8_t* hit;      // [K] batch-wide same-id flags (trid_queue_hit_mask)
+    float* part_l;           // [2][nwg][Bp]
+    float* part_o;           // [2][nwg][Bp][QC]
+    int B, Bp, K, tiles_per_wg, nwg;
+    float c1, c0;            // P = exp2(s * c1 + c0)
+};
+
+template <int NPL>
+__device__ __forceinline__ void split8(const float (&v)[8], uint4 (&out)[NPL]) {
+    unsigned w[NPL][4];
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+        float r0 = v[2 * qd], r1 = v[2 * qd + 1];
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) {
+            const unsigned h = cvt_pk_bf16(r0, r1);
+            w[pl][qd] = h;
+            if (pl + 1 < NPL) {
+                r0 -= __builtin_bit_cast(float, h << 16);
+                r1 -= __builtin_bit_cast(float, h & 0xffff0000u);
+            }
+        }
+    }
+#pragma unroll
+    for (int pl = 0; pl < NPL; ++pl) out[pl] = make_uint4(w[pl][0], w[pl][1], w[pl][2], w[pl][3]);
+}
+
+// rows of a 32-row tile owned by (kk, h): exactly the queue rows the accumulator layout of a 32x32 MFMA
+// puts in registers 8kk..8kk+7 of the lanes with (lane >> 5) == h
+__device__ __forceinline__ int tile_row(int kk, int h, int i) { return 16 * kk + 4 * h + (i & 3) + 8 * (i >> 2); }
+
+template <int NPL>
+__global__ __launch_bounds__(256, 1) void queue_nce_kernel(QnceParams p) {
+    constexpr int NPP = NPL == 3 ? 2 : 1;  // planes of P
+    extern __shared__ __attribute__((aligned(16))) uint4 qsm[];
+    uint4* A1 = qsm;                      // [NPL][A1_SLOTS]
+    uint4* A2 = qsm + NPL * A1_SLOTS;     // [NPL][A2_SLOTS]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int wg = blockIdx.x, bb = blockIdx.y, mod = blockIdx.z;
+    const float* __restrict__ Q = p.q[mod];
+    const float* __restrict__ Kq = p.queue[mod];
+
+    // ---- this wave's 32 queries as B-operand fragments (registers, all planes)
+    bf16x8 qf[NPL][QCH];
+    {
+        const int b = bb * QB + wave * 32 + l31;
+        const float* src = Q + (long long)(b < p.B ? b : 0) * QC + 8 * half;
+#pragma unroll
+        for (int ch = 0; ch < QCH; ++ch) {
+            float4 u = *reinterpret_cast<const float4*>(src + 16 * ch);
+            float4 v = *reinterpret_cast<const float4*>(src + 16 * ch + 4);
+            if (b >= p.B) u = v = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float vals[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
+            uint4 pl[NPL];
+            split8<NPL>(vals, pl);
+#pragma unroll
+            for (int k = 0; k < NPL; ++k) qf[k][ch] = __builtin_bit_cast(bf16x8, pl[k]);
+        }
+    }
+
+    v16f O[QCT];
+#pragma unroll
+    for (int ct = 0; ct < QCT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) O[ct][r] = 0.f;
+    float lsum = 0.f;
+
+    const int t_begin = wg * p.tiles_per_wg;
+    const int t_end = min(p.K / QTILE, t_begin + p.tiles_per_wg);
+    // loader role of this thread: wave -> (kk, h) row set, lane -> 4 consecutive columns
+    const int lkk = wave >> 1, lh = wave & 1;
+    float4 g[8];
+    auto load_tile = [&](int t) {
+        const float* base = Kq + (long long)t * QTILE * QC + 4 * lane;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) g[i] = *reinterpret_cast<const float4*>(base + (long long)tile_row(lkk, lh, i) * QC);
+    };
+    if (t_begin < t_end) load_tile(t_begin);
+
+    for (int t = t_begin; t < t_end; ++t) {
+        __syncthreads();  // every wave is done with the previous tile's LDS images
+        {   // ---- split the prefetched rows into planes and write both LDS images
+            unsigned w[8][NPL][2];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float r0 = g[i].x, r1 = g[i].y, r2 = g[i].z, r3 = g[i].w;
+#pragma unroll
+                for (int pl = 0; pl < NPL; ++pl) {
+                    const unsigned h0 = cvt_pk_bf16(r0, r1), h1 = cvt_pk_bf16(r2, r3);
+                    w[i][pl][0] = h0;
+                    w[i][pl][1] = h1;
+                    if (pl + 1 < NPL) {
+                        r0 -= __builtin_bit_cast(float, h0 << 16);
+                        r1 -= __builtin_bit_cast(float, h0 & 0xffff0000u);
+                        r2 -= __builtin_bit_cast(float, h1 << 16);
+                        r3 -= __builtin_bit_cast(float, h1 & 0xffff0000u);
+                    }
+                }
+            }
+            // image 1 (A operand of S^T): slot [(c >> 3)][row], this lane holds columns 4*lane .. +3 = half a slot
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    uint2* dst = reinterpret_cast<uint2*>(A1 + pl * A1_SLOTS + (lane >> 1) * 33 + tile_row(lkk, lh, i)) + (lane & 1);
+                    *dst = make_uint2(w[i][pl][0], w[i][pl][1]);
+                }
+            // image 2 (B operand of O): slot [kk*2 + h][c] = the 8 rows of this wave's row set for one column
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) {
+                    unsigned d[4];
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        const unsigned a = w[2 * m][pl][cc >> 1], b = w[2 * m + 1][pl][cc >> 1];
+                        d[m] = (cc & 1) ? ((a >> 16) | (b & 0xffff0000u)) : ((a & 0xffffu) | (b << 16));
+                    }
+                    A2[pl * A2_SLOTS + (lkk * 2 + lh) * QC + 4 * lane + cc] = make_uint4(d[0], d[1], d[2], d[3]);
+                }
+        }
+        __syncthreads();
+        if (t + 1 < t_end) load_tile(t + 1);  // in flight underneath the MFMA phases below
+
+        // ---- S^T = tile . Q^T  (rows = queue rows of the tile, columns = this wave's queries)
+        v16f s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+        constexpr int NTERM = (NPL == 3) ? 6 : 1;
+        constexpr int TA[6] = {1, 0, 2, 0, 1, 0};
+        constexpr int TB[6] = {1, 2, 0, 1, 0, 0};
+#pragma unroll
+        for (int ch = 0; ch < QCH; ++ch) {
+            bf16x8 a[NPL];
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) a[pl] = __builtin_bit_cast(bf16x8, A1[pl * A1_SLOTS + (ch * 2 + half) * 33 + l31]);
+#pragma unroll
+            for (int k = 6 - NTERM; k < 6; ++k)
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[TA[k] < NPL ? TA[k] : 0], qf[TB[k] < NPL ? TB[k] : 0][ch], s, 0, 0, 0);
+        }
+        // ---- P = exp((s - bound)/T) on the unfiltered rows; row of register r: (r&3) + 8(r>>2) + 4*half
+        const uint32_t* h32 = reinterpret_cast<const uint32_t*>(p.hit + (long long)t * QTILE);
+        float pv[16];
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            const uint32_t hw = h32[2 * gq + half];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = 4 * gq + e;
+                const float x = __builtin_amdgcn_exp2f(fmaf(s[r], p.c1, p.c0));
+                pv[r] = ((hw >> (8 * e)) & 0xffu) ? 0.f : x;
+                lsum += pv[r];
+            }
+        }
+        bf16x8 pf[NPP][2];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const float vals[8] = {pv[8 * kk], pv[8 * kk + 1], pv[8 * kk + 2], pv[8 * kk + 3],
+                                   pv[8 * kk + 4], pv[8 * kk + 5], pv[8 * kk + 6], pv[8 * kk + 7]};
+            uint4 pl[NPP];
+            split8<NPP>(vals, pl);
+#pragma unroll
+            for (int k = 0; k < NPP; ++k) pf[k][kk] = __builtin_bit_cast(bf16x8, pl[k]);
+        }
+        // ---- O[b, c] += sum_j P[j, b] * queue[j, c]: A = P (k-slot i of (kk, half) = tile_row(kk, half, i)), B = image 2
+        constexpr int OTERM = (NPL == 3) ? 5 : 1;
+        constexpr int OP[5] = {1, 0, 1, 0, 0};  // plane of P   (mm, hl, mh, hm, hh: smallest first)
+        constexpr int OK[5] = {1, 2, 0, 1, 0};  // plane of the queue tile
+#pragma unroll
+        for (int ct = 0; ct < QCT; ++ct)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                bf16x8 b[NPL];
+#pragma unroll
+                for (int pl = 0; pl < NPL; ++pl)
+                    b[pl] = __builtin_bit_cast(bf16x8, A2[pl * A2_SLOTS + (kk * 2 + half) * QC + ct * 32 + l31]);
+#pragma unroll
+                for (int k = 5 - OTERM; k < 5; ++k)
+                    O[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[OP[k] < NPP ? OP[k] : 0][kk], b[OK[k] < NPL ? OK[k] : 0], O[ct], 0, 0, 0);
+            }
+    }
+
+    // ---- partials of this workgroup's queue range
+    const long long slab = ((long long)mod * p.nwg + wg) * p.Bp + bb * QB + wave * 32;
+    const float l = lsum + __shfl_xor(lsum, 32, 64);
+    if (half == 0) p.part_l[slab + l31] = l;
+#pragma unroll
+    for (int ct = 0; ct < QCT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+            p.part_o[(slab + row) * QC + ct * 32 + l31] = O[ct][r];
+        }
+}
+
+// One workgroup per (query row, modality): positive logit, fold of the partials, loss row and dL/dq.
+__global__ __launch_bounds__(256) void queue_nce_finish_kernel(QnceParams p, const float* __restrict__ key0,
+                                                               const float* __restrict__ key1, float* __restrict__ loss_rows,
+                                                               float* __restrict__ dq, float invT, float shift, float gs) {
+    __shared__ float red[8];
+    const int b = blockIdx.x, mod = blockIdx.y, c = threadIdx.x;  // blockDim.x == QC
+    const float* __restrict__ qr = p.q[mod] + (long long)b * QC;
+    const float* __restrict__ kr = (mod == 0 ? key0 : key1) + (long long)b * QC;
+    const float kv = kr[c];
+    float d = wave_sum(qr[c] * kv);
+    if ((c & 63) == 0) red[c >> 6] = d;
+    float lpart = 0.f;
+    for (int w = c; w < p.nwg; w += QC) lpart += p.part_l[((long long)mod * p.nwg + w) * p.Bp + b];
+    lpart = wave_sum(lpart);
+    if ((c & 63) == 0) red[4 + (c >> 6)] = lpart;
+    __syncthreads();
+    const float pos = (red[0] + red[1]) + (red[2] + red[3]);
+    const float lneg = (red[4] + red[5]) + (red[6] + red[7]);
+    const float x0 = expf(pos * invT - shift);
+    const float ltot = lneg + x0;
+    float o = 0.f;
+    for (int w = 0; w < p.nwg; ++w) o += p.part_o[(((long long)mod * p.nwg + w) * p.Bp + b) * QC + c];
+    const float inv = 1.f / ltot;
+    dq[((long long)mod * p.B + b) * QC + c] = gs * (o * inv + (x0 * inv - 1.f) * kv);
+    // lse - pos/T = log(ltot / x0) = log1p(lneg / x0): no cancellation between the shift and log(ltot)
+    if (c == 0) loss_rows[(long long)mod * p.B + b] = log1pf(lneg / x0);
+}
+
+static int plan(int B, int K, int nwg_hint, int* nbb, int* nwg, int* tpw) {
+    *nbb = (B + QB - 1) / QB;
+    const int tiles = K / QTILE;
+    int want = nwg_hint > 0 ? nwg_hint : (128 / *nbb > 0 ? 128 / *nbb : 1);  // ~256 workgroups over both modalities
+    if (want > tiles) want = tiles;
+    *tpw = (tiles + want - 1) / want;
+    *nwg = (tiles + *tpw - 1) / *tpw;
+    return 0;
+}
+
+template <int NPL>
+static int launch_qnce(QnceParams& p, int nbb, hipStream_t stream) {
+    constexpr size_t lds = (size_t)NPL * (A1_SLOTS + A2_SLOTS) * sizeof(uint4);
+    static std::once_flag once;
+    static hipError_t attr_err = hipSuccess;
+    std::call_once(once, [] {
+        attr_err = hipFuncSetAttribute((const void*)queue_nce_kernel<NPL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    });
+    if (attr_err != hipSuccess) {
+        set_error("trid_queue_nce_f32: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(attr_err));
+        return (int)attr_err;
+    }
+    hipLaunchKernelGGL((queue_nce_kernel<NPL>), dim3(p.nwg, nbb, 2), dim3(256), lds, stream, p);
+    return check_launch("trid_queue_nce_f32");
+}
+
+}  // namespace trid
+
+using namespace trid;
+
+extern "C" long long trid_queue_nce_ws_floats(int B, int K, int C, int nwg_hint) {
+    if (B <= 0 || K <= 0 || C != QC || K % QTILE != 0) return 0;
+    int nbb, nwg, tpw;
+    plan(B, K, nwg_hint, &nbb, &nwg, &tpw);
+    return 2LL * nwg * (nbb * QB) * (QC + 1);
+}
+
+extern "C" int trid_queue_nce_f32(const float* v_q, const float* t_q, const float* v_key, const float* t_key,
+                                  const float* t_queue, const float* v_queue, const uint8_t* hit, float* loss_rows,
+                                  float* dq, int B, int K, int C, float invT, float logit_bound, float gscale,
+                                  int precision, int nwg_hint, float* ws, void* stream) {
+    TRID_REQUIRE(v_q && t_q && v_key && t_key && t_queue && v_queue && hit && loss_rows && dq && ws,
+                 "trid_queue_nce_f32: null pointer");
+    TRID_REQUIRE(B > 0 && K > 0 && invT > 0.f && logit_bound > 0.f, "trid_queue_nce_f32: bad sizes / scalars");
+    if (C != QC || K % QTILE != 0) {
+        set_error("trid_queue_nce_f32: built for C = %d and K %% %d == 0 (got C = %d, K = %d)", QC, QTILE, C, K);
+        return TRID_E_UNSUPPORTED;
+    }
+    TRID_REQUIRE(aligned16(v_q) && aligned16(t_q) && aligned16(t_queue) && aligned16(v_queue) &&
+                     (reinterpret_cast<uintptr_t>(hit) & 3) == 0,
+                 "trid_queue_nce_f32: queries / queues must be 16-byte and hit 4-byte aligned");
+    QnceParams p;
+    int nbb;
+    plan(B, K, nwg_hint, &nbb, &p.nwg, &p.tiles_per_wg);
+    p.q[0] = v_q;  p.queue[0] = t_queue;   // head.py:160-164: image queries against the text queue
+    p.q[1] = t_q;  p.queue[1] = v_queue;   // head.py:166-170: text queries against the image queue
+    p.hit = hit;
+    p.B = B;
+    p.Bp = nbb * QB;
+    p.K = K;
+    p.part_l = ws;
+    p.part_o = ws + 2LL * p.nwg * p.Bp;
+    const float log2e = 1.4426950408889634f;
+    const float shift = logit_bound * invT;
+    p.c1 = invT * log2e;
+    p.c0 = -shift * log2e;
+    const hipStream_t st = (hipStream_t)stream;
+    const int rc = (precision == 1) ? launch_qnce<1>(p, nbb, st) : launch_qnce<3>(p, nbb, st);
+    if (rc != TRID_OK) return rc;
+    hipLaunchKernelGGL(queue_nce_finish_kernel, dim3(B, 2), dim3(QC), 0, st, p, t_key, v_key, loss_rows, dq, invT, shift,
+                       gscale * invT / (float)B);
+    return check_launch("trid_queue_nce_f32(finish)");
+}

@@ -13,6 +13,8 @@ dL/dlogits; the gradient GEMMs run right away (the logits never outlive the
 forward) and backward only scales by the incoming gradient on device.
 """
 
+import os
+
 import torch
 
 from . import ops
@@ -147,17 +149,32 @@ def infonce_loss(v_pos, v_neg, t_pos, t_neg, T=0.07):
     return _InfoNCEFn.apply(v_pos, v_neg, t_pos, t_neg, T)
 
 
+FUSED_QUEUE_NCE = os.environ.get("TRID_FUSED_QNCE", "1") != "0"  # A/B switch: 0 = GEMM + row kernels
+QUEUE_NCE_WGS = int(os.environ.get("TRID_QNCE_WGS", "0"))            # workgroups per modality (0 = library default)
+
+
 class _QueueInfoNCEFn(torch.autograd.Function):
     """v_q,t_q [B,C] normalised queries; v_k,t_k keys; queues row-major [K,C]."""
 
     @staticmethod
-    def forward(ctx, v_q, t_q, v_k, t_k, ids, t_queue, v_queue, id_queue, T):
+    def forward(ctx, v_q, t_q, v_k, t_k, ids, t_queue, v_queue, id_queue, T, unit_norm):
         B, C = v_q.shape
         K = t_queue.shape[0]
         hit = torch.empty(K, dtype=torch.uint8, device=v_q.device)
         call("trid_queue_hit_mask", _p(id_queue), _p(ids.long().contiguous()), _p(hit), K, B, stream())
         loss = ops.empty((1,), v_q)
         rows = ops.empty((2, B), v_q)  # per-row losses of both modalities, summed by one launch
+        nws = ops.L.load().trid_queue_nce_ws_floats(B, K, C, QUEUE_NCE_WGS) if (FUSED_QUEUE_NCE and unit_norm) else 0
+        if nws > 0:
+            # ONE pass over both queues: similarity, filter, softmax and dL/dq fused, no [B,K] anywhere (queue_nce.hip)
+            dq = ops.empty((2, B, C), v_q)
+            ws = ops.empty((nws,), v_q)
+            call("trid_queue_nce_f32", _p(v_q.detach().contiguous()), _p(t_q.detach().contiguous()), _p(v_k.detach().contiguous()),
+                 _p(t_k.detach().contiguous()), _p(t_queue), _p(v_queue), _p(hit), _p(rows), _p(dq), B, K, C, 1.0 / T, 1.0, 1.0,
+                 1 if ops.GEMM_PRECISION == 1 else 6, QUEUE_NCE_WGS, _p(ws), stream())
+            ops.sum_to(rows.view(-1), loss, 1.0 / B)
+            ctx.saved = [dq[0], dq[1]]
+            return loss[0]
         grads = []
         for i, (q, key, queue) in enumerate(((v_q, t_k, t_queue), (t_q, v_k, v_queue))):
             q = q.detach().contiguous()
@@ -178,12 +195,17 @@ class _QueueInfoNCEFn(torch.autograd.Function):
     def backward(ctx, g):
         dv, dt = ctx.saved
         ctx.saved = None
-        return _scaled(g, dv), _scaled(g, dt), None, None, None, None, None, None, None
+        return _scaled(g, dv), _scaled(g, dt), None, None, None, None, None, None, None, None
 
 
-def queue_infonce_loss(v_q, t_q, v_k, t_k, ids, t_queue, v_queue, id_queue, T=0.07):
+def queue_infonce_loss(v_q, t_q, v_k, t_k, ids, t_queue, v_queue, id_queue, T=0.07, unit_norm=True):
+    """InfoNCE of both modalities against the [K,C] row-major queues with the batch-wide negative filter.
+    ``unit_norm``: queries, keys and queue rows are L2-normalised (they are in the MoCo head, head.py:128-145) -
+    the fused single-pass kernel relies on |logit| <= 1/T; pass False for arbitrary inputs (GEMM + row kernels)."""
     _check(v_q, t_q, v_k, t_k, ids, t_queue, v_queue, id_queue)
-    return _QueueInfoNCEFn.apply(v_q, t_q, v_k, t_k, ids, t_queue, v_queue, id_queue, T)
+    if not (t_queue.is_contiguous() and v_queue.is_contiguous()):
+        raise RuntimeError("queue_infonce_loss: queues must be row-major [K,C] contiguous")
+    return _QueueInfoNCEFn.apply(v_q, t_q, v_k, t_k, ids, t_queue, v_queue, id_queue, T, unit_norm)
 
 
 class _L2NormFn(torch.autograd.Function):
