@@ -210,8 +210,8 @@ int trid_infonce_queue_rows_f32(float* S, const float* q, const float* key, cons
  *   modality 0: image queries v_q against t_queue, positive key t_key (head.py:160-164);
  *   modality 1: text  queries t_q against v_queue, positive key v_key (head.py:166-170).
  * Queries and queue rows must be L2-normalised (head.py:128-129,140,145), |<q, k>| <= logit_bound (1 for unit
- * vectors): the kernel uses the fixed shift logit_bound/T instead of a running maximum.  hit[K] = batch-wide
- * same-id flags from trid_queue_hit_mask.  Outputs loss_rows[2][B] = lse - pos/T and dq[2][B][C] = dL/dq for
+ * vectors): the kernel uses the fixed shift logit_bound/T instead of a running maximum.  A queue row k is
+ * filtered when id_queue[k] equals ANY ids[i], i < B (one shared column set per batch, head.py:148-157).  Outputs loss_rows[2][B] = lse - pos/T and dq[2][B][C] = dL/dq for
  * L = gscale * mean_b(loss_rows) summed over the modalities.  precision: 6 = fp32-class (bf16 plane split as
  * trid_gemm_f32), 1 = bf16 operands.  nwg_hint: workgroups per modality (0 = default).  Built for C = 256 and
  * K % 32 == 0, otherwise TRID_E_UNSUPPORTED (the caller then takes trid_gemm_f32 + trid_infonce_queue_rows_f32).
@@ -219,9 +219,9 @@ int trid_infonce_queue_rows_f32(float* S, const float* q, const float* key, cons
  * sums are folded in a fixed order, no atomics. */
 long long trid_queue_nce_ws_floats(int B, int K, int C, int nwg_hint);
 int trid_queue_nce_f32(const float* v_q, const float* t_q, const float* v_key, const float* t_key,
-                       const float* t_queue, const float* v_queue, const uint8_t* hit, float* loss_rows, float* dq,
-                       int B, int K, int C, float invT, float logit_bound, float gscale, int precision, int nwg_hint,
-                       float* ws, void* stream);
+                       const float* t_queue, const float* v_queue, const int64_t* id_queue, const int64_t* ids,
+                       float* loss_rows, float* dq, int B, int K, int C, float invT, float logit_bound, float gscale,
+                       int precision, int nwg_hint, float* ws, void* stream);
 /* rowdot[b] = <x_b, y_b> */
 int trid_rowdot_f32(const float* x, const float* y, float* out, long long rows, int C, void* stream);
 /* dx[b,:] (+)= s[b]*y[b,:] */

@@ -15,7 +15,7 @@
 // so every logit lies in [-bound/T, bound/T] with bound = 1 and a FIXED shift replaces the running
 // maximum of an online softmax: exp((s - 1)/T) is in [e^-28.6, 1] at T = 0.07 - no rescaling of O, no
 // overflow, no underflow.  Each workgroup owns a contiguous range of queue rows for 128 queries (4 waves
-// x 32) and writes its partial (l, O); a finish kernel folds the partials in a fixed order (bit-
+// x 32) and writes its partial (l, O); a small pre-pass writes the batch-wide filter flags (one byte per queue row); a finish kernel folds the partials in a fixed order (bit-
 // reproducible, no atomics), adds the positive pair <q_b, key_b> and emits the per-row loss and dL/dq.
 //
 // Arithmetic: fp32-class.  fp32 operands are split on the fly into three bf16 planes exactly as in
@@ -34,13 +34,15 @@ constexpr int QCH = QC / 16;     // 16-wide K chunks of the similarity product
 constexpr int QCT = QC / 32;     // 32-wide column tiles of O
 constexpr int QTILE = 32;        // queue rows per tile
 constexpr int QB = 128;          // queries per workgroup (4 waves x 32)
+constexpr int QMAXB = 8192;      // largest (global) batch (limit of trid_queue_hit_mask)
 constexpr int A1_SLOTS = 2 * QCH * 33;  // [chunk*2 + half][33] 16-byte slots (row j at +j)
 constexpr int A2_SLOTS = 4 * QC;        // [kk*2 + half][c]
+__host__ __device__ constexpr int a2_sw(int c) { return c ^ ((c >> 3) & 3); }
 
 struct QnceParams {
     const float* q[2];       // [B, QC] normalised queries: modality 0 = image queries, 1 = text queries
     const float* queue[2];   // [K, QC] row-major: modality 0 reads the TEXT queue, 1 the IMAGE queue
-    const uint8_t* hit;      // [K] batch-wide same-id flags (trid_queue_hit_mask)
+    const uint8_t* hit;      // [K] batch-wide same-id flags: queue row k is filtered when id_queue[k] equals ANY id of the batch
     float* part_l;           // [2][nwg][Bp]
     float* part_o;           // [2][nwg][Bp][QC]
     int B, Bp, K, tiles_per_wg, nwg;
@@ -76,7 +78,7 @@ __global__ __launch_bounds__(256, 1) void queue_nce_kernel(QnceParams p) {
     constexpr int NPP = NPL == 3 ? 2 : 1;  // planes of P
     extern __shared__ __attribute__((aligned(16))) uint4 qsm[];
     uint4* A1 = qsm;                      // [NPL][A1_SLOTS]
-    uint4* A2 = qsm + NPL * A1_SLOTS;     // [NPL][A2_SLOTS]
+    uint4* A2 = qsm + NPL * A1_SLOTS;     // [NPL][A2_SLOTS], column c at slot sw(c): conflict-free writes AND reads
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
@@ -114,7 +116,9 @@ __global__ __launch_bounds__(256, 1) void queue_nce_kernel(QnceParams p) {
     // loader role of this thread: wave -> (kk, h) row set, lane -> 4 consecutive columns
     const int lkk = wave >> 1, lh = wave & 1;
     float4 g[8];
+    unsigned hpre = 0;  // this lane's dword of the prefetched tile's filter flags
     auto load_tile = [&](int t) {
+        hpre = reinterpret_cast<const unsigned*>(p.hit + (long long)t * QTILE)[lane & 7];
         const float* base = Kq + (long long)t * QTILE * QC + 4 * lane;
 #pragma unroll
         for (int i = 0; i < 8; ++i) g[i] = *reinterpret_cast<const float4*>(base + (long long)tile_row(lkk, lh, i) * QC);
@@ -160,41 +164,49 @@ __global__ __launch_bounds__(256, 1) void queue_nce_kernel(QnceParams p) {
                         const unsigned a = w[2 * m][pl][cc >> 1], b = w[2 * m + 1][pl][cc >> 1];
                         d[m] = (cc & 1) ? ((a >> 16) | (b & 0xffff0000u)) : ((a & 0xffffu) | (b << 16));
                     }
-                    A2[pl * A2_SLOTS + (lkk * 2 + lh) * QC + 4 * lane + cc] = make_uint4(d[0], d[1], d[2], d[3]);
+                    A2[pl * A2_SLOTS + (lkk * 2 + lh) * QC + a2_sw(4 * lane + cc)] = make_uint4(d[0], d[1], d[2], d[3]);
                 }
         }
         __syncthreads();
+        // ---- batch-wide negative filter of this tile (bit j set <=> queue row j carries an id of the batch): the
+        // flags of rows 4*(lane&7) .. +3 sit in this lane's prefetched dword -> one bit per row, OR over 8 lanes
+        unsigned hmask = ((hpre & 0xffu) ? 1u : 0u) | ((hpre & 0xff00u) ? 2u : 0u) | ((hpre & 0xff0000u) ? 4u : 0u) | ((hpre & 0xff000000u) ? 8u : 0u);
+        hmask <<= 4 * (lane & 7);
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) hmask |= __shfl_xor(hmask, o, 64);
         if (t + 1 < t_end) load_tile(t + 1);  // in flight underneath the MFMA phases below
 
-        // ---- S^T = tile . Q^T  (rows = queue rows of the tile, columns = this wave's queries)
-        v16f s;
+        // ---- S^T = tile . Q^T  (rows = queue rows of the tile, columns = this wave's queries).  Two accumulators
+        // (even / odd chunks): with ONE wave per SIMD nothing else hides a dependent-accumulator bubble.
+        v16f s, s1;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+        for (int r = 0; r < 16; ++r) s[r] = s1[r] = 0.f;
         constexpr int NTERM = (NPL == 3) ? 6 : 1;
         constexpr int TA[6] = {1, 0, 2, 0, 1, 0};
         constexpr int TB[6] = {1, 2, 0, 1, 0, 0};
 #pragma unroll
-        for (int ch = 0; ch < QCH; ++ch) {
-            bf16x8 a[NPL];
+        for (int ch = 0; ch < QCH; ch += 2) {
+            bf16x8 a[NPL], a1[NPL];
 #pragma unroll
-            for (int pl = 0; pl < NPL; ++pl) a[pl] = __builtin_bit_cast(bf16x8, A1[pl * A1_SLOTS + (ch * 2 + half) * 33 + l31]);
+            for (int pl = 0; pl < NPL; ++pl) {
+                a[pl] = __builtin_bit_cast(bf16x8, A1[pl * A1_SLOTS + (ch * 2 + half) * 33 + l31]);
+                a1[pl] = __builtin_bit_cast(bf16x8, A1[pl * A1_SLOTS + (ch * 2 + 2 + half) * 33 + l31]);
+            }
 #pragma unroll
-            for (int k = 6 - NTERM; k < 6; ++k)
+            for (int k = 6 - NTERM; k < 6; ++k) {
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[TA[k] < NPL ? TA[k] : 0], qf[TB[k] < NPL ? TB[k] : 0][ch], s, 0, 0, 0);
+                s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[TA[k] < NPL ? TA[k] : 0], qf[TB[k] < NPL ? TB[k] : 0][ch + 1], s1, 0, 0, 0);
+            }
         }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] += s1[r];
         // ---- P = exp((s - bound)/T) on the unfiltered rows; row of register r: (r&3) + 8(r>>2) + 4*half
-        const uint32_t* h32 = reinterpret_cast<const uint32_t*>(p.hit + (long long)t * QTILE);
         float pv[16];
 #pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-            const uint32_t hw = h32[2 * gq + half];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int r = 4 * gq + e;
-                const float x = __builtin_amdgcn_exp2f(fmaf(s[r], p.c1, p.c0));
-                pv[r] = ((hw >> (8 * e)) & 0xffu) ? 0.f : x;
-                lsum += pv[r];
-            }
+        for (int r = 0; r < 16; ++r) {
+            const float x = __builtin_amdgcn_exp2f(fmaf(s[r], p.c1, p.c0));
+            pv[r] = ((hmask >> ((r & 3) + 8 * (r >> 2) + 4 * half)) & 1u) ? 0.f : x;
+            lsum += pv[r];
         }
         bf16x8 pf[NPP][2];
 #pragma unroll
@@ -211,16 +223,20 @@ __global__ __launch_bounds__(256, 1) void queue_nce_kernel(QnceParams p) {
         constexpr int OP[5] = {1, 0, 1, 0, 0};  // plane of P   (mm, hl, mh, hm, hh: smallest first)
         constexpr int OK[5] = {1, 2, 0, 1, 0};  // plane of the queue tile
 #pragma unroll
-        for (int ct = 0; ct < QCT; ++ct)
+        for (int ct = 0; ct < QCT; ct += 2)
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
-                bf16x8 b[NPL];
+                bf16x8 b[NPL], b1[NPL];
 #pragma unroll
-                for (int pl = 0; pl < NPL; ++pl)
-                    b[pl] = __builtin_bit_cast(bf16x8, A2[pl * A2_SLOTS + (kk * 2 + half) * QC + ct * 32 + l31]);
+                for (int pl = 0; pl < NPL; ++pl) {
+                    b[pl] = __builtin_bit_cast(bf16x8, A2[pl * A2_SLOTS + (kk * 2 + half) * QC + a2_sw(ct * 32 + l31)]);
+                    b1[pl] = __builtin_bit_cast(bf16x8, A2[pl * A2_SLOTS + (kk * 2 + half) * QC + a2_sw(ct * 32 + 32 + l31)]);
+                }
 #pragma unroll
-                for (int k = 5 - OTERM; k < 5; ++k)
+                for (int k = 5 - OTERM; k < 5; ++k) {  // alternate the two accumulators
                     O[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[OP[k] < NPP ? OP[k] : 0][kk], b[OK[k] < NPL ? OK[k] : 0], O[ct], 0, 0, 0);
+                    O[ct + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[OP[k] < NPP ? OP[k] : 0][kk], b1[OK[k] < NPL ? OK[k] : 0], O[ct + 1], 0, 0, 0);
+                }
             }
     }
 
@@ -238,29 +254,45 @@ __global__ __launch_bounds__(256, 1) void queue_nce_kernel(QnceParams p) {
 }
 
 // One workgroup per (query row, modality): positive logit, fold of the partials, loss row and dL/dq.
+// Thread (grp = tid >> 6, c4 = tid & 63): group grp folds the partials w = grp, grp + 4, ... of columns
+// 4*c4 .. 4*c4+3 (float4 loads, independent accumulators), then the four groups are added in a fixed order.
 __global__ __launch_bounds__(256) void queue_nce_finish_kernel(QnceParams p, const float* __restrict__ key0,
                                                                const float* __restrict__ key1, float* __restrict__ loss_rows,
                                                                float* __restrict__ dq, float invT, float shift, float gs) {
     __shared__ float red[8];
+    __shared__ float4 osum[4][64];
     const int b = blockIdx.x, mod = blockIdx.y, c = threadIdx.x;  // blockDim.x == QC
+    const int grp = c >> 6, c4 = c & 63;
     const float* __restrict__ qr = p.q[mod] + (long long)b * QC;
     const float* __restrict__ kr = (mod == 0 ? key0 : key1) + (long long)b * QC;
-    const float kv = kr[c];
-    float d = wave_sum(qr[c] * kv);
+    float d = wave_sum(qr[c] * kr[c]);
     if ((c & 63) == 0) red[c >> 6] = d;
     float lpart = 0.f;
     for (int w = c; w < p.nwg; w += QC) lpart += p.part_l[((long long)mod * p.nwg + w) * p.Bp + b];
     lpart = wave_sum(lpart);
     if ((c & 63) == 0) red[4 + (c >> 6)] = lpart;
+    const float4* __restrict__ po = reinterpret_cast<const float4*>(p.part_o + (((long long)mod * p.nwg) * p.Bp + b) * QC) + c4;
+    const long long wstride = (long long)p.Bp * (QC / 4);
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+    int w = grp;
+    for (; w + 4 < p.nwg; w += 8) {
+        const float4 u = po[w * wstride], v = po[(w + 4) * wstride];
+        a0.x += u.x; a0.y += u.y; a0.z += u.z; a0.w += u.w;
+        a1.x += v.x; a1.y += v.y; a1.z += v.z; a1.w += v.w;
+    }
+    if (w < p.nwg) {
+        const float4 u = po[w * wstride];
+        a0.x += u.x; a0.y += u.y; a0.z += u.z; a0.w += u.w;
+    }
+    osum[grp][c4] = make_float4(a0.x + a1.x, a0.y + a1.y, a0.z + a1.z, a0.w + a1.w);
     __syncthreads();
     const float pos = (red[0] + red[1]) + (red[2] + red[3]);
     const float lneg = (red[4] + red[5]) + (red[6] + red[7]);
     const float x0 = expf(pos * invT - shift);
-    const float ltot = lneg + x0;
-    float o = 0.f;
-    for (int w = 0; w < p.nwg; ++w) o += p.part_o[(((long long)mod * p.nwg + w) * p.Bp + b) * QC + c];
-    const float inv = 1.f / ltot;
-    dq[((long long)mod * p.B + b) * QC + c] = gs * (o * inv + (x0 * inv - 1.f) * kv);
+    const float inv = 1.f / (lneg + x0);
+    const float* of = reinterpret_cast<const float*>(&osum[0][0]);
+    const float o = (of[c] + of[QC + c]) + (of[2 * QC + c] + of[3 * QC + c]);
+    dq[((long long)mod * p.B + b) * QC + c] = gs * (o * inv + (x0 * inv - 1.f) * kr[c]);
     // lse - pos/T = log(ltot / x0) = log1p(lneg / x0): no cancellation between the shift and log(ltot)
     if (c == 0) loss_rows[(long long)mod * p.B + b] = log1pf(lneg / x0);
 }
@@ -277,7 +309,7 @@ static int plan(int B, int K, int nwg_hint, int* nbb, int* nwg, int* tpw) {
 
 template <int NPL>
 static int launch_qnce(QnceParams& p, int nbb, hipStream_t stream) {
-    constexpr size_t lds = (size_t)NPL * (A1_SLOTS + A2_SLOTS) * sizeof(uint4);
+    constexpr size_t lds = (size_t)NPL * (A1_SLOTS + A2_SLOTS) * sizeof(uint4) ;
     static std::once_flag once;
     static hipError_t attr_err = hipSuccess;
     std::call_once(once, [] {
@@ -296,37 +328,41 @@ static int launch_qnce(QnceParams& p, int nbb, hipStream_t stream) {
 using namespace trid;
 
 extern "C" long long trid_queue_nce_ws_floats(int B, int K, int C, int nwg_hint) {
-    if (B <= 0 || K <= 0 || C != QC || K % QTILE != 0) return 0;
+    if (B <= 0 || B > QMAXB || K <= 0 || C != QC || K % QTILE != 0) return 0;
     int nbb, nwg, tpw;
     plan(B, K, nwg_hint, &nbb, &nwg, &tpw);
-    return 2LL * nwg * (nbb * QB) * (QC + 1);
+    return 2LL * nwg * (nbb * QB) * (QC + 1) + (K + 3) / 4;  // partials + the [K]-byte flag buffer of the large-batch path
 }
 
 extern "C" int trid_queue_nce_f32(const float* v_q, const float* t_q, const float* v_key, const float* t_key,
-                                  const float* t_queue, const float* v_queue, const uint8_t* hit, float* loss_rows,
-                                  float* dq, int B, int K, int C, float invT, float logit_bound, float gscale,
-                                  int precision, int nwg_hint, float* ws, void* stream) {
-    TRID_REQUIRE(v_q && t_q && v_key && t_key && t_queue && v_queue && hit && loss_rows && dq && ws,
+                                  const float* t_queue, const float* v_queue, const int64_t* id_queue, const int64_t* ids,
+                                  float* loss_rows, float* dq, int B, int K, int C, float invT, float logit_bound,
+                                  float gscale, int precision, int nwg_hint, float* ws, void* stream) {
+    TRID_REQUIRE(v_q && t_q && v_key && t_key && t_queue && v_queue && id_queue && ids && loss_rows && dq && ws,
                  "trid_queue_nce_f32: null pointer");
     TRID_REQUIRE(B > 0 && K > 0 && invT > 0.f && logit_bound > 0.f, "trid_queue_nce_f32: bad sizes / scalars");
-    if (C != QC || K % QTILE != 0) {
-        set_error("trid_queue_nce_f32: built for C = %d and K %% %d == 0 (got C = %d, K = %d)", QC, QTILE, C, K);
+    if (C != QC || K % QTILE != 0 || B > QMAXB) {
+        set_error("trid_queue_nce_f32: built for C = %d, K %% %d == 0, B <= %d (got C = %d, K = %d, B = %d)", QC, QTILE, QMAXB, C, K, B);
         return TRID_E_UNSUPPORTED;
     }
-    TRID_REQUIRE(aligned16(v_q) && aligned16(t_q) && aligned16(t_queue) && aligned16(v_queue) &&
-                     (reinterpret_cast<uintptr_t>(hit) & 3) == 0,
-                 "trid_queue_nce_f32: queries / queues must be 16-byte and hit 4-byte aligned");
+    TRID_REQUIRE(aligned16(v_q) && aligned16(t_q) && aligned16(t_queue) && aligned16(v_queue) && aligned16(ws),
+                 "trid_queue_nce_f32: queries / queues / workspace must be 16-byte aligned");
     QnceParams p;
     int nbb;
     plan(B, K, nwg_hint, &nbb, &p.nwg, &p.tiles_per_wg);
     p.q[0] = v_q;  p.queue[0] = t_queue;   // head.py:160-164: image queries against the text queue
     p.q[1] = t_q;  p.queue[1] = v_queue;   // head.py:166-170: text queries against the image queue
-    p.hit = hit;
     p.B = B;
     p.Bp = nbb * QB;
     p.K = K;
     p.part_l = ws;
     p.part_o = ws + 2LL * p.nwg * p.Bp;
+    {   // batch-wide negative filter (head.py:148-157) as one byte per queue row, consumed 32 rows per tile
+        uint8_t* flags = reinterpret_cast<uint8_t*>(ws + 2LL * p.nwg * p.Bp * (QC + 1));
+        const int rc0 = trid_queue_hit_mask(id_queue, ids, flags, K, B, stream);
+        if (rc0 != TRID_OK) return rc0;
+        p.hit = flags;
+    }
     const float log2e = 1.4426950408889634f;
     const float shift = logit_bound * invT;
     p.c1 = invT * log2e;

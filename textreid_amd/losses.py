@@ -160,21 +160,22 @@ class _QueueInfoNCEFn(torch.autograd.Function):
     def forward(ctx, v_q, t_q, v_k, t_k, ids, t_queue, v_queue, id_queue, T, unit_norm):
         B, C = v_q.shape
         K = t_queue.shape[0]
-        hit = torch.empty(K, dtype=torch.uint8, device=v_q.device)
-        call("trid_queue_hit_mask", _p(id_queue), _p(ids.long().contiguous()), _p(hit), K, B, stream())
         loss = ops.empty((1,), v_q)
         rows = ops.empty((2, B), v_q)  # per-row losses of both modalities, summed by one launch
+        ids = ids.long().contiguous()
         nws = ops.L.load().trid_queue_nce_ws_floats(B, K, C, QUEUE_NCE_WGS) if (FUSED_QUEUE_NCE and unit_norm) else 0
         if nws > 0:
-            # ONE pass over both queues: similarity, filter, softmax and dL/dq fused, no [B,K] anywhere (queue_nce.hip)
+            # ONE pass over both queues: negative filter, similarity, softmax and dL/dq fused, no [B,K] anywhere (queue_nce.hip)
             dq = ops.empty((2, B, C), v_q)
             ws = ops.empty((nws,), v_q)
             call("trid_queue_nce_f32", _p(v_q.detach().contiguous()), _p(t_q.detach().contiguous()), _p(v_k.detach().contiguous()),
-                 _p(t_k.detach().contiguous()), _p(t_queue), _p(v_queue), _p(hit), _p(rows), _p(dq), B, K, C, 1.0 / T, 1.0, 1.0,
-                 1 if ops.GEMM_PRECISION == 1 else 6, QUEUE_NCE_WGS, _p(ws), stream())
+                 _p(t_k.detach().contiguous()), _p(t_queue), _p(v_queue), _p(id_queue), _p(ids), _p(rows), _p(dq), B, K, C, 1.0 / T,
+                 1.0, 1.0, 1 if ops.GEMM_PRECISION == 1 else 6, QUEUE_NCE_WGS, _p(ws), stream())
             ops.sum_to(rows.view(-1), loss, 1.0 / B)
             ctx.saved = [dq[0], dq[1]]
             return loss[0]
+        hit = torch.empty(K, dtype=torch.uint8, device=v_q.device)
+        call("trid_queue_hit_mask", _p(id_queue), _p(ids), _p(hit), K, B, stream())
         grads = []
         for i, (q, key, queue) in enumerate(((v_q, t_k, t_queue), (t_q, v_k, v_queue))):
             q = q.detach().contiguous()
