@@ -47,8 +47,10 @@ def synth_batch(B, step, device, seed, vocab=49408, Lpad=105, L=64):
     return images.to(device), tokens.to(device), lengths.to(device), ids.to(device)
 
 
-def cpu_baseline(sample_b=32, steps=3):
-    """Oracle (port of the reference train step incl. Adam) on the host cores."""
+def cpu_baseline(sample_b=128, steps=2, warm_b=32):
+    """Oracle (port of the reference train step incl. Adam) on the host cores: configs[1]'s own batch
+    (B = 128), `steps` timed steps after one warm-up step at B = `warm_b` (thread pool,
+    allocator); the warm-up size is also timed for one more step and reported as a second point."""
     import oracle.fill as OF
     import oracle.head as OH
     import oracle.visual as OV
@@ -74,32 +76,36 @@ def cpu_baseline(sample_b=32, steps=3):
         st[k].requires_grad_(True)
         groups.append({"params": [st[k]], "lr": 2e-4 if "bias" in k else 1e-4, "weight_decay": 0.0 if "bias" in k else 4e-5})
     opt = torch.optim.Adam(groups, lr=1e-4)
-    times = []
-    for s in range(steps + 1):
-        images, tokens, lengths, ids = synth_batch(sample_b, s, "cpu", 1234)
+
+    def one(bsz, s):
+        images, tokens, lengths, ids = synth_batch(bsz, s, "cpu", 1234)
         t0 = time.time()
         ld = OH.train_forward(st, spec, table, images, tokens, lengths, ids, m=0.999, epsilon=0.1)
         opt.zero_grad()
         sum(ld.values()).backward()
         opt.step()
-        if s > 0:
-            times.append(time.time() - t0)
-        log("cpu_baseline step %d: %.1fs" % (s, time.time() - t0))
+        dt = time.time() - t0
+        log("cpu_baseline step B=%d: %.1fs" % (bsz, dt))
+        return dt
+
+    one(warm_b, 0)  # warm-up
+    small = one(warm_b, 1)
+    times = [one(sample_b, 2 + s) for s in range(steps)]
     dt = sum(times) / len(times)
     return {
         "value": sample_b / dt,
         "unit": "pairs/s",
         "cores": torch.get_num_threads(),
         "kind": "port",
-        "sample": "%d timed train steps (fwd q+k, bwd, Adam) at B=%d, K=8192, fp32, after 1 warm-up step; CPU oracle = port of the reference step" % (steps, sample_b),
+        "sample": "%d timed train steps (fwd q+k, bwd, Adam) at B=%d (configs[1]'s batch), K=8192, fp32, after 1 warm-up step at B=%d; CPU oracle = port of the reference step" % (steps, sample_b, warm_b),
+        "value_at_B%d" % warm_b: warm_b / small,
     }
 
 
 def queue_similarity_bench(device, B=128, C=256, K=8192, reps=20):
-    """The batch x queue similarity / masked-InfoNCE block on its own (head.py:148-170 + losses.py:206-217):
-    hit mask, two [B,C]x[C,K] similarity GEMMs, the row kernel that emits loss and dL/dS in place, two
-    [B,K]x[K,C] gradient GEMMs.  Algorithmic HBM bytes = both queues + ids + queries + gradients
-    (17.4 MB at K=8192); no [B,K] matrix is written to HBM beyond the in-place logits (L2/MALL)."""
+    """The batch x queue similarity / masked-InfoNCE block on its own (head.py:148-170 + losses.py:206-217),
+    forward AND gradient: the fused single-pass kernel of csrc/queue_nce.hip.  Algorithmic HBM bytes = both
+    queues + ids + queries + gradients (17.4 MB at K=8192); no [B,K] matrix exists."""
     from textreid_amd import losses
 
     g = torch.Generator(device="cpu").manual_seed(11)
@@ -122,7 +128,8 @@ def queue_similarity_bench(device, B=128, C=256, K=8192, reps=20):
     flops = 2 * 2 * 2.0 * B * C * K  # similarity + gradient GEMMs, both modalities
     return {"K": K, "ms": ms, "algorithmic_MB": nbytes / 1e6, "achieved_GB_per_s": nbytes / ms / 1e6,
             "achieved_TFLOP_per_s": flops / ms / 1e9,
-            "note": "5 small launches per modality (similarity GEMM, two segment-parallel InfoNCE passes, split-K gradient GEMM + slab reduce): launch-latency-bound at K=8192; HBM roofline would be %.1f us" % (nbytes / 8e12 * 1e6)}
+            "launches": 4,
+            "note": "fused single pass over both queues (queue_nce.hip): filter-flag pre-pass, ONE kernel for similarity + masked softmax + dL/dq of both modalities (no [B,K] matrix), partial fold, loss sum; fp32-class arithmetic = 11 bf16 MFMA products per (query, row, channel), so the block is MFMA-bound at B=128: HBM time of the algorithmic bytes at 8 TB/s would be %.1f us" % (nbytes / 8e12 * 1e6)}
 
 
 def encode_bench(model, images, tokens, lengths, reps=5):
@@ -149,15 +156,16 @@ def encode_bench(model, images, tokens, lengths, reps=5):
     return out
 
 
-def retrieval_bench(device, world, rank, G_total=1000000, Q=10000, k=10):
+def retrieval_bench(device, world, rank, G_total=1000000, Q=10000, k=10, shard_rows=None):
     """configs[4]: Q=1e4 text queries against a 1e6-image gallery whose rows are sharded over the ranks
-    (1/8 per GPU; a single GPU times one such shard): similarity + per-query top-10 on device; with
-    world > 1 the per-shard lists are all-gathered and merged (evaluation.similarity_topk).  Called on
-    EVERY rank (it contains collectives); returns the same dict everywhere."""
+    (G/world per GPU; ONE GPU scores the whole 1e6-row gallery, 1 GB of fp32 embeddings): similarity +
+    per-query top-10 on device; with world > 1 the per-shard lists are all-gathered and merged
+    (evaluation.similarity_topk).  `shard_rows` times a single shard of that size instead (the per-GPU
+    work of the 8-GPU configuration).  Called on EVERY rank (it contains collectives)."""
     import torch.distributed as dist
     from textreid_amd.evaluation import similarity_topk
 
-    shard = G_total // max(world, 8)
+    shard = G_total // world if shard_rows is None else shard_rows
     gen = torch.Generator(device="cpu").manual_seed(7)
     q = torch.nn.functional.normalize(torch.randn(Q, 256, generator=gen), dim=1).to(device)  # replicated queries
     gen.manual_seed(70 + rank)
@@ -264,7 +272,10 @@ def main():
     # live roofline of the dominant kernel: 3x3 implicit-GEMM conv, 128x128 tiles
     split = ops.GEMM_PRECISION in (1, 3, 6)
     dom = (ops.A_CONV, ops.B_KC, 128, 128, split)
-    ops.PROFILE = {"match": lambda key: key == dom, "events": []}
+    dom2 = (ops.A_KC, ops.B_KC, 128, 128, split)  # 1x1 convs / linears: the largest TOTAL time of any kernel
+    labels = {dom: "conv3x3", dom2: "gemm1x1"}
+    ops.PROFILE = {"match": labels.get, "events": []}
+    reducer.reset_stats()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -289,10 +300,16 @@ def main():
     dt = float(tmax.item())
     loss_val = float(last.item())
 
-    flops = sum(e[1] for e in prof["events"])
-    ms = sum(e[2].elapsed_time(e[3]) for e in prof["events"])
-    nlaunch = len(prof["events"])
+    def live(label):
+        ev = [e for e in prof["events"] if e[0] == label]
+        fl = sum(e[1] for e in ev)
+        t = sum(e[2].elapsed_time(e[3]) for e in ev)
+        return fl, t, len(ev)
+
+    flops, ms, nlaunch = live("conv3x3")
     achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    flops2, ms2, nlaunch2 = live("gemm1x1")
+    dp_stats = reducer.stats() if world > 1 else None
 
     # the same kernel alone on the GPU (no side-stream work sharing the CUs): the 3x3 layers of layer2-4
     iso_fl, iso_ms = 0.0, 0.0
@@ -329,19 +346,24 @@ def main():
         kname = "trid::gemm_kernel<A_CONV,B_KC,128,128,2,4> (3x3 implicit-GEMM conv fwd+dgrad, fp32 MFMA 32x32x2)"
         peak_note = "fp32-input MFMA dense peak"
         arith = "exact fp32-input MFMA"
-    # HBM-side bytes per launch of the dominant kernel from the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
-    # passes of this same command (profiles/r01j_pmc_hbm_traffic.txt, gfx950 2x FETCH_SIZE correction applied)
-    traffic, traffic_note = None, None
-    try:
-        here = os.path.dirname(os.path.abspath(__file__))
-        for line in open(os.path.join(here, "profiles", "r01j_pmc_hbm_traffic.txt")):
-            f = line.split()
-            if prec == 6 and len(f) > 5 and "gemm_bf16s_kernel<2," in line and line.rstrip().endswith("0, 3, 128>(trid::GemmParams)"):
-                traffic = (float(f[2]) + float(f[3])) * 1e6
-                traffic_note = "PMC passes of profiles/r01j (not re-measured in this run): read %s MB + write %s MB per launch; algorithmic input + weights + output of these layers ~ 58 + 9 + 58 MB (each of the 8 XCD L2s fetches its own copy of the filter)" % (f[2], f[3])
-                break
-    except OSError:
-        pass
+    # HBM-side bytes per launch of the dominant kernel: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same
+    # command, summarised by tools/pmc_summary.py into profiles/ (gfx950 2x FETCH_SIZE correction applied).  A STORED
+    # measurement of the committed build, not a counter read of this run: `traffic_source` names the file.
+    traffic, traffic_note, traffic_src = None, None, None
+    here = os.path.dirname(os.path.abspath(__file__))
+    for fn in ("r02_pmc_hbm_traffic.txt", "r01j_pmc_hbm_traffic.txt"):
+        try:
+            for line in open(os.path.join(here, "profiles", fn)):
+                f = line.split()
+                if prec == 6 and len(f) > 5 and "gemm_bf16s_kernel<2," in line and line.rstrip().endswith("0, 3, 128>(trid::GemmParams)"):
+                    traffic = (float(f[2]) + float(f[3])) * 1e6
+                    traffic_src = "profiles/" + fn
+                    traffic_note = "read %s MB + write %s MB per launch (separate --pmc passes, stored); algorithmic input + weights + output of these layers ~ 58 + 9 + 58 MB (each of the 8 XCD L2s fetches its own copy of the filter)" % (f[2], f[3])
+                    break
+        except OSError:
+            pass
+        if traffic is not None:
+            break
     roofline = {
         "bound": "mfma",
         "kernel": kname,
@@ -350,6 +372,7 @@ def main():
         "unit": "TFLOP/s",
         "frac": achieved / peak,
         "traffic": traffic,
+        "traffic_source": traffic_src,
         "traffic_note": traffic_note,
         "achieved_isolated": achieved_isolated,
         "frac_isolated": achieved_isolated / peak,
@@ -359,9 +382,26 @@ def main():
         "avg_launch_ms": ms / max(nlaunch, 1),
         "algorithmic_gflop_per_launch": flops / max(nlaunch, 1) / 1e9,
     }
+    # second roofline object: the 1x1-conv / linear kernel <A_KC,B_KC> has the largest TOTAL time per step
+    roofline_1x1 = {
+        "bound": "mfma",
+        "kernel": kname.replace("A_CONV,B_KC", "A_KC,B_KC").split(" (")[0] + " (1x1 convs fwd, linears; K = 64..2048: the short-K layers are HBM/launch-bound)",
+        "achieved": flops2 / (ms2 * 1e-3) / 1e12 if ms2 > 0 else 0.0,
+        "peak": peak,
+        "unit": "TFLOP/s",
+        "frac": (flops2 / (ms2 * 1e-3) / 1e12 / peak) if ms2 > 0 else 0.0,
+        "traffic": None,
+        "launches": nlaunch2,
+        "avg_launch_ms": ms2 / max(nlaunch2, 1),
+        "algorithmic_gflop_per_launch": flops2 / max(nlaunch2, 1) / 1e9,
+        "note": "live events around every launch of this kernel during the timed steps (all streams running)",
+    }
     retr = None
     if not args.no_retrieval:
         retr = retrieval_bench(device, world, rank)
+        if world == 1:  # the per-GPU work of configs[4]'s 8-GPU form: one 125 000-row shard
+            sh = retrieval_bench(device, world, rank, shard_rows=125000)
+            retr["one_of_8_shards"] = {k: sh[k] for k in ("value", "unit", "gallery_rows_scored", "seconds", "tflops")}
         retr.update(encode_bench(model, batches[0][0], batches[0][1], batches[0][2]))
         log("retrieval: %.1f M gallery imgs/s" % (retr["value"] / 1e6))
     qsim = [queue_similarity_bench(device, B=B, K=k) for k in sorted({args.queue, 65536})]
@@ -389,7 +429,13 @@ def main():
                 "final_loss": loss_val,
             },
             "roofline": roofline,
+            "roofline_1x1": roofline_1x1,
         }
+        if world > 1:
+            # data-parallel accounting of the timed steps: one RCCL rank per GPU, gradient bytes all-reduced per step,
+            # the fraction of them issued from INSIDE backward (overlapped) and the device time left exposed after it
+            out["data_parallel"] = dict(dp_stats, rccl_ranks=world, backend=dist.get_backend(),
+                                        embedding_allgather_bytes_per_rank=B * (4 * 256 + 2) * 4)
         out["retrieval"] = retr
         out["queue_similarity"] = qsim
         if not args.no_cpu_baseline and world == 1:

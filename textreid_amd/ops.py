@@ -33,8 +33,8 @@ def stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-# Optional live profiling hook (bench.py): when PROFILE is a dict with a "match"
-# predicate, every matching GEMM launch is bracketed by events on the launch stream.
+# Optional live profiling hook (bench.py): when PROFILE is a dict with a "match" function
+# (kernel key -> label or None), every labelled GEMM launch is bracketed by events on the launch stream.
 PROFILE = None
 
 
@@ -98,12 +98,13 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, a_mode=A_KC, b_mode=B_KC, alpha=1.0, a
     if prof is not None:
         split = _uses_split(M, N, K, a_mode, conv)
         key = (a_mode, b_mode) + ((128, 64 if N <= 64 else 128) if split else _gemm_tile(M, N, stats is not None)) + (split,)
-        if prof["match"](key):
+        label = prof["match"](key)
+        if label:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             call("trid_gemm_f32", ctypes.addressof(d), stream())
             e1.record()
-            prof["events"].append((key, 2.0 * M * N * K * batch, e0, e1))
+            prof["events"].append((label, 2.0 * M * N * K * batch, e0, e1))
             return
     call("trid_gemm_f32", ctypes.addressof(d), stream())
 

@@ -73,10 +73,13 @@ def gather_embeddings(v_embed, t_embed, v_key, t_key, ids):
     """Packed all-gather of the four [B,C] embedding blocks and the ids.
     Gradients flow to v_embed / t_embed only (keys are detached)."""
     B, C = v_embed.shape
-    packed = torch.cat([v_embed, t_embed, v_key.detach(), t_key.detach(), ids.to(v_embed.dtype).view(B, 1)], dim=1)
+    # ids travel as their own BITS: an int64 is two 32-bit lanes of the fp32 payload (a collective only moves
+    # bytes), exact for any id - an fp32 VALUE would be exact only below 2^24
+    id_lanes = ids.long().contiguous().view(B, 1).view(torch.float32)  # [B, 2]
+    packed = torch.cat([v_embed, t_embed, v_key.detach(), t_key.detach(), id_lanes], dim=1)
     g = _GatherRows.apply(packed)
     v, t, vk, tk = g[:, :C], g[:, C : 2 * C], g[:, 2 * C : 3 * C].detach(), g[:, 3 * C : 4 * C].detach()
-    gid = g[:, 4 * C].detach().round().long()
+    gid = g[:, 4 * C : 4 * C + 2].detach().contiguous().view(torch.int64).view(-1)
     return v.contiguous(), t.contiguous(), vk.contiguous(), tk.contiguous(), gid
 
 
@@ -100,6 +103,27 @@ class GradReducer:
         self._pending = []
         self._stages = []
         self._staged = set()
+        # accounting for bench.py (reset_stats() per timed region): bytes handed to all-reduce from inside
+        # backward (overlapped) and after it, and device time between "backward done" and "all gradients reduced"
+        self.bytes_staged = 0
+        self.bytes_post = 0
+        self.steps = 0
+        self._exposed = []
+
+    def reset_stats(self):
+        self.bytes_staged = self.bytes_post = self.steps = 0
+        self._exposed = []
+
+    def stats(self):
+        """{"allreduce_bytes_per_step", "staged_fraction", "exposed_ms_per_step"}; synchronises the device."""
+        n = max(self.steps, 1)
+        ms = 0.0
+        if self._exposed:
+            torch.cuda.synchronize()
+            ms = sum(a.elapsed_time(b) for a, b in self._exposed) / len(self._exposed)
+        tot = self.bytes_staged + self.bytes_post
+        return {"allreduce_bytes_per_step": tot // n, "staged_fraction": (self.bytes_staged / tot) if tot else 0.0,
+                "exposed_ms_per_step": ms}
 
     # ---- in-backward staging: the image encoder's backward hands over each residual stage's gradients
     # as soon as they are final, so their all-reduce runs under the backward of the earlier stages
@@ -119,6 +143,7 @@ class GradReducer:
                 flats.append(g.contiguous().view(-1))
                 layouts.append(("c", g.shape))
         flat = torch.cat(flats)
+        self.bytes_staged += flat.numel() * 4
         work = all_reduce_sum_(flat)
         self._stages.append((work, flat, list(params), layouts))
 
@@ -147,6 +172,11 @@ class GradReducer:
     def reduce(self, params):
         if world_size() == 1:
             return
+        self.steps += 1
+        self._t0 = None
+        if params and params[0].is_cuda:
+            self._t0 = torch.cuda.Event(enable_timing=True)
+            self._t0.record()  # backward is done on this stream
         bucket, n = [], 0
         for p in params:
             if p.grad is None or id(p) in self._staged:  # staged gradients were reduced inside backward
@@ -161,6 +191,7 @@ class GradReducer:
 
     def _launch(self, bucket):
         flat = torch.cat([p.grad.reshape(-1) for p in bucket])
+        self.bytes_post += flat.numel() * 4
         work = all_reduce_sum_(flat)
         self._pending.append((work, flat, bucket))
 
@@ -175,3 +206,8 @@ class GradReducer:
                 off += n
         self._pending = []
         self._staged = set()
+        if getattr(self, "_t0", None) is not None:
+            t1 = torch.cuda.Event(enable_timing=True)
+            t1.record()
+            self._exposed.append((self._t0, t1))
+            self._t0 = None
