@@ -73,11 +73,16 @@ typedef struct trid_gemm_desc {
     int32_t precision;  /* 0: exact fp32-input MFMA; 6 / 3: fp32 operands split on the fly into 3 / 2 bf16
                          * planes, 6 / 3 bf16 MFMAs per product, fp32 accumulate (6 is fp32-class, dropped
                          * terms <= 2^-26; 3 drops ~2^-17); 1: operands rounded to bf16, one MFMA per
-                         * product, fp32 accumulate (bf16-autocast arithmetic).  Shapes the split kernel
-                         * does not cover fall back to 0. */
+                         * product, fp32 accumulate (bf16-autocast arithmetic); 16: fp32 operands scaled by a
+                         * per-tensor power of two (a_amax / b_amax) and split into TWO fp16 planes (11 + 11
+                         * significand bits, residual scaled by 2^11), 3 fp16 MFMAs per product in two fp32
+                         * accumulators (representation + dropped term <= 3 * 2^-22 per product: fp32-class).
+                         * Shapes the split kernel does not cover fall back to 0. */
     const float* residual; /* NULL, or [M][ldres] added after bias (eval: identity / folded downsample branch) */
     int64_t ldres;
     int32_t relu;          /* != 0: C = max(C, 0) last (eval: BatchNorm folded into weights + bias, ReLU here) */
+    const float* a_amax;   /* precision 16 only: DEVICE scalars holding max|A| and max|B| over the whole operand */
+    const float* b_amax;   /* (trid_amax_f32); NULL = operand used unscaled (must then lie in fp16's range)      */
 } trid_gemm_desc;
 
 int trid_gemm_f32(const trid_gemm_desc* d, void* stream);
@@ -222,6 +227,12 @@ int trid_queue_nce_f32(const float* v_q, const float* t_q, const float* v_key, c
                        const float* t_queue, const float* v_queue, const int64_t* id_queue, const int64_t* ids,
                        float* loss_rows, float* dq, int B, int K, int C, float invT, float logit_bound, float gscale,
                        int precision, int nwg_hint, float* ws, void* stream);
+/* Largest magnitudes as device scalars (operand scales of trid_gemm_desc.precision == 16; no reference
+ * counterpart: PyTorch's fp32 convolutions need no range management).
+ * trid_amax_f32: out[0] = max(out[0], max|x|) - `out` must hold 0 (or an earlier partial maximum) on entry.
+ * trid_amax_multi_f32: out[t] = max|tensor t| for a device table of n_tensors pointers / element counts. */
+int trid_amax_f32(const float* x, long long n, float* out, void* stream);
+int trid_amax_multi_f32(const float* const* ptrs, const long long* sizes, int n_tensors, float* out, void* stream);
 /* rowdot[b] = <x_b, y_b> */
 int trid_rowdot_f32(const float* x, const float* y, float* out, long long rows, int C, void* stream);
 /* dx[b,:] (+)= s[b]*y[b,:] */

@@ -232,10 +232,11 @@ def test_small_ops(ops):
     assert rel(ops.softmax_rows_bwd(p, dev(dp), 193)[:, :193], sr.grad) < 1e-5
 
 
-@pytest.mark.parametrize("prec,tol", [(0, 2e-5), (6, 2e-5), (3, 1e-3), (1, 2e-2)])
+@pytest.mark.parametrize("prec,tol", [(0, 2e-5), (6, 2e-5), (16, 2e-5), (3, 1e-3), (1, 2e-2)])
 def test_gemm_arithmetic_modes(ops, prec, tol):
-    """precision 0 = exact fp32-input MFMA, 6 = 3-plane bf16 split (fp32-class), 3 = 2-plane,
-    1 = operands rounded to bf16 (configs[3] arithmetic; tolerance is bf16's 2^-8 operand rounding)."""
+    """precision 0 = exact fp32-input MFMA, 6 = 3-plane bf16 split (fp32-class), 16 = 2-plane fp16 split with
+    per-tensor power-of-two scales (fp32-class, 3 products), 3 = 2-plane bf16, 1 = operands rounded to bf16
+    (configs[3] arithmetic; tolerance is bf16's 2^-8 operand rounding)."""
     old = ops.GEMM_PRECISION
     ops.GEMM_PRECISION = prec
     try:

@@ -23,6 +23,8 @@
 
 #include <stdlib.h>
 
+#include <mutex>
+
 #include "gemm_common.h"
 
 namespace trid {
@@ -410,15 +412,17 @@ static int launch(GemmParams& p, hipStream_t stream) {
     constexpr int LDA = BM + (AMODE == A_MC ? 4 : 1);
     constexpr int LDB = BN + (BMODE == B_KC ? 1 : 4);
     constexpr size_t lds = 2 * (size_t)(BK * LDA + BK * LDB) * sizeof(float);
-    static bool attr_done = false;  // idempotent; a benign race sets it twice at worst
-    if (!attr_done && lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel<AMODE, BMODE, BM, BN, WAVES_M, WAVES_N>,
+    // once per kernel instantiation and process, safe under concurrent first calls from several host threads
+    static std::once_flag once;
+    static hipError_t attr_err = hipSuccess;
+    std::call_once(once, [] {
+        if (lds > 48 * 1024)
+            attr_err = hipFuncSetAttribute((const void*)gemm_kernel<AMODE, BMODE, BM, BN, WAVES_M, WAVES_N>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) {
-            set_error("trid_gemm_f32: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
-            return (int)e;
-        }
-        attr_done = true;
+    });
+    if (attr_err != hipSuccess) {
+        set_error("trid_gemm_f32: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(attr_err));
+        return (int)attr_err;
     }
     hipLaunchKernelGGL((gemm_kernel<AMODE, BMODE, BM, BN, WAVES_M, WAVES_N>), grid, dim3(WAVES_M * WAVES_N * 64), lds, stream, p);
     return check_launch("trid_gemm_f32");
@@ -502,7 +506,9 @@ int trid_gemm_launch(const trid_gemm_desc* d, const GemmFilter* filt, const int*
                             : am == A_MC ? (long long)d->K * d->lda : (long long)(d->M + 256 + 2 * d->W + 2) * d->Cin;
     const long long b_elems = bm == B_KC ? (long long)(d->N + 128) * d->ldb : bm == B_NC ? (long long)d->K * d->ldb : 0;
     const bool small_enough = a_elems < (1ll << 29) && b_elems < (1ll << 29);
-    if ((d->precision == 1 || d->precision == 3 || d->precision == 6) && d->K % 8 == 0 && d->K >= 32 && d->M >= 64 && d->N >= 64 &&
+    p.a_amax = d->a_amax;
+    p.b_amax = d->b_amax;
+    if ((d->precision == 1 || d->precision == 3 || d->precision == 6 || d->precision == 16) && d->K % 8 == 0 && d->K >= 32 && d->M >= 64 && d->N >= 64 &&
         (d->M >= 96 || d->N >= 96) && (am != A_CONV || d->Cin % 8 == 0) && small_enough) {
         rc = gemm_bf16_dispatch(p, am, bm, d->precision, stream);
         if (rc != TRID_E_UNSUPPORTED) return rc;

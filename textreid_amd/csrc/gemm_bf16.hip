@@ -16,6 +16,8 @@
 // row, slot = kgroup*(128+1) + row, one image per plane -> every MFMA operand fetch is one
 // conflict-free ds_read_b128 per plane.
 
+#include <mutex>
+
 #include "split_common.h"
 
 namespace trid {
@@ -32,8 +34,11 @@ constexpr int NT = 512;               // 8 waves
 // B image: the swizzled wide layout needs 576 slots; a K-contiguous 64-row image only 4 x 65
 __host__ __device__ constexpr int b_plane_slots(int bmode, int bn) { return (bmode == B_KC && bn == 64) ? 4 * (64 + 1) : plane_slots(bn); }
 
-template <int AMODE, int BMODE, int NPL, int BN>
-__global__ __launch_bounds__(NT, (BN == 64 && BMODE == B_KC && TRID_NARROW_WAVES > 0) ? TRID_NARROW_WAVES : 1) void gemm_bf16s_kernel(GemmParams p) {
+// ARITH: 1 / 2 / 3 = number of bf16 planes (1, 3, 6 products); 16 = two fp16 planes, 3 products, two accumulators
+template <int AMODE, int BMODE, int ARITH, int BN>
+__global__ __launch_bounds__(NT, (BN == 64 && BMODE == B_KC && TRID_NARROW_WAVES > 0 && ARITH != 16) ? TRID_NARROW_WAVES : 1) void gemm_bf16s_kernel(GemmParams p) {
+    constexpr bool F16 = (ARITH == 16);
+    constexpr int NPL = F16 ? 2 : ARITH;
     constexpr int BM = BM_T;
     constexpr int WAVES_N = BN / 32;           // 4 or 2
     constexpr int WAVES_M = 8 / WAVES_N;       // 2 or 4
@@ -46,6 +51,12 @@ __global__ __launch_bounds__(NT, (BN == 64 && BMODE == B_KC && TRID_NARROW_WAVES
     extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
 
     if (p.gate != nullptr && *p.gate == 0) return;  // predicated launch (retrieval overflow fallback)
+    // f16x3: per-tensor power-of-two scales from the operands' largest magnitudes (device scalars)
+    float scaleA = 1.f, scaleB = 1.f;
+    if (F16) {
+        if (p.a_amax != nullptr) scaleA = f16_scale_of(*p.a_amax);
+        if (p.b_amax != nullptr) scaleB = f16_scale_of(*p.b_amax);
+    }
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -223,6 +234,19 @@ __global__ __launch_bounds__(NT, (BN == 64 && BMODE == B_KC && TRID_NARROW_WAVES
     };
 
     auto store_tiles = [&](uint4* __restrict__ As, uint4* __restrict__ Bs) {
+        if (F16) {
+            if (A_WIDE) {
+                if (a_wide_lane) split_store_wide_f16<PA>(wa, scaleA, As, w_mq, w_kq);
+            } else {
+                split_store_f16<PA>(ra[0], scaleA, As + slot_of<true, BM>(a_kg, a_row));
+            }
+            if (B_WIDE) {
+                if (b_wide_lane && 4 * w_mq < BN) split_store_wide_f16<PB>(wb, scaleB, Bs, w_mq, w_kq);
+            } else if (b_row < BN) {
+                split_store_f16<PB>(rb, scaleB, Bs + slot_of<true, BN>(b_kg, b_row));
+            }
+            return;
+        }
         if (A_WIDE) {
             if (a_wide_lane) split_store_wide<NPL, PA>(wa, As, w_mq, w_kq);
         } else {
@@ -236,15 +260,38 @@ __global__ __launch_bounds__(NT, (BN == 64 && BMODE == B_KC && TRID_NARROW_WAVES
     };
 
     v16f acc[TM];
+    v16f acc_lo[F16 ? TM : 1];  // f16x3: the (hi*lo + lo*hi) group, worth 2^-11 of its face value
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        for (int r = 0; r < 16; ++r) {
+            acc[i][r] = 0.f;
+            if (F16) acc_lo[i][r] = 0.f;
+        }
 
     const int a_slot = wm * (32 * TM) + (lane & 31);
     const int b_slot = wn * 32 + (lane & 31);
 
     auto compute_step = [&](const uint4* __restrict__ As, const uint4* __restrict__ Bs, int ks) {
+        if constexpr (F16) {
+            f16x8 a[2][TM], b[2];
+            const int kg = 2 * ks + khalf;
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    a[pl][i] = __builtin_bit_cast(f16x8, As[pl * PA + slot_of<!A_WIDE, BM>(kg, a_slot + 32 * i)]);
+                b[pl] = __builtin_bit_cast(f16x8, Bs[pl * PB + slot_of<!B_WIDE, BN>(kg, b_slot)]);
+            }
+            // consecutive MFMAs hit different accumulators
+#pragma unroll
+            for (int i = 0; i < TM; ++i) acc_lo[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][i], b[1], acc_lo[i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][i], b[0], acc[i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) acc_lo[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][i], b[0], acc_lo[i], 0, 0, 0);
+            return;
+        }
         bf16x8 a[NPL][TM], b[NPL];
 #pragma unroll
         for (int pl = 0; pl < NPL; ++pl) {
@@ -296,6 +343,13 @@ __global__ __launch_bounds__(NT, (BN == 64 && BMODE == B_KC && TRID_NARROW_WAVES
     }
 
     // ---- epilogue (same contract as gemm.hip) -----------------------------------------
+    if (F16) {  // hi*hi + 2^-11 (hi*lo + lo*hi), then undo the operand scales (exact: powers of two)
+        const float unscale = 1.f / (scaleA * scaleB);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = fmaf(acc_lo[i][r], F16_LO_UNSCALE, acc[i][r]) * unscale;
+    }
     const int row_base = m0 + wm * (32 * TM) + 4 * khalf;
     const int col = n0 + wn * 32 + (lane & 31);
     if (p.filt.thr != nullptr) {
@@ -393,23 +447,26 @@ __global__ __launch_bounds__(NT, (BN == 64 && BMODE == B_KC && TRID_NARROW_WAVES
     }
 }
 
-template <int AMODE, int BMODE, int NPL, int BN>
+template <int AMODE, int BMODE, int ARITH, int BN>
 static int launch_bf16(GemmParams& p, hipStream_t stream) {
+    constexpr int NPL = ARITH == 16 ? 2 : ARITH;
     p.mblocks = (p.M + BM_T - 1) / BM_T;
     p.nblocks = (p.N + BN - 1) / BN;
     dim3 grid((unsigned)(p.mblocks * p.nblocks), 1, (unsigned)(p.batch * p.splits));
     constexpr size_t lds = (size_t)NPL * (plane_slots(BM_T) + b_plane_slots(BMODE, BN)) * sizeof(uint4);
-    static bool attr_done = false;
-    if (!attr_done && lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16s_kernel<AMODE, BMODE, NPL, BN>,
+    // once per kernel instantiation and process, safe under concurrent first calls from several host threads
+    static std::once_flag once;
+    static hipError_t attr_err = hipSuccess;
+    std::call_once(once, [] {
+        if (lds > 48 * 1024)
+            attr_err = hipFuncSetAttribute((const void*)gemm_bf16s_kernel<AMODE, BMODE, ARITH, BN>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) {
-            set_error("trid_gemm_f32(split): cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
-            return (int)e;
-        }
-        attr_done = true;
+    });
+    if (attr_err != hipSuccess) {
+        set_error("trid_gemm_f32(split): cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(attr_err));
+        return (int)attr_err;
     }
-    hipLaunchKernelGGL((gemm_bf16s_kernel<AMODE, BMODE, NPL, BN>), grid, dim3(NT), lds, stream, p);
+    hipLaunchKernelGGL((gemm_bf16s_kernel<AMODE, BMODE, ARITH, BN>), grid, dim3(NT), lds, stream, p);
     return check_launch("trid_gemm_f32(split)");
 }
 
@@ -433,6 +490,7 @@ static int dispatch_modes(GemmParams& p, int am, int bm, hipStream_t stream) {
 }
 
 int gemm_bf16_dispatch(GemmParams& p, int a_mode, int b_mode, int precision, hipStream_t stream) {
+    if (precision == 16) return dispatch_modes<16>(p, a_mode, b_mode, stream);
     if (precision == 6) return dispatch_modes<3>(p, a_mode, b_mode, stream);
     if (precision == 1) return dispatch_modes<1>(p, a_mode, b_mode, stream);
     return dispatch_modes<2>(p, a_mode, b_mode, stream);

@@ -45,6 +45,8 @@ struct GemmParams {
     int mblocks, nblocks;
     GemmFilter filt;   // filt.thr == nullptr: normal epilogue
     const int* gate;   // optional device flag: the whole launch is a no-op when *gate == 0
+    const float* a_amax;  // f16x3 arithmetic: device scalars holding max|A| / max|B| (null: operand used unscaled)
+    const float* b_amax;
 };
 
 constexpr int BK = 32;

@@ -78,6 +78,68 @@ __device__ __forceinline__ void split_store_wide(const float4 (&w)[4], uint4* __
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// fp16 two-plane split ("f16x3": 3 MFMA products per multiply-add).  x' = x * scale (per-tensor power of
+// two that puts max|x'| in [2^13, 2^14), far inside fp16's range), hi = fp16(x'), lo = fp16((x' - hi) * 2^11):
+// |x' - hi - lo * 2^-11| <= 2^-22 |x'| (11 + 11 significand bits; the residual is exact in fp32 and its
+// 2^11 scaling keeps it in fp16's NORMAL range whenever hi is).  A product is hi*hi + (hi*lo + lo*hi) * 2^-11,
+// the two groups in separate fp32 MFMA accumulators; the dropped lo*lo term is <= 2^-22 |ab|.  Elements
+// below 2^-28 of the tensor maximum lose relative (not absolute) precision: their absolute error stays
+// <= 2^-39 of the maximum.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+constexpr float F16_LO_SCALE = 2048.f;           // 2^11
+constexpr float F16_LO_UNSCALE = 1.f / 2048.f;
+
+__device__ __forceinline__ unsigned cvt_pk_f16(float lo, float hi) {
+    unsigned r;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+
+// power-of-two scale for a tensor whose largest magnitude is `amax`: max|x * scale| in [2^13, 2^14)
+__device__ __forceinline__ float f16_scale_of(float amax) {
+    const unsigned bits = __builtin_bit_cast(unsigned, amax);
+    const int e = (int)((bits >> 23) & 0xffu);           // biased exponent of amax (floor(log2) + 127)
+    if (e == 0 || e == 0xff) return 1.f;                 // zero / denormal / inf / nan: leave unscaled
+    return __builtin_bit_cast(float, (unsigned)(127 + 13 + 127 - e) << 23);  // 2^(13 - floor(log2 amax))
+}
+
+// two values -> (hi dword, lo dword) of packed fp16 pairs
+__device__ __forceinline__ void f16_split2(float x0, float x1, unsigned& hi, unsigned& lo) {
+    hi = cvt_pk_f16(x0, x1);
+    const f16x2 h = __builtin_bit_cast(f16x2, hi);
+    lo = cvt_pk_f16((x0 - (float)h.x) * F16_LO_SCALE, (x1 - (float)h.y) * F16_LO_SCALE);
+}
+
+template <int PLANE>
+__device__ __forceinline__ void split_store_f16(const float (&v)[8], float scale, uint4* __restrict__ dst) {
+    unsigned h[4], l[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) f16_split2(v[2 * q] * scale, v[2 * q + 1] * scale, h[q], l[q]);
+    dst[0] = make_uint4(h[0], h[1], h[2], h[3]);
+    dst[PLANE] = make_uint4(l[0], l[1], l[2], l[3]);
+}
+
+template <int PLANE>
+__device__ __forceinline__ void split_store_wide_f16(const float4 (&w)[4], float scale, uint4* __restrict__ base, int mq, int kq) {
+    const int kg = kq >> 1, half = kq & 1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float r0, r1, r2, r3;
+        if (j == 0) { r0 = w[0].x; r1 = w[1].x; r2 = w[2].x; r3 = w[3].x; }
+        else if (j == 1) { r0 = w[0].y; r1 = w[1].y; r2 = w[2].y; r3 = w[3].y; }
+        else if (j == 2) { r0 = w[0].z; r1 = w[1].z; r2 = w[2].z; r3 = w[3].z; }
+        else { r0 = w[0].w; r1 = w[1].w; r2 = w[2].w; r3 = w[3].w; }
+        uint2* dst = reinterpret_cast<uint2*>(base + slot_of<false, 128>(kg, 4 * mq + j)) + half;
+        unsigned h0, l0, h1, l1;
+        f16_split2(r0 * scale, r1 * scale, h0, l0);
+        f16_split2(r2 * scale, r3 * scale, h1, l1);
+        dst[0] = make_uint2(h0, h1);
+        dst[PLANE * 2] = make_uint2(l0, l1);
+    }
+}
+
 // predicated loads without divergent branches: read from a always-valid address, then select
 __device__ __forceinline__ float4 ld4_if(bool ok, const float* __restrict__ p, const float* __restrict__ safe) {
     const float4 v = *reinterpret_cast<const float4*>(ok ? p : safe);

@@ -47,6 +47,8 @@ class GemmDesc(ctypes.Structure):
         ("residual", ctypes.c_void_p),
         ("ldres", ctypes.c_int64),
         ("relu", ctypes.c_int32),
+        ("a_amax", ctypes.c_void_p),
+        ("b_amax", ctypes.c_void_p),
     ]
 
 

@@ -26,7 +26,17 @@ STATS_ROWS = 128  # rows per BatchNorm-statistics partial (GEMM tile height)
 #      tests pass at the same error level as the exact path) at ~1.5x the fp32-MFMA rate;
 #   0: exact fp32-input MFMA (v_mfma_f32_32x32x2_f32);
 #   3: 2 planes / 3 products (~2^-17 per product): faster, NOT parity-safe, never the default.
+#  16: fp32 operands scaled per tensor by a power of two and split into TWO fp16 planes (11 + 11 significand bits),
+#      3 fp16 MFMA products per multiply-add in two fp32 accumulators (error <= 3 * 2^-22 per product: fp32-class, half
+#      the MFMA work of 6); needs the operands' largest magnitudes as device scalars (`amax`).
 GEMM_PRECISION = int(__import__("os").environ.get("TRID_GEMM_PRECISION", "6"))
+# arithmetic of the image encoder's convolutions (95 % of the step's FLOPs); 6 = same as everything else
+CONV_PRECISION = int(__import__("os").environ.get("TRID_CONV_PRECISION", "16"))
+
+
+def conv_precision():
+    """16 only while the global mode is the fp32-class default; TRID_GEMM_PRECISION=0/1/3 overrides everything."""
+    return CONV_PRECISION if GEMM_PRECISION == 6 else GEMM_PRECISION
 
 
 def stream():
@@ -38,9 +48,9 @@ def stream():
 PROFILE = None
 
 
-def _uses_split(M, N, K, a_mode, conv):
+def _uses_split(M, N, K, a_mode, conv, prec=None):
     """Mirror of the split-kernel eligibility test in trid_gemm_f32()."""
-    return (GEMM_PRECISION in (1, 3, 6) and K % 8 == 0 and K >= 32 and M >= 64 and N >= 64 and (M >= 96 or N >= 96)
+    return ((GEMM_PRECISION if prec is None else prec) in (1, 3, 6, 16) and K % 8 == 0 and K >= 32 and M >= 64 and N >= 64 and (M >= 96 or N >= 96)
             and (a_mode != A_CONV or conv[2] % 8 == 0))
 
 
@@ -70,10 +80,35 @@ def empty(shape, like=None, dtype=torch.float32, device=None):
 
 
 # --------------------------------------------------------------------------- GEMM
+_amax_pool = {}
+
+
+def amax(t):
+    """Device scalar (1-element view) holding max|t|: one streaming pass.  Slots come from a zero-filled pool and are
+    written once, so no per-call memset; the view keeps its pool buffer alive."""
+    key = (t.device, torch.cuda.current_stream(t.device).cuda_stream)
+    ent = _amax_pool.get(key)
+    if ent is None or ent[1] >= ent[0].numel():
+        ent = [torch.zeros(4096, dtype=torch.float32, device=t.device), 0]
+        _amax_pool[key] = ent
+    slot = ent[0][ent[1] : ent[1] + 1]
+    ent[1] += 1
+    call("trid_amax_f32", _p(t), t.numel(), _p(slot), stream())
+    return slot
+
+
 def gemm(A, B, C, M, N, K, lda, ldb, ldc, a_mode=A_KC, b_mode=B_KC, alpha=1.0, accumulate=False, bias=None,
          stats=None, batch=1, strideA=0, strideB=0, strideC=0, splits=1, strideSplit=0, conv=None, a_off=0, b_off=0,
-         c_off=0, strideBias=0, bias_off=0, residual=None, ldres=0, relu=False):
-    """Raw descriptor call.  a_off/b_off/c_off are element offsets into A/B/C."""
+         c_off=0, strideBias=0, bias_off=0, residual=None, ldres=0, relu=False, precision=None, a_amax=None, b_amax=None):
+    """Raw descriptor call.  a_off/b_off/c_off are element offsets into A/B/C.  precision=16 (fp16-split
+    arithmetic) takes the operands' largest magnitudes as device scalars; a missing one is computed here over the
+    WHOLE tensor object passed (a superset of the operand is a valid, merely looser, scale)."""
+    prec = GEMM_PRECISION if precision is None else precision
+    if prec == 16 and _uses_split(M, N, K, a_mode, conv, 16):
+        if a_amax is None:
+            a_amax = amax(A)
+        if b_amax is None:
+            b_amax = amax(B)
     d = GemmDesc()
     d.A = _p(A) + 4 * a_off
     d.B = _p(B) + 4 * b_off
@@ -90,13 +125,15 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, a_mode=A_KC, b_mode=B_KC, alpha=1.0, a
     d.stats = _p(stats)
     if conv is not None:
         d.H, d.W, d.Cin = conv
-    d.precision = GEMM_PRECISION
+    d.precision = prec
+    d.a_amax = _p(a_amax)
+    d.b_amax = _p(b_amax)
     d.residual = _p(residual)
     d.ldres = ldres
     d.relu = 1 if relu else 0
     prof = PROFILE
     if prof is not None:
-        split = _uses_split(M, N, K, a_mode, conv)
+        split = _uses_split(M, N, K, a_mode, conv, prec)
         key = (a_mode, b_mode) + ((128, 64 if N <= 64 else 128) if split else _gemm_tile(M, N, stats is not None)) + (split,)
         label = prof["match"](key)
         if label:
@@ -109,17 +146,19 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, a_mode=A_KC, b_mode=B_KC, alpha=1.0, a
     call("trid_gemm_f32", ctypes.addressof(d), stream())
 
 
-def linear(x, w, bias=None, out=None, alpha=1.0, accumulate=False):
-    """y[M,N] = alpha * x[M,K] @ w[N,K]^T + bias.  x may be a strided row view."""
+def linear(x, w, bias=None, out=None, alpha=1.0, accumulate=False, prec=None, aa=None, ba=None):
+    """y[M,N] = alpha * x[M,K] @ w[N,K]^T + bias.  x may be a strided row view.
+    prec / aa / ba (here and below): GEMM arithmetic override and the two operands' amax device scalars."""
     M, K = x.shape
     N = w.shape[0]
     if out is None:
         out = empty((M, N), x)
-    gemm(x, w, out, M, N, K, x.stride(0), w.stride(0), out.stride(0), alpha=alpha, accumulate=accumulate, bias=bias)
+    gemm(x, w, out, M, N, K, x.stride(0), w.stride(0), out.stride(0), alpha=alpha, accumulate=accumulate, bias=bias,
+         precision=prec, a_amax=aa, b_amax=ba)
     return out
 
 
-def matmul_nn(a, b, out=None, alpha=1.0, accumulate=False):
+def matmul_nn(a, b, out=None, alpha=1.0, accumulate=False, prec=None, aa=None, ba=None):
     """out[M,N] = a[M,K] @ b[K,N] (b rows N-contiguous).  Skinny outputs with a long
     K (loss gradients: [B,K_queue]x[K_queue,C]) are split over K into slabs so the
     launch fills the chip instead of running a serial K loop on a handful of CUs."""
@@ -131,10 +170,11 @@ def matmul_nn(a, b, out=None, alpha=1.0, accumulate=False):
     splits = min(K // 128, (256 + tiles - 1) // tiles) if (tiles < 64 and K >= 1024 and out.stride(0) == N) else 1
     if splits <= 1:
         gemm(a, b, out, M, N, K, a.stride(0), b.stride(0), out.stride(0), b_mode=B_NC, alpha=alpha,
-             accumulate=accumulate)
+             accumulate=accumulate, precision=prec, a_amax=aa, b_amax=ba)
         return out
     slab = empty((splits, M, N), a)
-    gemm(a, b, slab, M, N, K, a.stride(0), b.stride(0), N, b_mode=B_NC, alpha=alpha, splits=splits, strideSplit=M * N)
+    gemm(a, b, slab, M, N, K, a.stride(0), b.stride(0), N, b_mode=B_NC, alpha=alpha, splits=splits, strideSplit=M * N,
+         precision=prec, a_amax=aa, b_amax=ba)
     call("trid_slab_reduce_f32", _p(slab), _p(out), M * N, splits, M * N, 1 if accumulate else 0, stream())
     return out
 
@@ -148,7 +188,7 @@ def _wgrad_splits(tiles, K, slots=512):
     return max(1, min(cap, (2 * slots) // tiles))
 
 
-def matmul_tn(a, b, out=None, alpha=1.0):
+def matmul_tn(a, b, out=None, alpha=1.0, prec=None, aa=None, ba=None):
     """out[Ma,Nb] = a[K,Ma]^T @ b[K,Nb]  (weight-gradient form, split-K over K)."""
     K, Ma = a.shape
     Nb = b.shape[1]
@@ -157,11 +197,12 @@ def matmul_tn(a, b, out=None, alpha=1.0):
     tiles = ((Ma + 127) // 128) * ((Nb + 127) // 128)
     splits = _wgrad_splits(tiles, K)
     if splits == 1 or out.stride(0) != Nb:
-        gemm(a, b, out, Ma, Nb, K, a.stride(0), b.stride(0), out.stride(0), a_mode=A_MC, b_mode=B_NC, alpha=alpha)
+        gemm(a, b, out, Ma, Nb, K, a.stride(0), b.stride(0), out.stride(0), a_mode=A_MC, b_mode=B_NC, alpha=alpha,
+             precision=prec, a_amax=aa, b_amax=ba)
         return out
     slab = empty((splits, Ma, Nb), a)
     gemm(a, b, slab, Ma, Nb, K, a.stride(0), b.stride(0), Nb, a_mode=A_MC, b_mode=B_NC, alpha=alpha, splits=splits,
-         strideSplit=Ma * Nb)
+         strideSplit=Ma * Nb, precision=prec, a_amax=aa, b_amax=ba)
     call("trid_slab_reduce_f32", _p(slab), _p(out), Ma * Nb, splits, Ma * Nb, 0, stream())
     return out
 
@@ -170,7 +211,7 @@ def stats_buffer(M, N, like):
     return empty(((M + STATS_ROWS - 1) // STATS_ROWS, N, 2), like)
 
 
-def conv1x1(x, w, stats=False, bias=None, relu=False, residual=None):
+def conv1x1(x, w, stats=False, bias=None, relu=False, residual=None, prec=None, aa=None, ba=None):
     """x [B,H,W,C] NHWC (or [M,C]), w [N,C] -> y [.., N]; optional BN partials (training) or the
     fused eval epilogue: + bias[N] (+ residual [.., N]) then ReLU."""
     C = x.shape[-1]
@@ -178,18 +219,20 @@ def conv1x1(x, w, stats=False, bias=None, relu=False, residual=None):
     N = w.shape[0]
     y = empty(x.shape[:-1] + (N,), x)
     st = stats_buffer(M, N, x) if stats else None
-    gemm(x, w, y, M, N, C, C, w.stride(0), N, stats=st, bias=bias, relu=relu, residual=residual, ldres=N)
+    gemm(x, w, y, M, N, C, C, w.stride(0), N, stats=st, bias=bias, relu=relu, residual=residual, ldres=N,
+         precision=prec, a_amax=aa, b_amax=ba)
     return (y, st) if stats else y
 
 
-def conv3x3(x, w, stats=False, bias=None, relu=False):
+def conv3x3(x, w, stats=False, bias=None, relu=False, prec=None, aa=None, ba=None):
     """x [B,H,W,C] NHWC, w [N, 9*C] (tap-major, channel-minor = OHWI) -> y [B,H,W,N]."""
     Bi, H, W, C = x.shape
     N = w.shape[0]
     M = Bi * H * W
     y = empty((Bi, H, W, N), x)
     st = stats_buffer(M, N, x) if stats else None
-    gemm(x, w, y, M, N, 9 * C, C, 9 * C, N, a_mode=A_CONV, stats=st, conv=(H, W, C), bias=bias, relu=relu)
+    gemm(x, w, y, M, N, 9 * C, C, 9 * C, N, a_mode=A_CONV, stats=st, conv=(H, W, C), bias=bias, relu=relu,
+         precision=prec, a_amax=aa, b_amax=ba)
     return (y, st) if stats else y
 
 
@@ -199,13 +242,13 @@ def fold_bn(w2d, st):
     return rowscale_add(st.scale, w2d), st.shift
 
 
-def conv1x1_wgrad(dy, x):
+def conv1x1_wgrad(dy, x, prec=None, aa=None, ba=None):
     """dW [N,C] = dy[M,N]^T @ x[M,C]."""
     N, C = dy.shape[-1], x.shape[-1]
-    return matmul_tn(dy.reshape(-1, N), x.reshape(-1, C))
+    return matmul_tn(dy.reshape(-1, N), x.reshape(-1, C), prec=prec, aa=aa, ba=ba)
 
 
-def conv3x3_wgrad(dy, x):
+def conv3x3_wgrad(dy, x, prec=None, aa=None, ba=None):
     """dW [N, 9*C] for the 3x3/s1/p1 conv; dy [B,H,W,N], x [B,H,W,C]."""
     Bi, H, W, C = x.shape
     N = dy.shape[-1]
@@ -215,10 +258,11 @@ def conv3x3_wgrad(dy, x):
     tiles = ((N + 127) // 128) * ((J + 127) // 128)
     splits = _wgrad_splits(tiles, M)
     if splits == 1:
-        gemm(dy, x, out, N, J, M, N, C, J, a_mode=A_MC, b_mode=B_CONV, conv=(H, W, C))
+        gemm(dy, x, out, N, J, M, N, C, J, a_mode=A_MC, b_mode=B_CONV, conv=(H, W, C), precision=prec, a_amax=aa, b_amax=ba)
         return out
     slab = empty((splits, N, J), x)
-    gemm(dy, x, slab, N, J, M, N, C, J, a_mode=A_MC, b_mode=B_CONV, conv=(H, W, C), splits=splits, strideSplit=N * J)
+    gemm(dy, x, slab, N, J, M, N, C, J, a_mode=A_MC, b_mode=B_CONV, conv=(H, W, C), splits=splits, strideSplit=N * J,
+         precision=prec, a_amax=aa, b_amax=ba)
     call("trid_slab_reduce_f32", _p(slab), _p(out), N * J, splits, N * J, 0, stream())
     return out
 
