@@ -120,10 +120,12 @@ int trid_bn_eval_coeffs_f32(const float* gamma, const float* beta, const float* 
  * trid_bn_bwd_* mask_mode 3.  Element quad i = (row*C + c)/4 -> 64-bit words (i/64)*4 + (c%4), bit i%64. */
 int trid_bn_apply_f32(const float* y, const float* scale, const float* shift, const float* res,
                       const float* rscale, const float* rshift, float* out, long long M, int C, int relu,
-                      uint64_t* relu_mask, void* stream);
-/* out[b,y/2,x/2,c] = mean over 2x2 of act(y*scale+shift)   (scale==NULL: plain pooling of y) */
+                      uint64_t* relu_mask, float* amax, void* stream);
+/* out[b,y/2,x/2,c] = mean over 2x2 of act(y*scale+shift)   (scale==NULL: plain pooling of y).
+ * amax (here, above and in trid_bn_bwd_apply_f32; may be NULL): device scalar, amax[0] = max(amax[0], max|out|) -
+ * the producer of a GEMM operand hands the consumer its precision-16 scale without another pass. */
 int trid_bn_apply_pool2_f32(const float* y, const float* scale, const float* shift, float* out, int B, int H,
-                            int W, int C, int relu, void* stream);
+                            int W, int C, int relu, float* amax, void* stream);
 /* dx[b,y,x,c] (+)= 0.25*g[b,y/2,x/2,c] */
 int trid_avgpool2_bwd_f32(const float* g, float* dx, int B, int H, int W, int C, int accumulate, void* stream);
 
@@ -141,7 +143,7 @@ int trid_bn_bwd_reduce_f32(const float* g, const float* y, const float* act, con
 int trid_bn_bwd_apply_f32(const float* g, const float* y, const float* act, const float* mean,
                           const float* invstd, const float* scale, const float* shift, const float* dgamma,
                           const float* dbeta, int mask_mode, int pooled, int B, int H, int W, int C, float* dy,
-                          float* dres, void* stream);
+                          float* dres, float* amax, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Attention pool (m_resnet.py:103-135), token-0 query only.
@@ -230,7 +232,8 @@ int trid_queue_nce_f32(const float* v_q, const float* t_q, const float* v_key, c
 /* Largest magnitudes as device scalars (operand scales of trid_gemm_desc.precision == 16; no reference
  * counterpart: PyTorch's fp32 convolutions need no range management).
  * trid_amax_f32: out[0] = max(out[0], max|x|) - `out` must hold 0 (or an earlier partial maximum) on entry.
- * trid_amax_multi_f32: out[t] = max|tensor t| for a device table of n_tensors pointers / element counts. */
+ * trid_amax_multi_f32: out[t] = max(out[t], max|tensor t|) for a device table of n_tensors pointers / element
+ * counts (out zeroed by the caller). */
 int trid_amax_f32(const float* x, long long n, float* out, void* stream);
 int trid_amax_multi_f32(const float* const* ptrs, const long long* sizes, int n_tensors, float* out, void* stream);
 /* rowdot[b] = <x_b, y_b> */

@@ -244,10 +244,34 @@ class ModifiedResNet(nn.Module):
         feat, _ = self._attnpool_forward(x, False)
         return feat
 
+    def _weight_amax(self):
+        """{id(conv weight): device scalar max|w|} for every conv filter, ONE multi-tensor launch (fp16-split
+        arithmetic, ops.CONV_PRECISION == 16).  The pointer table is rebuilt only when a parameter moves."""
+        convs = [m.weight for m in self.modules() if isinstance(m, nn.Conv2d)]
+        key = tuple(w.data_ptr() for w in convs)
+        plan = getattr(self, "_wamax_plan", None)
+        if plan is None or plan[0] != key:
+            dev = convs[0].device
+            ptrs = torch.tensor(list(key), dtype=torch.int64, device=dev)
+            sizes = torch.tensor([w.numel() for w in convs], dtype=torch.int64, device=dev)
+            plan = (key, ptrs, sizes)
+            self._wamax_plan = plan
+        out = torch.zeros(len(convs), dtype=torch.float32, device=convs[0].device)
+        ops.call("trid_amax_multi_f32", ops._p(plan[1]), ops._p(plan[2]), len(convs), ops._p(out), ops.stream())
+        return {id(w): out[i : i + 1] for i, w in enumerate(convs)}
+
     def _run_forward(self, images, save):
         training = self.training
         B = images.shape[0]
         S = {"B": B} if save else None
+        # fp16-split conv arithmetic: every GEMM operand comes with its largest magnitude as a device scalar
+        P = ops.conv_precision()
+        f16 = P == 16
+        WA = self._weight_amax() if f16 else {}
+        slot = (lambda: ops.amax_slot(images.device)) if f16 else (lambda: None)  # amax side outputs of the producers
+        wam = lambda conv: WA.get(id(conv.weight))
+        if not f16:
+            P = None
         # ---- stem (m_resnet.py:199-207)
         col, Ho, Wo = ops.stem_im2col(images)
         c1 = self.conv1.weight
@@ -261,13 +285,17 @@ class ModifiedResNet(nn.Module):
         w2 = _w3x3(self.conv2)
         y2, p2 = ops.conv3x3(a1, w2, stats=True) if training else (ops.conv3x3(a1, w2), None)
         st2 = _bn_coeffs(self.bn2, p2, B * Ho * Wo, training, nbt)
-        a2 = ops.bn_apply(y2, st2, relu=True)
+        a_a2 = slot()
+        a2 = ops.bn_apply(y2, st2, relu=True, amax=a_a2)
         w3 = _w3x3(self.conv3)
-        y3, p3 = ops.conv3x3(a2, w3, stats=True) if training else (ops.conv3x3(a2, w3), None)
+        kw3 = dict(prec=P, aa=a_a2, ba=wam(self.conv3))
+        y3, p3 = ops.conv3x3(a2, w3, stats=True, **kw3) if training else (ops.conv3x3(a2, w3, **kw3), None)
         st3 = _bn_coeffs(self.bn3, p3, B * Ho * Wo, training, nbt)
-        x = ops.bn_apply_pool2(y3, st3, relu=True)
+        ax = slot()
+        x = ops.bn_apply_pool2(y3, st3, relu=True, amax=ax)
         if save:
-            S["stem"] = (col, y1, st1, a1, y2, st2, a2, y3, st3)
+            S["stem"] = (col, y1, st1, a1, y2, st2, a2, y3, st3, a_a2)
+            S["wamax"] = WA
         # ---- residual layers (m_resnet.py:54-67)
         if save:
             S["blocks"] = []
@@ -279,31 +307,41 @@ class ModifiedResNet(nn.Module):
         for blk in self.blocks():
             stride = blk.stride
             wa = blk.conv1.weight.view(blk.conv1.out_channels, -1)
-            ya, pa = ops.conv1x1(x, wa, stats=True) if training else (ops.conv1x1(x, wa), None)
+            kwa = dict(prec=P, aa=ax, ba=wam(blk.conv1))
+            ya, pa = ops.conv1x1(x, wa, stats=True, **kwa) if training else (ops.conv1x1(x, wa, **kwa), None)
             Ma = ya.numel() // ya.shape[-1]
             sta = _bn_coeffs(blk.bn1, pa, Ma, training, nbt)
-            aa = ops.bn_apply(ya, sta, relu=True)
+            a_aa = slot()
+            aa = ops.bn_apply(ya, sta, relu=True, amax=a_aa)
             wb = _w3x3(blk.conv2)
-            yb, pb = ops.conv3x3(aa, wb, stats=True) if training else (ops.conv3x3(aa, wb), None)
+            kwb = dict(prec=P, aa=a_aa, ba=wam(blk.conv2))
+            yb, pb = ops.conv3x3(aa, wb, stats=True, **kwb) if training else (ops.conv3x3(aa, wb, **kwb), None)
             stb = _bn_coeffs(blk.bn2, pb, Ma, training, nbt)
-            ab = ops.bn_apply_pool2(yb, stb, relu=True) if stride > 1 else ops.bn_apply(yb, stb, relu=True)
+            a_ab = slot()
+            ab = ops.bn_apply_pool2(yb, stb, relu=True, amax=a_ab) if stride > 1 else ops.bn_apply(yb, stb, relu=True, amax=a_ab)
             wc = blk.conv3.weight.view(blk.conv3.out_channels, -1)
-            yc, pc = ops.conv1x1(ab, wc, stats=True) if training else (ops.conv1x1(ab, wc), None)
+            kwc = dict(prec=P, aa=a_ab, ba=wam(blk.conv3))
+            yc, pc = ops.conv1x1(ab, wc, stats=True, **kwc) if training else (ops.conv1x1(ab, wc, **kwc), None)
             Mc = yc.numel() // yc.shape[-1]
             stc = _bn_coeffs(blk.bn3, pc, Mc, training, nbt)
-            xd = yd = std = None
+            xd = yd = std = a_xd = None
             if blk.downsample is not None:
-                xd = ops.bn_apply_pool2(x, None) if stride > 1 else x
+                a_xd = slot() if stride > 1 else ax
+                xd = ops.bn_apply_pool2(x, None, amax=a_xd) if stride > 1 else x
                 wd = blk.downsample[1].weight.view(blk.downsample[1].out_channels, -1)
-                yd, pd = ops.conv1x1(xd, wd, stats=True) if training else (ops.conv1x1(xd, wd), None)
+                kwd = dict(prec=P, aa=a_xd, ba=wam(blk.downsample[1]))
+                yd, pd = ops.conv1x1(xd, wd, stats=True, **kwd) if training else (ops.conv1x1(xd, wd, **kwd), None)
                 std = _bn_coeffs(blk.downsample[2], pd, Mc, training, nbt)
-                out = ops.bn_apply(yc, stc, relu=True, res=yd, res_st=std, want_mask=save)
+                a_out = slot()
+                out = ops.bn_apply(yc, stc, relu=True, res=yd, res_st=std, want_mask=save, amax=a_out)
             else:
-                out = ops.bn_apply(yc, stc, relu=True, res=x, want_mask=save)
+                a_out = slot()
+                out = ops.bn_apply(yc, stc, relu=True, res=x, want_mask=save, amax=a_out)
             if save:
                 out, rmask = out  # 1-bit ReLU mask of the block output for the backward pass
-                S["blocks"].append((x, ya, sta, aa, yb, stb, ab, yc, stc, xd, yd, std, rmask))
+                S["blocks"].append((x, ya, sta, aa, yb, stb, ab, yc, stc, xd, yd, std, rmask, (ax, a_aa, a_ab, a_xd)))
             x = out
+            ax = a_out
             if taps is not None:
                 taps[names[id(blk)]] = out
         if nbt:
@@ -410,6 +448,10 @@ class ModifiedResNet(nn.Module):
         G = {}
         B = S["B"]
         ws = _WgradStream(gout.device)
+        WA = S.get("wamax", {})
+        P = 16 if WA else None  # the forward's conv arithmetic (its weight / activation amax scalars are reused here)
+        slot = (lambda: ops.amax_slot(gout.device)) if WA else (lambda: None)
+        wam = lambda conv: WA.get(id(conv.weight))
         g = self._attnpool_backward(S["attn"], gout, G)
         S["attn"] = None
         blocks = list(self.blocks())
@@ -429,49 +471,54 @@ class ModifiedResNet(nn.Module):
         first_of_layer = {id(layer[0]) for layer in (self.layer1, self.layer2, self.layer3, self.layer4)}
         dbg = getattr(self, "_debug_grads", None)
         for blk, rec in zip(reversed(blocks), reversed(S["blocks"])):
-            x, ya, sta, aa, yb, stb, ab, yc, stc, xd, yd, std, rmask = rec
+            x, ya, sta, aa, yb, stb, ab, yc, stc, xd, yd, std, rmask, (ax, a_aa, a_ab, a_xd) = rec
             if dbg is not None:
                 dbg.append(g)
             stride = blk.stride
             has_down = blk.downsample is not None
-            dyc, dg, db, dres = ops.bn_bwd(g, yc, stc, None, 3, act=rmask, want_dres=not has_down)
+            a_dyc = slot()
+            dyc, dg, db, dres = ops.bn_bwd(g, yc, stc, None, 3, act=rmask, want_dres=not has_down, amax=a_dyc)
             G[id(blk.bn3.weight)], G[id(blk.bn3.bias)] = dg, db
             if has_down:
-                dyd, dg, db, _ = ops.bn_bwd(g, yd, std, None, 3, act=rmask)
+                a_dyd = slot()
+                dyd, dg, db, _ = ops.bn_bwd(g, yd, std, None, 3, act=rmask, amax=a_dyd)
                 G[id(blk.downsample[2].weight)], G[id(blk.downsample[2].bias)] = dg, db
             wc = blk.conv3.weight.view(blk.conv3.out_channels, -1)
-            dab = ops.matmul_nn(dyc.view(-1, dyc.shape[-1]), wc).view(ab.shape)
-            G[id(blk.conv3.weight)] = ws.run(ops.conv1x1_wgrad, dyc, ab).view_as(blk.conv3.weight)
-            dyb, dg, db, _ = ops.bn_bwd(dab, yb, stb, None, 1, pooled=stride > 1)
+            dab = ops.matmul_nn(dyc.view(-1, dyc.shape[-1]), wc, prec=P, aa=a_dyc, ba=wam(blk.conv3)).view(ab.shape)
+            G[id(blk.conv3.weight)] = ws.run(lambda d_, x_: ops.conv1x1_wgrad(d_, x_, prec=P, aa=a_dyc, ba=a_ab), dyc, ab).view_as(blk.conv3.weight)
+            a_dyb = slot()
+            dyb, dg, db, _ = ops.bn_bwd(dab, yb, stb, None, 1, pooled=stride > 1, amax=a_dyb)
             G[id(blk.bn2.weight)], G[id(blk.bn2.bias)] = dg, db
             planes = blk.conv2.out_channels
             wbt = ops.weight_transpose(_w3x3(blk.conv2), planes, 9, planes, flip=True)
-            daa = ops.conv3x3(dyb, wbt)
-            G[id(blk.conv2.weight)] = _g3x3(ws.run(ops.conv3x3_wgrad, dyb, aa), planes, planes)
-            dya, dg, db, _ = ops.bn_bwd(daa, ya, sta, None, 1)
+            daa = ops.conv3x3(dyb, wbt, prec=P, aa=a_dyb, ba=wam(blk.conv2))
+            G[id(blk.conv2.weight)] = _g3x3(ws.run(lambda d_, x_: ops.conv3x3_wgrad(d_, x_, prec=P, aa=a_dyb, ba=a_aa), dyb, aa), planes, planes)
+            a_dya = slot()
+            dya, dg, db, _ = ops.bn_bwd(daa, ya, sta, None, 1, amax=a_dya)
             G[id(blk.bn1.weight)], G[id(blk.bn1.bias)] = dg, db
             wa = blk.conv1.weight.view(blk.conv1.out_channels, -1)
             if has_down:
                 wd = blk.downsample[1].weight.view(blk.downsample[1].out_channels, -1)
-                dxd = ops.matmul_nn(dyd.view(-1, dyd.shape[-1]), wd).view(xd.shape)
-                G[id(blk.downsample[1].weight)] = ws.run(ops.conv1x1_wgrad, dyd, xd).view_as(blk.downsample[1].weight)
+                dxd = ops.matmul_nn(dyd.view(-1, dyd.shape[-1]), wd, prec=P, aa=a_dyd, ba=wam(blk.downsample[1])).view(xd.shape)
+                G[id(blk.downsample[1].weight)] = ws.run(lambda d_, x_: ops.conv1x1_wgrad(d_, x_, prec=P, aa=a_dyd, ba=a_xd), dyd, xd).view_as(blk.downsample[1].weight)
                 dx = ops.avgpool2_bwd(dxd) if stride > 1 else dxd
             else:
                 dx = dres
-            ops.matmul_nn(dya.view(-1, dya.shape[-1]), wa, out=dx.view(-1, dx.shape[-1]), accumulate=True)
-            G[id(blk.conv1.weight)] = ws.run(ops.conv1x1_wgrad, dya, x).view_as(blk.conv1.weight)
+            ops.matmul_nn(dya.view(-1, dya.shape[-1]), wa, out=dx.view(-1, dx.shape[-1]), accumulate=True, prec=P, aa=a_dya, ba=wam(blk.conv1))
+            G[id(blk.conv1.weight)] = ws.run(lambda d_, x_: ops.conv1x1_wgrad(d_, x_, prec=P, aa=a_dya, ba=ax), dya, x).view_as(blk.conv1.weight)
             g = dx
             if id(blk) in first_of_layer:  # a whole residual layer (and, the first time, the attention pool) is done
                 stage_ready()
         S["blocks"] = None
         # ---- stem
-        col, y1, st1, a1, y2, st2, a2, y3, st3 = S["stem"]
-        dy3, dg, db, _ = ops.bn_bwd(g, y3, st3, None, 1, pooled=True)
+        col, y1, st1, a1, y2, st2, a2, y3, st3, a_a2 = S["stem"]
+        a_dy3 = slot()
+        dy3, dg, db, _ = ops.bn_bwd(g, y3, st3, None, 1, pooled=True, amax=a_dy3)
         G[id(self.bn3.weight)], G[id(self.bn3.bias)] = dg, db
         c3o, c3i = self.conv3.out_channels, self.conv3.in_channels
         w3t = ops.weight_transpose(_w3x3(self.conv3), c3o, 9, c3i, flip=True)
         da2 = ops.conv3x3(dy3, w3t)
-        G[id(self.conv3.weight)] = _g3x3(ws.run(ops.conv3x3_wgrad, dy3, a2), c3o, c3i)
+        G[id(self.conv3.weight)] = _g3x3(ws.run(lambda d_, x_: ops.conv3x3_wgrad(d_, x_, prec=P, aa=a_dy3, ba=a_a2), dy3, a2), c3o, c3i)
         dy2, dg, db, _ = ops.bn_bwd(da2, y2, st2, None, 1)
         G[id(self.bn2.weight)], G[id(self.bn2.bias)] = dg, db
         c2o, c2i = self.conv2.out_channels, self.conv2.in_channels

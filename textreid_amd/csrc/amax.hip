@@ -43,28 +43,33 @@ __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, 
     }
 }
 
-// one workgroup per tensor (weights: at most a few million elements each)
+// gridDim.y workgroups per tensor, each over a contiguous slice; `out` must start at 0
 __global__ __launch_bounds__(256) void amax_multi_kernel(const float* const* __restrict__ ptrs, const long long* __restrict__ sizes,
                                                          unsigned* __restrict__ out) {
     const float* x = ptrs[blockIdx.x];
     const long long n = sizes[blockIdx.x];
+    long long per = (n + gridDim.y - 1) / gridDim.y;
+    per = (per + 3) & ~3LL;  // slices start on a 16-byte boundary when the tensor does
+    const long long lo = (long long)blockIdx.y * per;
+    const long long hi = lo + per < n ? lo + per : n;
+    if (lo >= hi) return;
     unsigned m = 0;
     if ((reinterpret_cast<uintptr_t>(x) & 15) == 0) {
-        const long long n4 = n >> 2;
+        const long long q_lo = lo >> 2, q_hi = hi >> 2;
         const float4* x4 = reinterpret_cast<const float4*>(x);
-        for (long long i = threadIdx.x; i < n4; i += 256) {
+        for (long long i = q_lo + threadIdx.x; i < q_hi; i += 256) {
             const float4 v = x4[i];
             const unsigned a = absbits(v.x), b = absbits(v.y), c = absbits(v.z), d = absbits(v.w);
             const unsigned ab = a > b ? a : b, cd = c > d ? c : d;
             const unsigned q = ab > cd ? ab : cd;
             m = q > m ? q : m;
         }
-        for (long long i = (n4 << 2) + threadIdx.x; i < n; i += 256) {
+        for (long long i = (q_hi << 2) + threadIdx.x; i < hi; i += 256) {
             const unsigned a = absbits(x[i]);
             m = a > m ? a : m;
         }
     } else {
-        for (long long i = threadIdx.x; i < n; i += 256) {
+        for (long long i = lo + threadIdx.x; i < hi; i += 256) {
             const unsigned a = absbits(x[i]);
             m = a > m ? a : m;
         }
@@ -75,7 +80,8 @@ __global__ __launch_bounds__(256) void amax_multi_kernel(const float* const* __r
     __syncthreads();
     if (threadIdx.x == 0) {
         const unsigned a = red[0] > red[1] ? red[0] : red[1], b = red[2] > red[3] ? red[2] : red[3];
-        out[blockIdx.x] = a > b ? a : b;
+        const unsigned r = a > b ? a : b;
+        if (r != 0) atomicMax(out + blockIdx.x, r);
     }
 }
 
@@ -92,7 +98,7 @@ extern "C" int trid_amax_f32(const float* x, long long n, float* out, void* stre
 
 extern "C" int trid_amax_multi_f32(const float* const* ptrs, const long long* sizes, int n_tensors, float* out, void* stream) {
     TRID_REQUIRE(ptrs && sizes && out && n_tensors > 0, "trid_amax_multi_f32: bad arguments");
-    hipLaunchKernelGGL(amax_multi_kernel, dim3(n_tensors), dim3(256), 0, (hipStream_t)stream, ptrs, sizes,
+    hipLaunchKernelGGL(amax_multi_kernel, dim3(n_tensors, 16), dim3(256), 0, (hipStream_t)stream, ptrs, sizes,
                        reinterpret_cast<unsigned*>(out));
     return check_launch("trid_amax_multi_f32");
 }

@@ -116,6 +116,34 @@ __global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, con
     }
 }
 
+// ---------------------------------------------------------------- amax side output
+// The kernels that PRODUCE a GEMM operand can also fold max|out| into a device scalar (the operand scale of the
+// fp16-split GEMM arithmetic, trid_gemm_desc.precision == 16): per-thread running maximum, one wave / block fold,
+// one fire-and-forget integer atomicMax on the bit pattern per block.  `amax` must start at 0.
+__device__ __forceinline__ unsigned amax4(unsigned m, float4 v) {
+    const unsigned a = __builtin_bit_cast(unsigned, v.x) & 0x7fffffffu, b = __builtin_bit_cast(unsigned, v.y) & 0x7fffffffu;
+    const unsigned c = __builtin_bit_cast(unsigned, v.z) & 0x7fffffffu, d = __builtin_bit_cast(unsigned, v.w) & 0x7fffffffu;
+    const unsigned ab = a > b ? a : b, cd = c > d ? c : d;
+    const unsigned q = ab > cd ? ab : cd;
+    return q > m ? q : m;
+}
+__device__ __forceinline__ void amax_commit(unsigned m, float* amax) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned t = __shfl_xor(m, o, 64);
+        m = t > m ? t : m;
+    }
+    __shared__ unsigned amax_red[8];
+    const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    if ((threadIdx.x & 63) == 0) amax_red[w] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned r = 0;
+        for (int i = 0; i < nw; ++i) r = amax_red[i] > r ? amax_red[i] : r;
+        if (r != 0) atomicMax(reinterpret_cast<unsigned*>(amax), r);
+    }
+}
+
 // ---------------------------------------------------------------- BN apply (+res, +relu)
 __device__ __forceinline__ float4 affine4(float4 v, float4 s, float4 t) {
     return make_float4(fmaf(v.x, s.x, t.x), fmaf(v.y, s.y, t.y), fmaf(v.z, s.z, t.z), fmaf(v.w, s.w, t.w));
@@ -128,7 +156,8 @@ __global__ void bn_apply_kernel(const float4* __restrict__ y, const float4* __re
                                 const float4* __restrict__ shift, const float4* __restrict__ res,
                                 const float4* __restrict__ rscale, const float4* __restrict__ rshift,
                                 float4* __restrict__ out, long long total4, int CQ, int relu,
-                                unsigned long long* __restrict__ mask) {
+                                unsigned long long* __restrict__ mask, float* __restrict__ amax) {
+    unsigned am = 0;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4;
          i += (long long)gridDim.x * blockDim.x) {
         const int cq = (int)(i % CQ);
@@ -150,13 +179,16 @@ __global__ void bn_apply_kernel(const float4* __restrict__ y, const float4* __re
         }
         if (relu) v = relu4(v);
         out[i] = v;
+        am = amax4(am, v);
     }
+    if (amax != nullptr) amax_commit(am, amax);
 }
 
 __global__ void bn_apply_pool2_kernel(const float4* __restrict__ y, const float4* __restrict__ scale,
                                       const float4* __restrict__ shift, float4* __restrict__ out, int B, int H, int W,
-                                      int CQ, int relu, long long total4) {
+                                      int CQ, int relu, long long total4, float* __restrict__ amax) {
     const int Ho = H / 2, Wo = W / 2;
+    unsigned am = 0;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4;
          i += (long long)gridDim.x * blockDim.x) {
         const int cq = (int)(i % CQ);
@@ -177,8 +209,11 @@ __global__ void bn_apply_pool2_kernel(const float4* __restrict__ y, const float4
                 if (relu) v = relu4(v);
                 acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
             }
-        out[i] = make_float4(acc.x * 0.25f, acc.y * 0.25f, acc.z * 0.25f, acc.w * 0.25f);
+        const float4 o = make_float4(acc.x * 0.25f, acc.y * 0.25f, acc.z * 0.25f, acc.w * 0.25f);
+        out[i] = o;
+        am = amax4(am, o);
     }
+    if (amax != nullptr) amax_commit(am, amax);
 }
 
 __global__ void avgpool2_bwd_kernel(const float4* __restrict__ g, float4* __restrict__ dx, int B, int H, int W, int CQ,
@@ -320,7 +355,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_final_kernel(const float* _
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a, const float4* __restrict__ dgamma,
                                                            const float4* __restrict__ dbeta, float invM,
-                                                           float4* __restrict__ dy, float4* __restrict__ dres) {
+                                                           float4* __restrict__ dy, float4* __restrict__ dres,
+                                                           float* __restrict__ amax) {
+    unsigned am = 0;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < a.total4; i += (long long)gridDim.x * 256) {
         const int cq = (int)(i % a.CQ);
         float4 gm, xh;
@@ -332,8 +369,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a, const fl
         o.z = sc.z * (gm.z - db.z * invM - xh.z * dg.z * invM);
         o.w = sc.w * (gm.w - db.w * invM - xh.w * dg.w * invM);
         dy[i] = o;
+        am = amax4(am, o);
         if (dres != nullptr) dres[i] = gm;
     }
+    if (amax != nullptr) amax_commit(am, amax);
 }
 
 static int bn_bwd_grid(long long total4, int CQ) {
@@ -393,7 +432,7 @@ extern "C" int trid_bn_eval_coeffs_f32(const float* gamma, const float* beta, co
 
 extern "C" int trid_bn_apply_f32(const float* y, const float* scale, const float* shift, const float* res,
                                  const float* rscale, const float* rshift, float* out, long long M, int C, int relu,
-                                 uint64_t* relu_mask, void* stream) {
+                                 uint64_t* relu_mask, float* amax, void* stream) {
     TRID_REQUIRE(y && scale && shift && out && M > 0 && C > 0 && C % 4 == 0, "trid_bn_apply_f32: bad arguments (C%%4)");
     TRID_REQUIRE((rscale == nullptr) == (rshift == nullptr), "trid_bn_apply_f32: rscale/rshift both or none");
     TRID_REQUIRE(aligned16(y) && aligned16(out) && aligned16(scale) && aligned16(shift) && (!res || aligned16(res)), "trid_bn_apply_f32: 16-byte alignment");
@@ -401,18 +440,18 @@ extern "C" int trid_bn_apply_f32(const float* y, const float* scale, const float
     hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(total4, 256 * 4)), dim3(256), 0, (hipStream_t)stream,
                        (const float4*)y, (const float4*)scale, (const float4*)shift, (const float4*)res,
                        (const float4*)rscale, (const float4*)rshift, (float4*)out, total4, C / 4, relu,
-                       (unsigned long long*)relu_mask);
+                       (unsigned long long*)relu_mask, amax);
     return check_launch("trid_bn_apply_f32");
 }
 
 extern "C" int trid_bn_apply_pool2_f32(const float* y, const float* scale, const float* shift, float* out, int B, int H,
-                                       int W, int C, int relu, void* stream) {
+                                       int W, int C, int relu, float* amax, void* stream) {
     TRID_REQUIRE(y && out && B > 0 && H % 2 == 0 && W % 2 == 0 && C % 4 == 0, "trid_bn_apply_pool2_f32: bad arguments");
     TRID_REQUIRE((scale == nullptr) == (shift == nullptr), "trid_bn_apply_pool2_f32: scale/shift both or none");
     const long long total4 = (long long)B * (H / 2) * (W / 2) * (C / 4);
     hipLaunchKernelGGL(bn_apply_pool2_kernel, dim3(grid_for(total4, 256 * 2)), dim3(256), 0, (hipStream_t)stream,
                        (const float4*)y, (const float4*)scale, (const float4*)shift, (float4*)out, B, H, W, C / 4, relu,
-                       total4);
+                       total4, amax);
     return check_launch("trid_bn_apply_pool2_f32");
 }
 
@@ -470,13 +509,13 @@ extern "C" int trid_bn_bwd_reduce_f32(const float* g, const float* y, const floa
 extern "C" int trid_bn_bwd_apply_f32(const float* g, const float* y, const float* act, const float* mean,
                                      const float* invstd, const float* scale, const float* shift, const float* dgamma,
                                      const float* dbeta, int mask_mode, int pooled, int B, int H, int W, int C,
-                                     float* dy, float* dres, void* stream) {
+                                     float* dy, float* dres, float* amax, void* stream) {
     BnBwdArgs a;
     int rc = bn_bwd_fill(a, g, y, act, mean, invstd, scale, shift, mask_mode, pooled, B, H, W, C);
     if (rc) return rc;
     TRID_REQUIRE(dgamma && dbeta && dy, "trid_bn_bwd_apply_f32: null pointer");
     const float invM = 1.f / (float)((long long)B * H * W);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(a.total4, 256 * 4)), dim3(256), 0, (hipStream_t)stream, a,
-                       (const float4*)dgamma, (const float4*)dbeta, invM, (float4*)dy, (float4*)dres);
+                       (const float4*)dgamma, (const float4*)dbeta, invM, (float4*)dy, (float4*)dres, amax);
     return check_launch("trid_bn_bwd_apply_f32");
 }

@@ -83,16 +83,23 @@ def empty(shape, like=None, dtype=torch.float32, device=None):
 _amax_pool = {}
 
 
-def amax(t):
-    """Device scalar (1-element view) holding max|t|: one streaming pass.  Slots come from a zero-filled pool and are
-    written once, so no per-call memset; the view keeps its pool buffer alive."""
-    key = (t.device, torch.cuda.current_stream(t.device).cuda_stream)
+def amax_slot(device):
+    """A zero-initialised device scalar (1-element view) for a kernel's `amax` side output.  Slots come from a
+    zero-filled pool per (device, stream) and are written once, so there is no per-call memset; the view keeps its
+    pool buffer alive."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
     ent = _amax_pool.get(key)
     if ent is None or ent[1] >= ent[0].numel():
-        ent = [torch.zeros(4096, dtype=torch.float32, device=t.device), 0]
+        ent = [torch.zeros(4096, dtype=torch.float32, device=device), 0]
         _amax_pool[key] = ent
     slot = ent[0][ent[1] : ent[1] + 1]
     ent[1] += 1
+    return slot
+
+
+def amax(t):
+    """Device scalar holding max|t|: one streaming pass (operands whose producer has no amax side output)."""
+    slot = amax_slot(t.device)
     call("trid_amax_f32", _p(t), t.numel(), _p(slot), stream())
     return slot
 
@@ -310,25 +317,26 @@ def bn_eval_coeffs(gamma, beta, running_mean, running_var, eps=BN_EPS):
     return st
 
 
-def bn_apply(y, st, relu=True, res=None, res_st=None, out=None, want_mask=False):
+def bn_apply(y, st, relu=True, res=None, res_st=None, out=None, want_mask=False, amax=None):
     """out = act(bn(y) (+ res | bn(res))).  want_mask: also return the 1-bit-per-element ReLU mask
-    (int64 words) the backward pass uses instead of re-reading `out` (bn_bwd mask_mode 3)."""
+    (int64 words) the backward pass uses instead of re-reading `out` (bn_bwd mask_mode 3).
+    amax: a zeroed device scalar (amax_slot) that receives max|out|."""
     C = y.shape[-1]
     M = y.numel() // C
     if out is None:
         out = torch.empty_like(y)
     mask = torch.empty(((M * C // 4 + 63) // 64) * 4, dtype=torch.int64, device=y.device) if want_mask else None
     call("trid_bn_apply_f32", _p(y), _p(st.scale), _p(st.shift), _p(res), _p(res_st.scale) if res_st else None,
-         _p(res_st.shift) if res_st else None, _p(out), M, C, 1 if relu else 0, _p(mask), stream())
+         _p(res_st.shift) if res_st else None, _p(out), M, C, 1 if relu else 0, _p(mask), _p(amax), stream())
     return (out, mask) if want_mask else out
 
 
-def bn_apply_pool2(y, st, relu=True):
+def bn_apply_pool2(y, st, relu=True, amax=None):
     """avgpool2(act(bn(y))) ; st=None -> plain 2x2 average pooling."""
     Bi, H, W, C = y.shape
     out = empty((Bi, H // 2, W // 2, C), y)
     call("trid_bn_apply_pool2_f32", _p(y), _p(st.scale) if st else None, _p(st.shift) if st else None, _p(out), Bi, H, W,
-         C, 1 if (relu and st is not None) else 0, stream())
+         C, 1 if (relu and st is not None) else 0, _p(amax), stream())
     return out
 
 
@@ -352,9 +360,9 @@ def _bn_ws(C, like):
     return ws
 
 
-def bn_bwd(g, y, st, gamma_like, mask_mode, act=None, pooled=False, want_dres=False):
+def bn_bwd(g, y, st, gamma_like, mask_mode, act=None, pooled=False, want_dres=False, amax=None):
     """BatchNorm backward.  g: dL/d(out) ([B,H/2,W/2,C] when pooled).  Returns
-    (dy, dgamma, dbeta, dres)."""
+    (dy, dgamma, dbeta, dres).  amax: zeroed device scalar that receives max|dy|."""
     Bi, H, W, C = y.shape
     dg = empty((2, C), y)
     dgamma, dbeta = dg[0], dg[1]
@@ -364,7 +372,7 @@ def bn_bwd(g, y, st, gamma_like, mask_mode, act=None, pooled=False, want_dres=Fa
     dy = torch.empty_like(y)
     dres = torch.empty_like(y) if want_dres else None
     call("trid_bn_bwd_apply_f32", _p(g), _p(y), _p(act), _p(st.mean), _p(st.invstd), _p(st.scale), _p(st.shift),
-         _p(dgamma), _p(dbeta), mask_mode, 1 if pooled else 0, Bi, H, W, C, _p(dy), _p(dres), stream())
+         _p(dgamma), _p(dbeta), mask_mode, 1 if pooled else 0, Bi, H, W, C, _p(dy), _p(dres), _p(amax), stream())
     return dy, dgamma, dbeta, dres
 
 

@@ -17,27 +17,31 @@ def t(fn, reps=5):
     return e0.elapsed_time(e1) / reps
 rows = []
 FILT = os.environ.get("TRID_LB_FILTER", "")
+PREC = int(os.environ.get("TRID_LB_PREC", "6"))  # 6 = bf16x6, 16 = fp16x3 (operand amax passes NOT included: precomputed)
+def am(t): return ops.amax(t) if PREC == 16 else None
 def conv1(name, P, Ci, Co, count=1, acc=False):
     if FILT and not any(f in name for f in FILT.split(",")): return
     M = B * P
     x, w, dy = rnd(M, Ci), rnd(Co, Ci), rnd(M, Co)
     dx = torch.empty(M, Ci, device=dev)
     fl = 2.0 * M * Ci * Co
-    rows.append((name + " fwd", count, t(lambda: ops.conv1x1(x, w, stats=True)), fl))
+    ax, aw, ady = am(x), am(w), am(dy)
+    rows.append((name + " fwd", count, t(lambda: ops.conv1x1(x, w, stats=True, prec=PREC, aa=ax, ba=aw)), fl))
     if os.environ.get("TRID_DGRAD_T"):  # data gradient against a pre-transposed weight copy (K-contiguous B)
         wT = w.t().contiguous()
         rows.append((name + " dgrad", count, t(lambda: ops.linear(dy, wT, out=dx, accumulate=acc)), fl))
     else:
-        rows.append((name + " dgrad", count, t(lambda: ops.matmul_nn(dy, w, out=dx, accumulate=acc)), fl))
-    rows.append((name + " wgrad", count, t(lambda: ops.conv1x1_wgrad(dy, x)), fl))
+        rows.append((name + " dgrad", count, t(lambda: ops.matmul_nn(dy, w, out=dx, accumulate=acc, prec=PREC, aa=ady, ba=aw)), fl))
+    rows.append((name + " wgrad", count, t(lambda: ops.conv1x1_wgrad(dy, x, prec=PREC, aa=ady, ba=ax)), fl))
 def conv3(name, H, W, Ci, Co, count=1):
     if FILT and not any(f in name for f in FILT.split(",")): return
     x, w, dy = rnd(B, H, W, Ci), rnd(Co, 9 * Ci), rnd(B, H, W, Co)
     wt = rnd(Ci, 9 * Co)
     fl = 2.0 * B * H * W * Ci * Co * 9
-    rows.append((name + " fwd", count, t(lambda: ops.conv3x3(x, w, stats=True)), fl))
-    rows.append((name + " dgrad", count, t(lambda: ops.conv3x3(dy, wt)), fl))
-    rows.append((name + " wgrad", count, t(lambda: ops.conv3x3_wgrad(dy, x)), fl))
+    ax, aw, ady, awt = am(x), am(w), am(dy), am(wt)
+    rows.append((name + " fwd", count, t(lambda: ops.conv3x3(x, w, stats=True, prec=PREC, aa=ax, ba=aw)), fl))
+    rows.append((name + " dgrad", count, t(lambda: ops.conv3x3(dy, wt, prec=PREC, aa=ady, ba=awt)), fl))
+    rows.append((name + " wgrad", count, t(lambda: ops.conv3x3_wgrad(dy, x, prec=PREC, aa=ady, ba=ax)), fl))
 conv3("stem.conv2 3x3 32->32 @192x64", 192, 64, 32, 32)
 conv3("stem.conv3 3x3 32->64 @192x64", 192, 64, 32, 64)
 # layer1 @96x32 (3072 px)
