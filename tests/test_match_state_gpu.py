@@ -216,6 +216,61 @@ def test_fused_adam_matches_torch_adam(gpu):
         assert torch.allclose(a.detach(), b.detach(), rtol=1e-5, atol=1e-6), (float(d.max()), float((d / (b.detach().abs() + 1e-12)).max()))
 
 
+def test_fused_adam_resume_from_state_dict(gpu):
+    """Resume flow of the reference (train_net.py:69-72: build the optimiser, then Checkpointer.resume ->
+    optimizer.load_state_dict): after a state-dict round trip into a FRESH FusedAdam the bias-correction step
+    count and the moment tensors are the saved ones - the continued trajectory equals torch.optim.Adam's."""
+    from textreid_amd.solver import FusedAdam
+
+    torch.manual_seed(1)
+    shapes = [(33, 17), (64,), (8, 4, 3, 3)]
+    mk = lambda: [torch.nn.Parameter(torch.randn(s, device=gpu)) for s in shapes]
+    ref_p = mk()
+    fus_p = [torch.nn.Parameter(p.detach().clone()) for p in ref_p]
+    ref = torch.optim.Adam(ref_p, lr=1e-2)
+    fus = FusedAdam(fus_p, lr=1e-2)
+    grads = [[torch.randn(s, device=gpu) for s in shapes] for _ in range(6)]
+
+    def run(opt, ps, its):
+        for it in its:
+            for p, g in zip(ps, grads[it]):
+                p.grad = g.clone()
+            opt.step()
+
+    run(ref, ref_p, range(3))
+    run(fus, fus_p, range(3))
+    saved = fus.state_dict()
+    fus2_p = [torch.nn.Parameter(p.detach().clone()) for p in fus_p]
+    fus2 = FusedAdam(fus2_p, lr=1e-2)
+    run(fus2, fus2_p, [0])          # a step BEFORE loading: the cached pointer tables must not survive the load
+    for p, q in zip(fus2_p, fus_p):
+        p.data.copy_(q.data)
+    fus2.load_state_dict(saved)
+    run(ref, ref_p, range(3, 6))
+    run(fus2, fus2_p, range(3, 6))
+    for a, b in zip(fus2_p, ref_p):
+        assert torch.allclose(a.detach(), b.detach(), rtol=1e-5, atol=1e-6)
+    assert all(int(st["step"]) == 6 for st in fus2.state.values())
+
+
+def test_enqueue_with_a_misaligned_pointer_wraps(gpu):
+    """A queue_ptr that is not a multiple of the batch (checkpoint written with another batch / world size) must
+    wrap around the ring, never write past the end of the queues (the reference's slice assignment raises there)."""
+    from textreid_amd import ops
+
+    K, C, B = 64, 32, 16
+    vq, tq = torch.zeros(K + B, C, device=gpu), torch.zeros(K + B, C, device=gpu)  # B guard rows behind the queue
+    idq = -torch.ones(K + B, dtype=torch.int64, device=gpu)
+    ptr = torch.tensor([K - 8], dtype=torch.int64, device=gpu)
+    vk, tk = torch.randn(B, C, device=gpu), torch.randn(B, C, device=gpu)
+    ids = torch.arange(B, device=gpu) + 500
+    ops.call("trid_enqueue_f32", ops._p(vq), ops._p(tq), ops._p(idq), ops._p(ptr), ops._p(vk), ops._p(tk), ops._p(ids), K, C, B, ops.stream())
+    assert int(ptr) == 8
+    assert torch.equal(vq[K - 8 : K], vk[:8]) and torch.equal(vq[:8], vk[8:]) and torch.equal(tq[:8], tk[8:])
+    assert torch.equal(idq[K - 8 : K], ids[:8]) and torch.equal(idq[:8], ids[8:])
+    assert float(vq[K:].abs().max()) == 0.0 and bool((idq[K:] == -1).all())  # nothing behind the ring was touched
+
+
 def test_ema_and_enqueue(gpu):
     import types
 

@@ -77,17 +77,22 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(const uint64_t* __restr
 __global__ void enqueue_kernel(float* __restrict__ vq, float* __restrict__ tq, int64_t* __restrict__ idq,
                                const int64_t* __restrict__ ptr, const float* __restrict__ vk,
                                const float* __restrict__ tk, const int64_t* __restrict__ ids, int K, int C, int B) {
-    const long long p = ptr[0];
+    // The pointer comes from a buffer a checkpoint may have filled (another batch size, another world size): rows
+    // are addressed modulo K, so a pointer that is not a multiple of B wraps around instead of writing past the end.
+    const long long p = ((ptr[0] % K) + K) % K;
     const long long total = (long long)B * C;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (long long)gridDim.x * blockDim.x) {
-        vq[p * C + i] = vk[i];
-        tq[p * C + i] = tk[i];
-        if (i < B) idq[p + i] = ids[i];
+        const long long row = i / C, c = i - row * C;
+        long long dst = p + row;
+        if (dst >= K) dst -= K;
+        vq[dst * C + c] = vk[i];
+        tq[dst * C + c] = tk[i];
+        if (c == 0) idq[dst] = ids[row];
     }
 }
 __global__ void enqueue_advance_kernel(int64_t* ptr, int K, int B) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) ptr[0] = (ptr[0] + B) % K;
+    if (threadIdx.x == 0 && blockIdx.x == 0) ptr[0] = ((ptr[0] % K) + K + B) % K;
 }
 
 }  // namespace trid
@@ -120,7 +125,7 @@ extern "C" int trid_adam_multi_f32(const uint64_t* p_ptrs, const uint64_t* g_ptr
 extern "C" int trid_enqueue_f32(float* v_queue, float* t_queue, int64_t* id_queue, int64_t* ptr, const float* v_keys,
                                 const float* t_keys, const int64_t* ids, int K, int C, int B, void* stream) {
     TRID_REQUIRE(v_queue && t_queue && id_queue && ptr && v_keys && t_keys && ids, "trid_enqueue_f32: null pointer");
-    TRID_REQUIRE(K > 0 && C > 0 && B > 0 && K % B == 0, "trid_enqueue_f32: K (%d) must be a multiple of the batch (%d)", K, B);
+    TRID_REQUIRE(K > 0 && C > 0 && B > 0 && K % B == 0, "trid_enqueue_f32: K (%d) must be a multiple of the batch (%d)", K, B);  // head.py:101
     hipLaunchKernelGGL(enqueue_kernel, dim3(grid_for((long long)B * C, 256, 256)), dim3(256), 0, (hipStream_t)stream,
                        v_queue, t_queue, id_queue, ptr, v_keys, t_keys, ids, K, C, B);
     hipLaunchKernelGGL(enqueue_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ptr, K, B);

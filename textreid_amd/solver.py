@@ -25,8 +25,18 @@ class FusedAdam(torch.optim.Optimizer):
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         super().__init__(params, defaults)
         self.decoupled = decoupled
+        self._plan = None  # device pointer tables; rebuilt whenever a parameter, gradient or moment tensor moves
+
+    def load_state_dict(self, state_dict):
+        """torch.optim.Adam-compatible state (resume: Checkpointer.load -> optimizer.load_state_dict).  The loaded
+        moment tensors replace the ones the cached pointer tables refer to, and the bias-correction step count
+        lives in the per-parameter ``state[p]["step"]`` entries, which are restored here - nothing else to keep."""
+        super().load_state_dict(state_dict)
         self._plan = None
-        self._step = 0
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        self._plan = None
 
     def _build(self, items):
         dev = items[0][0].device
@@ -39,7 +49,7 @@ class FusedAdam(torch.optim.Optimizer):
                 ct.append(i)
                 co.append(off)
         self._plan = {
-            "key": tuple((p.data_ptr(), g.data_ptr()) for p, g, _ in items),
+            "key": self._key(items),
             "p": torch.from_numpy(np.array([p.data_ptr() for p, _, _ in items], dtype=np.uint64).view(np.int64)).to(dev),
             "g": torch.from_numpy(np.array([g.data_ptr() for _, g, _ in items], dtype=np.uint64).view(np.int64)).to(dev),
             "m": torch.from_numpy(np.array([s["exp_avg"].data_ptr() for _, _, s in items], dtype=np.uint64).view(np.int64)).to(dev),
@@ -51,6 +61,10 @@ class FusedAdam(torch.optim.Optimizer):
             "lrs": None,
             "lr_key": None,
         }
+
+    @staticmethod
+    def _key(items):
+        return tuple((p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()) for p, g, st in items)
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -80,8 +94,9 @@ class FusedAdam(torch.optim.Optimizer):
                     raise RuntimeError("FusedAdam: betas/eps must be shared by all groups")
         if not items:
             return loss
-        self._step += 1
-        key = tuple((p.data_ptr(), g.data_ptr()) for p, g, _ in items)
+        # step count = the saved per-parameter one (torch.optim.Adam's state layout; a tensor after load_state_dict)
+        t = max(int(st["step"]) for _, _, st in items) + 1
+        key = self._key(items)
         if self._plan is None or self._plan["key"] != key:
             self._build(items)
         pl = self._plan
@@ -91,7 +106,6 @@ class FusedAdam(torch.optim.Optimizer):
             pl["lrs"] = torch.tensor(lrs, dtype=torch.float32, device=dev)
             pl["wds"] = torch.tensor(wds, dtype=torch.float32, device=dev)
             pl["lr_key"] = lr_key
-        t = self._step
         for _, _, st in items:
             st["step"] = t
         ops.call("trid_adam_multi_f32", ops._p(pl["p"]), ops._p(pl["g"]), ops._p(pl["m"]), ops._p(pl["v"]),
