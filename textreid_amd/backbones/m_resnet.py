@@ -136,6 +136,11 @@ class _EncoderFn(torch.autograd.Function):
         if not mod.training and not save and mod.fold_eval_bn and getattr(mod, "_debug_taps", None) is None:
             out, saved = mod._run_forward_folded(images), None
         else:
+            if save and not mod.training:
+                # eval-mode BatchNorm (running statistics) has a different backward (dy = g * scale, no batch terms);
+                # only the train-mode backward is implemented - refuse rather than return batch-statistics gradients
+                raise NotImplementedError("ModifiedResNet: gradients through an eval-mode (running-statistics) forward are not "
+                                          "implemented; call under torch.no_grad() or in train() mode")
             out, saved = mod._run_forward(images, save)
         ctx.mod = mod
         ctx.saved = saved

@@ -27,10 +27,11 @@ class Caption:
     ``length`` the unpadded token count(s); free-form per-sample fields (``id``, ``image_id`` ...)
     ride along in ``extra_fields``.  A raw ``str`` caption is kept as is (word count as length)."""
 
-    __slots__ = ("text", "length", "max_length", "padded", "dtype", "extra_fields")
+    __slots__ = ("text", "length", "max_length", "padded", "dtype", "extra_fields", "host_length")
 
     def __init__(self, text, length=None, max_length=None, padded=False, dtype=torch.int64):
         self.dtype, self.padded, self.extra_fields = dtype, True, {}
+        self.host_length = None  # largest unpadded token count, known on the host when built from host data
         if isinstance(text, str):
             self.text, self.max_length = text, max_length
             self.length = len(text.split()) if length is None else length
@@ -46,8 +47,11 @@ class Caption:
         single = isinstance(text, torch.Tensor) and text.dim() == 1
         if length is None:
             length = torch.tensor(counts[0] if single else counts, dtype=torch.int64, device=device)
+            self.host_length = max(counts)  # token counts came from host data: no device read needed later
         self.length = length
         self.max_length = max(counts) if max_length is None else max_length
+        if self.host_length is not None:
+            self.host_length = min(self.host_length, self.max_length)
         self.text = self.pad(rows, self.max_length, device)
 
     @staticmethod
@@ -77,6 +81,7 @@ class Caption:
         else:
             moved = Caption(self.text.to(device), self.length.to(device), self.max_length, padded=True, dtype=self.dtype)
         moved.extra_fields = {k: (v.to(device) if hasattr(v, "to") else v) for k, v in self.extra_fields.items()}
+        moved.host_length = self.host_length
         return moved
 
     def __len__(self):
@@ -102,11 +107,15 @@ class CaptionBatch:
             return captions
         tokens = torch.stack([c.text.view(-1) for c in captions], dim=0)
         lengths = torch.stack([c.length.view(-1)[0] for c in captions], dim=0)
+        # batch-max length on the HOST when the captions carry it (no device round trip per encoder call)
+        host_max = None
+        if all(getattr(c, "host_length", None) is not None for c in captions):
+            host_max = max(int(c.host_length) for c in captions)
         ids = None
         if len(captions) and captions[0].has_field("id"):
             ids = torch.stack([torch.as_tensor(c.get_field("id")).view(-1)[0] for c in captions], dim=0).long()
             ids = ids.to(tokens.device)
-        return cls(tokens, lengths, ids)
+        return cls(tokens, lengths, ids, max_len=host_max)
 
     def to(self, device):
         return CaptionBatch(self.tokens.to(device), self.lengths.to(device),

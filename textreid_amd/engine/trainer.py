@@ -42,6 +42,9 @@ def do_train(model, data_loader, data_loader_val, optimizer, scheduler, checkpoi
         epoch += 1
         model.train()
         arguments["epoch"] = epoch
+        sampler = getattr(data_loader, "sampler", None)
+        if world_size() > 1 and hasattr(sampler, "set_epoch"):
+            sampler.set_epoch(epoch)  # trainer.py:66 (guarded: the reference's own call crashes on a batch_sampler loader)
         for step, (images, captions, _) in enumerate(data_loader):
             iteration += 1
             arguments["iteration"] = iteration

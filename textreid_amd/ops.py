@@ -352,7 +352,8 @@ _ws_cache = {}
 
 
 def _bn_ws(C, like):
-    key = (C, like.device)
+    # one workspace per (channels, device, STREAM): two backward passes on different streams must not share it
+    key = (C, like.device, torch.cuda.current_stream(like.device).cuda_stream)
     ws = _ws_cache.get(key)
     if ws is None:
         ws = empty((L.load().trid_bn_bwd_ws_floats(C),), like)
