@@ -325,3 +325,47 @@ def test_fused_queue_infonce(ops, B, K, wgs, prec):
     assert e[0] < tol_l and e[1] < tol_g and e[2] < tol_g, e
     assert torch.equal(out, out2)  # bit-reproducible (fixed-order fold of the partials, no atomics)
     assert rel(out3, ref) < tol_l
+
+
+def test_abi_is_reentrant_from_two_threads_on_two_streams(ops):
+    """C-ABI threading contract: entry points may be called concurrently from different host threads on
+    different streams (forward on the main thread, backward on autograd threads).  Two threads hammer the GEMM
+    (including its first-use attribute initialisation, std::call_once), BatchNorm backward (per-stream workspace)
+    and the fused queue kernel; every result must equal the single-threaded one bit for bit."""
+    import threading
+
+    x, w = dev(R("th:x", 4, 24, 8, 64)), dev(R("th:w", 128, 9 * 64, scale=0.1))
+    g, y = dev(R("th:g", 4, 24, 8, 128)), dev(R("th:y", 4, 24, 8, 128))
+    gamma = dev(R("th:gamma", 128))
+
+    def work():
+        yy, st = ops.conv3x3(x, w, stats=True)
+        bn = ops.bn_finalize(st, 4 * 24 * 8, gamma, gamma, None, None)
+        dy, dgam, dbet, _ = ops.bn_bwd(g, y, bn, None, 1)
+        return yy, dy, dgam, dbet
+
+    ref = [t.clone() for t in work()]
+    torch.cuda.synchronize()
+    errors, outs = [], {}
+
+    def runner(i):
+        try:
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s):
+                for _ in range(20):
+                    res = work()
+                s.synchronize()
+                outs[i] = [t.clone() for t in res]
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    ths = [threading.Thread(target=runner, args=(i,)) for i in range(2)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    torch.cuda.synchronize()
+    assert not errors, errors
+    for i in range(2):
+        for a, b in zip(outs[i], ref):
+            assert torch.equal(a, b)
