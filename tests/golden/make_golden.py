@@ -559,6 +559,20 @@ def gen_ingest(seed=13):
     out["filter_keys"] = np.array(sorted(flt.keys()))
     out["filter_pos"] = flt["attnpool.positional_embedding"].numpy()
     out["pos_in"] = pe.numpy()
+    # suffix-matching aligner of the Checkpointer (lib/utils/checkpoint.py:90-148): which loaded key each model key takes
+    import lib.utils.checkpoint as ref_ckpt
+
+    model_keys = ["embed_model.v_encoder_q.conv1.weight", "embed_model.v_encoder_q.layer1.0.conv1.weight", "visual_model.conv1.weight",
+                  "embed_model.v_encoder_k.layer1.0.bn1.running_mean", "embed_model.t_queue", "embed_model.loss_evaluator.projection",
+                  "embed_model.v_embed_layer.bias", "textual_model.gru.weight_hh_l0"]
+    loaded_keys = ["module.conv1.weight", "module.v_encoder_q.conv1.weight", "module.layer1.0.conv1.weight", "module.bn1.running_mean",
+                   "module.embed_model.t_queue", "module.projection", "module.unrelated.bias", "module.gru.weight_hh_l0"]
+    ms = {k: torch.full((1,), float(i)) for i, k in enumerate(model_keys)}
+    ls = ref_ckpt.strip_prefix_if_present({k: torch.full((1,), 100.0 + i) for i, k in enumerate(loaded_keys)}, prefix="module.")
+    ref_ckpt.align_and_update_state_dicts(ms, ls)
+    out["align_model_keys"] = np.array(model_keys)
+    out["align_loaded_keys"] = np.array(loaded_keys)
+    out["align_values"] = np.array([float(ms[k]) for k in model_keys])  # >= 100: taken from loaded key (value - 100)
     np.savez_compressed(os.path.join(HERE, "ingest.npz"), **out)
 
 

@@ -202,3 +202,70 @@ def test_clip_checkpoint_ingestion_matches_reference(golden_dir):
     flt = state_filter(sd, (6, 2))
     assert sorted(flt.keys()) == list(g["filter_keys"])
     assert np.allclose(flt["attnpool.positional_embedding"].numpy(), g["filter_pos"], atol=1e-6)
+
+
+def test_suffix_aligner_matches_reference_mapping(golden_dir):
+    """Checkpointer's loading rule (lib/utils/checkpoint.py:90-148): `module.` stripped, every model key takes the
+    loaded key that is its longest suffix, unmatched keys keep their value - against the mapping the reference's
+    own align_and_update_state_dicts produced for the same key lists."""
+    from textreid_amd.checkpoint import match_by_longest_suffix, strip_prefix_if_present
+
+    g = np.load(os.path.join(golden_dir, "ingest.npz"))
+    model_keys, loaded_keys = list(g["align_model_keys"]), list(g["align_loaded_keys"])
+    loaded = strip_prefix_if_present({k: 100.0 + i for i, k in enumerate(loaded_keys)})
+    m = match_by_longest_suffix(sorted(model_keys), sorted(loaded))
+    got = [loaded[m[k]] if k in m else float(i) for i, k in enumerate(model_keys)]
+    assert got == list(g["align_values"])
+
+
+def test_reference_best_pth_and_torchscript_clip_load(tmp_path):
+    """SURVEY 8 f5 end to end, on stand-ins built here (no CLIP weights / dataset in the image):
+    (a) a `best.pth`-shaped file - {"model": state saved from a DistributedDataParallel-wrapped model (`module.`
+        prefix), "epoch": ...} - loads through the suffix aligner and reproduces every tensor;
+    (b) a TorchScript archive exposing `visual.*` tensors with a 7x7 positional grid (what `RN50.pt` is) loads through
+        torch.jit.load + state_filter into an encoder with a 6x2 final grid: positional embedding resized, the rest
+        copied, text-tower tensors ignored."""
+    from textreid_amd.backbones.m_resnet import ModifiedResNet, resize_pos_embed
+    from textreid_amd.checkpoint import load_checkpoint_file, load_clip_visual
+
+    torch.manual_seed(3)
+    mk = lambda: ModifiedResNet([1, 1, 1, 1], 64, 4, 1, (96, 32), 16)
+    src, dst = mk(), mk()
+    for p in src.parameters():
+        p.data.normal_()
+    ck = {"model": {"module." + k: v.clone() for k, v in src.state_dict().items()}, "epoch": 7, "iteration": 123}
+    torch.save(ck, tmp_path / "best.pth")
+    rest = load_checkpoint_file(dst, str(tmp_path / "best.pth"))
+    assert rest == {"epoch": 7, "iteration": 123}
+    for (k, a), (_, b) in zip(src.state_dict().items(), dst.state_dict().items()):
+        assert torch.equal(a, b), k
+
+    class Tower(torch.nn.Module):  # stand-in for CLIP's scripted model: visual.* parameters + unrelated text tensors
+        def __init__(self, sd):
+            super().__init__()
+            self.visual = torch.nn.Module()
+            for k, v in sd.items():
+                mod = self.visual
+                parts = k.split(".")
+                for q in parts[:-1]:
+                    if not hasattr(mod, q):
+                        setattr(mod, q, torch.nn.Module())
+                    mod = getattr(mod, q)
+                mod.register_buffer(parts[-1], v.clone())
+            self.token_embedding = torch.nn.Embedding(5, 4)
+
+        def forward(self, x):
+            return x
+
+    sd = {k: v for k, v in src.state_dict().items() if "num_batches_tracked" not in k}
+    sd["attnpool.positional_embedding"] = torch.randn(50, 512)  # CLIP's 7x7 grid + class token
+    torch.jit.script(Tower(sd)).save(str(tmp_path / "RN_stub.pt"))
+    dst2 = mk()
+    missing, unexpected = load_clip_visual(dst2, str(tmp_path / "RN_stub.pt"))
+    assert not [k for k in missing if "num_batches_tracked" not in k]
+    assert all(k.startswith("token_embedding") for k in unexpected)
+    got = dst2.state_dict()
+    assert torch.allclose(got["attnpool.positional_embedding"], resize_pos_embed(sd["attnpool.positional_embedding"], (6, 2)))
+    for k, v in sd.items():
+        if k != "attnpool.positional_embedding":
+            assert torch.equal(got[k], v), k
