@@ -316,12 +316,14 @@ def main():
     for (Hh, Ww, Cc) in ((96, 32, 128), (48, 16, 128), (48, 16, 256), (24, 8, 256), (24, 8, 512)):
         xx = torch.randn(B, Hh, Ww, Cc, device=device)
         ww = torch.randn(Cc, 9 * Cc, device=device)
-        ops.conv3x3(xx, ww, stats=True)
+        cp = ops.conv_precision()
+        kw = dict(prec=cp, aa=ops.amax(xx), ba=ops.amax(ww)) if cp == 16 else {}  # the model's conv arithmetic
+        ops.conv3x3(xx, ww, stats=True, **kw)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(3):
-            ops.conv3x3(xx, ww, stats=True)
+            ops.conv3x3(xx, ww, stats=True, **kw)
         e1.record()
         torch.cuda.synchronize()
         iso_ms += e0.elapsed_time(e1) / 3
@@ -330,7 +332,14 @@ def main():
     achieved_isolated = iso_fl / (iso_ms * 1e-3) / 1e12
 
     prec = ops.GEMM_PRECISION
-    if prec in (3, 6):
+    cprec = ops.conv_precision()
+    if cprec == 16:
+        # the image encoder's convolutions run the fp16 two-plane split: 3 fp16 MFMA products per fp32 multiply-add
+        peak = BF16_MFMA_PEAK_TFLOPS / 3
+        kname = "trid::gemm_bf16s_kernel<A_CONV,B_KC,16,128> (3x3 implicit-GEMM conv fwd+dgrad; fp32 operands scaled per tensor by a power of two and split into 2 fp16 planes (11+11 significand bits), 3 fp16 MFMA 32x32x16 products per multiply-add in two fp32 accumulators)"
+        peak_note = "dense bf16/fp16 MFMA peak 2500 TFLOP/s / 3 products = fp32-equivalent peak; PMC MfmaUtil of this kernel 28-36 % at 2.04-2.2 GHz (profiles/r02a_pmc_mfma_util.txt)"
+        arith = "fp32 operands and accumulation; conv products evaluated as 3 fp16 MFMA terms of a scaled 2-way fp16 split (representation + dropped term <= 3*2^-22 per product), everything else as 6 bf16 MFMA terms of a 3-way bf16 split (<= 2^-26)"
+    elif prec in (3, 6):
         # the dominant kernel executes `prec` bf16 MFMA products per fp32 multiply-add
         peak = BF16_MFMA_PEAK_TFLOPS / prec
         kname = "trid::gemm_bf16s_kernel<A_CONV,B_KC,%d planes> (3x3 implicit-GEMM conv fwd+dgrad; fp32 operands split into bf16 planes, %d bf16 MFMA 32x32x16 products per multiply-add, fp32 accumulate)" % (prec // 2, prec)
@@ -351,14 +360,15 @@ def main():
     # measurement of the committed build, not a counter read of this run: `traffic_source` names the file.
     traffic, traffic_note, traffic_src = None, None, None
     here = os.path.dirname(os.path.abspath(__file__))
-    for fn in ("r02_pmc_hbm_traffic.txt", "r01j_pmc_hbm_traffic.txt"):
+    for fn in ("r02a_pmc_hbm_traffic.txt", "r01j_pmc_hbm_traffic.txt"):
         try:
             for line in open(os.path.join(here, "profiles", fn)):
                 f = line.split()
-                if prec == 6 and len(f) > 5 and "gemm_bf16s_kernel<2," in line and line.rstrip().endswith("0, 3, 128>(trid::GemmParams)"):
+                want = "0, 16, 128>(trid::GemmParams)" if cprec == 16 else "0, 3, 128>(trid::GemmParams)"
+                if prec == 6 and len(f) > 5 and "gemm_bf16s_kernel<2," in line and line.rstrip().endswith(want):
                     traffic = (float(f[2]) + float(f[3])) * 1e6
                     traffic_src = "profiles/" + fn
-                    traffic_note = "read %s MB + write %s MB per launch (separate --pmc passes, stored); algorithmic input + weights + output of these layers ~ 58 + 9 + 58 MB (each of the 8 XCD L2s fetches its own copy of the filter)" % (f[2], f[3])
+                    traffic_note = "read %s MB + write %s MB per launch (separate --pmc passes, stored; average over all launches of this kernel incl. layer1); algorithmic input + weights + output of the layer2-4 shapes ~ 58 + 9 + 58 MB" % (f[2], f[3])
                     break
         except OSError:
             pass

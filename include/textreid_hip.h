@@ -236,6 +236,19 @@ int trid_queue_nce_f32(const float* v_q, const float* t_q, const float* v_key, c
  * counts (out zeroed by the caller). */
 int trid_amax_f32(const float* x, long long n, float* out, void* stream);
 int trid_amax_multi_f32(const float* const* ptrs, const long long* sizes, int n_tensors, float* out, void* stream);
+/* Device-side image input pipeline (lib/data/transforms.py:4-43): B raw uint8 HWC images of arbitrary
+ * sizes (concatenated in `src`, byte offsets `offset[B]`, sizes `hw[B][2]`) -> out fp32 [B,3,H,W]:
+ * Resize((H,W)) exactly as Pillow's antialiased BILINEAR (two fixed-point passes rounding to uint8; the per-image
+ * weight tables xbounds[B][W][2] / xweights[B][W][KX] / ybounds[B][H][2] / yweights[B][H][KY] are
+ * Resample.c's precompute_coeffs + normalize_coeffs_8bpc), horizontal flip, zero Pad(pad) + crop at (top, left),
+ * /255, (x - mean) / std, erase rectangle filled with `erase` values.  params[B][8] = {flip, crop_top, crop_left,
+ * erase_i, erase_j, erase_h, erase_w, 0} (device); mean3_std3_erase3_host = 9 HOST floats.  ws bytes >=
+ * trid_image_pipeline_ws_bytes(B, max source height, W) holds the horizontally resampled rows. */
+long long trid_image_pipeline_ws_bytes(int B, int max_src_h, int W);
+int trid_image_pipeline_u8(const uint8_t* src, const long long* offset, const int* hw, const int* xbounds,
+                           const int* xweights, const int* ybounds, const int* yweights, const int* params, int B,
+                           int H, int W, int KX, int KY, int max_src_h, int pad, const float* mean3_std3_erase3_host,
+                           uint8_t* ws, float* out, void* stream);
 /* rowdot[b] = <x_b, y_b> */
 int trid_rowdot_f32(const float* x, const float* y, float* out, long long rows, int C, void* stream);
 /* dx[b,:] (+)= s[b]*y[b,:] */

@@ -269,3 +269,23 @@ def test_reference_best_pth_and_torchscript_clip_load(tmp_path):
     for k, v in sd.items():
         if k != "attnpool.positional_embedding":
             assert torch.equal(got[k], v), k
+
+
+def test_image_resize_restatement_is_pillow_bit_exact():
+    """SURVEY 8 f4 oracle pin: Resize on a PIL image is Pillow's antialiased two-pass fixed-point BILINEAR.  The
+    oracle's restatement of Resample.c and the product's vectorised weight tables reproduce Pillow (the library the
+    reference calls through torchvision) bit for bit on up-scaling, down-scaling and mixed cases."""
+    from PIL import Image
+
+    import oracle.transforms as OT
+    from textreid_amd.transforms import resample_tables
+
+    rs = np.random.RandomState(0)
+    for (h, w) in [(97, 53), (384, 128), (500, 200), (60, 30), (777, 333), (384, 53), (201, 128)]:
+        a = (rs.rand(h, w, 3) * 255).astype(np.uint8)
+        ref = np.asarray(Image.fromarray(a).resize((128, 384), Image.BILINEAR))
+        assert np.array_equal(OT.resize_bilinear_u8(a, 384, 128), ref), (h, w)
+    for n_in, n_out in [(53, 128), (500, 384), (333, 128), (128, 128), (3, 128), (1000, 384)]:
+        b0, k0 = OT.resample_coeffs(n_in, n_out)
+        b1, k1 = resample_tables(n_in, n_out)
+        assert np.array_equal(b0, b1) and np.array_equal(k0, k1), (n_in, n_out)

@@ -546,3 +546,40 @@ def test_do_train_config0_plumbing(gpu, tmp_path):
     assert torch.equal(head.id_queue[0, : 2 * B].cpu(), torch.cat([batches[0][3], batches[1][3]]))
     assert opt.param_groups[0]["lr"] != lr0 or sched.last_epoch == 1
 
+
+
+def test_device_image_pipeline_matches_oracle(gpu):
+    """raw uint8 images of mixed sizes -> fp32 NCHW batch on the device (resize as Pillow, flip, pad + crop,
+    ToTensor, Normalize, RandomErasing with value = PIXEL_MEAN) against the oracle chain (lib/data/transforms.py:15-27
+    order), BIT-exact: train with augmentation (every sample a different flip / crop / erase), train without, eval."""
+    import oracle.transforms as OT
+    from textreid_amd.transforms import BatchTransform, sample_params
+
+    H, W, mean, std = 384, 128, [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+    rs = np.random.RandomState(5)
+    sizes = [(97, 53), (384, 128), (500, 200), (60, 30), (701, 333), (384, 53), (201, 128), (130, 64)]
+    imgs = [(rs.rand(h, w, 3) * 255).astype(np.uint8) for h, w in sizes]
+    # train + augmentation, explicit parameters covering the corners
+    params = np.array([[1, 0, 0, 10, 20, 50, 30, 0], [0, 20, 20, 0, 0, 0, 0, 0], [1, 7, 13, 300, 100, 84, 28, 0], [0, 10, 10, 0, 0, 383, 127, 0],
+                       [1, 20, 0, 5, 5, 1, 1, 0], [0, 0, 20, 0, 0, 0, 0, 0], [1, 3, 17, 100, 3, 200, 120, 0], [0, 10, 10, 0, 0, 0, 0, 0]], dtype=np.int32)
+    t = BatchTransform(H, W, mean, std, is_train=True, use_aug=True, padding=10, device=gpu)
+    out = t(imgs, params=params).cpu().numpy()
+    for b, im in enumerate(imgs):
+        p = params[b]
+        ref = OT.pipeline(im, H, W, mean, std, flip=bool(p[0]), padding=10, crop=(int(p[1]), int(p[2])),
+                          erase=(int(p[3]), int(p[4]), int(p[5]), int(p[6])) if p[5] > 0 else None, erase_value=mean)
+        assert np.array_equal(out[b], ref), (b, float(np.abs(out[b] - ref).max()))
+    # train without augmentation (flip only) and eval (nothing random)
+    t2 = BatchTransform(H, W, mean, std, is_train=True, use_aug=False, device=gpu)
+    p2 = np.zeros((len(imgs), 8), dtype=np.int32)
+    p2[::2, 0] = 1
+    out2 = t2(imgs, params=p2).cpu().numpy()
+    t3 = BatchTransform(H, W, mean, std, is_train=False, device=gpu)
+    out3 = t3(imgs).cpu().numpy()
+    for b, im in enumerate(imgs):
+        assert np.array_equal(out2[b], OT.pipeline(im, H, W, mean, std, flip=bool(p2[b, 0])))
+        assert np.array_equal(out3[b], OT.pipeline(im, H, W, mean, std))
+    # sampled parameters are valid rectangles / offsets
+    sp = sample_params(256, H, W, 10, True, np.random.default_rng(0))
+    assert sp[:, 1:3].min() >= 0 and sp[:, 1:3].max() <= 20
+    assert bool(((sp[:, 3] + sp[:, 5] <= H) & (sp[:, 4] + sp[:, 6] <= W)).all()) and 0.3 < (sp[:, 5] > 0).mean() < 0.7
