@@ -95,6 +95,18 @@ def main():
         bad = {k: v for k, v in errs.items() if not v < 1e-3}
         assert not bad, bad
         print("DP_OK")
+    # ---- replicated state must be IDENTICAL on every rank after the step: queues, ids, pointer (every rank pushed the
+    # same gathered keys) and the unreduced post-gather parameter's gradient
+    sdr = head.state_dict()
+    for name, ten in (("v_queue", sdr["v_queue"]), ("t_queue", sdr["t_queue"]), ("id_queue", sdr["id_queue"].double()),
+                      ("queue_ptr", sdr["queue_ptr"].double()), ("projection.grad", head.loss_evaluator.projection.grad)):
+        mine = ten.detach().double().cpu().contiguous()
+        parts = [torch.empty_like(mine) for _ in range(W)]
+        dist.all_gather(parts, mine)
+        for w in range(W):
+            assert torch.equal(parts[w], parts[0]), "rank %d: %s differs between ranks 0 and %d" % (r, name, w)
+    if r == 0:
+        print("DP_REPLICAS_IDENTICAL")
     # ---- sharded retrieval: every rank scores its own (unevenly sized) gallery shard, lists are merged
     from textreid_amd.evaluation import similarity_topk
 

@@ -31,5 +31,5 @@ def test_dp_two_ranks_match_global_batch_oracle():
     outs = [p.communicate(timeout=600)[0] for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o[-3000:]
-    assert "DP_OK" in outs[0] and "DP_RETRIEVAL_OK" in outs[0], outs[0][-3000:]
+    assert "DP_OK" in outs[0] and "DP_REPLICAS_IDENTICAL" in outs[0] and "DP_RETRIEVAL_OK" in outs[0], outs[0][-3000:]
     print([ln for ln in outs[0].splitlines() if ln.startswith("DP_ERRS")])

@@ -173,6 +173,67 @@ def test_dp_gather_and_reduce_gloo_world2(tmp_path):
         assert "rank %d ok" % r in o
 
 
+STAGE_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from textreid_amd.parallel import gather_embeddings, GradReducer, world_size, rank
+dist.init_process_group("gloo", init_method="env://")
+W, r = world_size(), rank()
+torch.manual_seed(100 + r)
+# in-backward staging (ModifiedResNet.grad_sync): gradients arrive in channels_last (3x3 filters), contiguous and
+# strided layouts; finish_stages() must hand back the SUM in each gradient's ORIGINAL layout
+ps = [torch.nn.Parameter(torch.zeros(6, 4, 3, 3).contiguous(memory_format=torch.channels_last)), torch.nn.Parameter(torch.zeros(7)),
+      torch.nn.Parameter(torch.zeros(5, 3))]
+gs = [torch.randn(6, 4, 3, 3).contiguous(memory_format=torch.channels_last), torch.randn(7), torch.randn(3, 5).t()]
+red = GradReducer(bucket_mb=1)
+red.stage(ps[:2], gs[:2]); red.stage(ps[2:], gs[2:])
+out = red.finish_stages()
+ref = []
+for g in gs:
+    parts = [torch.empty_like(g.contiguous()) for _ in range(W)]
+    dist.all_gather(parts, g.contiguous())
+    ref.append(sum(parts))
+for p, g, want in zip(ps, gs, ref):
+    got = out[id(p)]
+    assert got.shape == g.shape and torch.allclose(got, want, atol=1e-6), (got.shape, g.shape)
+assert out[id(ps[0])].is_contiguous(memory_format=torch.channels_last)
+# staged parameters are skipped by the post-backward reduce; the rest is reduced there
+q = torch.nn.Parameter(torch.zeros(9)); q.grad = torch.full((9,), float(r + 1))
+for p, g in zip(ps, gs): p.grad = g
+red.reduce(ps + [q]); red.wait()
+assert torch.allclose(q.grad, torch.full((9,), float(sum(range(1, W + 1)))))
+assert torch.equal(ps[1].grad, gs[1])                                   # untouched: it was reduced in the stage
+st = red.stats()
+assert st["allreduce_bytes_per_step"] == 4 * (6 * 4 * 9 + 7 + 15 + 9) and 0.9 < st["staged_fraction"] < 1.0
+# ids beyond 2^24 survive the packed gather bit for bit (they travel as two 32-bit lanes, not as fp32 values)
+B, C = 3, 4
+ids = torch.tensor([2 ** 40 + 7 * r + 1, -5, 16777217 + r])
+e = torch.randn(B, C)
+v, t, vk, tk, gid = gather_embeddings(e, e + 1, e + 2, e + 3, ids)
+want = torch.cat([torch.tensor([2 ** 40 + 7 * k + 1, -5, 16777217 + k]) for k in range(W)])
+assert torch.equal(gid, want), (gid, want)
+print("rank", r, "ok")
+dist.destroy_process_group()
+"""
+
+
+def test_dp_stage_finish_layouts_and_id_lanes_gloo_world2(tmp_path):
+    """GradReducer's in-backward staging path with channels-last / strided gradients, the post-backward bucket path
+    skipping staged parameters, the per-step accounting bench.py prints, and exact 64-bit ids through the packed
+    embedding all-gather - two gloo ranks on CPU."""
+    script = tmp_path / "stage_worker.py"
+    script.write_text(STAGE_WORKER % ROOT)
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="2")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o
+        assert "rank %d ok" % r in o
+
+
 def test_lr_schedule_values():
     from textreid_amd.solver import LRSchedulerWithWarmup
 
