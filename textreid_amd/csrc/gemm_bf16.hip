@@ -263,14 +263,10 @@ __global__ __launch_bounds__(NT, (BN == 64 && BMODE == B_KC && TRID_NARROW_WAVES
     };
 
     v16f acc[TM];
-    v16f acc_lo[F16 ? TM : 1];  // f16x3: the (hi*lo + lo*hi) group, worth 2^-11 of its face value
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            acc[i][r] = 0.f;
-            if (F16) acc_lo[i][r] = 0.f;
-        }
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
     const int a_slot = wm * (32 * TM) + (lane & 31);
     const int b_slot = wn * 32 + (lane & 31);
@@ -286,13 +282,13 @@ __global__ __launch_bounds__(NT, (BN == 64 && BMODE == B_KC && TRID_NARROW_WAVES
                     a[pl][i] = __builtin_bit_cast(f16x8, As[pl * PA + slot_of<!A_WIDE, BM>(kg, a_slot + 32 * i)]);
                 b[pl] = __builtin_bit_cast(f16x8, Bs[pl * PB + slot_of<!B_WIDE, BN>(kg, b_slot)]);
             }
-            // consecutive MFMAs hit different accumulators
+            // small terms first; consecutive MFMAs hit different accumulators where the wave has two
 #pragma unroll
-            for (int i = 0; i < TM; ++i) acc_lo[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][i], b[1], acc_lo[i], 0, 0, 0);
+            for (int i = 0; i < TM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][i], b[1], acc[i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][i], b[0], acc[i], 0, 0, 0);
 #pragma unroll
             for (int i = 0; i < TM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][i], b[0], acc[i], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < TM; ++i) acc_lo[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][i], b[0], acc_lo[i], 0, 0, 0);
             return;
         }
         bf16x8 a[NPL][TM], b[NPL];
@@ -346,12 +342,12 @@ __global__ __launch_bounds__(NT, (BN == 64 && BMODE == B_KC && TRID_NARROW_WAVES
     }
 
     // ---- epilogue (same contract as gemm.hip) -----------------------------------------
-    if (F16) {  // hi*hi + 2^-11 (hi*lo + lo*hi), then undo the operand scales (exact: powers of two)
+    if (F16) {  // undo the operand scales (exact: powers of two)
         const float unscale = 1.f / (scaleA * scaleB);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][r] = fmaf(acc_lo[i][r], F16_LO_UNSCALE, acc[i][r]) * unscale;
+            for (int r = 0; r < 16; ++r) acc[i][r] *= unscale;
     }
     const int row_base = m0 + wm * (32 * TM) + 4 * khalf;
     const int col = n0 + wn * 32 + (lane & 31);

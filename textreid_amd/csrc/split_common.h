@@ -80,16 +80,16 @@ __device__ __forceinline__ void split_store_wide(const float4 (&w)[4], uint4* __
 
 // ---------------------------------------------------------------------------------------------------
 // fp16 two-plane split ("f16x3": 3 MFMA products per multiply-add).  x' = x * scale (per-tensor power of
-// two that puts max|x'| in [2^13, 2^14), far inside fp16's range), hi = fp16(x'), lo = fp16((x' - hi) * 2^11):
-// |x' - hi - lo * 2^-11| <= 2^-22 |x'| (11 + 11 significand bits; the residual is exact in fp32 and its
-// 2^11 scaling keeps it in fp16's NORMAL range whenever hi is).  A product is hi*hi + (hi*lo + lo*hi) * 2^-11,
-// the two groups in separate fp32 MFMA accumulators; the dropped lo*lo term is <= 2^-22 |ab|.  Elements
-// below 2^-28 of the tensor maximum lose relative (not absolute) precision: their absolute error stays
-// <= 2^-39 of the maximum.
+// two that puts max|x'| in [2^13, 2^14), inside fp16's range with 4x headroom), hi = fp16(x'),
+// lo = fp16(x' - hi) (the residual is exact in fp32; |lo| <= 2^-11 |x'|):
+// |x' - hi - lo| <= 2^-22 |x'| wherever the residual is a NORMAL fp16 number, i.e. for |x'| >= 2^-3 = 2^-16 of
+// the tensor maximum; smaller elements keep an ABSOLUTE error <= 2^-25 (fp16's subnormal quantum; 2^-14 if the
+// matrix pipe flushed subnormal inputs), i.e. <= 2^-38 (2^-27) of the maximum - far below the 2^-22 of the
+// maximum that the largest elements are allowed.  A product is hi*hi + hi*lo + lo*hi, all three in ONE fp32
+// MFMA accumulator (same scale: no 2^11 factor, no second accumulator, one multiply less per element than a
+// scaled residual); the dropped lo*lo term is <= 2^-22 |ab|.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-constexpr float F16_LO_SCALE = 2048.f;           // 2^11
-constexpr float F16_LO_UNSCALE = 1.f / 2048.f;
 
 __device__ __forceinline__ unsigned cvt_pk_f16(float lo, float hi) {
     unsigned r;
@@ -109,7 +109,7 @@ __device__ __forceinline__ float f16_scale_of(float amax) {
 __device__ __forceinline__ void f16_split2(float x0, float x1, unsigned& hi, unsigned& lo) {
     hi = cvt_pk_f16(x0, x1);
     const f16x2 h = __builtin_bit_cast(f16x2, hi);
-    lo = cvt_pk_f16((x0 - (float)h.x) * F16_LO_SCALE, (x1 - (float)h.y) * F16_LO_SCALE);
+    lo = cvt_pk_f16(x0 - (float)h.x, x1 - (float)h.y);
 }
 
 template <int PLANE>
