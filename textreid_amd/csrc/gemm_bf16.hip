@@ -24,6 +24,9 @@ namespace trid {
 
 constexpr int BM_T = 128;             // tile height
 constexpr int NT = 512;               // 8 waves
+#ifndef TRID_F16_WAVES_KC
+#define TRID_F16_WAVES_KC 6  // ... three where both operands are K-contiguous (fwd / 3x3 dgrad: 76-80 VGPRs, 37 KB of LDS each)
+#endif
 #ifndef TRID_F16_WAVES
 #define TRID_F16_WAVES 4  // fp16-split kernels: two 8-wave workgroups per CU (<= 128 VGPRs)
 #endif
@@ -39,7 +42,7 @@ __host__ __device__ constexpr int b_plane_slots(int bmode, int bn) { return (bmo
 
 // ARITH: 1 / 2 / 3 = number of bf16 planes (1, 3, 6 products); 16 = two fp16 planes, 3 products, two accumulators
 template <int AMODE, int BMODE, int ARITH, int BN>
-__global__ __launch_bounds__(NT, (BN == 64 && BMODE == B_KC && TRID_NARROW_WAVES > 0 && ARITH != 16) ? TRID_NARROW_WAVES : (ARITH == 16 ? TRID_F16_WAVES : 1)) void gemm_bf16s_kernel(GemmParams p) {
+__global__ __launch_bounds__(NT, (BN == 64 && BMODE == B_KC && TRID_NARROW_WAVES > 0 && ARITH != 16) ? TRID_NARROW_WAVES : (ARITH == 16 ? ((BMODE == B_KC && AMODE != A_MC) ? TRID_F16_WAVES_KC : TRID_F16_WAVES) : 1)) void gemm_bf16s_kernel(GemmParams p) {
     constexpr bool F16 = (ARITH == 16);
     constexpr int NPL = F16 ? 2 : ARITH;
     constexpr int BM = BM_T;
