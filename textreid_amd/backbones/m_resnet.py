@@ -286,9 +286,11 @@ class ModifiedResNet(nn.Module):
         nbt = []  # num_batches_tracked buffers, incremented together at the end of the pass
         st1 = _bn_coeffs(self.bn1, p1, y1.shape[0], training, nbt)
         y1 = y1.view(B, Ho, Wo, -1)
-        a1 = ops.bn_apply(y1, st1, relu=True)
+        a_a1 = slot()
+        a1 = ops.bn_apply(y1, st1, relu=True, amax=a_a1)
         w2 = _w3x3(self.conv2)
-        y2, p2 = ops.conv3x3(a1, w2, stats=True) if training else (ops.conv3x3(a1, w2), None)
+        kw2 = dict(prec=P, aa=a_a1, ba=wam(self.conv2))
+        y2, p2 = ops.conv3x3(a1, w2, stats=True, **kw2) if training else (ops.conv3x3(a1, w2, **kw2), None)
         st2 = _bn_coeffs(self.bn2, p2, B * Ho * Wo, training, nbt)
         a_a2 = slot()
         a2 = ops.bn_apply(y2, st2, relu=True, amax=a_a2)
@@ -299,7 +301,7 @@ class ModifiedResNet(nn.Module):
         ax = slot()
         x = ops.bn_apply_pool2(y3, st3, relu=True, amax=ax)
         if save:
-            S["stem"] = (col, y1, st1, a1, y2, st2, a2, y3, st3, a_a2)
+            S["stem"] = (col, y1, st1, a1, y2, st2, a2, y3, st3, a_a2, a_a1)
             S["wamax"] = WA
         # ---- residual layers (m_resnet.py:54-67)
         if save:
@@ -516,19 +518,20 @@ class ModifiedResNet(nn.Module):
                 stage_ready()
         S["blocks"] = None
         # ---- stem
-        col, y1, st1, a1, y2, st2, a2, y3, st3, a_a2 = S["stem"]
+        col, y1, st1, a1, y2, st2, a2, y3, st3, a_a2, a_a1 = S["stem"]
         a_dy3 = slot()
         dy3, dg, db, _ = ops.bn_bwd(g, y3, st3, None, 1, pooled=True, amax=a_dy3)
         G[id(self.bn3.weight)], G[id(self.bn3.bias)] = dg, db
         c3o, c3i = self.conv3.out_channels, self.conv3.in_channels
         w3t = ops.weight_transpose(_w3x3(self.conv3), c3o, 9, c3i, flip=True)
-        da2 = ops.conv3x3(dy3, w3t)
+        da2 = ops.conv3x3(dy3, w3t, prec=P, aa=a_dy3, ba=wam(self.conv3))
         G[id(self.conv3.weight)] = _g3x3(ws.run(lambda d_, x_: ops.conv3x3_wgrad(d_, x_, prec=P, aa=a_dy3, ba=a_a2), dy3, a2), c3o, c3i)
-        dy2, dg, db, _ = ops.bn_bwd(da2, y2, st2, None, 1)
+        a_dy2 = slot()
+        dy2, dg, db, _ = ops.bn_bwd(da2, y2, st2, None, 1, amax=a_dy2)
         G[id(self.bn2.weight)], G[id(self.bn2.bias)] = dg, db
         c2o, c2i = self.conv2.out_channels, self.conv2.in_channels
         w2t = ops.weight_transpose(_w3x3(self.conv2), c2o, 9, c2i, flip=True)
-        da1 = ops.conv3x3(dy2, w2t)
+        da1 = ops.conv3x3(dy2, w2t, prec=P, aa=a_dy2, ba=wam(self.conv2))
         G[id(self.conv2.weight)] = _g3x3(ws.run(ops.conv3x3_wgrad, dy2, a1), c2o, c2i)
         dy1, dg, db, _ = ops.bn_bwd(da1, y1, st1, None, 1)
         G[id(self.bn1.weight)], G[id(self.bn1.bias)] = dg, db

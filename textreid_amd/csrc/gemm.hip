@@ -508,7 +508,10 @@ int trid_gemm_launch(const trid_gemm_desc* d, const GemmFilter* filt, const int*
     const bool small_enough = a_elems < (1ll << 29) && b_elems < (1ll << 29);
     p.a_amax = d->a_amax;
     p.b_amax = d->b_amax;
-    if ((d->precision == 1 || d->precision == 3 || d->precision == 6 || d->precision == 16) && d->K % 8 == 0 && d->K >= 32 && d->M >= 64 && d->N >= 64 &&
+    // fp16-split arithmetic also takes 32..63-column outputs (stem convs) on its 128x64 tile: half the tile is idle, still
+    // 2x the exact fp32-MFMA kernel
+    const int min_n = d->precision == 16 ? 32 : 64;
+    if ((d->precision == 1 || d->precision == 3 || d->precision == 6 || d->precision == 16) && d->K % 8 == 0 && d->K >= 32 && d->M >= 64 && d->N >= min_n &&
         (d->M >= 96 || d->N >= 96) && (am != A_CONV || d->Cin % 8 == 0) && small_enough) {
         rc = gemm_bf16_dispatch(p, am, bm, d->precision, stream);
         if (rc != TRID_E_UNSUPPORTED) return rc;

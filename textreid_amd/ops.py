@@ -50,7 +50,8 @@ PROFILE = None
 
 def _uses_split(M, N, K, a_mode, conv, prec=None):
     """Mirror of the split-kernel eligibility test in trid_gemm_f32()."""
-    return ((GEMM_PRECISION if prec is None else prec) in (1, 3, 6, 16) and K % 8 == 0 and K >= 32 and M >= 64 and N >= 64 and (M >= 96 or N >= 96)
+    pr = GEMM_PRECISION if prec is None else prec
+    return (pr in (1, 3, 6, 16) and K % 8 == 0 and K >= 32 and M >= 64 and N >= (32 if pr == 16 else 64) and (M >= 96 or N >= 96)
             and (a_mode != A_CONV or conv[2] % 8 == 0))
 
 
