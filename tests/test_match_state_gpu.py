@@ -426,7 +426,14 @@ def test_evaluation_entry_point(gpu, tmp_path):
     rvn = OE.k_reciprocal(F.normalize(txt, dim=1), F.normalize(img, dim=1))
     cmc2, mAP2, _ = OE.rank(rvn + sim, tpid, ipid, (1, 5, 10), True)
     assert np.allclose(res["re-t2i"][0].cpu().numpy(), cmc2.numpy(), atol=1e-4) and abs(float(res["re-t2i"][1]) - float(mAP2)) < 1e-3
-    assert os.path.exists(os.path.join(str(tmp_path), "inference_data.npz"))
+    saved = np.load(os.path.join(str(tmp_path), "inference_data.npz"))
+    assert set(saved.files) == {"image_pid", "text_pid", "similarity", "rvn_mat", "rtn_mat"}  # evaluation.py:126-143
+    assert np.allclose(saved["rvn_mat"], rvn.numpy(), atol=1e-6)
+    # `test_net.py --load-result`: predictions=None re-reads the saved arrays and reproduces every metric
+    first = {k: (v[0].cpu().numpy().copy(), float(v[1])) for k, v in res.items()}
+    evaluation(DS(), None, str(tmp_path), [1, 5, 10], save_data=False, rerank=True)
+    for k, (c0, m0) in first.items():
+        assert np.allclose(evaluation.last_results[k][0].cpu().numpy(), c0, atol=1e-5) and abs(float(evaluation.last_results[k][1]) - m0) < 1e-4, k
     evaluation(DS(), preds, str(tmp_path), [1, 5, 10], save_data=False, rerank=False)
     cmc3, _ = OE.rank(sim, tpid, ipid, (1, 5, 10), False)
     assert np.allclose(evaluation.last_results["t2i"][0].cpu().numpy(), cmc3.numpy(), atol=1e-4)

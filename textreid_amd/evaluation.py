@@ -129,28 +129,52 @@ def get_unique(image_ids):
 
 def evaluation(dataset, predictions, output_folder, topk, save_data=True, rerank=True):
     logger = logging.getLogger("PersonSearch.inference")
-    image_ids, pids, image_global, text_global = [], [], [], []
-    for idx, prediction in predictions.items():
-        image_id, pid = dataset.get_id_info(idx)
-        image_ids.append(image_id)
-        pids.append(pid)
-        image_global.append(prediction[0])
-        text_global.append(prediction[1])
-    dev = image_global[0].device
-    image_pid = torch.tensor(pids, device=dev)
-    text_pid = torch.tensor(pids, device=dev)
-    image_global = torch.stack(image_global, dim=0)
-    text_global = torch.stack(text_global, dim=0)
-    keep = get_unique(image_ids).to(dev)
-    image_global = l2_normalize_rows(image_global[keep])
-    image_pid = image_pid[keep]
-    text_global = l2_normalize_rows(text_global)
-    sim = ops.linear(text_global, image_global)  # [texts, images]
+    data_dir = os.path.join(output_folder, "inference_data.npz") if output_folder else None
+    dev = torch.device("cuda")
+    rtn = rvn = None
+    if predictions is None:
+        # `test_net.py --load-result`: metrics from the arrays a previous run saved (evaluation.py:87-96)
+        data = np.load(data_dir)
+        logger.info("Load inference data from %s", data_dir)
+        image_pid = torch.as_tensor(data["image_pid"]).to(dev)
+        text_pid = torch.as_tensor(data["text_pid"]).to(dev)
+        sim = torch.as_tensor(data["similarity"]).float().to(dev).contiguous()
+        if rerank:
+            rvn = torch.as_tensor(data["rvn_mat"]).float().to(dev)
+            rtn = torch.as_tensor(data["rtn_mat"]).float().to(dev)
+    else:
+        image_ids, pids, image_global, text_global = [], [], [], []
+        for idx, prediction in predictions.items():
+            image_id, pid = dataset.get_id_info(idx)
+            image_ids.append(image_id)
+            pids.append(pid)
+            image_global.append(prediction[0])
+            text_global.append(prediction[1])
+        dev = image_global[0].device
+        image_pid = torch.tensor(pids, device=dev)
+        text_pid = torch.tensor(pids, device=dev)
+        image_global = torch.stack(image_global, dim=0)
+        text_global = torch.stack(text_global, dim=0)
+        keep = get_unique(image_ids).to(dev)
+        image_global = l2_normalize_rows(image_global[keep])
+        image_pid = image_pid[keep]
+        text_global = l2_normalize_rows(text_global)
+        sim = ops.linear(text_global, image_global)  # [texts, images]
+        if rerank:
+            rtn = k_reciprocal(image_global, text_global)  # [images, texts] (evaluation.py:122-124)
+            rvn = k_reciprocal(text_global, image_global)  # [texts, images]
+        if save_data and data_dir:
+            arrays = dict(image_pid=image_pid.cpu().numpy(), text_pid=text_pid.cpu().numpy(), similarity=sim.cpu().numpy())
+            if rerank:
+                arrays.update(rvn_mat=rvn.cpu().numpy(), rtn_mat=rtn.cpu().numpy())
+            np.savez(data_dir, **arrays)
     sim_t = sim.t().contiguous()
     results = {}
     if rerank:
-        re_i2t = k_reciprocal(image_global, text_global, base=sim_t)  # rtn_mat + similarity.t()
-        re_t2i = k_reciprocal(text_global, image_global, base=sim)    # rvn_mat + similarity
+        ones = torch.ones(3, device=dev)
+        re_i2t, re_t2i = torch.empty_like(rtn), torch.empty_like(rvn)
+        call("trid_axpby3_f32", _p(re_i2t), _p(rtn.contiguous()), _p(sim_t), None, _p(ones), rtn.numel(), stream())  # rtn_mat + similarity.t()
+        call("trid_axpby3_f32", _p(re_t2i), _p(rvn.contiguous()), _p(sim), None, _p(ones), rvn.numel(), stream())    # rvn_mat + similarity
         results["i2t"] = rank(sim_t, image_pid, text_pid, topk, get_mAP=True)[:2]
         results["t2i"] = rank(sim, text_pid, image_pid, topk, get_mAP=True)[:2]
         results["re-i2t"] = rank(re_i2t, image_pid, text_pid, topk, get_mAP=True)[:2]
@@ -161,8 +185,5 @@ def evaluation(dataset, predictions, output_folder, topk, save_data=True, rerank
         results["t2i"] = (rank(sim, text_pid, image_pid, topk, get_mAP=False)[0], None)
         results["i2t"] = (rank(sim_t, image_pid, text_pid, topk, get_mAP=False)[0], None)
         logger.info("topk %s  t2i %s  i2t %s", list(topk), results["t2i"][0].tolist(), results["i2t"][0].tolist())
-    if save_data and output_folder:
-        np.savez(os.path.join(output_folder, "inference_data.npz"), image_pid=image_pid.cpu().numpy(),
-                 text_pid=text_pid.cpu().numpy(), similarity=sim.cpu().numpy())
     evaluation.last_results = results
     return results["t2i"][0][0]

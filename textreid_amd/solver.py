@@ -142,7 +142,7 @@ class LRSchedulerWithWarmup(torch.optim.lr_scheduler._LRScheduler):
     def __init__(self, optimizer, milestones, gamma=0.1, mode="step", warmup_factor=1.0 / 3, warmup_epochs=10,
                  warmup_method="linear", total_epochs=100, target_lr=0, power=0.9, last_epoch=-1):
         if list(milestones) != sorted(milestones):
-            raise ValueError("Milestones should be a list of increasing integers. Got {}".format(milestones))
+            raise ValueError("SOLVER.STEPS must be sorted in increasing order, got %r" % (milestones,))
         if mode not in ("step", "exp", "poly", "cosine", "linear"):
             raise ValueError("unknown lr scheduler mode {}".format(mode))
         if warmup_method not in ("constant", "linear"):
