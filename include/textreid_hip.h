@@ -249,6 +249,8 @@ int trid_image_pipeline_u8(const uint8_t* src, const long long* offset, const in
                            const int* xweights, const int* ybounds, const int* yweights, const int* params, int B,
                            int H, int W, int KX, int KY, int max_src_h, int pad, const float* mean3_std3_erase3_host,
                            uint8_t* ws, float* out, void* stream);
+/* dx = act > 0 ? dy : 0 - backward of the nn.ReLU inside the MOCO.FC projection heads (head.py:33-42) */
+int trid_relu_bwd_f32(const float* dy, const float* act, float* dx, long long n, void* stream);
 /* rowdot[b] = <x_b, y_b> */
 int trid_rowdot_f32(const float* x, const float* y, float* out, long long rows, int C, void* stream);
 /* dx[b,:] (+)= s[b]*y[b,:] */

@@ -42,7 +42,7 @@ class _Sub(dict):
         self._state[self._prefix + "." + k] = v
 
 
-def state_shapes(spec, K, C=256, num_classes=11003, hidden=512, embed=512):
+def state_shapes(spec, K, C=256, num_classes=11003, hidden=512, embed=512, fc=False):
     sh = {}
     for enc in ("v_encoder_q", "v_encoder_k"):
         for k, s in V.state_shapes(spec).items():
@@ -50,6 +50,10 @@ def state_shapes(spec, K, C=256, num_classes=11003, hidden=512, embed=512):
     for enc in ("t_encoder_q", "t_encoder_k"):
         for k, s in T.state_shapes(hidden, embed).items():
             sh[enc + "." + k] = s
+    if fc:  # head.py:32-49 (module order of the reference: fc heads before the embed layers)
+        for nm, cin in (("v_fc_q", spec.output_dim), ("t_fc_q", 2 * hidden), ("v_fc_k", spec.output_dim), ("t_fc_k", 2 * hidden)):
+            sh[nm + ".0.weight"], sh[nm + ".0.bias"] = (C, cin), (C,)
+            sh[nm + ".2.weight"], sh[nm + ".2.bias"] = (C, C), (C,)
     sh["v_embed_layer.weight"] = (C, spec.output_dim)
     sh["v_embed_layer.bias"] = (C,)
     sh["t_embed_layer.weight"] = (C, 2 * hidden)
@@ -68,7 +72,7 @@ def trainable_names(state):
     for k, v in state.items():
         if not v.dtype.is_floating_point:
             continue
-        if k.startswith(("v_encoder_k.", "t_encoder_k.")) or k in ("t_queue", "v_queue"):
+        if k.startswith(("v_encoder_k.", "t_encoder_k.", "v_fc_k.", "t_fc_k.")) or k in ("t_queue", "v_queue"):
             continue
         if not V.is_param(k):
             continue
@@ -79,7 +83,7 @@ def trainable_names(state):
 def ema_names(state):
     """(q_name, k_name) pairs touched by the momentum update, reference order."""
     pairs = []
-    for enc in ("v_encoder", "t_encoder"):
+    for enc in ("v_encoder", "t_encoder", "v_fc", "t_fc"):  # fc heads only exist with MODEL.MOCO.FC (head.py:86-94)
         for k in state:
             if k.startswith(enc + "_q.") and V.is_param(k):
                 pairs.append((k, enc + "_k." + k[len(enc) + 3 :]))
@@ -97,6 +101,15 @@ def encode(state, which, spec, table, images, tokens, lengths, training, vtaps=N
     v = V.visual_forward(_Sub(state, "v_encoder_" + which), images, spec, training, vtaps)
     t = T.text_forward(sub(state, "t_encoder_" + which), table, tokens, lengths)
     return v, t
+
+
+def fc_pair(state, which, v_feat, t_feat):
+    """The MOCO.FC projection heads: Linear -> ReLU -> Linear (head.py:33-42)."""
+    out = []
+    for nm, x in (("v_fc_" + which, v_feat), ("t_fc_" + which, t_feat)):
+        h = F.relu(F.linear(x, state[nm + ".0.weight"], state[nm + ".0.bias"]))
+        out.append(F.linear(h, state[nm + ".2.weight"], state[nm + ".2.bias"]))
+    return out
 
 
 def embed_pair(state, v_feat, t_feat):
@@ -149,12 +162,14 @@ def train_forward(state, spec, table, images, tokens, lengths, ids, m=0.999, eps
     id_q = ids.long()
     vtaps = taps.setdefault("visual_q", {}) if taps is not None else None  # per-stage taps + ReLU margin of the query encoder
     v_feat, t_feat = encode(state, "q", spec, table, images, tokens, lengths, True, vtaps)
+    fc = "v_fc_q.0.weight" in state
     v_embed, t_embed = embed_pair(state, v_feat, t_feat)
-    v_q, t_q = F.normalize(v_embed, dim=1), F.normalize(t_embed, dim=1)
+    vq_src, tq_src = fc_pair(state, "q", v_feat, t_feat) if fc else (v_embed, t_embed)  # head.py:117-129
+    v_q, t_q = F.normalize(vq_src, dim=1), F.normalize(tq_src, dim=1)
     with torch.no_grad():
         momentum_update(state, m)
         vk_feat, tk_feat = encode(state, "k", spec, table, images, tokens, lengths, True)
-        v_k, t_k = embed_pair(state, vk_feat, tk_feat)
+        v_k, t_k = fc_pair(state, "k", vk_feat, tk_feat) if fc else embed_pair(state, vk_feat, tk_feat)
         v_k, t_k = F.normalize(v_k, dim=1), F.normalize(t_k, dim=1)
     out = losses_from_embeddings(state, v_embed, t_embed, v_q, t_q, v_k, t_k, id_q, epsilon)
     if taps is not None:

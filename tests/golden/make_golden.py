@@ -361,7 +361,7 @@ def head_step_inputs(s, spec, B, vocab, Lpad, seed):
     return x, tok, ln, ids
 
 
-def gen_head(seed=5, steps=3):
+def gen_head(seed=5, steps=3, fc=False, fname="head.npz"):
     """Tiny visual encoder + small BiGRU + MoCo head, 3 optimiser steps with the reference's
     make_optimizer rule (SOLVER.OPTIMIZER "SGD", momentum 0.9, bias lr x2 / wd 0; lib/solver/build.py:6-23).
     SGD, not Adam: Adam's first steps are lr*sign(g), which turns rounding noise on near-zero gradients
@@ -376,10 +376,10 @@ def gen_head(seed=5, steps=3):
     ref_gru.load_vocab_dict = lambda root, onehot: table.numpy()
     vis = ref_visual(spec)
     txt = ref_gru.GRU(hidden, embed, embed, 1, 0.0, True, "clip_vit", "./")
-    cfg = ns(MODEL=ns(EMBEDDING=ns(FEATURE_SIZE=C, EPSILON=0.1), MOCO=ns(K=K, M=0.9, FC=False), NUM_CLASSES=NC))
+    cfg = ns(MODEL=ns(EMBEDDING=ns(FEATURE_SIZE=C, EPSILON=0.1), MOCO=ns(K=K, M=0.9, FC=fc), NUM_CLASSES=NC))
     head = MoCoHead(cfg, vis, txt)
     sd = head.state_dict()
-    shapes = OH.state_shapes(spec, K, C, NC, hidden, embed)
+    shapes = OH.state_shapes(spec, K, C, NC, hidden, embed, fc=fc)
     assert {k: tuple(v.shape) for k, v in sd.items()} == {k: tuple(s) for k, s in shapes.items()}, "head state mismatch"
     filled = OF.fill_state(sd, seed, "head.", style="margin")
     st0 = {k: v.clone() for k, v in filled.items()}
@@ -442,7 +442,8 @@ def gen_head(seed=5, steps=3):
             print("  reference fp32 vs fp64 truth (conditioning): worst", [(k, "%.1e" % v) for k, v in top])
             assert top[0][1] < 5e-4, ("fixture is not well-conditioned", top)
             out["conditioning"] = np.array(top[0][1])
-    np.savez_compressed(os.path.join(HERE, "head.npz"), **f32(out))
+    out["fc"] = np.array(int(fc))
+    np.savez_compressed(os.path.join(HERE, fname), **f32(out))
 
 
 def head_oracle(out, filled, spec, table, dt):
@@ -577,7 +578,7 @@ def gen_ingest(seed=13):
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["losses", "rank", "text", "tiny", "head", "rn50", "rn101", "ingest"]
+    which = sys.argv[1:] or ["losses", "rank", "text", "tiny", "head", "head_fc", "rn50", "rn101", "ingest"]
     if "ingest" in which:
         gen_ingest()
     if "losses" in which:
@@ -590,6 +591,8 @@ if __name__ == "__main__":
         gen_visual("tiny", OV.TINY, 4, 1, grads=("conv1.weight", "bn1.weight", "conv2.weight", "layer1.0.conv2.weight", "layer2.0.downsample.0.weight", "layer3.0.conv2.weight", "layer4.0.bn3.bias", "attnpool.k_proj.weight", "attnpool.q_proj.bias", "attnpool.positional_embedding", "attnpool.c_proj.weight"))
     if "head" in which:
         gen_head()
+    if "head_fc" in which:  # MODEL.MOCO.FC = True (the default of lib/config/defaults.py:56): projection-head branch
+        gen_head(seed=6, steps=2, fc=True, fname="head_fc.npz")
     if "rn50" in which:
         gen_visual_full("rn50", OV.RN50, 8, 2)
     if "rn101" in which:

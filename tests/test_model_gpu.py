@@ -251,8 +251,10 @@ def ns(**kw):
     return types.SimpleNamespace(**kw)
 
 
-def test_moco_head_three_steps(gpu, golden_dir):
-    """Tiny encoders + MoCo head, three optimiser steps (the reference's make_optimizer rule with
+@pytest.mark.parametrize("fname", ["head.npz", "head_fc.npz"])
+def test_moco_head_three_steps(gpu, golden_dir, fname):
+    """(head_fc.npz: the same with MODEL.MOCO.FC = True - Linear/ReLU/Linear projection heads and their momentum copies.)
+    Tiny encoders + MoCo head, three optimiser steps (the reference's make_optimizer rule with
     SOLVER.OPTIMIZER "SGD"): losses per step, EVERY step-0 gradient, the ENTIRE state after the last step
     (parameters, key encoders, BatchNorm statistics, queues; ids / pointer bit-exact) and the eval
     embeddings against the reference-captured trajectory, flat 1e-3."""
@@ -262,16 +264,18 @@ def test_moco_head_three_steps(gpu, golden_dir):
     from textreid_amd.caption import CaptionBatch
     from textreid_amd.embeddings.moco_head.head import MoCoHead
 
-    g = load(golden_dir, "head.npz")
+    g = load(golden_dir, fname)
+    fc = bool(int(g["fc"])) if "fc" in g.files else False
     hidden, embed, vocab, Lpad, C, K, NC, B, seed, steps = (int(v) for v in g["dims"])
     lr, mom, wd = (float(v) for v in g["sgd"])
     spec = OV.TINY
     table = OF.randn("vocab_table_head", (vocab, embed), seed, 0.5)
     vis = ModifiedResNet(list(spec.layers), spec.output_dim, spec.heads, spec.last_stride, (spec.height, spec.in_width), spec.width)
     txt = GRU(hidden, embed, embed, 1, 0.0, True, "clip_vit", "./", vocab_dict=table)
-    cfg = ns(MODEL=ns(EMBEDDING=ns(FEATURE_SIZE=C, EPSILON=0.1), MOCO=ns(K=K, M=float(g["m"]), FC=False), NUM_CLASSES=NC))
+    cfg = ns(MODEL=ns(EMBEDDING=ns(FEATURE_SIZE=C, EPSILON=0.1), MOCO=ns(K=K, M=float(g["m"]), FC=fc), NUM_CLASSES=NC))
     head = MoCoHead(cfg, vis, txt)
     sd = head.state_dict()
+    assert {k: tuple(v.shape) for k, v in sd.items()} == {k: tuple(s) for k, s in OH.state_shapes(spec, K, C, NC, hidden, embed, fc=fc).items()}
     filled = OF.fill_state(sd, seed, "head.", style="margin")
     st = {k: torch.zeros(tuple(s), dtype=torch.int64) if k in ("id_queue", "queue_ptr") else torch.zeros(tuple(s)) for k, s in OH.state_shapes(spec, K, C, NC, hidden, embed).items() if k in ("t_queue", "v_queue", "id_queue", "queue_ptr")}
     OH.init_queues(st, seed)

@@ -138,7 +138,7 @@ def head_setup(g):
     hidden, embed, vocab, Lpad, C, K, NC, B, seed, steps = (int(v) for v in g["dims"])
     spec = OV.TINY
     table = OF.randn("vocab_table_head", (vocab, embed), seed, 0.5)
-    shapes = OH.state_shapes(spec, K, C, NC, hidden, embed)
+    shapes = OH.state_shapes(spec, K, C, NC, hidden, embed, fc=bool(int(g["fc"])) if "fc" in g.files else False)
     st = {}
     for k, s in shapes.items():
         if k.endswith("num_batches_tracked"):
@@ -156,12 +156,14 @@ def sgd_groups(named, lr, wd):
     return [{"params": [p], "lr": 2 * lr if "bias" in k else lr, "weight_decay": 0.0 if "bias" in k else wd} for k, p in named]
 
 
-def test_head_three_steps(golden_dir):
-    """Three SGD steps of the whole MoCo head on the oracle against the reference-captured trajectory:
-    losses, every step-0 gradient, the entire final state, eval embeddings."""
+@pytest.mark.parametrize("fname", ["head.npz", "head_fc.npz"])
+def test_head_three_steps(golden_dir, fname):
+    """SGD steps of the whole MoCo head on the oracle against the reference-captured trajectory: losses, every
+    step-0 gradient, the entire final state, eval embeddings.  head_fc.npz: MODEL.MOCO.FC = True (projection heads
+    with momentum copies, head.py:32-49,86-94,117-144)."""
     from fixture_check import assert_within, head_errors
 
-    g = load(golden_dir, "head.npz")
+    g = load(golden_dir, fname)
     st, spec, table, dims = head_setup(g)
     steps = dims[-1]
     lr, mom, wd = (float(v) for v in g["sgd"])

@@ -342,6 +342,12 @@ __global__ __launch_bounds__(256) void sum_kernel(const float* __restrict__ x, f
     if (threadIdx.x == 0) out[0] = accumulate ? out[0] + s * scale : s * scale;
 }
 
+// dx = act > 0 ? dy : 0   (ReLU backward of the MoCo head's fc branches, head.py:33-42)
+__global__ void relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ act, float* __restrict__ dx, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        dx[i] = act[i] > 0.f ? dy[i] : 0.f;
+}
+
 // out = g[0]*a + g[1]*b + g[2]*c with device-resident scalars (b, c optional)
 __global__ void axpby3_kernel(float* __restrict__ out, const float* __restrict__ a, const float* __restrict__ b,
                               const float* __restrict__ c, const float* __restrict__ g, long long n) {
@@ -357,6 +363,12 @@ __global__ void axpby3_kernel(float* __restrict__ out, const float* __restrict__
 }  // namespace trid
 
 using namespace trid;
+
+extern "C" int trid_relu_bwd_f32(const float* dy, const float* act, float* dx, long long n, void* stream) {
+    TRID_REQUIRE(dy && act && dx && n > 0, "trid_relu_bwd_f32: bad arguments");
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid_for(n, 256 * 4, 2048)), dim3(256), 0, (hipStream_t)stream, dy, act, dx, n);
+    return check_launch("trid_relu_bwd_f32");
+}
 
 extern "C" int trid_axpby3_f32(float* out, const float* a, const float* b, const float* c, const float* g3,
                                long long n, void* stream) {

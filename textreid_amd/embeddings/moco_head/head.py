@@ -57,8 +57,6 @@ class MoCoHead(nn.Module):
         self.K = cfg.MODEL.MOCO.K
         self.m = cfg.MODEL.MOCO.M
         self.fc = cfg.MODEL.MOCO.FC
-        if self.fc:
-            raise NotImplementedError("MODEL.MOCO.FC=True is not on the accelerated path (shipped MoCo configs use FC=False)")
         self.v_encoder_q = visual_model
         self.t_encoder_q = textual_model
         self.v_encoder_k = copy.deepcopy(visual_model)
@@ -67,6 +65,14 @@ class MoCoHead(nn.Module):
             p.requires_grad = False
         for p in self.t_encoder_k.parameters():
             p.requires_grad = False
+        if self.fc:  # head.py:32-49: two-layer projection heads for the contrastive branch, momentum copies for the keys
+            mk = lambda cin: nn.Sequential(nn.Linear(cin, self.embed_size), nn.ReLU(), nn.Linear(self.embed_size, self.embed_size))
+            self.v_fc_q = mk(visual_model.out_channels)
+            self.t_fc_q = mk(textual_model.out_channels)
+            self.v_fc_k = copy.deepcopy(self.v_fc_q)
+            self.t_fc_k = copy.deepcopy(self.t_fc_q)
+            for p in list(self.v_fc_k.parameters()) + list(self.t_fc_k.parameters()):
+                p.requires_grad = False
         self.v_embed_layer = nn.Linear(visual_model.out_channels, self.embed_size)
         self.t_embed_layer = nn.Linear(textual_model.out_channels, self.embed_size)
         # queues: storage [K,C] row-major, registered as the reference-shaped [C,K] transposed views
@@ -103,6 +109,9 @@ class MoCoHead(nn.Module):
     def _ema_pairs(self):
         pairs = list(zip(self.v_encoder_q.parameters(), self.v_encoder_k.parameters()))
         pairs += list(zip(self.t_encoder_q.parameters(), self.t_encoder_k.parameters()))
+        if self.fc:  # head.py:86-94
+            pairs += list(zip(self.v_fc_q.parameters(), self.v_fc_k.parameters()))
+            pairs += list(zip(self.t_fc_q.parameters(), self.t_fc_k.parameters()))
         return pairs
 
     @torch.no_grad()
@@ -169,13 +178,23 @@ class MoCoHead(nn.Module):
             t_embed = losses.linear(t_feat, self.t_embed_layer.weight, self.t_embed_layer.bias)
             id_q = cb.ids.long()
             with torch.no_grad():
-                v_embed_k = losses.l2_normalize(losses.linear(vk_feat, self.v_embed_layer.weight, self.v_embed_layer.bias))
-                t_embed_k = losses.l2_normalize(losses.linear(tk_feat, self.t_embed_layer.weight, self.t_embed_layer.bias))
-            if world_size() > 1:
-                # one packed RCCL all-gather; every rank then evaluates the GLOBAL losses
-                v_embed, t_embed, v_embed_k, t_embed_k, id_q = gather_embeddings(v_embed, t_embed, v_embed_k, t_embed_k, id_q)
-            v_embed_q = losses.l2_normalize(v_embed)
-            t_embed_q = losses.l2_normalize(t_embed)
+                if self.fc:  # keys through the momentum projection heads (head.py:135-144)
+                    v_embed_k = losses.l2_normalize(losses.mlp(vk_feat, self.v_fc_k))
+                    t_embed_k = losses.l2_normalize(losses.mlp(tk_feat, self.t_fc_k))
+                else:
+                    v_embed_k = losses.l2_normalize(losses.linear(vk_feat, self.v_embed_layer.weight, self.v_embed_layer.bias))
+                    t_embed_k = losses.l2_normalize(losses.linear(tk_feat, self.t_embed_layer.weight, self.t_embed_layer.bias))
+            if self.fc:
+                if world_size() > 1:
+                    raise NotImplementedError("MODEL.MOCO.FC=True under data parallelism: the packed gather carries one query embedding per modality")
+                v_embed_q = losses.l2_normalize(losses.mlp(v_feat, self.v_fc_q))  # head.py:118-124
+                t_embed_q = losses.l2_normalize(losses.mlp(t_feat, self.t_fc_q))
+            else:
+                if world_size() > 1:
+                    # one packed RCCL all-gather; every rank then evaluates the GLOBAL losses
+                    v_embed, t_embed, v_embed_k, t_embed_k, id_q = gather_embeddings(v_embed, t_embed, v_embed_k, t_embed_k, id_q)
+                v_embed_q = losses.l2_normalize(v_embed)
+                t_embed_q = losses.l2_normalize(t_embed)
             out = self.loss_evaluator.forward_fused(
                 v_embed, t_embed, v_embed_q, t_embed_q, v_embed_k, t_embed_k, id_q,
                 self._queue_kc("t_queue"), self._queue_kc("v_queue"), self.id_queue,

@@ -249,3 +249,32 @@ def linear(x, weight, bias=None):
     """F.linear on the MFMA GEMM (embed layers, head.py:50-51)."""
     _check(x, weight)
     return _LinearFn.apply(x, weight, bias)
+
+
+class _MlpFn(torch.autograd.Function):
+    """Linear -> ReLU -> Linear (the `*_fc_q` / `*_fc_k` projection heads of MODEL.MOCO.FC, head.py:33-42): the ReLU
+    rides in the first GEMM's epilogue, its backward is one masking kernel."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        xd = x.detach().contiguous()
+        h = ops.linear(xd, w1.detach(), b1.detach(), relu=True)
+        ctx.saved = (xd, h, w1, w2)
+        return ops.linear(h, w2.detach(), b2.detach())
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, h, w1, w2 = ctx.saved
+        ctx.saved = None
+        dy = dy.contiguous()
+        dh = ops.matmul_nn(dy, w2.detach())
+        dhm = torch.empty_like(dh)
+        call("trid_relu_bwd_f32", _p(dh), _p(h), _p(dhm), dh.numel(), stream())
+        dx = ops.matmul_nn(dhm, w1.detach()) if ctx.needs_input_grad[0] else None
+        return dx, ops.matmul_tn(dhm, x), ops.colsum(dhm), ops.matmul_tn(dy, h), ops.colsum(dy)
+
+
+def mlp(x, fc):
+    """fc: nn.Sequential(Linear, ReLU, Linear) used as a parameter holder."""
+    _check(x)
+    return _MlpFn.apply(x, fc[0].weight, fc[0].bias, fc[2].weight, fc[2].bias)

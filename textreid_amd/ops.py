@@ -154,7 +154,7 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, a_mode=A_KC, b_mode=B_KC, alpha=1.0, a
     call("trid_gemm_f32", ctypes.addressof(d), stream())
 
 
-def linear(x, w, bias=None, out=None, alpha=1.0, accumulate=False, prec=None, aa=None, ba=None):
+def linear(x, w, bias=None, out=None, alpha=1.0, accumulate=False, prec=None, aa=None, ba=None, relu=False):
     """y[M,N] = alpha * x[M,K] @ w[N,K]^T + bias.  x may be a strided row view.
     prec / aa / ba (here and below): GEMM arithmetic override and the two operands' amax device scalars."""
     M, K = x.shape
@@ -162,7 +162,7 @@ def linear(x, w, bias=None, out=None, alpha=1.0, accumulate=False, prec=None, aa
     if out is None:
         out = empty((M, N), x)
     gemm(x, w, out, M, N, K, x.stride(0), w.stride(0), out.stride(0), alpha=alpha, accumulate=accumulate, bias=bias,
-         precision=prec, a_amax=aa, b_amax=ba)
+         precision=prec, a_amax=aa, b_amax=ba, relu=relu)
     return out
 
 
