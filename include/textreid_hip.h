@@ -189,6 +189,32 @@ int trid_gru_cell_bwd_f32(const float* dout, const int32_t* argt, const float* g
                           int B, int Hd, long long gates_dstride, long long hprev_dstride, long long dgh_dstride,
                           void* stream);
 
+/* --- One launch per time step (gru_step.hip): recurrent product + gates + state + running max fused, both
+ * directions, fp32-class arithmetic (fp16 two-plane split, 3 MFMA products).  Replaces the trid_gemm_f32 +
+ * trid_gru_cell_* pair of a step (gru.py:66-82); built for H % 32 == 0, 32 <= H <= 768, else TRID_E_UNSUPPORTED.
+ * trid_gru_pack_whh_f16: w_hh [2, 3H, H] (forward, reverse) -> the forward and backward fragment images (each
+ * trid_gru_whh_image_bytes(H) bytes, 0 = unsupported H), once per pass; w_amax = device scalar max|w_hh|
+ * (trid_amax_f32), also handed to every step.
+ * Forward step s: hp_in / hp_out [2, Bp, H] uint32 = the hidden state entering / leaving the step as packed fp16
+ * planes ((hi | lo << 16) of h * 2^13; Bp = B rounded up to 16, padding rows zero; all-zero before step 0; the
+ * caller alternates two buffers); everything else as trid_gru_cell_fwd_f32 (h [2,B,H] in place, gates / hprev
+ * slices of this step or NULL, maxv / argt).
+ * Backward step s (descending): dgh_in = the [2,B,3H] slice written by step s+1 and amax_in = the scalar it
+ * published (both NULL at the first processed step); amax_out = zeroed scalar receiving max|dgh| of this step;
+ * dh [2,B,H] carries dL/dh in place: dh <- (dh + dgh_in @ W_hh [+ dout where argt == t]) * z; the rest as
+ * trid_gru_cell_bwd_f32. */
+long long trid_gru_whh_image_bytes(int H);
+int trid_gru_pack_whh_f16(const float* w_hh, const float* w_amax, void* img_fwd, void* img_bwd, int H, void* stream);
+int trid_gru_step_fwd_f32(const void* img_fwd, const float* w_amax, const void* hp_in, void* hp_out, float* h,
+                          const float* gi, const int64_t* lengths, float* gates, float* hprev, float* maxv,
+                          int32_t* argt, int s, int Lmax, int L, int B, int Bp, int H, long long gates_dstride,
+                          long long hprev_dstride, void* stream);
+int trid_gru_step_bwd_f32(const void* img_bwd, const float* w_amax, const float* dgh_in, const float* amax_in,
+                          float* amax_out, const float* dout, const int32_t* argt, const float* gates,
+                          const float* hprev, const int64_t* lengths, float* dh, float* dGi, float* dgh_out, int s,
+                          int Lmax, int L, int B, int H, long long gates_dstride, long long hprev_dstride,
+                          long long dgh_dstride, void* stream);
+
 /* ------------------------------------------------------------------------- *
  * Embedding head and losses (head.py:126-175, losses.py, moco_head/loss.py).
  * ------------------------------------------------------------------------- */
@@ -219,8 +245,8 @@ int trid_infonce_queue_rows_f32(float* S, const float* q, const float* key, cons
  * Queries and queue rows must be L2-normalised (head.py:128-129,140,145), |<q, k>| <= logit_bound (1 for unit
  * vectors): the kernel uses the fixed shift logit_bound/T instead of a running maximum.  A queue row k is
  * filtered when id_queue[k] equals ANY ids[i], i < B (one shared column set per batch, head.py:148-157).  Outputs loss_rows[2][B] = lse - pos/T and dq[2][B][C] = dL/dq for
- * L = gscale * mean_b(loss_rows) summed over the modalities.  precision: 6 = fp32-class (bf16 plane split as
- * trid_gemm_f32), 1 = bf16 operands.  nwg_hint: workgroups per modality (0 = default).  Built for C = 256 and
+ * L = gscale * mean_b(loss_rows) summed over the modalities.  precision: 6 = fp32-class (fp16 two-plane split with fixed
+ * scales, 6 MFMA products per query x row x channel), 3 = fp32-class on three bf16 planes (11 products), 1 = bf16 operands.  nwg_hint: workgroups per modality (0 = default).  Built for C = 256 and
  * K % 32 == 0, otherwise TRID_E_UNSUPPORTED (the caller then takes trid_gemm_f32 + trid_infonce_queue_rows_f32).
  * ws floats >= trid_queue_nce_ws_floats(B, K, C, nwg_hint) (0 = unsupported shape).  Bit-reproducible: partial
  * sums are folded in a fixed order, no atomics. */

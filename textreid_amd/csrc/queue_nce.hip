@@ -18,12 +18,14 @@
 // x 32) and writes its partial (l, O); a small pre-pass writes the batch-wide filter flags (one byte per queue row); a finish kernel folds the partials in a fixed order (bit-
 // reproducible, no atomics), adds the positive pair <q_b, key_b> and emits the per-row loss and dL/dq.
 //
-// Arithmetic: fp32-class.  fp32 operands are split on the fly into three bf16 planes exactly as in
-// gemm_bf16.hip; S uses the six significant plane products (dropped terms <= 2^-26), P (two planes,
-// relative error 2^-17) times the three queue planes uses five.  precision = 1 keeps one plane of
-// everything (bf16-autocast arithmetic, configs[3]).
+// Arithmetic: fp32-class.  Default (precision 6): queue_nce_f16_kernel below - fp16 two-plane split with fixed
+// scales, 3 + 3 MFMA products per (query, row, channel), hand-pipelined.  precision = 3: fp32 operands split on
+// the fly into three bf16 planes exactly as in gemm_bf16.hip; S uses the six significant plane products (dropped
+// terms <= 2^-26), P (two planes, relative error 2^-17) times the three queue planes uses five.  precision = 1
+// keeps one bf16 plane of everything (bf16-autocast arithmetic, configs[3]).
 
 #include <mutex>
+#include <type_traits>
 
 #include "split_common.h"
 
@@ -253,6 +255,217 @@ __global__ __launch_bounds__(256, 1) void queue_nce_kernel(QnceParams p) {
         }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// fp32-class arithmetic on HALF the MFMA work: fp16 two-plane split with FIXED power-of-two scales.  Every
+// operand is bounded by construction - queries and queue rows are unit vectors (|x| <= 1, scale 2^13), P =
+// exp((s - bound)/T) lies in (0, 1] (scale 2^15) - so no amax pass is needed: x' = x * 2^e, hi = fp16(x'),
+// lo = fp16(x' - hi), and a product is hi*hi + hi*lo + lo*hi in ONE fp32 accumulator (dropped lo*lo <= 2^-22),
+// 3 MFMAs where the bf16 form needs 6 (S) / 5 (O).  With one wave per SIMD nothing else hides the loader, so the
+// tile loop is software-pipelined by hand: two LDS buffers (2 planes x 2 images x 2 = 130 KB), the rows of tile
+// t+1 are split and written to the other buffer BETWEEN the MFMAs of tile t (ONE barrier per tile), and the global
+// loads of tile t+2 are issued a full tile ahead into a second register set.
+constexpr int F_BUF = 2 * (A1_SLOTS + A2_SLOTS);  // 16-byte slots of one buffer: [A1 hi | A1 lo | A2 hi | A2 lo]
+constexpr float F_SC = 8192.f;                    // 2^13: scale of queries and queue rows
+constexpr int F_SP_LOG2 = 15;                     // P' = P * 2^15
+constexpr int F_OPAD = QC + 4;                    // row pitch (floats) of the epilogue's LDS transpose
+
+typedef std::integral_constant<int, 0> par0;
+typedef std::integral_constant<int, 1> par1;
+
+__global__ __launch_bounds__(256, 1) void queue_nce_f16_kernel(QnceParams p) {
+    extern __shared__ __attribute__((aligned(16))) uint4 qsm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int wg = blockIdx.x, bb = blockIdx.y, mod = blockIdx.z;
+    const float* __restrict__ Q = p.q[mod];
+    const float* __restrict__ Kq = p.queue[mod];
+
+    // ---- this wave's 32 queries as B-operand fragments (registers, both planes)
+    f16x8 qf[2][QCH];
+    {
+        const int b = bb * QB + wave * 32 + l31;
+        const float* src = Q + (long long)(b < p.B ? b : 0) * QC + 8 * half;
+#pragma unroll
+        for (int ch = 0; ch < QCH; ++ch) {
+            float4 u = *reinterpret_cast<const float4*>(src + 16 * ch);
+            float4 v = *reinterpret_cast<const float4*>(src + 16 * ch + 4);
+            if (b >= p.B) u = v = make_float4(0.f, 0.f, 0.f, 0.f);
+            unsigned h[4], l[4];
+            f16_split2(u.x * F_SC, u.y * F_SC, h[0], l[0]);
+            f16_split2(u.z * F_SC, u.w * F_SC, h[1], l[1]);
+            f16_split2(v.x * F_SC, v.y * F_SC, h[2], l[2]);
+            f16_split2(v.z * F_SC, v.w * F_SC, h[3], l[3]);
+            qf[0][ch] = __builtin_bit_cast(f16x8, make_uint4(h[0], h[1], h[2], h[3]));
+            qf[1][ch] = __builtin_bit_cast(f16x8, make_uint4(l[0], l[1], l[2], l[3]));
+        }
+    }
+
+    v16f O[QCT];
+#pragma unroll
+    for (int ct = 0; ct < QCT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) O[ct][r] = 0.f;
+    float lsum = 0.f;
+
+    const int t_begin = wg * p.tiles_per_wg;
+    const int t_end = min(p.K / QTILE, t_begin + p.tiles_per_wg);
+    const int lkk = wave >> 1, lh = wave & 1;  // loader role: wave -> (kk, h) row set, lane -> 4 consecutive columns
+    float4 g[8];         // the next tile to stage (loaded one O phase + half an S phase ahead of its first use)
+    unsigned hpre = 0;   // this lane's dword of its filter flags
+    unsigned w[8][2][2]; // staged tile: [row][plane][column pair]
+    auto load_tile = [&](int t) {
+        t = min(t, t_end - 1);  // past the end: a harmless reload of the last tile (never consumed)
+        hpre = reinterpret_cast<const unsigned*>(p.hit + (long long)t * QTILE)[lane & 7];
+        const float* base = Kq + (long long)t * QTILE * QC + 4 * lane;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) g[i] = *reinterpret_cast<const float4*>(base + (long long)tile_row(lkk, lh, i) * QC);
+    };
+    // batch-wide negative filter of the tile in `g` (bit j set <=> queue row j carries an id of the batch): the flags
+    // of rows 4*(lane&7) .. +3 sit in this lane's prefetched dword -> one bit per row, OR over 8 lanes
+    auto tile_mask = [&]() {
+        unsigned m = ((hpre & 0xffu) ? 1u : 0u) | ((hpre & 0xff00u) ? 2u : 0u) | ((hpre & 0xff0000u) ? 4u : 0u) | ((hpre & 0xff000000u) ? 8u : 0u);
+        m <<= 4 * (lane & 7);
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) m |= __shfl_xor(m, o, 64);
+        return m;
+    };
+    // split row i of the register tile into the two planes and write image 1 (A operand of S^T):
+    // slot [(c >> 3)][row]; this lane holds columns 4*lane .. +3 = half a slot
+    auto stage_row = [&](uint4* buf, int i) {
+        f16_split2(g[i].x * F_SC, g[i].y * F_SC, w[i][0][0], w[i][1][0]);
+        f16_split2(g[i].z * F_SC, g[i].w * F_SC, w[i][0][1], w[i][1][1]);
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+            uint2* dst = reinterpret_cast<uint2*>(buf + pl * A1_SLOTS + (lane >> 1) * 33 + tile_row(lkk, lh, i)) + (lane & 1);
+            *dst = make_uint2(w[i][pl][0], w[i][pl][1]);
+        }
+    };
+    // image 2 (B operand of O): slot [kk*2 + h][c] = the 8 rows of this wave's row set for column c = 4*lane + cc
+    auto stage_col = [&](uint4* buf, int pl, int cc) {
+        unsigned d[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const unsigned a = w[2 * m][pl][cc >> 1], b = w[2 * m + 1][pl][cc >> 1];
+            d[m] = (cc & 1) ? ((a >> 16) | (b & 0xffff0000u)) : ((a & 0xffffu) | (b << 16));
+        }
+        buf[2 * A1_SLOTS + pl * A2_SLOTS + (lkk * 2 + lh) * QC + a2_sw(4 * lane + cc)] = make_uint4(d[0], d[1], d[2], d[3]);
+    };
+
+    const float c1 = p.c1 * (1.f / (F_SC * F_SC));
+    const float c0 = p.c0 + (float)F_SP_LOG2;
+    unsigned hmask_next = 0;
+    auto tile = [&](int par, int t) {
+        const uint4* cur = qsm + par * F_BUF;
+        uint4* nxt = qsm + (par ^ 1) * F_BUF;
+        __syncthreads();  // `cur` is complete, and every wave is done reading `nxt` (tile t-1)
+        const unsigned hmask = hmask_next;
+
+        // ---- S^T = tile . Q^T (rows = queue rows, columns = this wave's queries), two accumulators (even / odd
+        // chunks), fragments fetched one group ahead; tile t+1 (in `g`) is split and its image 1 written between
+        // the MFMAs of the second half
+        v16f s, s1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = s1[r] = 0.f;
+        f16x8 a[2][2], a1[2][2];
+        auto fetch_a = [&](int slot, int ch) {
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+                a[slot][pl] = __builtin_bit_cast(f16x8, cur[pl * A1_SLOTS + (ch * 2 + half) * 33 + l31]);
+                a1[slot][pl] = __builtin_bit_cast(f16x8, cur[pl * A1_SLOTS + (ch * 2 + 2 + half) * 33 + l31]);
+            }
+        };
+        fetch_a(0, 0);
+#pragma unroll
+        for (int ch = 0; ch < QCH; ch += 2) {
+            const int sl = (ch >> 1) & 1;
+            if (ch + 2 < QCH) fetch_a(sl ^ 1, ch + 2);
+            // (inline asm: the low plane of the queries lives in AGPRs - MFMA reads them there directly - which is
+            // what leaves the compiler enough VGPRs to fetch fragments ahead; accumulate chains need no wait states)
+            s = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[sl][1], qf[0][ch], s, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[sl][1], qf[0][ch + 1], s1, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[sl][0], qf[1][ch], s, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[sl][0], qf[1][ch + 1], s1, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[sl][0], qf[0][ch], s, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[sl][0], qf[0][ch + 1], s1, 0, 0, 0);
+            if (ch >= QCH / 2) {
+                stage_row(nxt, ch - QCH / 2);
+                stage_row(nxt, ch - QCH / 2 + 1);
+            }
+        }
+        hmask_next = tile_mask();
+        load_tile(t + 2);  // `g` is free again: a full O phase and half an S phase before it is needed
+        // ---- P' = 2^15 exp((s - bound)/T) on the unfiltered rows; row of register r: (r&3) + 8(r>>2) + 4*half
+        unsigned ph[2][4], pl_[2][4];
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            float x0 = __builtin_amdgcn_exp2f(fmaf(s[r] + s1[r], c1, c0));
+            float x1 = __builtin_amdgcn_exp2f(fmaf(s[r + 1] + s1[r + 1], c1, c0));
+            x0 = ((hmask >> ((r & 3) + 8 * (r >> 2) + 4 * half)) & 1u) ? 0.f : x0;
+            x1 = ((hmask >> (((r + 1) & 3) + 8 * ((r + 1) >> 2) + 4 * half)) & 1u) ? 0.f : x1;
+            lsum += x0 + x1;
+            f16_split2(x0, x1, ph[r >> 3][(r & 7) >> 1], pl_[r >> 3][(r & 7) >> 1]);
+        }
+        f16x8 pf[2][2];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            pf[0][kk] = __builtin_bit_cast(f16x8, make_uint4(ph[kk][0], ph[kk][1], ph[kk][2], ph[kk][3]));
+            pf[1][kk] = __builtin_bit_cast(f16x8, make_uint4(pl_[kk][0], pl_[kk][1], pl_[kk][2], pl_[kk][3]));
+        }
+        // ---- O[b, c] += sum_j P[j, b] * queue[j, c]: A = P (k-slot i of (kk, half) = tile_row(kk, half, i)),
+        // B = image 2 (fetched one group ahead); image 2 of tile t+1 is written between the MFMA groups
+        f16x8 b[2][2], b1[2][2];
+        auto fetch_b = [&](int slot, int grp) {
+            const int ct = (grp >> 1) * 2, kk = grp & 1;
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+                b[slot][pl] = __builtin_bit_cast(f16x8, cur[2 * A1_SLOTS + pl * A2_SLOTS + (kk * 2 + half) * QC + a2_sw(ct * 32 + l31)]);
+                b1[slot][pl] = __builtin_bit_cast(f16x8, cur[2 * A1_SLOTS + pl * A2_SLOTS + (kk * 2 + half) * QC + a2_sw(ct * 32 + 32 + l31)]);
+            }
+        };
+        fetch_b(0, 0);
+#pragma unroll
+        for (int grp = 0; grp < QCT; ++grp) {
+            const int ct = (grp >> 1) * 2, kk = grp & 1, sl = grp & 1;
+            if (grp + 1 < QCT) fetch_b(sl ^ 1, grp + 1);
+            O[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pf[1][kk], b[sl][0], O[ct], 0, 0, 0);
+            O[ct + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pf[1][kk], b1[sl][0], O[ct + 1], 0, 0, 0);
+            O[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pf[0][kk], b[sl][1], O[ct], 0, 0, 0);
+            O[ct + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pf[0][kk], b1[sl][1], O[ct + 1], 0, 0, 0);
+            O[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pf[0][kk], b[sl][0], O[ct], 0, 0, 0);
+            O[ct + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pf[0][kk], b1[sl][0], O[ct + 1], 0, 0, 0);
+            stage_col(nxt, grp & 1, grp >> 1);  // (plane, column) pairs (0..1, 0..3) over the eight groups
+        }
+    };
+
+    if (t_begin < t_end) {
+        load_tile(t_begin);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) stage_row(qsm, i);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) stage_col(qsm, k & 1, k >> 1);
+        hmask_next = tile_mask();
+        load_tile(t_begin + 1);
+        for (int t = t_begin; t < t_end; ++t) tile((t - t_begin) & 1, t);
+    }
+
+    // ---- partials of this workgroup's queue range: transpose through LDS (the tile buffers are free) so that
+    // every store instruction writes one full 1 KB row
+    __syncthreads();
+    float* ot = reinterpret_cast<float*>(qsm) + wave * (32 * F_OPAD);
+    constexpr float unscale = 1.f / (F_SC * (float)(1 << F_SP_LOG2));
+#pragma unroll
+    for (int ct = 0; ct < QCT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ot[((r & 3) + 8 * (r >> 2) + 4 * half) * F_OPAD + ct * 32 + l31] = O[ct][r] * unscale;
+    const long long slab = ((long long)mod * p.nwg + wg) * p.Bp + bb * QB + wave * 32;
+    const float l = (lsum + __shfl_xor(lsum, 32, 64)) * (1.f / (float)(1 << F_SP_LOG2));
+    if (half == 0) p.part_l[slab + l31] = l;
+    // (each wave reads back only what it wrote: no barrier)
+#pragma unroll 8
+    for (int row = 0; row < 32; ++row)
+        *reinterpret_cast<float4*>(p.part_o + (slab + row) * QC + 4 * lane) = *reinterpret_cast<const float4*>(ot + row * F_OPAD + 4 * lane);
+}
+
 // One workgroup per (query row, modality): positive logit, fold of the partials, loss row and dL/dq.
 // Thread (grp = tid >> 6, c4 = tid & 63): group grp folds the partials w = grp, grp + 4, ... of columns
 // 4*c4 .. 4*c4+3 (float4 loads, independent accumulators), then the four groups are added in a fixed order.
@@ -323,6 +536,22 @@ static int launch_qnce(QnceParams& p, int nbb, hipStream_t stream) {
     return check_launch("trid_queue_nce_f32");
 }
 
+static int launch_qnce_f16(QnceParams& p, int nbb, hipStream_t stream) {
+    constexpr size_t lds = (size_t)2 * F_BUF * sizeof(uint4);
+    static_assert(lds >= (size_t)4 * 32 * F_OPAD * sizeof(float), "the epilogue transpose must fit in the tile buffers");
+    static std::once_flag once;
+    static hipError_t attr_err = hipSuccess;
+    std::call_once(once, [] {
+        attr_err = hipFuncSetAttribute((const void*)queue_nce_f16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    });
+    if (attr_err != hipSuccess) {
+        set_error("trid_queue_nce_f32: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(attr_err));
+        return (int)attr_err;
+    }
+    hipLaunchKernelGGL(queue_nce_f16_kernel, dim3(p.nwg, nbb, 2), dim3(256), lds, stream, p);
+    return check_launch("trid_queue_nce_f32");
+}
+
 }  // namespace trid
 
 using namespace trid;
@@ -368,7 +597,7 @@ extern "C" int trid_queue_nce_f32(const float* v_q, const float* t_q, const floa
     p.c1 = invT * log2e;
     p.c0 = -shift * log2e;
     const hipStream_t st = (hipStream_t)stream;
-    const int rc = (precision == 1) ? launch_qnce<1>(p, nbb, st) : launch_qnce<3>(p, nbb, st);
+    const int rc = (precision == 1) ? launch_qnce<1>(p, nbb, st) : (precision == 3) ? launch_qnce<3>(p, nbb, st) : launch_qnce_f16(p, nbb, st);
     if (rc != TRID_OK) return rc;
     hipLaunchKernelGGL(queue_nce_finish_kernel, dim3(B, 2), dim3(QC), 0, st, p, t_key, v_key, loss_rows, dq, invT, shift,
                        gscale * invT / (float)B);

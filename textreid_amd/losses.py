@@ -170,7 +170,7 @@ class _QueueInfoNCEFn(torch.autograd.Function):
             ws = ops.empty((nws,), v_q)
             call("trid_queue_nce_f32", _p(v_q.detach().contiguous()), _p(t_q.detach().contiguous()), _p(v_k.detach().contiguous()),
                  _p(t_k.detach().contiguous()), _p(t_queue), _p(v_queue), _p(id_queue), _p(ids), _p(rows), _p(dq), B, K, C, 1.0 / T,
-                 1.0, 1.0, 1 if ops.GEMM_PRECISION == 1 else 6, QUEUE_NCE_WGS, _p(ws), stream())
+                 1.0, 1.0, {1: 1, 3: 3}.get(ops.GEMM_PRECISION, 6), QUEUE_NCE_WGS, _p(ws), stream())
             ops.sum_to(rows.view(-1), loss, 1.0 / B)
             ctx.saved = [dq[0], dq[1]]
             return loss[0]
