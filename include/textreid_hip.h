@@ -199,11 +199,13 @@ int trid_gru_cell_bwd_f32(const float* dout, const int32_t* argt, const float* g
  * planes ((hi | lo << 16) of h * 2^13; Bp = B rounded up to 16, padding rows zero; all-zero before step 0; the
  * caller alternates two buffers); everything else as trid_gru_cell_fwd_f32 (h [2,B,H] in place, gates / hprev
  * slices of this step or NULL, maxv / argt).
- * Backward step s (descending): dgh_in = the [2,B,3H] slice written by step s+1 and amax_in = the scalar it
- * published (both NULL at the first processed step); amax_out = zeroed scalar receiving max|dgh| of this step;
+ * Backward step s (descending): dgh_in = the [2,B,3H] slice written by step s+1 and amax_in = the per-workgroup
+ * maxima it published (both NULL at the first processed step); amax_out receives this step's: both are
+ * trid_gru_step_workgroups(B, H) floats;
  * dh [2,B,H] carries dL/dh in place: dh <- (dh + dgh_in @ W_hh [+ dout where argt == t]) * z; the rest as
  * trid_gru_cell_bwd_f32. */
 long long trid_gru_whh_image_bytes(int H);
+int trid_gru_step_workgroups(int B, int H);
 int trid_gru_pack_whh_f16(const float* w_hh, const float* w_amax, void* img_fwd, void* img_bwd, int H, void* stream);
 int trid_gru_step_fwd_f32(const void* img_fwd, const float* w_amax, const void* hp_in, void* hp_out, float* h,
                           const float* gi, const int64_t* lengths, float* gates, float* hprev, float* maxv,

@@ -28,6 +28,9 @@ def load_vocab_dict(root, use_onehot):
     return np.load(os.path.join(root, "./datasets/cuhkpedes", names[use_onehot]))
 
 
+FUSED_GRU_STEP = os.environ.get("TRID_FUSED_GRU", "1") != "0"  # A/B switch: 0 = one GEMM + one cell kernel per step
+
+
 class _GRUFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, mod, tokens, lengths, lmax, save, w_ih_f, w_hh_f, w_ih_r, w_hh_r):
@@ -46,39 +49,69 @@ class _GRUFn(torch.autograd.Function):
         ops.gemm(x, w_ih_r, gi, B * L, 3 * H, E, E, E, 6 * H, c_off=3 * H)
         whh = torch.stack([w_hh_f.detach(), w_hh_r.detach()])  # [2,3H,H] (plumbing copy)
         h = torch.zeros(2, B, H, device=table.device)
-        gh = ops.empty((2, B, 3 * H), table)
         maxv = ops.empty((B, 2 * H), table)
         argt = torch.empty(B, 2 * H, dtype=torch.int32, device=table.device)
         ops.call("trid_gru_max_init_f32", ops._p(maxv), ops._p(argt), ops._p(lengths), L, B, H, st)
         gates = ops.empty((2, L, B, 4 * H), table) if save else None
         hprev = ops.empty((2, L, B, H), table) if save else None
-        for s in range(L):
-            ops.gemm(h, whh, gh, B, 3 * H, H, H, H, 3 * H, batch=2, strideA=B * H, strideB=3 * H * H,
-                     strideC=B * 3 * H)
-            ops.call("trid_gru_cell_fwd_f32", ops._p(gi), ops._p(gh), ops._p(h), ops._p(lengths),
-                     (ops._p(gates) + 4 * s * B * 4 * H) if save else None,
-                     (ops._p(hprev) + 4 * s * B * H) if save else None, ops._p(maxv), ops._p(argt), s, L, L, B, H,
-                     L * B * 4 * H, L * B * H, st)
+        img_bytes = ops.L.load().trid_gru_whh_image_bytes(H) if FUSED_GRU_STEP else 0
+        fused = None
+        if img_bytes > 0:
+            # ONE launch per step (gru_step.hip): W_hh split once into MFMA fragment images, the state carried as
+            # packed fp16 planes between the steps
+            wamax = ops.amax(whh)
+            img_f = torch.empty(img_bytes, dtype=torch.uint8, device=table.device)
+            img_b = torch.empty(img_bytes, dtype=torch.uint8, device=table.device)
+            ops.call("trid_gru_pack_whh_f16", ops._p(whh), ops._p(wamax), ops._p(img_f), ops._p(img_b), H, st)
+            Bp = (B + 15) // 16 * 16
+            hp = torch.zeros(2, 2, Bp, H, dtype=torch.int32, device=table.device)
+            for s in range(L):
+                ops.call("trid_gru_step_fwd_f32", ops._p(img_f), ops._p(wamax), ops._p(hp[s & 1]), ops._p(hp[(s + 1) & 1]),
+                         ops._p(h), ops._p(gi), ops._p(lengths), (ops._p(gates) + 4 * s * B * 4 * H) if save else None,
+                         (ops._p(hprev) + 4 * s * B * H) if save else None, ops._p(maxv), ops._p(argt), s, L, L, B, Bp, H,
+                         L * B * 4 * H, L * B * H, st)
+            fused = (img_b, wamax)
+        else:
+            gh = ops.empty((2, B, 3 * H), table)
+            for s in range(L):
+                ops.gemm(h, whh, gh, B, 3 * H, H, H, H, 3 * H, batch=2, strideA=B * H, strideB=3 * H * H,
+                         strideC=B * 3 * H)
+                ops.call("trid_gru_cell_fwd_f32", ops._p(gi), ops._p(gh), ops._p(h), ops._p(lengths),
+                         (ops._p(gates) + 4 * s * B * 4 * H) if save else None,
+                         (ops._p(hprev) + 4 * s * B * H) if save else None, ops._p(maxv), ops._p(argt), s, L, L, B, H,
+                         L * B * 4 * H, L * B * H, st)
         if save:
-            ctx.saved = (x, whh, gates, hprev, argt, lengths, B, H, E, L)
+            ctx.saved = (x, whh, gates, hprev, argt, lengths, B, H, E, L, fused)
         return maxv
 
     @staticmethod
     def backward(ctx, dout):
-        x, whh, gates, hprev, argt, lengths, B, H, E, L = ctx.saved
+        x, whh, gates, hprev, argt, lengths, B, H, E, L, fused = ctx.saved
         ctx.saved = None
         dout = dout.contiguous()
         st = ops.stream()
         dh = torch.zeros(2, B, H, device=dout.device)
         dGi = ops.empty((B * L, 6 * H), dout)
         dgh = ops.empty((2, L, B, 3 * H), dout)
-        for s in range(L - 1, -1, -1):
-            ops.call("trid_gru_cell_bwd_f32", ops._p(dout), ops._p(argt), ops._p(gates) + 4 * s * B * 4 * H,
-                     ops._p(hprev) + 4 * s * B * H, ops._p(lengths), ops._p(dh), ops._p(dGi),
-                     ops._p(dgh) + 4 * s * B * 3 * H, s, L, L, B, H, L * B * 4 * H, L * B * H, L * B * 3 * H, st)
-            # dh[d] += dgh[d,s] @ W_hh[d]
-            ops.gemm(dgh, whh, dh, B, H, 3 * H, 3 * H, H, H, b_mode=ops.B_NC, batch=2, strideA=L * B * 3 * H,
-                     strideB=3 * H * H, strideC=B * H, accumulate=True, a_off=s * B * 3 * H)
+        if fused is not None:
+            img_b, wamax = fused
+            nwg = ops.L.load().trid_gru_step_workgroups(B, H)
+            amax = ops.empty((L + 1, nwg), dout)  # per-workgroup max|dgh| published by each step
+            for s in range(L - 1, -1, -1):
+                more = s + 1 < L
+                ops.call("trid_gru_step_bwd_f32", ops._p(img_b), ops._p(wamax),
+                         (ops._p(dgh) + 4 * (s + 1) * B * 3 * H) if more else None, (ops._p(amax) + 4 * (s + 1) * nwg) if more else None,
+                         ops._p(amax) + 4 * s * nwg, ops._p(dout), ops._p(argt), ops._p(gates) + 4 * s * B * 4 * H,
+                         ops._p(hprev) + 4 * s * B * H, ops._p(lengths), ops._p(dh), ops._p(dGi), ops._p(dgh) + 4 * s * B * 3 * H,
+                         s, L, L, B, H, L * B * 4 * H, L * B * H, L * B * 3 * H, st)
+        else:
+            for s in range(L - 1, -1, -1):
+                ops.call("trid_gru_cell_bwd_f32", ops._p(dout), ops._p(argt), ops._p(gates) + 4 * s * B * 4 * H,
+                         ops._p(hprev) + 4 * s * B * H, ops._p(lengths), ops._p(dh), ops._p(dGi),
+                         ops._p(dgh) + 4 * s * B * 3 * H, s, L, L, B, H, L * B * 4 * H, L * B * H, L * B * 3 * H, st)
+                # dh[d] += dgh[d,s] @ W_hh[d]
+                ops.gemm(dgh, whh, dh, B, H, 3 * H, 3 * H, H, H, b_mode=ops.B_NC, batch=2, strideA=L * B * 3 * H,
+                         strideB=3 * H * H, strideC=B * H, accumulate=True, a_off=s * B * 3 * H)
         # dW_hh[d] = sum_{s,b} dgh[d,s,b,:]^T hprev[d,s,b,:]
         KK = L * B
         splits = max(1, min(8, KK // 512))
