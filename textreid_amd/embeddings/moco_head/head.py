@@ -18,6 +18,8 @@ flag consumed by the InfoNCE row kernel instead of nonzero/unique/gather.
 import copy
 
 import numpy as np
+import os
+
 import torch
 import torch.nn as nn
 
@@ -157,18 +159,34 @@ class MoCoHead(nn.Module):
             side = self._side_stream(images.device)
             with torch.no_grad():
                 self._momentum_update_key_encoder()
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                t_feat = self.t_encoder_q(cb)
-                with torch.no_grad():
-                    tk_feat = self.t_encoder_k(cb)
-            # The key image encoder (no_grad) runs on a second side stream: its HBM-bound
-            # BatchNorm / pooling passes overlap the MFMA-bound GEMMs of the query encoder.
+            # Issue order = how soon each stream has work: the query image encoder (the head of the critical path:
+            # its backward follows) is enqueued FIRST, so the side streams wait on an event recorded right after the
+            # momentum update instead of on whatever the main stream holds by the time the host gets to them.
+            ema_done = torch.cuda.Event()
+            ema_done.record(main)
+            order = os.environ.get("TRID_ISSUE_ORDER", "qtk")
             side_k = self._side_stream(images.device, "_key_stream")
-            side_k.wait_stream(main)
-            with torch.cuda.stream(side_k), torch.no_grad():
-                vk_feat = self.v_encoder_k(images)
-            v_feat = self.v_encoder_q(images)
+
+            def issue(which):
+                nonlocal t_feat, tk_feat, vk_feat, v_feat
+                if which == "q":
+                    v_feat = self.v_encoder_q(images)
+                elif which == "k":
+                    # The key image encoder (no_grad) runs on a second side stream: its HBM-bound
+                    # BatchNorm / pooling passes overlap the MFMA-bound GEMMs of the query encoder.
+                    side_k.wait_event(ema_done)
+                    with torch.cuda.stream(side_k), torch.no_grad():
+                        vk_feat = self.v_encoder_k(images)
+                else:
+                    side.wait_event(ema_done)
+                    with torch.cuda.stream(side):
+                        t_feat = self.t_encoder_q(cb)
+                        with torch.no_grad():
+                            tk_feat = self.t_encoder_k(cb)
+
+            t_feat = tk_feat = vk_feat = v_feat = None
+            for which in order:
+                issue(which)
             main.wait_stream(side)
             main.wait_stream(side_k)
             t_feat.record_stream(main)

@@ -39,6 +39,10 @@ class FusedAdam(torch.optim.Optimizer):
         self._plan = None
 
     def _build(self, items):
+        """Static part of the plan: parameter / moment pointer tables and the chunk map (re-made only when a parameter
+        or moment tensor moves).  Gradient tensors are fresh allocations every step: their table goes up per step
+        through pinned staging buffers with an asynchronous copy - a pageable host-to-device copy would wait for the
+        whole backward pass and stop the host from running ahead of the GPU."""
         dev = items[0][0].device
         for p, g, st in items:
             if not (p.is_contiguous() or p.is_contiguous(memory_format=torch.channels_last)):
@@ -48,23 +52,52 @@ class FusedAdam(torch.optim.Optimizer):
             for off in range(0, p.numel(), ADAM_CHUNK):
                 ct.append(i)
                 co.append(off)
+        n = len(items)
+
+        def up(values, dtype):
+            return torch.from_numpy(np.asarray(values, dtype=dtype)).to(dev)
+
         self._plan = {
             "key": self._key(items),
-            "p": torch.from_numpy(np.array([p.data_ptr() for p, _, _ in items], dtype=np.uint64).view(np.int64)).to(dev),
-            "g": torch.from_numpy(np.array([g.data_ptr() for _, g, _ in items], dtype=np.uint64).view(np.int64)).to(dev),
-            "m": torch.from_numpy(np.array([s["exp_avg"].data_ptr() for _, _, s in items], dtype=np.uint64).view(np.int64)).to(dev),
-            "v": torch.from_numpy(np.array([s["exp_avg_sq"].data_ptr() for _, _, s in items], dtype=np.uint64).view(np.int64)).to(dev),
-            "sizes": torch.tensor([p.numel() for p, _, _ in items], dtype=torch.int64, device=dev),
-            "ct": torch.tensor(ct, dtype=torch.int32, device=dev),
-            "co": torch.tensor(co, dtype=torch.int64, device=dev),
+            "p": up(np.array([p.data_ptr() for p, _, _ in items], dtype=np.uint64).view(np.int64), np.int64),
+            "m": up(np.array([s["exp_avg"].data_ptr() for _, _, s in items], dtype=np.uint64).view(np.int64), np.int64),
+            "v": up(np.array([s["exp_avg_sq"].data_ptr() for _, _, s in items], dtype=np.uint64).view(np.int64), np.int64),
+            "sizes": up([p.numel() for p, _, _ in items], np.int64),
+            "ct": up(ct, np.int32),
+            "co": up(co, np.int64),
             "n": len(ct),
-            "lrs": None,
-            "lr_key": None,
+            # per-step tables in one row of 8-byte slots: [n gradient pointers | n fp32 lr | n fp32 weight decay], double-buffered
+            "dyn": [torch.empty(2 * n + 1, dtype=torch.int64, device=dev) for _ in range(2)],
+            "stage": [torch.empty(2 * n + 1, dtype=torch.int64).pin_memory() if dev.type == "cuda" else torch.empty(2 * n + 1, dtype=torch.int64)
+                      for _ in range(2)],
+            "done": [None, None],
+            "turn": 0,
         }
 
     @staticmethod
     def _key(items):
-        return tuple((p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()) for p, g, st in items)
+        return tuple((p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()) for p, _, st in items)
+
+    def _upload(self, items, lrs, wds):
+        """This step's gradient pointers and per-group lr / weight decay -> device, without a host sync."""
+        pl = self._plan
+        n = len(items)
+        k = pl["turn"]
+        pl["turn"] = k ^ 1
+        if pl["done"][k] is not None:
+            pl["done"][k].synchronize()  # the copy issued two steps ago read this staging buffer (long finished)
+        host = pl["stage"][k].numpy()
+        host[:n] = np.array([g.data_ptr() for _, g, _ in items], dtype=np.uint64).view(np.int64)
+        f = host[n:].view(np.float32)
+        f[:n] = np.asarray(lrs, dtype=np.float32)
+        f[n : 2 * n] = np.asarray(wds, dtype=np.float32)
+        dyn = pl["dyn"][k]
+        dyn.copy_(pl["stage"][k], non_blocking=True)
+        if dyn.is_cuda:
+            ev = torch.cuda.Event()
+            ev.record()
+            pl["done"][k] = ev
+        return dyn
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -100,16 +133,12 @@ class FusedAdam(torch.optim.Optimizer):
         if self._plan is None or self._plan["key"] != key:
             self._build(items)
         pl = self._plan
-        lr_key = (tuple(lrs), tuple(wds))
-        if pl["lr_key"] != lr_key:
-            dev = items[0][0].device
-            pl["lrs"] = torch.tensor(lrs, dtype=torch.float32, device=dev)
-            pl["wds"] = torch.tensor(wds, dtype=torch.float32, device=dev)
-            pl["lr_key"] = lr_key
+        n = len(items)
+        dyn = self._upload(items, lrs, wds)
         for _, _, st in items:
             st["step"] = t
-        ops.call("trid_adam_multi_f32", ops._p(pl["p"]), ops._p(pl["g"]), ops._p(pl["m"]), ops._p(pl["v"]),
-                 ops._p(pl["sizes"]), ops._p(pl["lrs"]), ops._p(pl["wds"]), ops._p(pl["ct"]), ops._p(pl["co"]), pl["n"],
+        ops.call("trid_adam_multi_f32", ops._p(pl["p"]), ops._p(dyn), ops._p(pl["m"]), ops._p(pl["v"]),
+                 ops._p(pl["sizes"]), ops._p(dyn) + 8 * n, ops._p(dyn) + 12 * n, ops._p(pl["ct"]), ops._p(pl["co"]), pl["n"],
                  ADAM_CHUNK, float(b1), float(b2), float(eps), 1.0 - b1 ** t, (1.0 - b2 ** t) ** 0.5,
                  1 if self.decoupled else 0, ops.stream())
         return loss
