@@ -197,7 +197,7 @@ def retrieval_bench(device, world, rank, G_total=1000000, Q=10000, k=10, shard_r
         "seconds": dt,
         "tflops": 2.0 * Q * scored * 256 / dt / 1e12,
         "algorithmic_bytes_per_gpu": shard * 256 * 4 + Q * 256 * 4 + Q * k * 12,
-        "note": "fp32 embeddings, split-bf16 (fp32-class) similarity GEMM, exact top-10: first 8192 gallery rows via a [Q,8192] panel + streaming scan, the rest via the GEMM's admission-filter epilogue (no similarity matrix in HBM)",
+        "note": "fp32 embeddings, fp16 two-plane split (fp32-class) similarity GEMM, exact top-10: first 8192 gallery rows via a [Q,8192] panel + streaming scan, the rest via the GEMM's admission-filter epilogue (no similarity matrix in HBM)",
     }
 
 

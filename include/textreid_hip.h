@@ -337,11 +337,12 @@ int trid_enqueue_f32(float* v_queue, float* t_queue, int64_t* id_queue, int64_t*
  * The first 8192 gallery rows go through a [Q, 8192] similarity panel and a streaming row scan; the rest
  * through ONE GEMM whose epilogue keeps only elements that reach the row's current k-th value (exact for
  * any input order: list overflow falls back to panel passes on device, without a host round trip).
- * precision: arithmetic of the similarity GEMM, as trid_gemm_desc.precision (6: split bf16, fp32-class;
- * 0: exact fp32-input MFMA). */
+ * precision: arithmetic of the similarity GEMM, as trid_gemm_desc.precision (16: fp16 two-plane split, fp32-class,
+ * needs q_amax / g_amax = device scalars max|q|, max|g| (trid_amax_f32; NULL -> runs as 6); 6: split bf16,
+ * fp32-class; 0: exact fp32-input MFMA). */
 long long trid_topk_ws_floats(int Q, int G, int k);
 int trid_sim_topk_f32(const float* q, const float* g, float* out_val, int64_t* out_idx, int Q, int G, int C,
-                      int k, long long idx_offset, int precision, float* ws, void* stream);
+                      int k, long long idx_offset, int precision, const float* q_amax, const float* g_amax, float* ws, void* stream);
 
 /* per-row top-k of a given similarity matrix (rank(get_mAP=False), evaluation.py:17-19) */
 int trid_topk_rows_f32(const float* sim, int ld, int Q, int G, int k, float* out_val, int64_t* out_idx,

@@ -277,11 +277,13 @@ static void launch_cands(const float* cand, const int* cnt, int cap, int Q, long
 // so the result is exact for any input.  Shapes / precisions the split kernel does not cover run the
 // dense passes unconditionally.
 extern "C" int trid_sim_topk_f32(const float* q, const float* g, float* out_val, int64_t* out_idx, int Q, int G, int C,
-                                 int k, long long idx_offset, int precision, float* ws, void* stream_) {
+                                 int k, long long idx_offset, int precision, const float* q_amax, const float* g_amax, float* ws,
+                                 void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     TRID_REQUIRE(q && g && out_val && out_idx && ws, "trid_sim_topk_f32: null pointer");
     TRID_REQUIRE(Q > 0 && G > 0 && C > 0 && C % 4 == 0, "trid_sim_topk_f32: bad shape (C%%4)");
     TRID_REQUIRE(k >= 1 && k <= TOPK_MAX && k <= G, "trid_sim_topk_f32: k must be in [1,%d] and <= G", TOPK_MAX);
+    if (precision == 16 && !(q_amax && g_amax)) precision = 6;  // the fp16 split needs the operands' magnitudes
     const int Gc = topk_chunk_cols(G);
     int* cnt = reinterpret_cast<int*>(ws + (long long)Q * Gc);
     int* overflow = cnt + Q;
@@ -296,6 +298,7 @@ extern "C" int trid_sim_topk_f32(const float* q, const float* g, float* out_val,
         d.batch = 1; d.splits = 1; d.alpha = 1.f;
         d.a_mode = TRID_A_KC; d.b_mode = TRID_B_KC;
         d.precision = precision;
+        d.a_amax = q_amax; d.b_amax = g_amax;
         return trid_gemm_launch(&d, nullptr, gate, stream);
     };
     auto dense_pass = [&](int c0, const int* gate) {
@@ -325,6 +328,7 @@ extern "C" int trid_sim_topk_f32(const float* q, const float* g, float* out_val,
         d.batch = 1; d.splits = 1; d.alpha = 1.f;
         d.a_mode = TRID_A_KC; d.b_mode = TRID_B_KC;
         d.precision = precision;
+        d.a_amax = q_amax; d.b_amax = g_amax;
         GemmFilter f;
         f.thr = out_val + (k - 1); f.thr_stride = k;
         f.cnt = cnt; f.cand = ws; f.cap = cap; f.col0 = Gc; f.overflow = overflow;

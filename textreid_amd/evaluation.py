@@ -62,6 +62,15 @@ def _metrics(indices, q_pids, g_pids, topk_t, get_mAP):
     return cmc, mAP[0], indices
 
 
+def _sim_precision(q, g):
+    """Arithmetic of the similarity GEMM: the fp16 two-plane split (half the MFMA work of the bf16 one, same fp32-class
+    accuracy) while the library-wide mode is the fp32-class default; it needs the operands' largest magnitudes as
+    device scalars (one streaming pass each - the gallery pass is ~1 % of the scoring time)."""
+    if ops.GEMM_PRECISION != 6 or ops.CONV_PRECISION != 16:
+        return ops.GEMM_PRECISION, None, None
+    return 16, ops.amax(q), ops.amax(g)
+
+
 def similarity_topk(text_embed, image_embed, k=10, normalize=True):
     """Per-query top-k of text @ image.T without materialising [Q,G]; gallery rows
     sharded across ranks when torch.distributed is initialised (each rank passes
@@ -82,7 +91,8 @@ def similarity_topk(text_embed, image_embed, k=10, normalize=True):
 
         sizes = all_gather_rows(torch.tensor([G], dtype=torch.int64, device=q.device))
         offset = int(sizes[: dist_rank()].sum())
-    call("trid_sim_topk_f32", _p(q), _p(g), _p(vals), _p(idx), Q, G, C, k, offset, ops.GEMM_PRECISION, _p(ws), stream())
+    prec, qa, ga = _sim_precision(q, g)
+    call("trid_sim_topk_f32", _p(q), _p(g), _p(vals), _p(idx), Q, G, C, k, offset, prec, _p(qa), _p(ga), _p(ws), stream())
     if W == 1:
         return vals, idx
     # per-shard lists -> every rank: [W*Q, k] rank-major, then one row top-k over the W*k candidates
@@ -102,7 +112,8 @@ def _topk_neighbours(q, g, k):
     vals = torch.empty(Q, k, dtype=torch.float32, device=q.device)
     idx = torch.empty(Q, k, dtype=torch.int64, device=q.device)
     ws = ops.empty((ops.L.load().trid_topk_ws_floats(Q, G, k),), q)
-    call("trid_sim_topk_f32", _p(q), _p(g), _p(vals), _p(idx), Q, G, C, k, 0, ops.GEMM_PRECISION, _p(ws), stream())
+    prec, qa, ga = _sim_precision(q, g)
+    call("trid_sim_topk_f32", _p(q), _p(g), _p(vals), _p(idx), Q, G, C, k, 0, prec, _p(qa), _p(ga), _p(ws), stream())
     return idx
 
 
