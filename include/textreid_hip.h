@@ -347,8 +347,13 @@ int trid_sim_topk_f32(const float* q, const float* g, float* out_val, int64_t* o
 /* per-row top-k of a given similarity matrix (rank(get_mAP=False), evaluation.py:17-19) */
 int trid_topk_rows_f32(const float* sim, int ld, int Q, int G, int k, float* out_val, int64_t* out_idx,
                        void* stream);
-/* per-row full descending argsort (rank(get_mAP=True), evaluation.py:14); G <= 16384 */
-int trid_argsort_rows_desc_f32(const float* sim, int ld, int Q, int G, int64_t* out_idx, void* stream);
+/* per-row full descending argsort (rank(get_mAP=True), evaluation.py:14), ties -> lower column first.  G <= 16384:
+ * one in-LDS bitonic sort per row, no workspace (ws may be NULL).  Larger rows: packed keys + rocPRIM segmented radix
+ * sort in the caller's workspace of trid_argsort_ws_bytes(Q, G) bytes (256-byte aligned; 0 = none needed, or Q*G >= 2^31:
+ * sort the rows in batches). */
+long long trid_argsort_ws_bytes(int Q, int G);
+int trid_argsort_rows_desc_f32(const float* sim, int ld, int Q, int G, int64_t* out_idx, void* ws, long long ws_bytes,
+                               void* stream);
 /* matches = g_pids[indices] == q_pids; first_hit[q] = rank of the first match (INT_MAX if none);
  * ap[q] = average precision over the R ranked items (NaN without relevant items);
  * cmc[t] = 100*mean(first_hit < topk[t])  (evaluation.py:20-36) */

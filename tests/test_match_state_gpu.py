@@ -114,6 +114,33 @@ def test_fused_similarity_topk_shape_edges(gpu, Q, G, k):
     assert torch.allclose(vals.cpu(), rv, atol=2e-6)
 
 
+def test_rank_full_argsort_beyond_the_lds_sort(gpu):
+    """rank(get_mAP=True) on a gallery wider than the in-LDS bitonic sort (G > 16384: ICFG-PEDES i2t has 19 848
+    captions): packed keys + segmented radix sort (argsort_large.hip).  Index-exact against a stable descending sort,
+    with heavy ties (quantised similarities, +-0) - ties resolve to the lower column, like the in-LDS kernel."""
+    from textreid_amd.evaluation import rank
+
+    Q, G = 37, 20011
+    gen = torch.Generator().manual_seed(11)
+    sim = torch.randn(Q, G, generator=gen)
+    sim[:20] = (sim[:20] * 4).round() / 4          # many exact ties
+    sim[5, ::3] = 0.0
+    sim[5, 1::3] = -0.0                             # signed zeros compare equal
+    q_pids = torch.randint(0, 50, (Q,), generator=gen)
+    g_pids = torch.randint(0, 50, (G,), generator=gen)
+    cmc, mAP, idx = rank(sim.to(gpu), q_pids, g_pids, topk=[1, 5, 10], get_mAP=True)
+    ref = torch.sort(sim.double(), dim=1, descending=True, stable=True).indices
+    assert torch.equal(idx.cpu(), ref)
+    # metrics against the reference formulas (evaluation.py:20-36) on the same ranking
+    matches = (g_pids[ref] == q_pids[:, None]).float()
+    first = matches.argmax(dim=1)
+    for t, k in enumerate([1, 5, 10]):
+        assert abs(float(cmc[t]) - 100.0 * float((first < k).float().mean())) < 1e-3
+    prec = matches.cumsum(1) / torch.arange(1, G + 1)[None, :]
+    ap = (prec * matches).sum(1) / matches.sum(1)
+    assert abs(float(mAP) - 100.0 * float(ap.mean())) < 1e-2
+
+
 def test_fused_similarity_topk_overflow_fallback(gpu):
     """Gallery ordered so that every later column beats the thresholds set by the first chunk: the
     admission-filter candidate lists overflow and the gated dense passes must produce the exact answer.

@@ -134,8 +134,9 @@ class MoCoHead(nn.Module):
         B = v_keys.shape[0]
         assert self.K % B == 0  # head.py:101
         vq, tq = self._queue_kc("v_queue"), self._queue_kc("t_queue")
+        vk, tk, ik = v_keys.contiguous(), t_keys.contiguous(), id_keys.long().contiguous()  # alive until the call returns
         ops.call("trid_enqueue_f32", ops._p(vq), ops._p(tq), ops._p(self.id_queue), ops._p(self.queue_ptr),
-                 ops._p(v_keys.contiguous()), ops._p(t_keys.contiguous()), ops._p(id_keys.long().contiguous()), self.K,
+                 ops._p(vk), ops._p(tk), ops._p(ik), self.K,
                  self.embed_size, B, ops.stream())
 
     # ---------------------------------------------------------------- forward

@@ -39,7 +39,14 @@ def rank(similarity, q_pids, g_pids, topk=(1, 5, 10), get_mAP=True):
     Q, G = sim.shape
     if get_mAP:
         indices = torch.empty(Q, G, dtype=torch.int64, device=dev)
-        call("trid_argsort_rows_desc_f32", _p(sim), G, Q, G, _p(indices), stream())
+        # rows beyond the in-LDS sort (G > 16384, e.g. ICFG-PEDES i2t) go through a segmented radix sort in a workspace;
+        # row batches keep Q*G below the sort's 2^31-item limit
+        rows_per = Q if G <= 16384 else max(1, min(Q, ((1 << 31) - 1) // G))
+        for q0 in range(0, Q, rows_per):
+            nq = min(rows_per, Q - q0)
+            nws = ops.L.load().trid_argsort_ws_bytes(nq, G)
+            ws = torch.empty(nws, dtype=torch.uint8, device=dev) if nws > 0 else None
+            call("trid_argsort_rows_desc_f32", _p(sim[q0:]), G, nq, G, _p(indices[q0:]), _p(ws), nws, stream())
     else:
         vals = torch.empty(Q, max_rank, dtype=torch.float32, device=dev)
         indices = torch.empty(Q, max_rank, dtype=torch.int64, device=dev)
@@ -53,7 +60,11 @@ def _metrics(indices, q_pids, g_pids, topk_t, get_mAP):
     first = torch.empty(Q, dtype=torch.int32, device=dev)
     ap = torch.empty(Q, dtype=torch.float32, device=dev)
     cmc = torch.empty(topk_t.numel(), dtype=torch.float32, device=dev)
-    call("trid_rank_metrics", _p(indices), _p(q_pids.to(dev).long().contiguous()), _p(g_pids.to(dev).long().contiguous()),
+    # (locals: a temporary passed straight into _p() is freed before the next argument is built, and the caching
+    # allocator may hand its block to that next temporary - the kernel would then read the wrong ids)
+    qp = q_pids.to(dev).long().contiguous()
+    gp = g_pids.to(dev).long().contiguous()
+    call("trid_rank_metrics", _p(indices), _p(qp), _p(gp),
          Q, R, _p(first), _p(ap), _p(topk_t), topk_t.numel(), _p(cmc), stream())
     if not get_mAP:
         return cmc, indices
@@ -184,8 +195,9 @@ def evaluation(dataset, predictions, output_folder, topk, save_data=True, rerank
     if rerank:
         ones = torch.ones(3, device=dev)
         re_i2t, re_t2i = torch.empty_like(rtn), torch.empty_like(rvn)
-        call("trid_axpby3_f32", _p(re_i2t), _p(rtn.contiguous()), _p(sim_t), None, _p(ones), rtn.numel(), stream())  # rtn_mat + similarity.t()
-        call("trid_axpby3_f32", _p(re_t2i), _p(rvn.contiguous()), _p(sim), None, _p(ones), rvn.numel(), stream())    # rvn_mat + similarity
+        rtn, rvn = rtn.contiguous(), rvn.contiguous()
+        call("trid_axpby3_f32", _p(re_i2t), _p(rtn), _p(sim_t), None, _p(ones), rtn.numel(), stream())  # rtn_mat + similarity.t()
+        call("trid_axpby3_f32", _p(re_t2i), _p(rvn), _p(sim), None, _p(ones), rvn.numel(), stream())    # rvn_mat + similarity
         results["i2t"] = rank(sim_t, image_pid, text_pid, topk, get_mAP=True)[:2]
         results["t2i"] = rank(sim, text_pid, image_pid, topk, get_mAP=True)[:2]
         results["re-i2t"] = rank(re_i2t, image_pid, text_pid, topk, get_mAP=True)[:2]

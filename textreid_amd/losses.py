@@ -28,7 +28,8 @@ def _pad16(n):
 def _scaled(g, a):
     """g (0-d device tensor) * a, through the axpby3 kernel (no host sync)."""
     out = torch.empty_like(a)
-    call("trid_axpby3_f32", _p(out), _p(a), None, None, _p(g.reshape(1).float().contiguous()), a.numel(), stream())
+    gs = g.reshape(1).float().contiguous()  # (a local: temporaries must outlive the call that takes their address)
+    call("trid_axpby3_f32", _p(out), _p(a), None, None, _p(gs), a.numel(), stream())
     return out
 
 
@@ -92,7 +93,8 @@ class _GlobalAlignFn(torch.autograd.Function):
             vp, tp = vn, tn
         S = ops.linear(vp, tp)  # [Bp,Bp] cosine (padding rows / columns are zero and stay zero)
         rows = ops.empty((B,), v)
-        call("trid_global_align_rows_f32", _p(S), _p(labels.long().contiguous()), _p(rows), B, Bp, float(alpha),
+        lab = labels.long().contiguous()
+        call("trid_global_align_rows_f32", _p(S), _p(lab), _p(rows), B, Bp, float(alpha),
              float(beta), float(scale_pos), float(scale_neg), 1.0, stream())
         loss = ops.empty((1,), v)
         ops.sum_to(rows, loss, 1.0)
@@ -130,7 +132,8 @@ class _InfoNCEFn(torch.autograd.Function):
             rows = ops.empty((B,), S)
             dpos = ops.empty((B,), S)
             ws = ops.empty((ops.L.load().trid_infonce_ws_floats(B, K),), S)
-            call("trid_infonce_rows_f32", _p(S), _p(pos.detach().reshape(-1).contiguous()), _p(hit), _p(rows), _p(dpos),
+            posv = pos.detach().reshape(-1).contiguous()
+            call("trid_infonce_rows_f32", _p(S), _p(posv), _p(hit), _p(rows), _p(dpos),
                  B, K, K, 1.0 / T, 1.0, _p(ws), stream())
             ops.sum_to(rows, loss, 1.0 / B, accumulate=i > 0)
             outs += [dpos.view(B, 1), S]
@@ -168,8 +171,9 @@ class _QueueInfoNCEFn(torch.autograd.Function):
             # ONE pass over both queues: negative filter, similarity, softmax and dL/dq fused, no [B,K] anywhere (queue_nce.hip)
             dq = ops.empty((2, B, C), v_q)
             ws = ops.empty((nws,), v_q)
-            call("trid_queue_nce_f32", _p(v_q.detach().contiguous()), _p(t_q.detach().contiguous()), _p(v_k.detach().contiguous()),
-                 _p(t_k.detach().contiguous()), _p(t_queue), _p(v_queue), _p(id_queue), _p(ids), _p(rows), _p(dq), B, K, C, 1.0 / T,
+            vq_, tq_, vk_, tk_ = (x.detach().contiguous() for x in (v_q, t_q, v_k, t_k))  # alive until the call returns
+            call("trid_queue_nce_f32", _p(vq_), _p(tq_), _p(vk_),
+                 _p(tk_), _p(t_queue), _p(v_queue), _p(id_queue), _p(ids), _p(rows), _p(dq), B, K, C, 1.0 / T,
                  1.0, 1.0, {1: 1, 3: 3}.get(ops.GEMM_PRECISION, 6), QUEUE_NCE_WGS, _p(ws), stream())
             ops.sum_to(rows.view(-1), loss, 1.0 / B)
             ctx.saved = [dq[0], dq[1]]
