@@ -43,6 +43,8 @@ static hipError_t sort_rows(void* temp, size_t& temp_bytes, const unsigned long 
     return hipcub::DeviceSegmentedRadixSort::SortKeys(temp, temp_bytes, in, out, Q * G, Q, begin, end, 32, 64, stream);
 }
 
+int argsort_rows_desc_large(const float* sim, int ld, int Q, int G, int64_t* out_idx, void* ws, long long ws_bytes, void* stream_);
+
 }  // namespace trid
 
 using namespace trid;
@@ -56,8 +58,8 @@ extern "C" long long trid_argsort_ws_bytes(int Q, int G) {
 }
 
 // called by trid_argsort_rows_desc_f32 (retrieval.hip) for G > 16384
-extern "C" int trid_argsort_rows_desc_large(const float* sim, int ld, int Q, int G, int64_t* out_idx, void* ws, long long ws_bytes,
-                                            void* stream_) {
+int trid::argsort_rows_desc_large(const float* sim, int ld, int Q, int G, int64_t* out_idx, void* ws, long long ws_bytes,
+                                  void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     TRID_REQUIRE((long long)Q * G < (1ll << 31), "trid_argsort_rows_desc_f32: Q * G = %lld exceeds 2^31 - sort the rows in batches",
                  (long long)Q * G);

@@ -362,13 +362,14 @@ extern "C" int trid_topk_rows_f32(const float* sim, int ld, int Q, int G, int k,
     return check_launch("trid_topk_rows_f32");
 }
 
-extern "C" int trid_argsort_rows_desc_large(const float* sim, int ld, int Q, int G, int64_t* out_idx, void* ws, long long ws_bytes,
-                                            void* stream);
+namespace trid {
+int argsort_rows_desc_large(const float* sim, int ld, int Q, int G, int64_t* out_idx, void* ws, long long ws_bytes, void* stream);
+}
 
 extern "C" int trid_argsort_rows_desc_f32(const float* sim, int ld, int Q, int G, int64_t* out_idx, void* ws, long long ws_bytes,
                                           void* stream) {
     TRID_REQUIRE(sim && out_idx && Q > 0 && G > 0 && ld >= G, "trid_argsort_rows_desc_f32: bad arguments");
-    if (G > 16384) return trid_argsort_rows_desc_large(sim, ld, Q, G, out_idx, ws, ws_bytes, stream);  // argsort_large.hip
+    if (G > 16384) return trid::argsort_rows_desc_large(sim, ld, Q, G, out_idx, ws, ws_bytes, stream);  // argsort_large.hip
     int P = 2;
     while (P < G) P <<= 1;
     const size_t lds = (size_t)P * 8;
