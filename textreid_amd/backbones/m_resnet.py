@@ -98,6 +98,10 @@ def _bn_coeffs(bn, partials, M, training, counters=None):
     return ops.bn_eval_coeffs(bn.weight, bn.bias, bn.running_mean, bn.running_var)
 
 
+import os as _os
+_SERIAL_WGRAD = _os.environ.get("TRID_SERIAL_WGRAD", "0") == "1"  # experiment: weight gradients on the main stream
+
+
 class _WgradStream:
     """Weight-gradient GEMMs are off the critical path of backward (nothing downstream in the
     chain consumes them), so they run on a side HIP stream underneath the dgrad GEMMs and the
@@ -112,6 +116,8 @@ class _WgradStream:
 
     def run(self, fn, *tensors):
         """fn(*tensors) on the side stream, after everything enqueued so far on main."""
+        if _SERIAL_WGRAD:
+            return fn(*tensors)
         ev = torch.cuda.Event()
         ev.record(self.main)
         self.side.wait_event(ev)

@@ -175,6 +175,10 @@ class MoCoHead(nn.Module):
                 elif which == "k":
                     # The key image encoder (no_grad) runs on a second side stream: its HBM-bound
                     # BatchNorm / pooling passes overlap the MFMA-bound GEMMs of the query encoder.
+                    if os.environ.get("TRID_SERIAL_K", "0") == "1":  # experiment: key encoder on the main stream
+                        with torch.no_grad():
+                            vk_feat = self.v_encoder_k(images)
+                        return
                     side_k.wait_event(ema_done)
                     with torch.cuda.stream(side_k), torch.no_grad():
                         vk_feat = self.v_encoder_k(images)
