@@ -328,7 +328,7 @@ def test_fused_queue_infonce(ops, B, K, wgs, prec):
     assert rel(out3, ref) < tol_l
 
 
-@pytest.mark.parametrize("B,H,L", [(5, 64, 7), (130, 512, 12), (128, 512, 64), (16, 96, 3)])
+@pytest.mark.parametrize("B,H,L", [(5, 64, 7), (130, 512, 12), (128, 512, 64), (16, 96, 3), (1, 32, 1), (33, 768, 5)])
 def test_fused_gru_step_matches_unfused(ops, B, H, L):
     """gru_step.hip - one launch per time step (recurrent product + gates + state + max fused, fp16 two-plane split
     with the packed state / published max|dgh| hand-offs) against the GEMM + cell-kernel form of the same step
