@@ -170,8 +170,18 @@ def test_eval_bn_folding_matches_unfolded(gpu):
         ref = m(x)
         m.fold_eval_bn = True
         out = m(x)
-    # folding rounds w*scale once more per layer; 50 random-weight layers amplify that to ~5e-5
-    assert rel(out, ref) < 2e-4, rel(out, ref)
+        again = m(x)  # second call: the folded filters come from the cache
+        # folding rounds w*scale once more per layer; 50 random-weight layers amplify that to ~5e-5
+        assert rel(out, ref) < 2e-4, rel(out, ref)
+        assert torch.equal(out, again)
+        # an in-place parameter / buffer update (optimizer step, load_state_dict) invalidates the cached filters
+        m.layer3[1].conv2.weight.mul_(1.25)
+        m.layer2[0].bn3.running_mean.add_(0.05)
+        out2 = m(x)
+        m.fold_eval_bn = False
+        ref2 = m(x)
+    assert rel(out2, ref2) < 2e-4, rel(out2, ref2)
+    assert rel(out2, out) > 1e-3  # (the update is visible)
 
 
 def test_text_encoder(gpu, golden_dir):

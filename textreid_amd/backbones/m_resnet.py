@@ -223,35 +223,56 @@ class ModifiedResNet(nn.Module):
         pools.  Same values as the unfolded eval path up to fp32 rounding of the folded weights."""
         B = images.shape[0]
         col, Ho, Wo = ops.stem_im2col(images)
-        c1 = self.conv1.weight
-        w1p = torch.zeros(c1.shape[0], col.shape[1], device=c1.device, dtype=c1.dtype)
-        w1p[:, : c1[0].numel()] = c1.detach().reshape(c1.shape[0], -1)
+        # fp16-split conv arithmetic needs every operand's largest magnitude: one streaming pass per activation (there
+        # is no BatchNorm kernel here to emit it on the side) - ~4 % of the pass, which it halves
+        P = 16 if ops.conv_precision() == 16 else None
+        am = ops.amax if P else (lambda t: None)
+        # the folded filters (and their magnitudes) depend on the parameters only: kept across calls until a parameter
+        # or BatchNorm buffer is replaced or modified in place (an inference run encodes thousands of batches)
+        key = (P, images.device) + tuple((t.data_ptr(), t._version) for t in list(self.parameters()) + list(self.buffers()))
+        cache = getattr(self, "_folded_cache", None)
+        fresh = cache is None or cache[0] != key
+        if fresh:
+            cache = (key, [])
+            self._folded_cache = cache
+        entries, pos = cache[1], [0]
 
-        def folded(w2d, bn):
-            return ops.fold_bn(w2d, _bn_coeffs(bn, None, 0, False))
+        def folded(make_w2d, bn):
+            """(folded filter, bias, max|filter|) of the next conv in call order"""
+            if fresh:
+                w_, b_ = ops.fold_bn(make_w2d(), _bn_coeffs(bn, None, 0, False))
+                entries.append((w_, b_, am(w_)))
+            e = entries[pos[0]]
+            pos[0] += 1
+            return e
 
-        w, b = folded(w1p, self.bn1)
-        a1 = ops.conv1x1(col, w, bias=b, relu=True).view(B, Ho, Wo, -1)
-        w, b = folded(_w3x3(self.conv2), self.bn2)
-        a2 = ops.conv3x3(a1, w, bias=b, relu=True)
-        w, b = folded(_w3x3(self.conv3), self.bn3)
-        x = ops.bn_apply_pool2(ops.conv3x3(a2, w, bias=b, relu=True), None)
+        def c1x1(x_, wb, **kw):
+            return ops.conv1x1(x_, wb[0], bias=wb[1], prec=P, aa=am(x_), ba=wb[2], **kw)
+
+        def c3x3(x_, wb):
+            return ops.conv3x3(x_, wb[0], bias=wb[1], relu=True, prec=P, aa=am(x_), ba=wb[2])
+
+        def stem_w():
+            c1 = self.conv1.weight
+            w1p = torch.zeros(c1.shape[0], col.shape[1], device=c1.device, dtype=c1.dtype)
+            w1p[:, : c1[0].numel()] = c1.detach().reshape(c1.shape[0], -1)
+            return w1p
+
+        a1 = c1x1(col, folded(stem_w, self.bn1), relu=True).view(B, Ho, Wo, -1)
+        a2 = c3x3(a1, folded(lambda: _w3x3(self.conv2), self.bn2))
+        x = ops.bn_apply_pool2(c3x3(a2, folded(lambda: _w3x3(self.conv3), self.bn3)), None)
         for blk in self.blocks():
             stride = blk.stride
-            w, b = folded(blk.conv1.weight.view(blk.conv1.out_channels, -1), blk.bn1)
-            aa = ops.conv1x1(x, w, bias=b, relu=True)
-            w, b = folded(_w3x3(blk.conv2), blk.bn2)
-            ab = ops.conv3x3(aa, w, bias=b, relu=True)
+            aa = c1x1(x, folded(lambda: blk.conv1.weight.view(blk.conv1.out_channels, -1), blk.bn1), relu=True)
+            ab = c3x3(aa, folded(lambda: _w3x3(blk.conv2), blk.bn2))
             if stride > 1:
                 ab = ops.bn_apply_pool2(ab, None)
             if blk.downsample is not None:
                 xd = ops.bn_apply_pool2(x, None) if stride > 1 else x
-                w, b = folded(blk.downsample[1].weight.view(blk.downsample[1].out_channels, -1), blk.downsample[2])
-                ident = ops.conv1x1(xd, w, bias=b)
+                ident = c1x1(xd, folded(lambda: blk.downsample[1].weight.view(blk.downsample[1].out_channels, -1), blk.downsample[2]))
             else:
                 ident = x
-            w, b = folded(blk.conv3.weight.view(blk.conv3.out_channels, -1), blk.bn3)
-            x = ops.conv1x1(ab, w, bias=b, relu=True, residual=ident)
+            x = c1x1(ab, folded(lambda: blk.conv3.weight.view(blk.conv3.out_channels, -1), blk.bn3), relu=True, residual=ident)
         feat, _ = self._attnpool_forward(x, False)
         return feat
 
