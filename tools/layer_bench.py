@@ -29,7 +29,8 @@ def conv1(name, P, Ci, Co, count=1, acc=False):
     rows.append((name + " fwd", count, t(lambda: ops.conv1x1(x, w, stats=True, prec=PREC, aa=ax, ba=aw)), fl))
     if os.environ.get("TRID_DGRAD_T"):  # data gradient against a pre-transposed weight copy (K-contiguous B)
         wT = w.t().contiguous()
-        rows.append((name + " dgrad", count, t(lambda: ops.linear(dy, wT, out=dx, accumulate=acc)), fl))
+        awT = am(wT)
+        rows.append((name + " dgrad", count, t(lambda: ops.linear(dy, wT, out=dx, accumulate=acc, prec=PREC, aa=ady, ba=awT)), fl))
     else:
         rows.append((name + " dgrad", count, t(lambda: ops.matmul_nn(dy, w, out=dx, accumulate=acc, prec=PREC, aa=ady, ba=aw)), fl))
     rows.append((name + " wgrad", count, t(lambda: ops.conv1x1_wgrad(dy, x, prec=PREC, aa=ady, ba=ax)), fl))
