@@ -337,7 +337,7 @@ def main():
         # the image encoder's convolutions run the fp16 two-plane split: 3 fp16 MFMA products per fp32 multiply-add
         peak = BF16_MFMA_PEAK_TFLOPS / 3
         kname = "trid::gemm_bf16s_kernel<A_CONV,B_KC,16,128> (3x3 implicit-GEMM conv fwd+dgrad; fp32 operands scaled per tensor by a power of two and split into 2 fp16 planes (11+11 significand bits), 3 fp16 MFMA 32x32x16 products per multiply-add in one fp32 accumulator)"
-        peak_note = "dense bf16/fp16 MFMA peak 2500 TFLOP/s / 3 products = fp32-equivalent peak; PMC MfmaUtil of this kernel 29-47 % at 1.8-2.2 GHz (profiles/r02c_pmc_mfma_util.txt)"
+        peak_note = "dense bf16/fp16 MFMA peak 2500 TFLOP/s / 3 products = fp32-equivalent peak; PMC MfmaUtil of this kernel 29-47 % at 1.8-2.2 GHz (profiles/r02d_pmc_mfma_util.txt)"
         arith = "fp32 operands and accumulation; conv products evaluated as 3 fp16 MFMA terms of a scaled 2-way fp16 split (representation + dropped term <= 3*2^-22 per product), everything else as 6 bf16 MFMA terms of a 3-way bf16 split (<= 2^-26)"
     elif prec in (3, 6):
         # the dominant kernel executes `prec` bf16 MFMA products per fp32 multiply-add
@@ -360,7 +360,7 @@ def main():
     # measurement of the committed build, not a counter read of this run: `traffic_source` names the file.
     traffic, traffic_note, traffic_src = None, None, None
     here = os.path.dirname(os.path.abspath(__file__))
-    for fn in ("r02c_pmc_hbm_traffic.txt", "r02a_pmc_hbm_traffic.txt", "r01j_pmc_hbm_traffic.txt"):
+    for fn in ("r02d_pmc_hbm_traffic.txt", "r02c_pmc_hbm_traffic.txt", "r02a_pmc_hbm_traffic.txt", "r01j_pmc_hbm_traffic.txt"):
         try:
             for line in open(os.path.join(here, "profiles", fn)):
                 f = line.split()
