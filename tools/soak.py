@@ -1,26 +1,34 @@
-import sys, time, torch
-sys.path.insert(0, '.')
-import bench
+#!/usr/bin/env python3
+"""Soak run: N training steps of configs[1] on synthetic data; prints loss, step time and allocator statistics every 50
+steps (memory growth, non-finite losses and step-time drift show up here, not in a 10-step bench).
+GPU box:  python tools/soak.py [steps]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch, bench
 from textreid_amd.caption import CaptionBatch
 from textreid_amd.config import moco_cfg
 from textreid_amd.model import build_model
 from textreid_amd.solver import make_optimizer
-dev = torch.device("cuda")
-torch.manual_seed(0)
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+dev = torch.device("cuda"); torch.manual_seed(0)
 cfg = moco_cfg("m_resnet50", K=8192)
-model = build_model(cfg, vocab_dict=torch.randn(49408, 512) * 0.02).to(dev).train()
+model = build_model(cfg, vocab_dict=torch.randn(49408, 512) * 0.02).to(dev); model.train()
 opt = make_optimizer(cfg, model)
 B = 128
 batches = [bench.synth_batch(B, s, dev, 1234) for s in range(8)]
-t0 = time.time(); hist = []
-for i in range(400):
-    im, tk, ln, ids = batches[i % 8]
-    ld = model(im, CaptionBatch(tk, ln, (ids + (i // 8) * 8 * 32) % 11003, max_len=64))
-    loss = sum(ld.values())
-    opt.zero_grad(); loss.backward(); opt.step()
-    if i % 50 == 0 or i == 399:
-        v = {k: float(x) for k, x in ld.items()}
-        assert all(x == x and abs(x) < 1e6 for x in v.values()), v
-        hist.append((i, round(sum(v.values()), 3), round(torch.cuda.max_memory_allocated() / 2**30, 2)))
-torch.cuda.synchronize()
-print("400 steps in %.1fs" % (time.time() - t0)); print(hist)
+t0 = time.perf_counter(); last = None
+for i in range(N):
+    images, tokens, lengths, ids = batches[i % 8]
+    cb = CaptionBatch(tokens, lengths, (ids + (i // 8) * 8 * (B // 4)) % 11003, max_len=64)
+    ld = model(images, cb)
+    loss = sum(ld.values()); opt.zero_grad(); loss.backward(); opt.step()
+    if (i + 1) % 50 == 0:
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 50 * 1e3; t0 = time.perf_counter()
+        vals = {k: float(v) for k, v in ld.items()}
+        ok = all(v == v and abs(v) < 1e6 for v in vals.values())
+        print("step %4d  %.2f ms/step  alloc %.3f GB in %d blocks  reserved %.2f GB  losses %s%s" % (
+            i + 1, dt, torch.cuda.memory_allocated() / 2**30, torch.cuda.memory_stats()["allocation.all.current"],
+            torch.cuda.memory_reserved() / 2**30,
+            {k: round(v, 4) for k, v in vals.items()}, "" if ok else "  NON-FINITE"), flush=True)
