@@ -132,7 +132,7 @@ __device__ __forceinline__ void stage_image(uint4* __restrict__ dst, const uint4
 }
 
 __global__ __launch_bounds__(GTHREADS) void gru_step_fwd_kernel(GruFwdParams p) {
-    extern __shared__ __attribute__((aligned(16))) uint4 wsm[];  // [plane][gate][kstep][64]; later the K-quarter partials
+    extern __shared__ __attribute__((aligned(16))) uint4 wsm[];  // [plane][gate][kstep][64]; later the K-slice partials
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ub = blockIdx.x, d = blockIdx.y, mb = blockIdx.z;
     const int H = p.H, KS = H / 32, KQ = (KS + GKQ - 1) / GKQ;
@@ -255,7 +255,7 @@ struct GruBwdParams {
 };
 
 __global__ __launch_bounds__(GTHREADS) void gru_step_bwd_kernel(GruBwdParams p) {
-    extern __shared__ __attribute__((aligned(16))) uint4 wsm[];  // [plane][kstep over 3H][64]; later the K-quarter partials
+    extern __shared__ __attribute__((aligned(16))) uint4 wsm[];  // [plane][kstep over 3H][64]; later the K-slice partials
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ub = blockIdx.x, d = blockIdx.y, mb = blockIdx.z;
     const int H = p.H, KS = 3 * H / 32, KQ = (KS + GKQ - 1) / GKQ;
