@@ -223,6 +223,7 @@ class _L2NormFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         y, inv = ctx.saved
+        ctx.saved = None  # y is this node's own output: holding it would keep a reference cycle alive until the cyclic GC runs
         return ops.l2norm_rows_bwd(dy.contiguous(), y, inv)
 
 
@@ -242,6 +243,7 @@ class _LinearFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, w = ctx.saved
+        ctx.saved = None
         dy = dy.contiguous()
         dx = ops.matmul_nn(dy, w.detach()) if ctx.needs_input_grad[0] else None
         dw = ops.matmul_tn(dy, x) if ctx.needs_input_grad[1] else None
