@@ -45,8 +45,17 @@ class _GRUFn(torch.autograd.Function):
         ops.call("trid_embedding_gather_f32", ops._p(table), ops._p(tokens), ops._p(x), B, L, tokens.stride(0), E,
                  table.shape[0], st)
         gi = ops.empty((B * L, 6 * H), table)
-        ops.gemm(x, w_ih_f, gi, B * L, 3 * H, E, E, E, 6 * H)
-        ops.gemm(x, w_ih_r, gi, B * L, 3 * H, E, E, E, 6 * H, c_off=3 * H)
+        # fp16-split arithmetic for the big text GEMMs while that is the library's conv mode: every gathered row is a row
+        # of the frozen table, so max|x| <= max|table| (computed once per table)
+        P = 16 if ops.conv_precision() == 16 else None
+        a_x = None
+        if P:
+            if getattr(mod, "_table_amax", None) is None or mod._table_amax[0] is not table:
+                mod._table_amax = (table, ops.amax(table))
+            a_x = mod._table_amax[1]
+        ops.gemm(x, w_ih_f, gi, B * L, 3 * H, E, E, E, 6 * H, precision=P, a_amax=a_x, b_amax=ops.amax(w_ih_f) if P else None)
+        ops.gemm(x, w_ih_r, gi, B * L, 3 * H, E, E, E, 6 * H, c_off=3 * H, precision=P, a_amax=a_x,
+                 b_amax=ops.amax(w_ih_r) if P else None)
         whh = torch.stack([w_hh_f.detach(), w_hh_r.detach()])  # [2,3H,H] (plumbing copy)
         h = torch.zeros(2, B, H, device=table.device)
         maxv = ops.empty((B, 2 * H), table)
@@ -81,12 +90,12 @@ class _GRUFn(torch.autograd.Function):
                          (ops._p(hprev) + 4 * s * B * H) if save else None, ops._p(maxv), ops._p(argt), s, L, L, B, H,
                          L * B * 4 * H, L * B * H, st)
         if save:
-            ctx.saved = (x, whh, gates, hprev, argt, lengths, B, H, E, L, fused)
+            ctx.saved = (x, whh, gates, hprev, argt, lengths, B, H, E, L, fused, a_x)
         return maxv
 
     @staticmethod
     def backward(ctx, dout):
-        x, whh, gates, hprev, argt, lengths, B, H, E, L, fused = ctx.saved
+        x, whh, gates, hprev, argt, lengths, B, H, E, L, fused, a_x = ctx.saved
         ctx.saved = None
         dout = dout.contiguous()
         st = ops.stream()
@@ -117,20 +126,31 @@ class _GRUFn(torch.autograd.Function):
         splits = max(1, min(8, KK // 512))
         dwhh = ops.empty((2, 3 * H, H), dout)
         dwih = ops.empty((2, 3 * H, E), dout)
+        # operand magnitudes of the fp16-split form: |hprev| < 1 by construction; max|dgh| is the maximum the backward
+        # steps published (dGi's r / z rows equal dgh's, its n row is dgh's divided by a gate <= 1: one streaming pass)
+        P = 16 if (a_x is not None and fused is not None) else None
+        kw_hh = kw_ih = {}
+        if P:
+            one = getattr(_GRUFn, "_one", None)
+            if one is None or one.device != dout.device:
+                one = _GRUFn._one = torch.ones(1, device=dout.device)
+            a_dgh = torch.amax(amax[:L]).reshape(1)
+            kw_hh = dict(precision=P, a_amax=a_dgh, b_amax=one)
+            kw_ih = dict(precision=P, a_amax=ops.amax(dGi), b_amax=a_x)
         if splits == 1:
             ops.gemm(dgh, hprev, dwhh, 3 * H, H, KK, 3 * H, H, H, a_mode=ops.A_MC, b_mode=ops.B_NC, batch=2,
-                     strideA=KK * 3 * H, strideB=KK * H, strideC=3 * H * H)
+                     strideA=KK * 3 * H, strideB=KK * H, strideC=3 * H * H, **kw_hh)
             ops.gemm(dGi, x, dwih, 3 * H, E, KK, 6 * H, E, E, a_mode=ops.A_MC, b_mode=ops.B_NC, batch=2,
-                     strideA=3 * H, strideB=0, strideC=3 * H * E)
+                     strideA=3 * H, strideB=0, strideC=3 * H * E, **kw_ih)
         else:
             slab = ops.empty((splits, 2, 3 * H, max(H, E)), dout)
             n = 2 * 3 * H * H
             ops.gemm(dgh, hprev, slab, 3 * H, H, KK, 3 * H, H, H, a_mode=ops.A_MC, b_mode=ops.B_NC, batch=2,
-                     strideA=KK * 3 * H, strideB=KK * H, strideC=3 * H * H, splits=splits, strideSplit=n)
+                     strideA=KK * 3 * H, strideB=KK * H, strideC=3 * H * H, splits=splits, strideSplit=n, **kw_hh)
             ops.call("trid_slab_reduce_f32", ops._p(slab), ops._p(dwhh), n, splits, n, 0, st)
             n = 2 * 3 * H * E
             ops.gemm(dGi, x, slab, 3 * H, E, KK, 6 * H, E, E, a_mode=ops.A_MC, b_mode=ops.B_NC, batch=2,
-                     strideA=3 * H, strideB=0, strideC=3 * H * E, splits=splits, strideSplit=n)
+                     strideA=3 * H, strideB=0, strideC=3 * H * E, splits=splits, strideSplit=n, **kw_ih)
             ops.call("trid_slab_reduce_f32", ops._p(slab), ops._p(dwih), n, splits, n, 0, st)
         return None, None, None, None, None, dwih[0], dwhh[0], dwih[1], dwhh[1]
 
