@@ -75,8 +75,8 @@ typedef struct trid_gemm_desc {
                          * terms <= 2^-26; 3 drops ~2^-17); 1: operands rounded to bf16, one MFMA per
                          * product, fp32 accumulate (bf16-autocast arithmetic); 16: fp32 operands scaled by a
                          * per-tensor power of two (a_amax / b_amax) and split into TWO fp16 planes (11 + 11
-                         * significand bits, residual scaled by 2^11), 3 fp16 MFMAs per product in two fp32
-                         * accumulators (representation + dropped term <= 3 * 2^-22 per product: fp32-class).
+                         * significand bits, residual kept in the scaled domain), 3 fp16 MFMAs per product in one
+                         * fp32 accumulator (representation + dropped term <= 3 * 2^-22 per product: fp32-class).
                          * Shapes the split kernel does not cover fall back to 0. */
     const float* residual; /* NULL, or [M][ldres] added after bias (eval: identity / folded downsample branch) */
     int64_t ldres;

@@ -40,7 +40,7 @@ constexpr int NT = 512;               // 8 waves
 // B image: the swizzled wide layout needs 576 slots; a K-contiguous 64-row image only 4 x 65
 __host__ __device__ constexpr int b_plane_slots(int bmode, int bn) { return (bmode == B_KC && bn == 64) ? 4 * (64 + 1) : plane_slots(bn); }
 
-// ARITH: 1 / 2 / 3 = number of bf16 planes (1, 3, 6 products); 16 = two fp16 planes, 3 products, two accumulators
+// ARITH: 1 / 2 / 3 = number of bf16 planes (1, 3, 6 products); 16 = two fp16 planes, 3 products, one accumulator
 template <int AMODE, int BMODE, int ARITH, int BN>
 __global__ __launch_bounds__(NT, (BN == 64 && BMODE == B_KC && TRID_NARROW_WAVES > 0 && ARITH != 16) ? TRID_NARROW_WAVES : (ARITH == 16 ? ((BMODE == B_KC && AMODE != A_MC) ? TRID_F16_WAVES_KC : TRID_F16_WAVES) : 1)) void gemm_bf16s_kernel(GemmParams p) {
     constexpr bool F16 = (ARITH == 16);
