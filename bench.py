@@ -128,8 +128,8 @@ def queue_similarity_bench(device, B=128, C=256, K=8192, reps=20):
     flops = 2 * 2 * 2.0 * B * C * K  # similarity + gradient GEMMs, both modalities
     return {"K": K, "ms": ms, "algorithmic_MB": nbytes / 1e6, "achieved_GB_per_s": nbytes / ms / 1e6,
             "achieved_TFLOP_per_s": flops / ms / 1e9,
-            "launches": 4,
-            "note": "fused single pass over both queues (queue_nce.hip): filter-flag pre-pass, ONE kernel for similarity + masked softmax + dL/dq of both modalities (no [B,K] matrix), partial fold, loss sum; fp32-class arithmetic = 6 fp16 MFMA products per (query, row, channel) (two-plane split, fixed scales), so the block is MFMA-issue-bound at B=128: HBM time of the algorithmic bytes at 8 TB/s would be %.1f us" % (nbytes / 8e12 * 1e6)}
+            "launches": 3,
+            "note": "fused single pass over both queues (queue_nce.hip): ONE kernel for the batch-wide negative filter (hashed id set in LDS) + similarity + masked softmax + dL/dq of both modalities (no [B,K] matrix), partial fold, loss sum; fp32-class arithmetic = 6 fp16 MFMA products per (query, row, channel) (two-plane split, fixed scales), so the block is MFMA-issue-bound at B=128: HBM time of the algorithmic bytes at 8 TB/s would be %.1f us" % (nbytes / 8e12 * 1e6)}
 
 
 def encode_bench(model, images, tokens, lengths, reps=5):

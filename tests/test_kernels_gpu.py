@@ -283,7 +283,7 @@ def test_abi_argument_errors_are_reported_not_fatal(ops):
 
 
 @pytest.mark.parametrize("B,K,wgs,prec", [(128, 8192, 0, 6), (5, 64, 0, 6), (130, 96, 0, 6), (128, 2048, 3, 6), (33, 65536, 0, 6), (128, 8192, 0, 1), (300, 1024, 0, 6), (128, 8192, 0, 3),
-                                           (128, 32, 0, 6), (7, 2080, 1, 6)])
+                                           (128, 32, 0, 6), (7, 2080, 1, 6), (600, 1024, 0, 6)])
 def test_fused_queue_infonce(ops, B, K, wgs, prec):
     """queue_nce.hip - ONE pass over both [K,256] queues: similarity, batch-wide negative filter, InfoNCE and
     dL/dq - against the oracle's materialised form (head.py:148-170 + losses.py:206-217) evaluated in fp64.

@@ -45,6 +45,8 @@ struct QnceParams {
     const float* q[2];       // [B, QC] normalised queries: modality 0 = image queries, 1 = text queries
     const float* queue[2];   // [K, QC] row-major: modality 0 reads the TEXT queue, 1 the IMAGE queue
     const uint8_t* hit;      // [K] batch-wide same-id flags: queue row k is filtered when id_queue[k] equals ANY id of the batch
+    const long long* id_queue;  // [K] and
+    const long long* ids;       // [B]: the hashed in-kernel filter of queue_nce_f16_kernel<true> (B <= F_HASH_MAXB) reads these instead
     float* part_l;           // [2][nwg][Bp]
     float* part_o;           // [2][nwg][Bp][QC]
     int B, Bp, K, tiles_per_wg, nwg;
@@ -268,10 +270,18 @@ constexpr int F_BUF = 2 * (A1_SLOTS + A2_SLOTS);  // 16-byte slots of one buffer
 constexpr float F_SC = 8192.f;                    // 2^13: scale of queries and queue rows
 constexpr int F_SP_LOG2 = 15;                     // P' = P * 2^15
 constexpr int F_OPAD = QC + 4;                    // row pitch (floats) of the epilogue's LDS transpose
+constexpr int F_HASH_SLOTS = 1024;                // open-addressing id set in LDS (8 KB behind the tile buffers)
+constexpr int F_HASH_MAXB = 512;                  // ... for batches up to half its size; larger ones use the flag pre-pass
+constexpr unsigned long long F_HASH_EMPTY = 0x8000000000000000ull;
+__device__ __forceinline__ int id_hash(unsigned long long id) { return (int)((id * 0x9E3779B97F4A7C15ull) >> 54); }
 
 typedef std::integral_constant<int, 0> par0;
 typedef std::integral_constant<int, 1> par1;
 
+// HASH: the batch-wide negative filter (head.py:148-157) is evaluated IN the kernel - the batch's ids go into an
+// open-addressing set in LDS once per workgroup, each tile's 32 queue ids are looked up by 32 lanes (1-2 probes) and
+// one ballot is the tile's mask - instead of a [K]-byte flag pre-pass (a 6 us launch in front of a 20-70 us kernel).
+template <bool HASH>
 __global__ __launch_bounds__(256, 1) void queue_nce_f16_kernel(QnceParams p) {
     extern __shared__ __attribute__((aligned(16))) uint4 qsm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -311,18 +321,52 @@ __global__ __launch_bounds__(256, 1) void queue_nce_f16_kernel(QnceParams p) {
     const int t_end = min(p.K / QTILE, t_begin + p.tiles_per_wg);
     const int lkk = wave >> 1, lh = wave & 1;  // loader role: wave -> (kk, h) row set, lane -> 4 consecutive columns
     float4 g[8];         // the next tile to stage (loaded one O phase + half an S phase ahead of its first use)
-    unsigned hpre = 0;   // this lane's dword of its filter flags
+    unsigned hpre = 0;   // this lane's dword of its filter flags (flag path)
+    unsigned long long idpre = 0;  // lanes 0..31: the id of queue row (tile, lane) (hash path)
     unsigned w[8][2][2]; // staged tile: [row][plane][column pair]
+    unsigned long long* idset = reinterpret_cast<unsigned long long*>(qsm + 2 * F_BUF);  // [F_HASH_SLOTS] + [1] sentinel flag
+    if (HASH) {
+        for (int i = tid; i <= F_HASH_SLOTS; i += 256) idset[i] = i < F_HASH_SLOTS ? F_HASH_EMPTY : 0ull;
+        __syncthreads();
+        for (int i = tid; i < p.B; i += 256) {
+            const unsigned long long id = (unsigned long long)p.ids[i];
+            if (id == F_HASH_EMPTY) { idset[F_HASH_SLOTS] = 1ull; continue; }  // the one value the table cannot hold
+            int sl = id_hash(id);
+            while (true) {
+                const unsigned long long old = atomicCAS(&idset[sl], F_HASH_EMPTY, id);
+                if (old == F_HASH_EMPTY || old == id) break;
+                sl = (sl + 1) & (F_HASH_SLOTS - 1);
+            }
+        }
+        __syncthreads();
+    }
     auto load_tile = [&](int t) {
         t = min(t, t_end - 1);  // past the end: a harmless reload of the last tile (never consumed)
-        hpre = reinterpret_cast<const unsigned*>(p.hit + (long long)t * QTILE)[lane & 7];
+        if (HASH) idpre = (unsigned long long)p.id_queue[(long long)t * QTILE + l31];
+        else hpre = reinterpret_cast<const unsigned*>(p.hit + (long long)t * QTILE)[lane & 7];
         const float* base = Kq + (long long)t * QTILE * QC + 4 * lane;
 #pragma unroll
         for (int i = 0; i < 8; ++i) g[i] = *reinterpret_cast<const float4*>(base + (long long)tile_row(lkk, lh, i) * QC);
     };
-    // batch-wide negative filter of the tile in `g` (bit j set <=> queue row j carries an id of the batch): the flags
-    // of rows 4*(lane&7) .. +3 sit in this lane's prefetched dword -> one bit per row, OR over 8 lanes
+    // batch-wide negative filter of the tile in `g` (bit j set <=> queue row j carries an id of the batch).  Hash path:
+    // lane j < 32 looks row j's id up in the LDS set, one ballot is the mask.  Flag path: the flags of rows
+    // 4*(lane&7) .. +3 sit in this lane's prefetched dword -> one bit per row, OR over 8 lanes
     auto tile_mask = [&]() {
+        if (HASH) {
+            bool hit = false;
+            if (idpre == F_HASH_EMPTY) {
+                hit = idset[F_HASH_SLOTS] != 0ull;
+            } else {
+                int sl = id_hash(idpre);
+                while (true) {
+                    const unsigned long long e = idset[sl];
+                    if (e == idpre) { hit = true; break; }
+                    if (e == F_HASH_EMPTY) break;
+                    sl = (sl + 1) & (F_HASH_SLOTS - 1);
+                }
+            }
+            return (unsigned)(__ballot(hit && lane < 32) & 0xffffffffull);
+        }
         unsigned m = ((hpre & 0xffu) ? 1u : 0u) | ((hpre & 0xff00u) ? 2u : 0u) | ((hpre & 0xff0000u) ? 4u : 0u) | ((hpre & 0xff000000u) ? 8u : 0u);
         m <<= 4 * (lane & 7);
 #pragma unroll
@@ -536,19 +580,20 @@ static int launch_qnce(QnceParams& p, int nbb, hipStream_t stream) {
     return check_launch("trid_queue_nce_f32");
 }
 
+template <bool HASH>
 static int launch_qnce_f16(QnceParams& p, int nbb, hipStream_t stream) {
-    constexpr size_t lds = (size_t)2 * F_BUF * sizeof(uint4);
-    static_assert(lds >= (size_t)4 * 32 * F_OPAD * sizeof(float), "the epilogue transpose must fit in the tile buffers");
+    constexpr size_t lds = (size_t)2 * F_BUF * sizeof(uint4) + (HASH ? (F_HASH_SLOTS + 2) * sizeof(unsigned long long) : 0);
+    static_assert((size_t)2 * F_BUF * sizeof(uint4) >= (size_t)4 * 32 * F_OPAD * sizeof(float), "the epilogue transpose must fit in the tile buffers");
     static std::once_flag once;
     static hipError_t attr_err = hipSuccess;
     std::call_once(once, [] {
-        attr_err = hipFuncSetAttribute((const void*)queue_nce_f16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_err = hipFuncSetAttribute((const void*)queue_nce_f16_kernel<HASH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     });
     if (attr_err != hipSuccess) {
         set_error("trid_queue_nce_f32: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(attr_err));
         return (int)attr_err;
     }
-    hipLaunchKernelGGL(queue_nce_f16_kernel, dim3(p.nwg, nbb, 2), dim3(256), lds, stream, p);
+    hipLaunchKernelGGL(queue_nce_f16_kernel<HASH>, dim3(p.nwg, nbb, 2), dim3(256), lds, stream, p);
     return check_launch("trid_queue_nce_f32");
 }
 
@@ -586,7 +631,11 @@ extern "C" int trid_queue_nce_f32(const float* v_q, const float* t_q, const floa
     p.K = K;
     p.part_l = ws;
     p.part_o = ws + 2LL * p.nwg * p.Bp;
-    {   // batch-wide negative filter (head.py:148-157) as one byte per queue row, consumed 32 rows per tile
+    p.id_queue = reinterpret_cast<const long long*>(id_queue);
+    p.ids = reinterpret_cast<const long long*>(ids);
+    p.hit = nullptr;
+    const bool hashed = precision != 1 && precision != 3 && B <= F_HASH_MAXB;  // the fp16 kernel filters in-kernel
+    if (!hashed) {  // batch-wide negative filter (head.py:148-157) as one byte per queue row, consumed 32 rows per tile
         uint8_t* flags = reinterpret_cast<uint8_t*>(ws + 2LL * p.nwg * p.Bp * (QC + 1));
         const int rc0 = trid_queue_hit_mask(id_queue, ids, flags, K, B, stream);
         if (rc0 != TRID_OK) return rc0;
@@ -597,7 +646,7 @@ extern "C" int trid_queue_nce_f32(const float* v_q, const float* t_q, const floa
     p.c1 = invT * log2e;
     p.c0 = -shift * log2e;
     const hipStream_t st = (hipStream_t)stream;
-    const int rc = (precision == 1) ? launch_qnce<1>(p, nbb, st) : (precision == 3) ? launch_qnce<3>(p, nbb, st) : launch_qnce_f16(p, nbb, st);
+    const int rc = (precision == 1) ? launch_qnce<1>(p, nbb, st) : (precision == 3) ? launch_qnce<3>(p, nbb, st) : hashed ? launch_qnce_f16<true>(p, nbb, st) : launch_qnce_f16<false>(p, nbb, st);
     if (rc != TRID_OK) return rc;
     hipLaunchKernelGGL(queue_nce_finish_kernel, dim3(B, 2), dim3(QC), 0, st, p, t_key, v_key, loss_rows, dq, invT, shift,
                        gscale * invT / (float)B);
