@@ -38,14 +38,17 @@ constexpr int NT = 512;               // 8 waves
 //   4 x 2 waves, 32 x 32 per wave - half the MFMA work per tile for the same A staging, still ahead
 //   of the fp32-input MFMA kernel whose peak is 16x lower.
 // B image: the swizzled wide layout needs 576 slots; a K-contiguous 64-row image only 4 x 65
-__host__ __device__ constexpr int b_plane_slots(int bmode, int bn) { return (bmode == B_KC && bn == 64) ? 4 * (64 + 1) : plane_slots(bn); }
+__host__ __device__ constexpr int b_plane_slots(int bmode, int bn) { return (bmode == B_KC && bn <= 64) ? 4 * (bn + 1) : plane_slots(bn); }
+// BN = 32 (the 32-channel stem convolutions): 256 x 32 tiles, 8 x 1 waves of 32 x 32 - on the 128 x 64 tile half of the
+// waves had no columns to work on
+__host__ __device__ constexpr int tile_rows(int bn) { return bn == 32 ? 256 : BM_T; }
 
 // ARITH: 1 / 2 / 3 = number of bf16 planes (1, 3, 6 products); 16 = two fp16 planes, 3 products, one accumulator
 template <int AMODE, int BMODE, int ARITH, int BN>
-__global__ __launch_bounds__(NT, (BN == 64 && BMODE == B_KC && TRID_NARROW_WAVES > 0 && ARITH != 16) ? TRID_NARROW_WAVES : (ARITH == 16 ? ((BMODE == B_KC && AMODE != A_MC) ? TRID_F16_WAVES_KC : TRID_F16_WAVES) : 1)) void gemm_bf16s_kernel(GemmParams p) {
+__global__ __launch_bounds__(NT, (BN == 64 && BMODE == B_KC && TRID_NARROW_WAVES > 0 && ARITH != 16) ? TRID_NARROW_WAVES : (ARITH == 16 ? ((BMODE == B_KC && AMODE != A_MC && BN != 32) ? TRID_F16_WAVES_KC : TRID_F16_WAVES) : 1)) void gemm_bf16s_kernel(GemmParams p) {
     constexpr bool F16 = (ARITH == 16);
     constexpr int NPL = F16 ? 2 : ARITH;
-    constexpr int BM = BM_T;
+    constexpr int BM = tile_rows(BN);
     constexpr int WAVES_N = BN / 32;           // 4 or 2
     constexpr int WAVES_M = 8 / WAVES_N;       // 2 or 4
     constexpr int TM = BM / (32 * WAVES_M);    // 32-row MFMA tiles per wave: 2 or 1
@@ -111,7 +114,7 @@ __global__ __launch_bounds__(NT, (BN == 64 && BMODE == B_KC && TRID_NARROW_WAVES
     const long long b_rows = (BMODE == B_KC) ? p.N : p.K;
     const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)Bp, 0, (unsigned)(b_rows * p.ldb * 4), 0x00020000);
 
-    constexpr int APASS = 1;  // one loader pass covers the 128 A rows
+    constexpr int APASS = BM / 128;  // a loader pass covers 128 A rows
     int a_y[APASS], a_x[APASS];
     unsigned voA[APASS], amask[APASS];
 #pragma unroll
@@ -244,7 +247,8 @@ __global__ __launch_bounds__(NT, (BN == 64 && BMODE == B_KC && TRID_NARROW_WAVES
             if (A_WIDE) {
                 if (a_wide_lane) split_store_wide_f16<PA>(wa, scaleA, As, w_mq, w_kq);
             } else {
-                split_store_f16<PA>(ra[0], scaleA, As + slot_of<true, BM>(a_kg, a_row));
+#pragma unroll
+                for (int ps = 0; ps < APASS; ++ps) split_store_f16<PA>(ra[ps], scaleA, As + slot_of<true, BM>(a_kg, a_row + 128 * ps));
             }
             if (B_WIDE) {
                 if (b_wide_lane && 4 * w_mq < BN) split_store_wide_f16<PB>(wb, scaleB, Bs, w_mq, w_kq);
@@ -256,7 +260,8 @@ __global__ __launch_bounds__(NT, (BN == 64 && BMODE == B_KC && TRID_NARROW_WAVES
         if (A_WIDE) {
             if (a_wide_lane) split_store_wide<NPL, PA>(wa, As, w_mq, w_kq);
         } else {
-            split_store<NPL, PA>(ra[0], As + slot_of<true, BM>(a_kg, a_row));
+#pragma unroll
+            for (int ps = 0; ps < APASS; ++ps) split_store<NPL, PA>(ra[ps], As + slot_of<true, BM>(a_kg, a_row + 128 * ps));
         }
         if (B_WIDE) {
             if (b_wide_lane && 4 * w_mq < BN) split_store_wide<NPL, PB>(wb, Bs, w_mq, w_kq);
@@ -405,20 +410,23 @@ __global__ __launch_bounds__(NT, (BN == 64 && BMODE == B_KC && TRID_NARROW_WAVES
     }
 
     if (p.stats != nullptr) {
-        // BatchNorm partials of this 128-row tile: column (mean, M2) over the rows < M
+        // BatchNorm partials per 128-row slab of the tile (one slab, or two for the 256-row tile): column (mean, M2)
+        // over the slab's rows < M
         __syncthreads();
         float* red = reinterpret_cast<float*>(smem4);  // [WAVES_M][BN]
-        const int rows_left = p.M - m0;
+        constexpr int WPS = 128 / (32 * TM);            // waves (along M) per slab
+        const int slab = wm / WPS;
+        const int rows_left = p.M - (m0 + 128 * slab);
         const int cnt = rows_left < 128 ? rows_left : 128;
-        const float inv = 1.f / (float)cnt;
+        const float inv = cnt > 0 ? 1.f / (float)cnt : 0.f;
         const int cl = wn * 32 + (lane & 31);
-        auto column_total = [&](float s) {  // sum over the tile's 128 rows of a per-lane partial
+        auto column_total = [&](float s) {  // sum over the slab's 128 rows of a per-lane partial
             s += __shfl_xor(s, 32, 64);
             if (khalf == 0) red[wm * BN + cl] = s;
             __syncthreads();
             float t = 0.f;
 #pragma unroll
-            for (int w = 0; w < WAVES_M; ++w) t += red[w * BN + cl];
+            for (int w = 0; w < WPS; ++w) t += red[(slab * WPS + w) * BN + cl];
             __syncthreads();
             return t;
         };
@@ -441,8 +449,8 @@ __global__ __launch_bounds__(NT, (BN == 64 && BMODE == B_KC && TRID_NARROW_WAVES
                 if (row < p.M) s += d * d;
             }
         const float m2 = column_total(s);
-        if (wm == 0 && khalf == 0 && col < p.N) {
-            float* dst = p.stats + ((long long)mb * p.N + col) * 2;
+        if ((wm % WPS) == 0 && khalf == 0 && col < p.N && cnt > 0) {
+            float* dst = p.stats + (((long long)mb * (BM / 128) + slab) * p.N + col) * 2;
             dst[0] = mean;
             dst[1] = m2;
         }
@@ -452,10 +460,10 @@ __global__ __launch_bounds__(NT, (BN == 64 && BMODE == B_KC && TRID_NARROW_WAVES
 template <int AMODE, int BMODE, int ARITH, int BN>
 static int launch_bf16(GemmParams& p, hipStream_t stream) {
     constexpr int NPL = ARITH == 16 ? 2 : ARITH;
-    p.mblocks = (p.M + BM_T - 1) / BM_T;
+    p.mblocks = (p.M + tile_rows(BN) - 1) / tile_rows(BN);
     p.nblocks = (p.N + BN - 1) / BN;
     dim3 grid((unsigned)(p.mblocks * p.nblocks), 1, (unsigned)(p.batch * p.splits));
-    constexpr size_t lds = (size_t)NPL * (plane_slots(BM_T) + b_plane_slots(BMODE, BN)) * sizeof(uint4);
+    constexpr size_t lds = (size_t)NPL * (plane_slots(tile_rows(BN)) + b_plane_slots(BMODE, BN)) * sizeof(uint4);
     // once per kernel instantiation and process, safe under concurrent first calls from several host threads
     static std::once_flag once;
     static hipError_t attr_err = hipSuccess;
@@ -477,6 +485,9 @@ static int pick_tile(GemmParams& p, hipStream_t stream) {
     // 128-row tiles, two workgroups per CU; 64 columns when the output is that narrow.  (A 256x128
     // double-buffered tile with one workgroup per CU and a role-alternating 256x128 schedule were both
     // measured 3-4 % slower on the same box)
+    if constexpr (NPL == 16 && BMODE == B_KC && AMODE != A_MC) {
+        if (p.N <= 32) return launch_bf16<AMODE, BMODE, NPL, 32>(p, stream);  // stem convolutions
+    }
     if (p.N <= 64) return launch_bf16<AMODE, BMODE, NPL, 64>(p, stream);
     return launch_bf16<AMODE, BMODE, NPL, 128>(p, stream);
 }
