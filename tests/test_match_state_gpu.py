@@ -575,7 +575,9 @@ def test_do_train_config0_plumbing(gpu, tmp_path):
     do_train(model, TrainLoader(), [ValLoader()], opt, sched, None, Meters(), gpu, checkpoint_period=10, evaluate_period=1,
              arguments=args, log_period=1)
     head = model.embed_model
-    assert args["iteration"] == 2 and args["epoch"] == 1 and len(seen) == 2
+    steps_seen = [kw for kw in seen if "loss" in kw]
+    assert args["iteration"] == 2 and args["epoch"] == 1 and len(steps_seen) == 2
+    assert any("top1" in kw for kw in seen)  # the evaluation's R@1 reaches the meters (trainer.py:124)
     assert all(np.isfinite(v) for kw in seen for v in kw.values())
     assert int(head.queue_ptr) == (2 * B) % K
     assert torch.equal(head.id_queue[0, : 2 * B].cpu(), torch.cat([batches[0][3], batches[1][3]]))

@@ -3,8 +3,8 @@ same op order per step -- model(images, captions) -> sum(loss_dict) -> zero_grad
 backward -> step -- per-epoch scheduler.step(), evaluation every EVALUATE_PERIOD
 epochs with rerank=False, best / periodic checkpoints.  Differences: gradients of
 pre-gather parameters are SUM-reduced over RCCL by ``GradReducer`` (the reference's
-DDP path crashes), and logging reads losses every ``log_period``
-steps instead of forcing a device sync every step."""
+DDP path crashes), and logging accumulates the per-step losses ON DEVICE and reads their
+mean every ``log_period`` steps instead of forcing a device sync every step."""
 
 import logging
 import time
@@ -37,6 +37,7 @@ def do_train(model, data_loader, data_loader_val, optimizer, scheduler, checkpoi
     if world_size() > 1 and hasattr(getattr(model, "embed_model", None), "v_encoder_q"):
         model.embed_model.v_encoder_q.grad_sync = reducer  # conv gradients all-reduced from inside backward
     best_top1 = 0.0
+    running, n_running = None, 0
     start = time.time()
     while epoch < max_epoch:
         epoch += 1
@@ -51,13 +52,23 @@ def do_train(model, data_loader, data_loader_val, optimizer, scheduler, checkpoi
             images = images.to(device)
             captions = captions.to(device) if hasattr(captions, "to") else [c.to(device) for c in captions]
             loss_dict, losses = train_step(model, optimizer, images, captions, reducer, pre_gather)
-            if meters is not None and iteration % log_period == 0:
-                meters.update(loss=float(losses), **{k: float(v) for k, v in loss_dict.items()})
-                logger.info("epoch [%d][%d/%d] %s lr: %.6f", epoch, step, len(data_loader), str(meters),
-                            optimizer.param_groups[-1]["lr"])
+            if meters is not None:
+                # every step counts (trainer.py:92-93 updates the meters per step): summed on device, one read per period
+                with torch.no_grad():
+                    vals = torch.stack([losses.detach()] + [v.detach() for v in loss_dict.values()])
+                    running = vals if running is None else running + vals
+                    n_running += 1
+                if iteration % log_period == 0:
+                    mean = (running / n_running).tolist()  # the period's only host read
+                    meters.update(loss=mean[0], **{k: m for k, m in zip(loss_dict.keys(), mean[1:])})
+                    running, n_running = None, 0
+                    logger.info("epoch [%d][%d/%d] %s lr: %.6f", epoch, step, len(data_loader), str(meters),
+                                optimizer.param_groups[-1]["lr"])
         scheduler.step()
         if data_loader_val is not None and epoch % evaluate_period == 0:
             top1 = inference(model, data_loader_val[0], device=device, save_data=False, rerank=False)
+            if meters is not None and top1 is not None:
+                meters.update(top1=float(top1))  # trainer.py:124
             if top1 is not None and float(top1) > best_top1:
                 best_top1 = float(top1)
                 if checkpointer is not None:
