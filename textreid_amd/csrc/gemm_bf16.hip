@@ -38,7 +38,7 @@ constexpr int NT = 512;               // 8 waves
 //   4 x 2 waves, 32 x 32 per wave - half the MFMA work per tile for the same A staging, still ahead
 //   of the fp32-input MFMA kernel whose peak is 16x lower.
 // B image: the swizzled wide layout needs 576 slots; a K-contiguous 64-row image only 4 x 65
-__host__ __device__ constexpr int b_plane_slots(int bmode, int bn) { return (bmode == B_KC && bn <= 64) ? 4 * (bn + 1) : plane_slots(bn); }
+__host__ __device__ constexpr int b_plane_slots(int bmode, int bn) { return (bmode == B_KC && bn <= 64) ? 4 * (bn + TRID_KC_PAD) : plane_slots(bn); }
 // BN = 32 (the 32-channel stem convolutions): 256 x 32 tiles, 8 x 1 waves of 32 x 32 - on the 128 x 64 tile half of the
 // waves had no columns to work on
 __host__ __device__ constexpr int tile_rows(int bn) { return bn == 32 ? 256 : BM_T; }

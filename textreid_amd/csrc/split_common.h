@@ -13,10 +13,16 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 //     -> a lane that loaded a float4 ALONG the rows writes its 4 rows to 4 slot runs that are
 //        consecutive across lanes, and MFMA fragment reads (32 consecutive rows per half-wave) stay
 //        conflict-free for ds_read_b128's 16-lane groups ((row%4)*4 + row/4 is distinct mod 16).
-__host__ __device__ constexpr int plane_slots(int R) { return 4 * (R + 1) > 4 * 144 ? 4 * (R + 1) : 4 * 144; }
+#ifndef TRID_KC_PAD
+#define TRID_KC_PAD 2  // row pitch of a K-contiguous plane = R + 2 slots: see slot_of
+#endif
+__host__ __device__ constexpr int plane_slots(int R) { return 4 * (R + TRID_KC_PAD) > 4 * 144 ? 4 * (R + TRID_KC_PAD) : 4 * 144; }
 template <bool KCONTIG, int R>
 __device__ __forceinline__ int slot_of(int kg, int row) {
-    if (KCONTIG) return kg * (R + 1) + row;
+    // pitch R + 2: the loader's eight-lane store groups hold (kg 0..3) x (2 rows); with a pitch = 2 (mod 8) slots their
+    // eight 16-byte slots fall into eight different 4-bank groups of the 32-bank store path (pitch R + 1 made
+    // (kg+1, row) collide with (kg, row+1): SQ_LDS_BANK_CONFLICT was 28 % of the LDS-active cycles)
+    if (KCONTIG) return kg * (R + TRID_KC_PAD) + row;
     return kg * 144 + (row & 3) * 36 + (row >> 2);
 }
 
