@@ -101,7 +101,10 @@ __global__ __launch_bounds__(NT, (BN == 64 && BMODE == B_KC && TRID_NARROW_WAVES
     constexpr bool A_K = (AMODE != A_MC);
     const int a_kg = A_K ? (tid & 3) : (tid >> 7), a_row = A_K ? (tid >> 2) : (tid & 127);
     const int b_kg = tid & 3, b_row = tid >> 2;  // B_KC only
-    const int w_mq = tid & 31, w_kq = (tid & 255) >> 5;
+    // wide lanes: (mq, kq) with kq's low bit (the 8-byte half of a slot) in the lane's low bit, so that two neighbouring
+    // lanes fill one 16-byte slot and a 16-lane ds_write_b64 group writes 128 contiguous bytes (with mq in the low
+    // bits the group strode 16 bytes and used half of the banks: 29 % of the LDS-active cycles were conflicts)
+    const int w_mq = (tid >> 1) & 31, w_kq = 2 * ((tid & 255) >> 6) + (tid & 1);
     const bool a_wide_lane = tid < 256, b_wide_lane = tid >= 256;
     constexpr unsigned OOB = 0x80000000u;
     // channel-group-major K order of the 3x3 implicit GEMM (see tile_k below): tap is uniform per tile
