@@ -515,6 +515,45 @@ def test_inference_dedupes_image_encodes(gpu):
         assert torch.allclose(a[i][0], b[i][0], rtol=1e-5, atol=1e-6) and torch.equal(a[i][1], b[i][1])
 
 
+def test_train_step_has_no_host_device_sync(gpu):
+    """SURVEY 8 b2 ("no host reads of device scalars"): after warm-up a whole training step - encoders, losses, queue
+    push, backward, FusedAdam - must not synchronise the host with the device (torch's sync debug mode raises on any
+    blocking copy / .item()).  Round 2 found nine such copies per step in the optimizer's pointer-table upload."""
+    import bench
+    from textreid_amd.caption import CaptionBatch
+    from textreid_amd.config import moco_cfg
+    from textreid_amd.model import build_model
+    from textreid_amd.solver import make_optimizer
+
+    B = 8
+    torch.manual_seed(0)
+    cfg = moco_cfg("m_resnet50", K=64)
+    model = build_model(cfg, vocab_dict=torch.randn(49408, 512) * 0.02).to(gpu)
+    model.train()
+    opt = make_optimizer(cfg, model)
+    batches = [bench.synth_batch(B, s, gpu, 5) for s in range(2)]
+
+    def step(i):
+        images, tokens, lengths, ids = batches[i % 2]
+        cb = CaptionBatch(tokens, lengths, ids % 11003, max_len=64)
+        loss = sum(model(images, cb).values())
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        return loss
+
+    for i in range(3):
+        step(i)
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        last = step(3)
+        last = step(4)
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    assert bool(torch.isfinite(last))
+
+
 def test_do_train_config0_plumbing(gpu, tmp_path):
     """BASELINE configs[0] on the GPU box: moco_gru_cliprn50 at bs128, K=2048, 256 synthetic 384x128 images +
     64-token captions, ONE epoch (2 steps) of engine.trainer.do_train + the per-epoch evaluation through
