@@ -47,7 +47,7 @@ def synth_batch(B, step, device, seed, vocab=49408, Lpad=105, L=64):
     return images.to(device), tokens.to(device), lengths.to(device), ids.to(device)
 
 
-def cpu_baseline(sample_b=128, steps=2, warm_b=32):
+def cpu_baseline(sample_b=128, steps=3, warm_b=32):
     """Oracle (port of the reference train step incl. Adam) on the host cores: configs[1]'s own batch
     (B = 128), `steps` timed steps after one warm-up step at B = `warm_b` (thread pool,
     allocator); the warm-up size is also timed for one more step and reported as a second point."""
@@ -201,6 +201,29 @@ def retrieval_bench(device, world, rank, G_total=1000000, Q=10000, k=10, shard_r
     }
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N rank processes (one per GPU, env:// rendezvous on
+    127.0.0.1) and return the worst exit code.  This parent never initialises the GPU (device_count() does not)."""
+    import socket
+    import subprocess
+
+    have = torch.cuda.device_count()
+    if have < n:
+        print("bench.py: --gpus %d requested but only %d GPU(s) are visible; refusing to print a smaller job's line" % (n, have),
+              file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    codes = [p.wait() for p in procs]
+    return max(abs(c) for c in codes)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -216,15 +239,26 @@ def main():
 
     import torch.distributed as dist
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus))  # no launcher: become one (before anything touches the GPU)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    local = local % max(torch.cuda.device_count(), 1)  # (debug: several ranks may share one GPU under gloo)
+    backend = os.environ.get("TRID_DIST_BACKEND", "nccl")
+    if world != args.gpus:
+        print("bench.py: --gpus %d but the launcher started %d rank(s)" % (args.gpus, world), file=sys.stderr)
+        sys.exit(2)
+    ndev = torch.cuda.device_count()
+    if backend == "gloo":
+        local = local % max(ndev, 1)  # (debug transport: several ranks may share one GPU)
+    elif local >= ndev:
+        print("bench.py: rank %d needs GPU %d but only %d GPU(s) are visible (one RCCL rank per GPU)" % (rank, local, ndev), file=sys.stderr)
+        sys.exit(2)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend=os.environ.get("TRID_DIST_BACKEND", "nccl"), init_method="env://")
+        dist.init_process_group(backend=backend, init_method="env://")
 
     from textreid_amd import ops
     from textreid_amd.caption import CaptionBatch

@@ -317,11 +317,12 @@ int trid_ema_multi_f32(const uint64_t* k_ptrs, const uint64_t* q_ptrs, const int
                        const int32_t* chunk_tensor, const int64_t* chunk_off, int n_chunks, int chunk_len, float m,
                        float one_minus_m, void* stream);
 /* Multi-tensor Adam / AdamW step (torch.optim.Adam semantics, lib/solver/build.py:6-40:
- * per-tensor lr and weight decay).  step_size = lr/(1-b1^t), bc2 = sqrt(1-b2^t). */
+ * per-tensor lr and weight decay).  bias_c1[i] = 1-b1^t_i, bias_c2[i] = sqrt(1-b2^t_i): DEVICE arrays, one
+ * entry per tensor (torch.optim.Adam keeps one step count t_i per parameter); step_size = lr/bias_c1. */
 int trid_adam_multi_f32(const uint64_t* p_ptrs, const uint64_t* g_ptrs, const uint64_t* m_ptrs,
                         const uint64_t* v_ptrs, const int64_t* sizes, const float* lrs, const float* wds,
                         const int32_t* chunk_tensor, const int64_t* chunk_off, int n_chunks, int chunk_len,
-                        float beta1, float beta2, float eps, float bias_c1, float bias_c2, int decoupled,
+                        float beta1, float beta2, float eps, const float* bias_c1, const float* bias_c2, int decoupled,
                         void* stream);
 /* Ring-buffer push at device-resident pointer: queue row-major [K, C]
  * (transpose of the reference's [C,K], so the push is one contiguous slab). */

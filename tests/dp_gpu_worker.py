@@ -32,7 +32,8 @@ def main():
     table = OF.randn("vocab_table_dp", (vocab, embed), seed, 0.5)
     vis = ModifiedResNet(list(spec.layers), spec.output_dim, spec.heads, spec.last_stride, (spec.height, spec.in_width), spec.width)
     txt = GRU(hidden, embed, embed, 1, 0.0, True, "clip_vit", "./", vocab_dict=table)
-    cfg = ns(MODEL=ns(EMBEDDING=ns(FEATURE_SIZE=C, EPSILON=0.1), MOCO=ns(K=K, M=0.9, FC=False), NUM_CLASSES=NC))
+    fc = os.environ.get("TRID_TEST_FC", "0") == "1"  # MODEL.MOCO.FC: projection heads (six gathered blocks)
+    cfg = ns(MODEL=ns(EMBEDDING=ns(FEATURE_SIZE=C, EPSILON=0.1), MOCO=ns(K=K, M=0.9, FC=fc), NUM_CLASSES=NC))
     head = MoCoHead(cfg, vis, txt)
     filled = OF.fill_state(head.state_dict(), seed, "dp.")
     st = {k: v.clone() for k, v in filled.items()}
@@ -62,7 +63,7 @@ def main():
         for k in OH.trainable_names(st):
             st[k].requires_grad_(True)
         # oracle: per-shard encoders (own BN statistics), global losses
-        vq, tq, vk, tk = [], [], [], []
+        vq, tq, vk, tk, vs, ts = [], [], [], [], [], []
         with torch.no_grad():
             OH.momentum_update(st, 0.9)
         for w in range(W):
@@ -71,19 +72,24 @@ def main():
             ve, te = OH.embed_pair(st, vf, tf)
             vq.append(ve)
             tq.append(te)
+            if fc:  # head.py:117-124: the contrastive branch goes through the projection heads
+                a, b = OH.fc_pair(st, "q", vf, tf)
+                vs.append(a)
+                ts.append(b)
             with torch.no_grad():
                 vkf, tkf = OH.encode(st, "k", spec, table, x[s2], tok[s2], ln[s2], True)
-                a, b = OH.embed_pair(st, vkf, tkf)
+                a, b = OH.fc_pair(st, "k", vkf, tkf) if fc else OH.embed_pair(st, vkf, tkf)
                 vk.append(F.normalize(a, dim=1))
                 tk.append(F.normalize(b, dim=1))
         v_embed, t_embed = torch.cat(vq), torch.cat(tq)
-        old = OH.losses_from_embeddings(st, v_embed, t_embed, F.normalize(v_embed, dim=1), F.normalize(t_embed, dim=1),
+        v_src, t_src = (torch.cat(vs), torch.cat(ts)) if fc else (v_embed, t_embed)
+        old = OH.losses_from_embeddings(st, v_embed, t_embed, F.normalize(v_src, dim=1), F.normalize(t_src, dim=1),
                                         torch.cat(vk), torch.cat(tk), ids, 0.1)
         sum(old.values()).backward()
         rel = lambda a, b: float((a.detach().double().cpu() - b.detach().double().cpu()).abs().max() / (b.detach().double().abs().max() + 1e-30))
         errs = {k: rel(ld[k], old[k]) for k in old}
         named = dict(head.named_parameters())
-        for k in ("v_embed_layer.weight", "t_embed_layer.weight", "loss_evaluator.projection", "t_encoder_q.gru.weight_ih_l0",
+        for k in (("v_fc_q.0.weight", "t_fc_q.2.bias") if fc else ()) + ("v_embed_layer.weight", "t_embed_layer.weight", "loss_evaluator.projection", "t_encoder_q.gru.weight_ih_l0",
                   "v_encoder_q.attnpool.c_proj.weight", "v_encoder_q.layer4.0.conv3.weight",
                   "v_encoder_q.layer3.0.conv2.weight", "v_encoder_q.layer1.0.bn2.bias", "v_encoder_q.conv1.weight"):
             errs["grad:" + k] = rel(named[k].grad, st[k].grad)
@@ -100,13 +106,15 @@ def main():
     sdr = head.state_dict()
     for name, ten in (("v_queue", sdr["v_queue"]), ("t_queue", sdr["t_queue"]), ("id_queue", sdr["id_queue"].double()),
                       ("queue_ptr", sdr["queue_ptr"].double()), ("projection.grad", head.loss_evaluator.projection.grad)):
-        mine = ten.detach().double().cpu().contiguous()
+        mine = ten.detach().double().contiguous()
+        mine = mine if dist.get_backend() == "nccl" else mine.cpu()  # RCCL moves device buffers, gloo host buffers
         parts = [torch.empty_like(mine) for _ in range(W)]
         dist.all_gather(parts, mine)
         for w in range(W):
             assert torch.equal(parts[w], parts[0]), "rank %d: %s differs between ranks 0 and %d" % (r, name, w)
     if r == 0:
         print("DP_REPLICAS_IDENTICAL")
+        print("DP_TRANSPORT backend=%s world=%d staged_bytes=%d post_bytes=%d" % (dist.get_backend(), W, red.bytes_staged, red.bytes_post))
     # ---- sharded retrieval: every rank scores its own (unevenly sized) gallery shard, lists are merged
     from textreid_amd.evaluation import similarity_topk
 

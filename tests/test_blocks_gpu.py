@@ -1,0 +1,187 @@
+"""GPU parity at the BENCHMARKED shapes with UNSTRUCTURED ReLU masks.
+
+The full-size fixtures use the `margin` fill (every ReLU all-on or all-off per channel) because a deep He-style
+network's gradients are discontinuous at fp32 resolution.  That leaves the 1-bit ReLU mask path, `mask_mode 3` and the
+fp16-split GEMM variants at bench tile shapes seeing only trivial masks.  Here ONE Bottleneck (three ReLUs: flips
+stay countable) and the stem run at B = 128 on every distinct RN50 block shape with He-style weights and post-ReLU
+style inputs - random, unstructured masks - through the model's own code path (`block_forward` / `block_backward`,
+fp16 two-plane split convolutions with producer-side amax scalars, weight gradients on the side stream), against the
+CPU oracle (`oracle/visual.py:bottleneck`, reference `m_resnet.py:54-67,198-217`) evaluated in fp64 (truth) and in
+fp32 (the reference's arithmetic):
+
+  * forward output, every weight / BatchNorm gradient, BatchNorm running statistics: flat 1e-3 of the tensor maximum;
+  * dx (the only quantity a flipped ReLU changes pointwise): q99.9 of |err| / max|ref| <= 1e-3, and its maximum bounded
+    by what the reference's OWN fp32 evaluation deviates from fp64 (x4, floor 1e-3).
+"""
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+import oracle.fill as OF  # noqa: E402
+import oracle.visual as OV  # noqa: E402
+
+TOL = 1e-3
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import textreid_amd  # noqa: F401
+
+    return torch.device("cuda")
+
+
+def _randn(shape, seed):
+    return torch.randn(shape, generator=torch.Generator().manual_seed(seed))
+
+
+def relmax(a, b):
+    a, b = torch.as_tensor(a).detach().double().cpu(), torch.as_tensor(b).detach().double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def quantile_err(a, b, q=0.999):
+    """(q-quantile, max) of |a - b| / max|b| (kthvalue: exact, any size)."""
+    a, b = torch.as_tensor(a).detach().cpu().double().reshape(-1), torch.as_tensor(b).detach().cpu().double().reshape(-1)
+    e = ((a - b).abs() / (b.abs().max() + 1e-30)).float()
+    k = max(1, int(q * e.numel()))
+    return float(e.kthvalue(k)[0]), float(e.max())
+
+
+# (name, inplanes, planes, stride, H, W): every distinct Bottleneck shape of CLIP-RN50 at 384x128 (block_plan(RN50))
+RN50_BLOCKS = [
+    ("layer1.0", 64, 64, 1, 96, 32),
+    ("layer1.1", 256, 64, 1, 96, 32),
+    ("layer2.0", 256, 128, 2, 96, 32),
+    ("layer2.1", 512, 128, 1, 48, 16),
+    ("layer3.0", 512, 256, 2, 48, 16),
+    ("layer3.1", 1024, 256, 1, 24, 8),
+    ("layer4.0", 1024, 512, 1, 24, 8),
+    ("layer4.1", 2048, 512, 1, 24, 8),
+]
+
+
+def _oracle_block(st, name, x, gout, stride, has_down, dtype):
+    s = {k: (v.to(dtype).clone() if v.dtype.is_floating_point else v.clone()) for k, v in st.items()}
+    for k in s:
+        if OV.is_param(k):
+            s[k].requires_grad_(True)
+    xr = x.to(dtype).clone().requires_grad_(True)
+    out = OV.bottleneck(s, name, xr, stride, has_down, True)
+    out.backward(gout.to(dtype))
+    return out.detach(), xr.grad, {k: v.grad for k, v in s.items() if OV.is_param(k)}, s
+
+
+@pytest.mark.parametrize("name,inpl,planes,stride,H,W", RN50_BLOCKS, ids=[b[0] for b in RN50_BLOCKS])
+def test_bottleneck_b128_unstructured_masks(gpu, name, inpl, planes, stride, H, W):
+    from textreid_amd import ops
+    from textreid_amd.backbones import m_resnet as M
+
+    B, seed = 128, 11
+    assert ops.conv_precision() == 16  # the bench's conv arithmetic
+    blk = M.Bottleneck(inpl, planes, stride)
+    has_down = blk.downsample is not None
+    shapes = {k: tuple(v.shape) for k, v in blk.state_dict().items()}
+    # oracle names follow the reference's state dict: downsample.{0,1} for the conv / BatchNorm (the module's "-1" pool has no state)
+    st = {}
+    for k, shp in shapes.items():
+        st[name + "." + k] = torch.zeros((), dtype=torch.int64) if k.endswith("num_batches_tracked") else OF.fill(name + "." + k, shp, seed)
+    blk.load_state_dict({k: st[name + "." + k].clone() for k in shapes})
+    blk = blk.to(gpu).train()
+    for m in blk.modules():
+        if isinstance(m, torch.nn.Conv2d) and m.kernel_size == (3, 3):
+            m.weight.data = m.weight.data.contiguous(memory_format=torch.channels_last)
+    # block input = a post-ReLU activation (half zeros, unstructured); upstream gradient dense
+    x = F.relu(_randn((B, inpl, H, W), seed))
+    Ho, Wo = H // stride, W // stride
+    gout = _randn((B, planes * 4, Ho, Wo), seed + 1)
+
+    xd = x.permute(0, 2, 3, 1).contiguous().to(gpu)
+    gd = gout.permute(0, 2, 3, 1).contiguous().to(gpu)
+    ar = M.ConvArith(gpu, M.weight_amax(blk))
+    ax = ops.amax(xd)
+    nbt = []
+    out, a_out, rec = M.block_forward(blk, xd, ax, ar, True, True, nbt)
+    ws = M._WgradStream(gpu)
+    G = {}
+    dx = M.block_backward(blk, rec, gd, ar, ws, G)
+    ws.join()
+    torch.cuda.synchronize()
+    assert len(nbt) == (4 if has_down else 3)
+
+    o64, dx64, g64, s64 = _oracle_block(st, name, x, gout, stride, has_down, torch.float64)
+    o32, dx32, g32, _ = _oracle_block(st, name, x, gout, stride, has_down, torch.float32)
+
+    errs = {"out": relmax(out.permute(0, 3, 1, 2), o64)}
+    named = dict(blk.named_parameters())
+    for k, p in named.items():
+        errs["grad:" + k] = relmax(G[id(p)].reshape(p.shape), g64[name + "." + k])
+    sd = blk.state_dict()
+    for k in sd:
+        if k.endswith(("running_mean", "running_var")):
+            errs["state:" + k] = relmax(sd[k], s64[name + "." + k])
+    q, mx = quantile_err(dx.permute(0, 3, 1, 2), dx64)
+    ref_q, ref_mx = quantile_err(dx32, dx64)
+    amax_err = relmax(a_out, o64.abs().max())
+    print("%s B=%d: worst flat %.1e; dx q99.9 %.1e max %.1e (oracle fp32 vs fp64: q99.9 %.1e max %.1e); amax(out) %.1e" % (
+        name, B, max(errs.values()), q, mx, ref_q, ref_mx, amax_err))
+    bad = {k: v for k, v in errs.items() if not v <= TOL}
+    assert not bad, bad
+    assert q <= TOL, (q, mx)
+    assert mx <= max(TOL, 4.0 * ref_mx), (mx, ref_mx)
+    assert amax_err <= 1e-4  # the producer-side amax scalar the NEXT block's GEMM would scale by
+
+
+def test_stem_b128_unstructured_masks(gpu):
+    """The stem at the benchmarked size: 3x3/s2 conv through im2col + GEMM, the two 32-channel 3x3 convolutions on the
+    256x32 / 128x64 fp16-split tiles, BatchNorm + ReLU with random masks, 2x2 average pool - forward, all nine
+    gradients, running statistics against the oracle (m_resnet.py:198-207)."""
+    from textreid_amd import ops
+    from textreid_amd.backbones import m_resnet as M
+
+    B, seed = 128, 12
+    spec = OV.RN50
+    m = M.ModifiedResNet(list(spec.layers), spec.output_dim, spec.heads, spec.last_stride, (spec.height, spec.in_width), spec.width)
+    keys = [k for k in m.state_dict() if k.split(".")[0] in ("conv1", "bn1", "conv2", "bn2", "conv3", "bn3")]
+    st = {k: (torch.zeros((), dtype=torch.int64) if k.endswith("num_batches_tracked") else OF.fill(k, m.state_dict()[k].shape, seed)) for k in keys}
+    m.load_state_dict({k: v.clone() for k, v in st.items()}, strict=False)
+    m = m.to(gpu).train()
+    images = _randn((B, 3, spec.height, spec.in_width), seed)
+    gout = _randn((B, spec.width, spec.height // 4, spec.in_width // 4), seed + 1)
+    ar = M.ConvArith(gpu, M.weight_amax(m))
+    nbt = []
+    x, ax, rec = M.stem_forward(m, images.to(gpu), ar, True, nbt)
+    ws = M._WgradStream(gpu)
+    G = {}
+    M.stem_backward(m, rec, gout.permute(0, 2, 3, 1).contiguous().to(gpu), ar, ws, G)
+    ws.join()
+    torch.cuda.synchronize()
+
+    def oracle(dtype):
+        s = {k: (v.to(dtype).clone() if v.dtype.is_floating_point else v.clone()) for k, v in st.items()}
+        for k in s:
+            if OV.is_param(k):
+                s[k].requires_grad_(True)
+        y = images.to(dtype)
+        y = F.relu(OV._bn(s, "bn1", F.conv2d(y, s["conv1.weight"], stride=2, padding=1), True))
+        y = F.relu(OV._bn(s, "bn2", F.conv2d(y, s["conv2.weight"], padding=1), True))
+        y = F.relu(OV._bn(s, "bn3", F.conv2d(y, s["conv3.weight"], padding=1), True))
+        y = F.avg_pool2d(y, 2)
+        y.backward(gout.to(dtype))
+        return y.detach(), s
+
+    o64, s64 = oracle(torch.float64)
+    errs = {"out": relmax(x.permute(0, 3, 1, 2), o64)}
+    named = dict(m.named_parameters())
+    for k in keys:
+        if OV.is_param(k):
+            errs["grad:" + k] = relmax(G[id(named[k])].reshape(named[k].shape), s64[k].grad)
+        elif k.endswith(("running_mean", "running_var")):
+            errs["state:" + k] = relmax(m.state_dict()[k], s64[k])
+    print("stem B=%d:" % B, {k: "%.1e" % v for k, v in errs.items()})
+    bad = {k: v for k, v in errs.items() if not v <= TOL}
+    assert not bad, bad

@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_dp_two_ranks_match_global_batch_oracle():
+def _run_ranks(world, **extra_env):
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     s = socket.socket()
@@ -23,13 +23,35 @@ def test_dp_two_ranks_match_global_batch_oracle():
     port = s.getsockname()[1]
     s.close()
     procs = []
-    for r in range(2):
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   TRID_DIST_BACKEND="gloo", OMP_NUM_THREADS="8")
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   OMP_NUM_THREADS="8", HSA_ENABLE_IPC_MODE_LEGACY="0", **extra_env)
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dp_gpu_worker.py")], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = [p.communicate(timeout=600)[0] for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o[-3000:]
     assert "DP_OK" in outs[0] and "DP_REPLICAS_IDENTICAL" in outs[0] and "DP_RETRIEVAL_OK" in outs[0], outs[0][-3000:]
-    print([ln for ln in outs[0].splitlines() if ln.startswith("DP_ERRS")])
+    print([ln for ln in outs[0].splitlines() if ln.startswith(("DP_ERRS", "DP_TRANSPORT"))])
+    return outs[0]
+
+
+@pytest.mark.parametrize("fc", ["0", "1"], ids=["FC=False", "FC=True"])
+def test_dp_two_ranks_match_global_batch_oracle(fc):
+    """(FC=True: MODEL.MOCO.FC projection heads - the packed gather then carries six embedding blocks.)"""
+    _run_ranks(2, TRID_DIST_BACKEND="gloo", TRID_TEST_FC=fc)
+
+
+def test_dp_collectives_execute_on_rccl():
+    """The SAME step with backend `nccl` (= RCCL on ROCm) in a ONE-rank group with TRID_DP_FORCE=1: the packed
+    `all_gather_into_tensor` inside the forward, the asynchronous SUM all-reduce of staged flats issued from inside
+    the image encoder's backward (`GradReducer.stage`, joined with `work.wait()` there), the bucketed post-backward
+    all-reduce and the sharded-retrieval merge all execute on RCCL's streams on this box's one GPU; results are
+    checked against the oracle exactly as in the two-rank gloo run (a one-rank SUM is the identity, so any stream-order
+    or staged-buffer-lifetime bug shows up as a wrong gradient)."""
+    out = _run_ranks(1, TRID_DIST_BACKEND="nccl", TRID_DP_FORCE="1")
+    line = [ln for ln in out.splitlines() if ln.startswith("DP_TRANSPORT")][0]
+    assert "backend=nccl" in line
+    staged = int(line.split("staged_bytes=")[1].split()[0])
+    post = int(line.split("post_bytes=")[1].split()[0])
+    assert staged > 0 and post > 0, line  # both reducer entry points really ran their collectives

@@ -88,21 +88,34 @@ def ohwi(w):
     return w.permute(0, 2, 3, 1).contiguous().reshape(w.shape[0], -1)
 
 
-@pytest.mark.parametrize("B,C,H,W,N", [(2, 16, 12, 8, 32), (3, 64, 24, 8, 64), (2, 8, 48, 16, 8), (4, 32, 10, 6, 128), (1, 128, 96, 32, 128)])
-def test_conv3x3_fwd_dgrad_wgrad(ops, B, C, H, W, N):
+def _prec_kw(ops, prec, a, b):
+    """Keyword arguments that select the GEMM arithmetic: None = the library default (bf16 x 6); 16 = the image
+    encoder's fp16 two-plane split, operands' amax scalars supplied as the model supplies them."""
+    return {} if prec is None else dict(prec=prec, aa=ops.amax(a), ba=ops.amax(b))
+
+
+# small shapes (ragged tiles, tiny channel counts) + the RN50 layer shapes at a reduced batch: stem 32->32 (256x32 tile),
+# stem 32->64 and layer1 64->64 (128x64 tile), layer2 / layer3 / layer4 (128x128 tile, K = 1152 / 2304 / 4608)
+CONV3_SHAPES = [(2, 16, 12, 8, 32), (3, 64, 24, 8, 64), (2, 8, 48, 16, 8), (4, 32, 10, 6, 128), (1, 128, 96, 32, 128),
+                (1, 32, 192, 64, 32), (1, 32, 192, 64, 64), (2, 64, 96, 32, 64), (4, 128, 48, 16, 128), (8, 256, 24, 8, 256), (6, 512, 24, 8, 512)]
+
+
+@pytest.mark.parametrize("prec", [None, 16], ids=["bf16x6", "f16x3"])
+@pytest.mark.parametrize("B,C,H,W,N", CONV3_SHAPES)
+def test_conv3x3_fwd_dgrad_wgrad(ops, B, C, H, W, N, prec):
     x, w, gy = R("cx", B, C, H, W), R("cw", N, C, 3, 3, scale=0.1), R("cg", B, N, H, W)
     xr = x.clone().requires_grad_(True)
     wr = w.clone().requires_grad_(True)
     y_ref = F.conv2d(xr, wr, padding=1)
     y_ref.backward(gy)
     xd, wd, gd = dev(nhwc(x)), dev(ohwi(w)), dev(nhwc(gy))
-    y, st = ops.conv3x3(xd, wd, stats=True)
+    y, st = ops.conv3x3(xd, wd, stats=True, **_prec_kw(ops, prec, xd, wd))
     assert rel(y.permute(0, 3, 1, 2), y_ref) < TOL
     # dgrad = conv with rotated/transposed weights
     wt = ops.weight_transpose(wd, N, 9, C, flip=True)
-    dx = ops.conv3x3(gd, wt)
+    dx = ops.conv3x3(gd, wt, **_prec_kw(ops, prec, gd, wt))
     assert rel(dx.permute(0, 3, 1, 2), xr.grad) < TOL
-    dw = ops.conv3x3_wgrad(gd, xd)
+    dw = ops.conv3x3_wgrad(gd, xd, **_prec_kw(ops, prec, gd, xd))
     assert rel(dw, ohwi(wr.grad)) < TOL
     # BN statistics partials -> finalize == batch stats
     gamma, beta = R("g", N).abs() + 0.5, R("b", N)
@@ -115,17 +128,27 @@ def test_conv3x3_fwd_dgrad_wgrad(ops, B, C, H, W, N):
     assert rel(rmd, rm) < 1e-5 and rel(rvd, rv) < 1e-5
 
 
-@pytest.mark.parametrize("B,C,H,W,N", [(2, 64, 12, 8, 256), (4, 256, 6, 2, 64), (3, 16, 24, 8, 16)])
-def test_conv1x1_all(ops, B, C, H, W, N):
+# small shapes + every distinct RN50 1x1 layer shape (K -> N) at a reduced batch
+CONV1_SHAPES = [(2, 64, 12, 8, 256), (4, 256, 6, 2, 64), (3, 16, 24, 8, 16),
+                (1, 64, 96, 32, 64), (1, 64, 96, 32, 256), (1, 256, 96, 32, 64), (2, 256, 48, 16, 512), (2, 512, 48, 16, 128),
+                (4, 512, 24, 8, 1024), (4, 1024, 24, 8, 256), (4, 1024, 24, 8, 2048), (4, 2048, 24, 8, 512)]
+
+
+@pytest.mark.parametrize("prec", [None, 16], ids=["bf16x6", "f16x3"])
+@pytest.mark.parametrize("B,C,H,W,N", CONV1_SHAPES)
+def test_conv1x1_all(ops, B, C, H, W, N, prec):
     x, w, gy = R("px", B, C, H, W), R("pw", N, C, 1, 1, scale=0.2), R("pg", B, N, H, W)
     xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
     y_ref = F.conv2d(xr, wr)
     y_ref.backward(gy)
     xd, wd, gd = dev(nhwc(x)), dev(w.reshape(N, C)), dev(nhwc(gy))
-    assert rel(ops.conv1x1(xd, wd).permute(0, 3, 1, 2), y_ref) < TOL
+    assert rel(ops.conv1x1(xd, wd, **_prec_kw(ops, prec, xd, wd)).permute(0, 3, 1, 2), y_ref) < TOL
     wt = ops.weight_transpose(wd, N, 1, C, flip=False)
-    assert rel(ops.conv1x1(gd, wt).permute(0, 3, 1, 2), xr.grad) < TOL
-    assert rel(ops.conv1x1_wgrad(gd, xd), wr.grad.reshape(N, C)) < TOL
+    assert rel(ops.conv1x1(gd, wt, **_prec_kw(ops, prec, gd, wt)).permute(0, 3, 1, 2), xr.grad) < TOL
+    # the model's data-gradient form: dy [M,N] @ w [N,C] with the weight read N-contiguous (no transposed copy)
+    dx2 = ops.matmul_nn(gd.reshape(-1, N), wd, **_prec_kw(ops, prec, gd, wd))
+    assert rel(dx2.reshape(B, H, W, C).permute(0, 3, 1, 2), xr.grad) < TOL
+    assert rel(ops.conv1x1_wgrad(gd, xd, **_prec_kw(ops, prec, gd, xd)), wr.grad.reshape(N, C)) < TOL
 
 
 def test_stem_im2col_conv(ops):
@@ -365,6 +388,42 @@ def test_fused_gru_step_matches_unfused(ops, B, H, L):
     for k in res[True][2]:
         errs["grad:" + k] = rel(res[True][2][k], res[False][2][k].cpu())
     print("fused GRU step B=%d H=%d L=%d:" % (B, H, L), {k: "%.1e" % v for k, v in errs.items()})
+    assert all(v < 2e-5 for v in errs.values()), errs
+
+
+@pytest.mark.parametrize("B,H,L", [(5, 64, 7), (16, 96, 3), (1, 32, 1), (1, 512, 9), (33, 768, 5), (130, 512, 12)])
+def test_fused_gru_step_vs_oracle(ops, B, H, L):
+    """gru_step.hip against the ORACLE's masked time loop (oracle/text.py = reference gru.py:48-82) evaluated in fp64,
+    at the sizes the golden fixture (H = 512 only) does not pin: H = 32 / 64 / 96 / 768, B = 1, batches that are not a
+    multiple of the 16-row MFMA tile; ragged lengths including 1 and L (the zero-pad-enters-the-max quirk is live
+    whenever a caption is shorter than the batch maximum).  Output and all four weight gradients, 2e-5."""
+    import oracle.text as OT
+    from textreid_amd.backbones import gru as G
+    from textreid_amd.caption import CaptionBatch
+
+    vocab = 40
+    table = R("go:table%d" % H, vocab, H, scale=0.5)
+    m = G.GRU(H, H, H, 1, 0.0, True, "clip_vit", "./", vocab_dict=table)
+    with torch.no_grad():
+        for k, p_ in m.named_parameters():
+            p_.copy_(R("go:%s%d" % (k, H), *p_.shape, scale=1.5 / H ** 0.5))
+    st = {k: p_.detach().double().clone().requires_grad_(True) for k, p_ in m.named_parameters()}
+    m = m.to("cuda")
+    lengths = OF.randint("go:len%d" % B, 1, L + 1, (B,), 3)
+    lengths[0] = L
+    if B > 1:
+        lengths[-1] = 1
+    tokens = OF.randint("go:tok%d" % B, 0, vocab, (B, L), 4)
+    gout = R("go:gout%d%d" % (B, H), B, 2 * H)
+    assert G.FUSED_GRU_STEP
+    y = m(CaptionBatch(dev(tokens), dev(lengths), max_len=L))
+    (y * dev(gout)).sum().backward()
+    yo = OT.text_forward(st, table.double(), tokens, lengths)
+    (yo * gout.double()).sum().backward()
+    errs = {"out": rel(y, yo)}
+    for k, p_ in m.named_parameters():
+        errs["grad:" + k] = rel(p_.grad, st[k].grad)
+    print("fused GRU step vs oracle B=%d H=%d L=%d:" % (B, H, L), {k: "%.1e" % v for k, v in errs.items()})
     assert all(v < 2e-5 for v in errs.values()), errs
 
 

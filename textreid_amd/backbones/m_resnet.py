@@ -114,14 +114,16 @@ class _WgradStream:
 
     _streams = {}
 
-    def run(self, fn, *tensors):
-        """fn(*tensors) on the side stream, after everything enqueued so far on main."""
+    def run(self, fn, *tensors, keep=()):
+        """fn(*tensors) on the side stream, after everything enqueued so far on main.  `keep`: further tensors the
+        side-stream kernels read through closures (the operands' amax scalars): their storage must not be recycled
+        by the main stream's allocator before the side stream is done with it either."""
         if _SERIAL_WGRAD:
             return fn(*tensors)
         ev = torch.cuda.Event()
         ev.record(self.main)
         self.side.wait_event(ev)
-        for t in tensors:
+        for t in tensors + tuple(k for k in keep if k is not None):
             t.record_stream(self.side)  # keep the operands alive for the side stream
         with torch.cuda.stream(self.side):
             out = fn(*tensors)
@@ -130,6 +132,175 @@ class _WgradStream:
 
     def join(self):
         self.main.wait_stream(self.side)
+
+
+class ConvArith:
+    """Conv arithmetic of one encoder pass.  With the fp16 two-plane split (ops.conv_precision() == 16) every GEMM
+    operand travels with its largest magnitude as a device scalar: `WA` maps id(conv weight) -> max|w| (weight_amax),
+    `slot()` hands out zeroed scalars for the amax side outputs of the BatchNorm kernels that produce activations."""
+
+    def __init__(self, device, WA):
+        self.device, self.WA = device, WA
+        self.P = 16 if WA else None
+
+    def slot(self):
+        return ops.amax_slot(self.device) if self.WA else None
+
+    def wam(self, conv):
+        return self.WA.get(id(conv.weight))
+
+
+def weight_amax(mod):
+    """{id(conv weight): device scalar max|w|} for every conv filter under `mod`, ONE multi-tensor launch (fp16-split
+    arithmetic, ops.CONV_PRECISION == 16).  The pointer table is rebuilt only when a parameter moves."""
+    convs = [m.weight for m in mod.modules() if isinstance(m, nn.Conv2d)]
+    key = tuple(w.data_ptr() for w in convs)
+    plan = getattr(mod, "_wamax_plan", None)
+    if plan is None or plan[0] != key:
+        dev = convs[0].device
+        ptrs = torch.tensor(list(key), dtype=torch.int64, device=dev)
+        sizes = torch.tensor([w.numel() for w in convs], dtype=torch.int64, device=dev)
+        plan = (key, ptrs, sizes)
+        mod._wamax_plan = plan
+    out = torch.zeros(len(convs), dtype=torch.float32, device=convs[0].device)
+    ops.call("trid_amax_multi_f32", ops._p(plan[1]), ops._p(plan[2]), len(convs), ops._p(out), ops.stream())
+    return {id(w): out[i : i + 1] for i, w in enumerate(convs)}
+
+
+def stem_forward(mod, images, ar, training, nbt):
+    """Three conv -> BatchNorm -> ReLU units + 2x2 average pool (m_resnet.py:199-207).  Returns
+    (x NHWC, its amax scalar, record for stem_backward)."""
+    B = images.shape[0]
+    P = ar.P
+    col, Ho, Wo = ops.stem_im2col(images)
+    c1 = mod.conv1.weight
+    w1p = torch.zeros(c1.shape[0], col.shape[1], device=c1.device, dtype=c1.dtype)
+    w1p[:, : c1[0].numel()] = c1.detach().reshape(c1.shape[0], -1)
+    y1, p1 = ops.conv1x1(col, w1p, stats=True) if training else (ops.conv1x1(col, w1p), None)
+    st1 = _bn_coeffs(mod.bn1, p1, y1.shape[0], training, nbt)
+    y1 = y1.view(B, Ho, Wo, -1)
+    a_a1 = ar.slot()
+    a1 = ops.bn_apply(y1, st1, relu=True, amax=a_a1)
+    w2 = _w3x3(mod.conv2)
+    kw2 = dict(prec=P, aa=a_a1, ba=ar.wam(mod.conv2))
+    y2, p2 = ops.conv3x3(a1, w2, stats=True, **kw2) if training else (ops.conv3x3(a1, w2, **kw2), None)
+    st2 = _bn_coeffs(mod.bn2, p2, B * Ho * Wo, training, nbt)
+    a_a2 = ar.slot()
+    a2 = ops.bn_apply(y2, st2, relu=True, amax=a_a2)
+    w3 = _w3x3(mod.conv3)
+    kw3 = dict(prec=P, aa=a_a2, ba=ar.wam(mod.conv3))
+    y3, p3 = ops.conv3x3(a2, w3, stats=True, **kw3) if training else (ops.conv3x3(a2, w3, **kw3), None)
+    st3 = _bn_coeffs(mod.bn3, p3, B * Ho * Wo, training, nbt)
+    ax = ar.slot()
+    x = ops.bn_apply_pool2(y3, st3, relu=True, amax=ax)
+    return x, ax, (col, y1, st1, a1, y2, st2, a2, y3, st3, a_a2, a_a1)
+
+
+def stem_backward(mod, rec, g, ar, ws, G):
+    """Backward of stem_forward: fills G[id(param)] for the stem's nine parameters (the input image needs no gradient)."""
+    col, y1, st1, a1, y2, st2, a2, y3, st3, a_a2, a_a1 = rec
+    P = ar.P
+    a_dy3 = ar.slot()
+    dy3, dg, db, _ = ops.bn_bwd(g, y3, st3, None, 1, pooled=True, amax=a_dy3)
+    G[id(mod.bn3.weight)], G[id(mod.bn3.bias)] = dg, db
+    c3o, c3i = mod.conv3.out_channels, mod.conv3.in_channels
+    w3t = ops.weight_transpose(_w3x3(mod.conv3), c3o, 9, c3i, flip=True)
+    da2 = ops.conv3x3(dy3, w3t, prec=P, aa=a_dy3, ba=ar.wam(mod.conv3))
+    G[id(mod.conv3.weight)] = _g3x3(ws.run(lambda d_, x_: ops.conv3x3_wgrad(d_, x_, prec=P, aa=a_dy3, ba=a_a2), dy3, a2, keep=(a_dy3, a_a2)), c3o, c3i)
+    a_dy2 = ar.slot()
+    dy2, dg, db, _ = ops.bn_bwd(da2, y2, st2, None, 1, amax=a_dy2)
+    G[id(mod.bn2.weight)], G[id(mod.bn2.bias)] = dg, db
+    c2o, c2i = mod.conv2.out_channels, mod.conv2.in_channels
+    w2t = ops.weight_transpose(_w3x3(mod.conv2), c2o, 9, c2i, flip=True)
+    da1 = ops.conv3x3(dy2, w2t, prec=P, aa=a_dy2, ba=ar.wam(mod.conv2))
+    G[id(mod.conv2.weight)] = _g3x3(ws.run(ops.conv3x3_wgrad, dy2, a1), c2o, c2i)
+    dy1, dg, db, _ = ops.bn_bwd(da1, y1, st1, None, 1)
+    G[id(mod.bn1.weight)], G[id(mod.bn1.bias)] = dg, db
+    dw1 = ws.run(ops.conv1x1_wgrad, dy1, col)  # [32, 28]
+    c1 = mod.conv1.weight
+    G[id(c1)] = dw1[:, : c1[0].numel()].reshape(c1.shape)
+
+
+def block_forward(blk, x, ax, ar, training, save, nbt):
+    """One Bottleneck (m_resnet.py:54-67) on NHWC activations.  x: block input, ax: its amax scalar (or None).
+    Returns (out, amax scalar of out, record for block_backward or None)."""
+    P = ar.P
+    stride = blk.stride
+    wa = blk.conv1.weight.view(blk.conv1.out_channels, -1)
+    kwa = dict(prec=P, aa=ax, ba=ar.wam(blk.conv1))
+    ya, pa = ops.conv1x1(x, wa, stats=True, **kwa) if training else (ops.conv1x1(x, wa, **kwa), None)
+    Ma = ya.numel() // ya.shape[-1]
+    sta = _bn_coeffs(blk.bn1, pa, Ma, training, nbt)
+    a_aa = ar.slot()
+    aa = ops.bn_apply(ya, sta, relu=True, amax=a_aa)
+    wb = _w3x3(blk.conv2)
+    kwb = dict(prec=P, aa=a_aa, ba=ar.wam(blk.conv2))
+    yb, pb = ops.conv3x3(aa, wb, stats=True, **kwb) if training else (ops.conv3x3(aa, wb, **kwb), None)
+    stb = _bn_coeffs(blk.bn2, pb, Ma, training, nbt)
+    a_ab = ar.slot()
+    ab = ops.bn_apply_pool2(yb, stb, relu=True, amax=a_ab) if stride > 1 else ops.bn_apply(yb, stb, relu=True, amax=a_ab)
+    wc = blk.conv3.weight.view(blk.conv3.out_channels, -1)
+    kwc = dict(prec=P, aa=a_ab, ba=ar.wam(blk.conv3))
+    yc, pc = ops.conv1x1(ab, wc, stats=True, **kwc) if training else (ops.conv1x1(ab, wc, **kwc), None)
+    Mc = yc.numel() // yc.shape[-1]
+    stc = _bn_coeffs(blk.bn3, pc, Mc, training, nbt)
+    xd = yd = std = a_xd = None
+    a_out = ar.slot()
+    if blk.downsample is not None:
+        a_xd = ar.slot() if stride > 1 else ax
+        xd = ops.bn_apply_pool2(x, None, amax=a_xd) if stride > 1 else x
+        wd = blk.downsample[1].weight.view(blk.downsample[1].out_channels, -1)
+        kwd = dict(prec=P, aa=a_xd, ba=ar.wam(blk.downsample[1]))
+        yd, pd = ops.conv1x1(xd, wd, stats=True, **kwd) if training else (ops.conv1x1(xd, wd, **kwd), None)
+        std = _bn_coeffs(blk.downsample[2], pd, Mc, training, nbt)
+        out = ops.bn_apply(yc, stc, relu=True, res=yd, res_st=std, want_mask=save, amax=a_out)
+    else:
+        out = ops.bn_apply(yc, stc, relu=True, res=x, want_mask=save, amax=a_out)
+    rec = None
+    if save:
+        out, rmask = out  # 1-bit ReLU mask of the block output for the backward pass
+        rec = (x, ya, sta, aa, yb, stb, ab, yc, stc, xd, yd, std, rmask, (ax, a_aa, a_ab, a_xd))
+    return out, a_out, rec
+
+
+def block_backward(blk, rec, g, ar, ws, G):
+    """Backward of block_forward.  g: dL/d(out).  Fills G[id(param)] for the block's parameters (weight gradients on
+    the side stream `ws`) and returns dL/d(x)."""
+    x, ya, sta, aa, yb, stb, ab, yc, stc, xd, yd, std, rmask, (ax, a_aa, a_ab, a_xd) = rec
+    P = ar.P
+    stride = blk.stride
+    has_down = blk.downsample is not None
+    a_dyc = ar.slot()
+    dyc, dg, db, dres = ops.bn_bwd(g, yc, stc, None, 3, act=rmask, want_dres=not has_down, amax=a_dyc)
+    G[id(blk.bn3.weight)], G[id(blk.bn3.bias)] = dg, db
+    if has_down:
+        a_dyd = ar.slot()
+        dyd, dg, db, _ = ops.bn_bwd(g, yd, std, None, 3, act=rmask, amax=a_dyd)
+        G[id(blk.downsample[2].weight)], G[id(blk.downsample[2].bias)] = dg, db
+    wc = blk.conv3.weight.view(blk.conv3.out_channels, -1)
+    dab = ops.matmul_nn(dyc.view(-1, dyc.shape[-1]), wc, prec=P, aa=a_dyc, ba=ar.wam(blk.conv3)).view(ab.shape)
+    G[id(blk.conv3.weight)] = ws.run(lambda d_, x_: ops.conv1x1_wgrad(d_, x_, prec=P, aa=a_dyc, ba=a_ab), dyc, ab, keep=(a_dyc, a_ab)).view_as(blk.conv3.weight)
+    a_dyb = ar.slot()
+    dyb, dg, db, _ = ops.bn_bwd(dab, yb, stb, None, 1, pooled=stride > 1, amax=a_dyb)
+    G[id(blk.bn2.weight)], G[id(blk.bn2.bias)] = dg, db
+    planes = blk.conv2.out_channels
+    wbt = ops.weight_transpose(_w3x3(blk.conv2), planes, 9, planes, flip=True)
+    daa = ops.conv3x3(dyb, wbt, prec=P, aa=a_dyb, ba=ar.wam(blk.conv2))
+    G[id(blk.conv2.weight)] = _g3x3(ws.run(lambda d_, x_: ops.conv3x3_wgrad(d_, x_, prec=P, aa=a_dyb, ba=a_aa), dyb, aa, keep=(a_dyb, a_aa)), planes, planes)
+    a_dya = ar.slot()
+    dya, dg, db, _ = ops.bn_bwd(daa, ya, sta, None, 1, amax=a_dya)
+    G[id(blk.bn1.weight)], G[id(blk.bn1.bias)] = dg, db
+    wa = blk.conv1.weight.view(blk.conv1.out_channels, -1)
+    if has_down:
+        wd = blk.downsample[1].weight.view(blk.downsample[1].out_channels, -1)
+        dxd = ops.matmul_nn(dyd.view(-1, dyd.shape[-1]), wd, prec=P, aa=a_dyd, ba=ar.wam(blk.downsample[1])).view(xd.shape)
+        G[id(blk.downsample[1].weight)] = ws.run(lambda d_, x_: ops.conv1x1_wgrad(d_, x_, prec=P, aa=a_dyd, ba=a_xd), dyd, xd, keep=(a_dyd, a_xd)).view_as(blk.downsample[1].weight)
+        dx = ops.avgpool2_bwd(dxd) if stride > 1 else dxd
+    else:
+        dx = dres
+    ops.matmul_nn(dya.view(-1, dya.shape[-1]), wa, out=dx.view(-1, dx.shape[-1]), accumulate=True, prec=P, aa=a_dya, ba=ar.wam(blk.conv1))
+    G[id(blk.conv1.weight)] = ws.run(lambda d_, x_: ops.conv1x1_wgrad(d_, x_, prec=P, aa=a_dya, ba=ax), dya, x, keep=(a_dya, ax)).view_as(blk.conv1.weight)
+    return dx
 
 
 class _EncoderFn(torch.autograd.Function):
@@ -229,7 +400,9 @@ class ModifiedResNet(nn.Module):
         am = ops.amax if P else (lambda t: None)
         # the folded filters (and their magnitudes) depend on the parameters only: kept across calls until a parameter
         # or BatchNorm buffer is replaced or modified in place (an inference run encodes thousands of batches)
-        key = (P, images.device) + tuple((t.data_ptr(), t._version) for t in list(self.parameters()) + list(self.buffers()))
+        # (ops.parameter_generation(): the library's own writers - FusedAdam, EMA, running statistics - write through
+        # raw pointers and do not bump torch's _version)
+        key = (P, images.device, ops.parameter_generation()) + tuple((t.data_ptr(), t._version) for t in list(self.parameters()) + list(self.buffers()))
         cache = getattr(self, "_folded_cache", None)
         fresh = cache is None or cache[0] != key
         if fresh:
@@ -277,59 +450,20 @@ class ModifiedResNet(nn.Module):
         return feat
 
     def _weight_amax(self):
-        """{id(conv weight): device scalar max|w|} for every conv filter, ONE multi-tensor launch (fp16-split
-        arithmetic, ops.CONV_PRECISION == 16).  The pointer table is rebuilt only when a parameter moves."""
-        convs = [m.weight for m in self.modules() if isinstance(m, nn.Conv2d)]
-        key = tuple(w.data_ptr() for w in convs)
-        plan = getattr(self, "_wamax_plan", None)
-        if plan is None or plan[0] != key:
-            dev = convs[0].device
-            ptrs = torch.tensor(list(key), dtype=torch.int64, device=dev)
-            sizes = torch.tensor([w.numel() for w in convs], dtype=torch.int64, device=dev)
-            plan = (key, ptrs, sizes)
-            self._wamax_plan = plan
-        out = torch.zeros(len(convs), dtype=torch.float32, device=convs[0].device)
-        ops.call("trid_amax_multi_f32", ops._p(plan[1]), ops._p(plan[2]), len(convs), ops._p(out), ops.stream())
-        return {id(w): out[i : i + 1] for i, w in enumerate(convs)}
+        return weight_amax(self)
 
     def _run_forward(self, images, save):
         training = self.training
         B = images.shape[0]
         S = {"B": B} if save else None
         # fp16-split conv arithmetic: every GEMM operand comes with its largest magnitude as a device scalar
-        P = ops.conv_precision()
-        f16 = P == 16
-        WA = self._weight_amax() if f16 else {}
-        slot = (lambda: ops.amax_slot(images.device)) if f16 else (lambda: None)  # amax side outputs of the producers
-        wam = lambda conv: WA.get(id(conv.weight))
-        if not f16:
-            P = None
-        # ---- stem (m_resnet.py:199-207)
-        col, Ho, Wo = ops.stem_im2col(images)
-        c1 = self.conv1.weight
-        w1p = torch.zeros(c1.shape[0], col.shape[1], device=c1.device, dtype=c1.dtype)
-        w1p[:, : c1[0].numel()] = c1.detach().reshape(c1.shape[0], -1)
-        y1, p1 = ops.conv1x1(col, w1p, stats=True) if training else (ops.conv1x1(col, w1p), None)
+        ar = ConvArith(images.device, weight_amax(self) if ops.conv_precision() == 16 else {})
         nbt = []  # num_batches_tracked buffers, incremented together at the end of the pass
-        st1 = _bn_coeffs(self.bn1, p1, y1.shape[0], training, nbt)
-        y1 = y1.view(B, Ho, Wo, -1)
-        a_a1 = slot()
-        a1 = ops.bn_apply(y1, st1, relu=True, amax=a_a1)
-        w2 = _w3x3(self.conv2)
-        kw2 = dict(prec=P, aa=a_a1, ba=wam(self.conv2))
-        y2, p2 = ops.conv3x3(a1, w2, stats=True, **kw2) if training else (ops.conv3x3(a1, w2, **kw2), None)
-        st2 = _bn_coeffs(self.bn2, p2, B * Ho * Wo, training, nbt)
-        a_a2 = slot()
-        a2 = ops.bn_apply(y2, st2, relu=True, amax=a_a2)
-        w3 = _w3x3(self.conv3)
-        kw3 = dict(prec=P, aa=a_a2, ba=wam(self.conv3))
-        y3, p3 = ops.conv3x3(a2, w3, stats=True, **kw3) if training else (ops.conv3x3(a2, w3, **kw3), None)
-        st3 = _bn_coeffs(self.bn3, p3, B * Ho * Wo, training, nbt)
-        ax = slot()
-        x = ops.bn_apply_pool2(y3, st3, relu=True, amax=ax)
+        # ---- stem (m_resnet.py:199-207)
+        x, ax, srec = stem_forward(self, images, ar, training, nbt)
         if save:
-            S["stem"] = (col, y1, st1, a1, y2, st2, a2, y3, st3, a_a2, a_a1)
-            S["wamax"] = WA
+            S["stem"] = srec
+            S["wamax"] = ar.WA
         # ---- residual layers (m_resnet.py:54-67)
         if save:
             S["blocks"] = []
@@ -339,45 +473,11 @@ class ModifiedResNet(nn.Module):
             names = {id(blk): "layer%d.%d" % (li + 1, bi) for li, layer in enumerate((self.layer1, self.layer2, self.layer3, self.layer4))
                      for bi, blk in enumerate(layer)}
         for blk in self.blocks():
-            stride = blk.stride
-            wa = blk.conv1.weight.view(blk.conv1.out_channels, -1)
-            kwa = dict(prec=P, aa=ax, ba=wam(blk.conv1))
-            ya, pa = ops.conv1x1(x, wa, stats=True, **kwa) if training else (ops.conv1x1(x, wa, **kwa), None)
-            Ma = ya.numel() // ya.shape[-1]
-            sta = _bn_coeffs(blk.bn1, pa, Ma, training, nbt)
-            a_aa = slot()
-            aa = ops.bn_apply(ya, sta, relu=True, amax=a_aa)
-            wb = _w3x3(blk.conv2)
-            kwb = dict(prec=P, aa=a_aa, ba=wam(blk.conv2))
-            yb, pb = ops.conv3x3(aa, wb, stats=True, **kwb) if training else (ops.conv3x3(aa, wb, **kwb), None)
-            stb = _bn_coeffs(blk.bn2, pb, Ma, training, nbt)
-            a_ab = slot()
-            ab = ops.bn_apply_pool2(yb, stb, relu=True, amax=a_ab) if stride > 1 else ops.bn_apply(yb, stb, relu=True, amax=a_ab)
-            wc = blk.conv3.weight.view(blk.conv3.out_channels, -1)
-            kwc = dict(prec=P, aa=a_ab, ba=wam(blk.conv3))
-            yc, pc = ops.conv1x1(ab, wc, stats=True, **kwc) if training else (ops.conv1x1(ab, wc, **kwc), None)
-            Mc = yc.numel() // yc.shape[-1]
-            stc = _bn_coeffs(blk.bn3, pc, Mc, training, nbt)
-            xd = yd = std = a_xd = None
-            if blk.downsample is not None:
-                a_xd = slot() if stride > 1 else ax
-                xd = ops.bn_apply_pool2(x, None, amax=a_xd) if stride > 1 else x
-                wd = blk.downsample[1].weight.view(blk.downsample[1].out_channels, -1)
-                kwd = dict(prec=P, aa=a_xd, ba=wam(blk.downsample[1]))
-                yd, pd = ops.conv1x1(xd, wd, stats=True, **kwd) if training else (ops.conv1x1(xd, wd, **kwd), None)
-                std = _bn_coeffs(blk.downsample[2], pd, Mc, training, nbt)
-                a_out = slot()
-                out = ops.bn_apply(yc, stc, relu=True, res=yd, res_st=std, want_mask=save, amax=a_out)
-            else:
-                a_out = slot()
-                out = ops.bn_apply(yc, stc, relu=True, res=x, want_mask=save, amax=a_out)
+            x, ax, rec = block_forward(blk, x, ax, ar, training, save, nbt)
             if save:
-                out, rmask = out  # 1-bit ReLU mask of the block output for the backward pass
-                S["blocks"].append((x, ya, sta, aa, yb, stb, ab, yc, stc, xd, yd, std, rmask, (ax, a_aa, a_ab, a_xd)))
-            x = out
-            ax = a_out
+                S["blocks"].append(rec)
             if taps is not None:
-                taps[names[id(blk)]] = out
+                taps[names[id(blk)]] = x
         if nbt:
             torch._foreach_add_(nbt, 1)  # one launch instead of one per BatchNorm layer
         # ---- attention pool (m_resnet.py:103-135), token-0 query only
@@ -480,12 +580,8 @@ class ModifiedResNet(nn.Module):
 
     def _run_backward(self, S, gout):
         G = {}
-        B = S["B"]
         ws = _WgradStream(gout.device)
-        WA = S.get("wamax", {})
-        P = 16 if WA else None  # the forward's conv arithmetic (its weight / activation amax scalars are reused here)
-        slot = (lambda: ops.amax_slot(gout.device)) if WA else (lambda: None)
-        wam = lambda conv: WA.get(id(conv.weight))
+        ar = ConvArith(gout.device, S.get("wamax", {}))  # the forward's conv arithmetic (its weight / activation amax scalars are reused here)
         g = self._attnpool_backward(S["attn"], gout, G)
         S["attn"] = None
         blocks = list(self.blocks())
@@ -505,66 +601,13 @@ class ModifiedResNet(nn.Module):
         first_of_layer = {id(layer[0]) for layer in (self.layer1, self.layer2, self.layer3, self.layer4)}
         dbg = getattr(self, "_debug_grads", None)
         for blk, rec in zip(reversed(blocks), reversed(S["blocks"])):
-            x, ya, sta, aa, yb, stb, ab, yc, stc, xd, yd, std, rmask, (ax, a_aa, a_ab, a_xd) = rec
             if dbg is not None:
                 dbg.append(g)
-            stride = blk.stride
-            has_down = blk.downsample is not None
-            a_dyc = slot()
-            dyc, dg, db, dres = ops.bn_bwd(g, yc, stc, None, 3, act=rmask, want_dres=not has_down, amax=a_dyc)
-            G[id(blk.bn3.weight)], G[id(blk.bn3.bias)] = dg, db
-            if has_down:
-                a_dyd = slot()
-                dyd, dg, db, _ = ops.bn_bwd(g, yd, std, None, 3, act=rmask, amax=a_dyd)
-                G[id(blk.downsample[2].weight)], G[id(blk.downsample[2].bias)] = dg, db
-            wc = blk.conv3.weight.view(blk.conv3.out_channels, -1)
-            dab = ops.matmul_nn(dyc.view(-1, dyc.shape[-1]), wc, prec=P, aa=a_dyc, ba=wam(blk.conv3)).view(ab.shape)
-            G[id(blk.conv3.weight)] = ws.run(lambda d_, x_: ops.conv1x1_wgrad(d_, x_, prec=P, aa=a_dyc, ba=a_ab), dyc, ab).view_as(blk.conv3.weight)
-            a_dyb = slot()
-            dyb, dg, db, _ = ops.bn_bwd(dab, yb, stb, None, 1, pooled=stride > 1, amax=a_dyb)
-            G[id(blk.bn2.weight)], G[id(blk.bn2.bias)] = dg, db
-            planes = blk.conv2.out_channels
-            wbt = ops.weight_transpose(_w3x3(blk.conv2), planes, 9, planes, flip=True)
-            daa = ops.conv3x3(dyb, wbt, prec=P, aa=a_dyb, ba=wam(blk.conv2))
-            G[id(blk.conv2.weight)] = _g3x3(ws.run(lambda d_, x_: ops.conv3x3_wgrad(d_, x_, prec=P, aa=a_dyb, ba=a_aa), dyb, aa), planes, planes)
-            a_dya = slot()
-            dya, dg, db, _ = ops.bn_bwd(daa, ya, sta, None, 1, amax=a_dya)
-            G[id(blk.bn1.weight)], G[id(blk.bn1.bias)] = dg, db
-            wa = blk.conv1.weight.view(blk.conv1.out_channels, -1)
-            if has_down:
-                wd = blk.downsample[1].weight.view(blk.downsample[1].out_channels, -1)
-                dxd = ops.matmul_nn(dyd.view(-1, dyd.shape[-1]), wd, prec=P, aa=a_dyd, ba=wam(blk.downsample[1])).view(xd.shape)
-                G[id(blk.downsample[1].weight)] = ws.run(lambda d_, x_: ops.conv1x1_wgrad(d_, x_, prec=P, aa=a_dyd, ba=a_xd), dyd, xd).view_as(blk.downsample[1].weight)
-                dx = ops.avgpool2_bwd(dxd) if stride > 1 else dxd
-            else:
-                dx = dres
-            ops.matmul_nn(dya.view(-1, dya.shape[-1]), wa, out=dx.view(-1, dx.shape[-1]), accumulate=True, prec=P, aa=a_dya, ba=wam(blk.conv1))
-            G[id(blk.conv1.weight)] = ws.run(lambda d_, x_: ops.conv1x1_wgrad(d_, x_, prec=P, aa=a_dya, ba=ax), dya, x).view_as(blk.conv1.weight)
-            g = dx
+            g = block_backward(blk, rec, g, ar, ws, G)
             if id(blk) in first_of_layer:  # a whole residual layer (and, the first time, the attention pool) is done
                 stage_ready()
         S["blocks"] = None
-        # ---- stem
-        col, y1, st1, a1, y2, st2, a2, y3, st3, a_a2, a_a1 = S["stem"]
-        a_dy3 = slot()
-        dy3, dg, db, _ = ops.bn_bwd(g, y3, st3, None, 1, pooled=True, amax=a_dy3)
-        G[id(self.bn3.weight)], G[id(self.bn3.bias)] = dg, db
-        c3o, c3i = self.conv3.out_channels, self.conv3.in_channels
-        w3t = ops.weight_transpose(_w3x3(self.conv3), c3o, 9, c3i, flip=True)
-        da2 = ops.conv3x3(dy3, w3t, prec=P, aa=a_dy3, ba=wam(self.conv3))
-        G[id(self.conv3.weight)] = _g3x3(ws.run(lambda d_, x_: ops.conv3x3_wgrad(d_, x_, prec=P, aa=a_dy3, ba=a_a2), dy3, a2), c3o, c3i)
-        a_dy2 = slot()
-        dy2, dg, db, _ = ops.bn_bwd(da2, y2, st2, None, 1, amax=a_dy2)
-        G[id(self.bn2.weight)], G[id(self.bn2.bias)] = dg, db
-        c2o, c2i = self.conv2.out_channels, self.conv2.in_channels
-        w2t = ops.weight_transpose(_w3x3(self.conv2), c2o, 9, c2i, flip=True)
-        da1 = ops.conv3x3(dy2, w2t, prec=P, aa=a_dy2, ba=wam(self.conv2))
-        G[id(self.conv2.weight)] = _g3x3(ws.run(ops.conv3x3_wgrad, dy2, a1), c2o, c2i)
-        dy1, dg, db, _ = ops.bn_bwd(da1, y1, st1, None, 1)
-        G[id(self.bn1.weight)], G[id(self.bn1.bias)] = dg, db
-        dw1 = ws.run(ops.conv1x1_wgrad, dy1, col)  # [32, 28]
-        c1 = self.conv1.weight
-        G[id(c1)] = dw1[:, : c1[0].numel()].reshape(c1.shape)
+        stem_backward(self, S["stem"], g, ar, ws, G)
         ws.join()
         if sync is not None:
             stage_ready()  # the stem

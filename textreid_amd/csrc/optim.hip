@@ -49,7 +49,8 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(const uint64_t* __restr
                                                          const float* __restrict__ wds,
                                                          const int32_t* __restrict__ chunk_tensor,
                                                          const int64_t* __restrict__ chunk_off, int chunk_len, float b1,
-                                                         float b2, float eps, float bc1, float bc2, int decoupled) {
+                                                         float b2, float eps, const float* __restrict__ bc1s,
+                                                         const float* __restrict__ bc2s, int decoupled) {
     const int c = blockIdx.x;
     const int ti = chunk_tensor[c];
     const long long off = chunk_off[c];
@@ -60,6 +61,7 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(const uint64_t* __restr
     long long n = sizes[ti] - off;
     if (n > chunk_len) n = chunk_len;
     const float lr = lrs[ti], wd = wds[ti];
+    const float bc1 = bc1s[ti], bc2 = bc2s[ti];  // per tensor: torch.optim.Adam keeps one step count per parameter
     const float step = lr / bc1;       // lr / (1 - b1^t)
     const float inv_bc2s = 1.f / bc2;  // 1 / sqrt(1 - b2^t)
     for (long long i = threadIdx.x; i < n; i += 256) {
@@ -112,11 +114,11 @@ extern "C" int trid_ema_multi_f32(const uint64_t* k_ptrs, const uint64_t* q_ptrs
 extern "C" int trid_adam_multi_f32(const uint64_t* p_ptrs, const uint64_t* g_ptrs, const uint64_t* m_ptrs,
                                    const uint64_t* v_ptrs, const int64_t* sizes, const float* lrs, const float* wds,
                                    const int32_t* chunk_tensor, const int64_t* chunk_off, int n_chunks, int chunk_len,
-                                   float beta1, float beta2, float eps, float bias_c1, float bias_c2, int decoupled,
-                                   void* stream) {
-    TRID_REQUIRE(p_ptrs && g_ptrs && m_ptrs && v_ptrs && sizes && lrs && wds && chunk_tensor && chunk_off,
+                                   float beta1, float beta2, float eps, const float* bias_c1, const float* bias_c2,
+                                   int decoupled, void* stream) {
+    TRID_REQUIRE(p_ptrs && g_ptrs && m_ptrs && v_ptrs && sizes && lrs && wds && chunk_tensor && chunk_off && bias_c1 && bias_c2,
                  "trid_adam_multi_f32: null pointer");
-    TRID_REQUIRE(n_chunks > 0 && chunk_len > 0 && bias_c1 > 0.f && bias_c2 > 0.f, "trid_adam_multi_f32: bad arguments");
+    TRID_REQUIRE(n_chunks > 0 && chunk_len > 0, "trid_adam_multi_f32: bad arguments");
     hipLaunchKernelGGL(adam_multi_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, p_ptrs, g_ptrs, m_ptrs, v_ptrs,
                        sizes, lrs, wds, chunk_tensor, chunk_off, chunk_len, beta1, beta2, eps, bias_c1, bias_c2, decoupled);
     return check_launch("trid_adam_multi_f32");

@@ -25,7 +25,7 @@ import torch.nn as nn
 
 from ... import losses, ops
 from ...caption import CaptionBatch
-from ...parallel import gather_embeddings, world_size
+from ...parallel import dp_active, gather_embeddings
 from .loss import make_loss_evaluator
 
 EMA_CHUNK = 65536
@@ -128,6 +128,7 @@ class MoCoHead(nn.Module):
         pl = self._ema_plan
         ops.call("trid_ema_multi_f32", ops._p(pl.k_ptrs), ops._p(pl.q_ptrs), ops._p(pl.sizes), ops._p(pl.chunk_tensor),
                  ops._p(pl.chunk_off), pl.n_chunks, EMA_CHUNK, float(self.m), 1.0 - float(self.m), ops.stream())
+        ops.note_parameter_write()  # raw-pointer write: torch's tensor._version does not move
 
     @torch.no_grad()
     def _dequeue_and_enqueue(self, v_keys, t_keys, id_keys):
@@ -208,12 +209,15 @@ class MoCoHead(nn.Module):
                     v_embed_k = losses.l2_normalize(losses.linear(vk_feat, self.v_embed_layer.weight, self.v_embed_layer.bias))
                     t_embed_k = losses.l2_normalize(losses.linear(tk_feat, self.t_embed_layer.weight, self.t_embed_layer.bias))
             if self.fc:
-                if world_size() > 1:
-                    raise NotImplementedError("MODEL.MOCO.FC=True under data parallelism: the packed gather carries one query embedding per modality")
-                v_embed_q = losses.l2_normalize(losses.mlp(v_feat, self.v_fc_q))  # head.py:118-124
-                t_embed_q = losses.l2_normalize(losses.mlp(t_feat, self.t_fc_q))
+                v_src, t_src = losses.mlp(v_feat, self.v_fc_q), losses.mlp(t_feat, self.t_fc_q)  # head.py:118-124
+                if dp_active():
+                    # the packed gather carries the two projection-head query embeddings as well (six blocks + ids)
+                    v_embed, t_embed, v_embed_k, t_embed_k, id_q, v_src, t_src = gather_embeddings(
+                        v_embed, t_embed, v_embed_k, t_embed_k, id_q, extra=(v_src, t_src))
+                v_embed_q = losses.l2_normalize(v_src)
+                t_embed_q = losses.l2_normalize(t_src)
             else:
-                if world_size() > 1:
+                if dp_active():
                     # one packed RCCL all-gather; every rank then evaluates the GLOBAL losses
                     v_embed, t_embed, v_embed_k, t_embed_k, id_q = gather_embeddings(v_embed, t_embed, v_embed_k, t_embed_k, id_q)
                 v_embed_q = losses.l2_normalize(v_embed)

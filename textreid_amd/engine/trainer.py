@@ -3,15 +3,16 @@ same op order per step -- model(images, captions) -> sum(loss_dict) -> zero_grad
 backward -> step -- per-epoch scheduler.step(), evaluation every EVALUATE_PERIOD
 epochs with rerank=False, best / periodic checkpoints.  Differences: gradients of
 pre-gather parameters are SUM-reduced over RCCL by ``GradReducer`` (the reference's
-DDP path crashes), and logging accumulates the per-step losses ON DEVICE and reads their
-mean every ``log_period`` steps instead of forcing a device sync every step."""
+DDP path crashes), and logging keeps the per-step losses ON DEVICE and reads them back once every
+``log_period`` steps (one host sync per period instead of one per loss per step); the meters still receive every
+step's value, in order, as ``trainer.py:92-93`` feeds them."""
 
 import logging
 import time
 
 import torch
 
-from ..parallel import GradReducer, world_size
+from ..parallel import GradReducer, dp_active, world_size
 from .inference import inference
 
 
@@ -20,7 +21,7 @@ def train_step(model, optimizer, images, captions, reducer=None, pre_gather=None
     losses = sum(loss for loss in loss_dict.values())
     optimizer.zero_grad()
     losses.backward()
-    if reducer is not None and world_size() > 1:
+    if reducer is not None and dp_active():
         reducer.reduce(pre_gather)
         reducer.wait()
     optimizer.step()
@@ -34,10 +35,20 @@ def do_train(model, data_loader, data_loader_val, optimizer, scheduler, checkpoi
     max_epoch, epoch, iteration = arguments["max_epoch"], arguments["epoch"], arguments["iteration"]
     reducer = GradReducer()
     pre_gather = [p for n, p in model.named_parameters() if p.requires_grad and "loss_evaluator" not in n][::-1]
-    if world_size() > 1 and hasattr(getattr(model, "embed_model", None), "v_encoder_q"):
+    if dp_active() and hasattr(getattr(model, "embed_model", None), "v_encoder_q"):
         model.embed_model.v_encoder_q.grad_sync = reducer  # conv gradients all-reduced from inside backward
     best_top1 = 0.0
-    running, n_running = None, 0
+    pending, keys = [], None  # per-step loss vectors still on the device
+
+    def flush_meters():
+        """One host read for all pending steps; the meters see every step's value (median / windowed average over
+        step values, as in the reference)."""
+        if not pending:
+            return
+        for row in torch.stack(pending).tolist():
+            meters.update(loss=row[0], **{k: m for k, m in zip(keys, row[1:])})
+        pending.clear()
+
     start = time.time()
     while epoch < max_epoch:
         epoch += 1
@@ -53,15 +64,12 @@ def do_train(model, data_loader, data_loader_val, optimizer, scheduler, checkpoi
             captions = captions.to(device) if hasattr(captions, "to") else [c.to(device) for c in captions]
             loss_dict, losses = train_step(model, optimizer, images, captions, reducer, pre_gather)
             if meters is not None:
-                # every step counts (trainer.py:92-93 updates the meters per step): summed on device, one read per period
+                # every step counts (trainer.py:92-93 updates the meters per step): kept on device, one read per period
                 with torch.no_grad():
-                    vals = torch.stack([losses.detach()] + [v.detach() for v in loss_dict.values()])
-                    running = vals if running is None else running + vals
-                    n_running += 1
+                    keys = list(loss_dict.keys())
+                    pending.append(torch.stack([losses.detach()] + [v.detach() for v in loss_dict.values()]))
                 if iteration % log_period == 0:
-                    mean = (running / n_running).tolist()  # the period's only host read
-                    meters.update(loss=mean[0], **{k: m for k, m in zip(loss_dict.keys(), mean[1:])})
-                    running, n_running = None, 0
+                    flush_meters()  # the period's only host read
                     logger.info("epoch [%d][%d/%d] %s lr: %.6f", epoch, step, len(data_loader), str(meters),
                                 optimizer.param_groups[-1]["lr"])
         scheduler.step()
@@ -75,4 +83,6 @@ def do_train(model, data_loader, data_loader_val, optimizer, scheduler, checkpoi
                     checkpointer.save("best", **arguments)
         if checkpointer is not None and epoch % checkpoint_period == 0:
             checkpointer.save("epoch_{:d}".format(epoch), **arguments)
+    if meters is not None:
+        flush_meters()  # trailing partial period
     logger.info("Total training time: %.1fs", time.time() - start)

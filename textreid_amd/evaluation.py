@@ -97,14 +97,17 @@ def similarity_topk(text_embed, image_embed, k=10, normalize=True):
     idx = torch.empty(Q, k, dtype=torch.int64, device=q.device)
     ws = ops.empty((ops.L.load().trid_topk_ws_floats(Q, G, k),), q)
     offset = 0
-    if W > 1:
+    from .parallel import dp_active
+
+    dp = dp_active()  # more than one rank (or a forced one-rank group: the RCCL transport test)
+    if dp:
         from .parallel import all_gather_rows
 
         sizes = all_gather_rows(torch.tensor([G], dtype=torch.int64, device=q.device))
         offset = int(sizes[: dist_rank()].sum())
     prec, qa, ga = _sim_precision(q, g)
     call("trid_sim_topk_f32", _p(q), _p(g), _p(vals), _p(idx), Q, G, C, k, offset, prec, _p(qa), _p(ga), _p(ws), stream())
-    if W == 1:
+    if not dp:
         return vals, idx
     # per-shard lists -> every rank: [W*Q, k] rank-major, then one row top-k over the W*k candidates
     av = all_gather_rows(vals).view(W, Q, k)

@@ -43,6 +43,21 @@ def stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+# Generation counter of raw-pointer parameter / buffer writes.  The library's own writers (FusedAdam.step, the EMA
+# kernel, the running-statistics update of bn_finalize) go through device pointers, so torch's `tensor._version`
+# does not move; anything cached as a function of parameter VALUES (the eval path's BatchNorm-folded filters) keys
+# on this counter as well.
+_param_generation = [0]
+
+
+def note_parameter_write():
+    _param_generation[0] += 1
+
+
+def parameter_generation():
+    return _param_generation[0]
+
+
 # Optional live profiling hook (bench.py): when PROFILE is a dict with a "match" function
 # (kernel key -> label or None), every labelled GEMM launch is bracketed by events on the launch stream.
 PROFILE = None
@@ -307,6 +322,8 @@ def bn_finalize(partials, M, gamma, beta, running_mean, running_var, momentum=BN
     call("trid_bn_finalize_f32", _p(partials), partials.shape[0], STATS_ROWS, M, C, _p(gamma), _p(beta),
          _p(running_mean), _p(running_var), momentum, eps, _p(st.mean), _p(st.invstd), _p(st.scale), _p(st.shift),
          stream())
+    if running_mean is not None:
+        note_parameter_write()
     return st
 
 

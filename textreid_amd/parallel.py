@@ -12,12 +12,23 @@ Gradients of pre-gather parameters are then SUM-reduced across ranks
 identical on every rank and are not reduced.  SURVEY.md section 8e.
 """
 
+import os
+
 import torch
 import torch.distributed as dist
 
 
 def world_size():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def dp_active():
+    """True when the data-parallel exchange steps (embedding all-gather, gradient all-reduce) run: a process group
+    with more than one rank - or, with TRID_DP_FORCE=1, ANY initialised process group, so that a one-rank `nccl`
+    group drives every RCCL call of the step on a single-GPU box (tests/test_dp_gpu.py)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or os.environ.get("TRID_DP_FORCE", "0") == "1"
 
 
 def rank():
@@ -69,18 +80,21 @@ class _GatherRows(torch.autograd.Function):
         return g[r * ctx.rows : (r + 1) * ctx.rows].contiguous()
 
 
-def gather_embeddings(v_embed, t_embed, v_key, t_key, ids):
-    """Packed all-gather of the four [B,C] embedding blocks and the ids.
-    Gradients flow to v_embed / t_embed only (keys are detached)."""
+def gather_embeddings(v_embed, t_embed, v_key, t_key, ids, extra=()):
+    """Packed all-gather of the four [B,C] embedding blocks and the ids (+ `extra`: further differentiable [B,C]
+    blocks - with MODEL.MOCO.FC the two projection-head query embeddings, head.py:117-124).
+    Gradients flow to v_embed / t_embed / extra only (keys are detached).
+    Returns (v, t, v_key, t_key, ids[, *extra]) of the GLOBAL batch, rank-major."""
     B, C = v_embed.shape
     # ids travel as their own BITS: an int64 is two 32-bit lanes of the fp32 payload (a collective only moves
     # bytes), exact for any id - an fp32 VALUE would be exact only below 2^24
     id_lanes = ids.long().contiguous().view(B, 1).view(torch.float32)  # [B, 2]
-    packed = torch.cat([v_embed, t_embed, v_key.detach(), t_key.detach(), id_lanes], dim=1)
+    packed = torch.cat([v_embed, t_embed, v_key.detach(), t_key.detach(), id_lanes] + list(extra), dim=1)
     g = _GatherRows.apply(packed)
     v, t, vk, tk = g[:, :C], g[:, C : 2 * C], g[:, 2 * C : 3 * C].detach(), g[:, 3 * C : 4 * C].detach()
     gid = g[:, 4 * C : 4 * C + 2].detach().contiguous().view(torch.int64).view(-1)
-    return v.contiguous(), t.contiguous(), vk.contiguous(), tk.contiguous(), gid
+    more = tuple(g[:, 4 * C + 2 + i * C : 4 * C + 2 + (i + 1) * C].contiguous() for i in range(len(extra)))
+    return (v.contiguous(), t.contiguous(), vk.contiguous(), tk.contiguous(), gid) + more
 
 
 class GradReducer:
@@ -128,8 +142,8 @@ class GradReducer:
     # ---- in-backward staging: the image encoder's backward hands over each residual stage's gradients
     # as soon as they are final, so their all-reduce runs under the backward of the earlier stages
     def stage(self, params, grads):
-        """Start the SUM all-reduce of `grads` (gradients of `params`, same order).  No-op at world size 1."""
-        if world_size() == 1 or not grads:
+        """Start the SUM all-reduce of `grads` (gradients of `params`, same order).  No-op without data parallelism."""
+        if not dp_active() or not grads:
             return
         flats, layouts = [], []
         for g in grads:
@@ -170,7 +184,7 @@ class GradReducer:
         return out
 
     def reduce(self, params):
-        if world_size() == 1:
+        if not dp_active():
             return
         self.steps += 1
         self._t0 = None

@@ -32,6 +32,9 @@ class FusedAdam(torch.optim.Optimizer):
         moment tensors replace the ones the cached pointer tables refer to, and the bias-correction step count
         lives in the per-parameter ``state[p]["step"]`` entries, which are restored here - nothing else to keep."""
         super().load_state_dict(state_dict)
+        for st in self.state.values():  # torch saves the step as a tensor: one conversion here, no host sync per step later
+            if "step" in st and not isinstance(st["step"], int):
+                st["step"] = int(st["step"])
         self._plan = None
 
     def __setstate__(self, state):
@@ -66,9 +69,10 @@ class FusedAdam(torch.optim.Optimizer):
             "ct": up(ct, np.int32),
             "co": up(co, np.int64),
             "n": len(ct),
-            # per-step tables in one row of 8-byte slots: [n gradient pointers | n fp32 lr | n fp32 weight decay], double-buffered
-            "dyn": [torch.empty(2 * n + 1, dtype=torch.int64, device=dev) for _ in range(2)],
-            "stage": [torch.empty(2 * n + 1, dtype=torch.int64).pin_memory() if dev.type == "cuda" else torch.empty(2 * n + 1, dtype=torch.int64)
+            # per-step tables in one row of 8-byte slots: [n gradient pointers | n fp32 lr | n fp32 weight decay |
+            # n fp32 1-b1^t | n fp32 sqrt(1-b2^t)], double-buffered
+            "dyn": [torch.empty(3 * n + 1, dtype=torch.int64, device=dev) for _ in range(2)],
+            "stage": [torch.empty(3 * n + 1, dtype=torch.int64).pin_memory() if dev.type == "cuda" else torch.empty(3 * n + 1, dtype=torch.int64)
                       for _ in range(2)],
             "done": [None, None],
             "turn": 0,
@@ -78,8 +82,9 @@ class FusedAdam(torch.optim.Optimizer):
     def _key(items):
         return tuple((p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()) for p, _, st in items)
 
-    def _upload(self, items, lrs, wds):
-        """This step's gradient pointers and per-group lr / weight decay -> device, without a host sync."""
+    def _upload(self, items, lrs, wds, bc1, bc2):
+        """This step's gradient pointers, per-group lr / weight decay and per-parameter bias corrections -> device,
+        without a host sync."""
         pl = self._plan
         n = len(items)
         k = pl["turn"]
@@ -91,6 +96,8 @@ class FusedAdam(torch.optim.Optimizer):
         f = host[n:].view(np.float32)
         f[:n] = np.asarray(lrs, dtype=np.float32)
         f[n : 2 * n] = np.asarray(wds, dtype=np.float32)
+        f[2 * n : 3 * n] = np.asarray(bc1, dtype=np.float32)
+        f[3 * n : 4 * n] = np.asarray(bc2, dtype=np.float32)
         dyn = pl["dyn"][k]
         dyn.copy_(pl["stage"][k], non_blocking=True)
         if dyn.is_cuda:
@@ -127,20 +134,25 @@ class FusedAdam(torch.optim.Optimizer):
                     raise RuntimeError("FusedAdam: betas/eps must be shared by all groups")
         if not items:
             return loss
-        # step count = the saved per-parameter one (torch.optim.Adam's state layout; a tensor after load_state_dict)
-        t = max(int(st["step"]) for _, _, st in items) + 1
+        # one step count PER PARAMETER, as torch.optim.Adam keeps it (a parameter that starts receiving gradients later,
+        # or a resumed state with unequal counts, gets its own bias correction)
+        bc1, bc2 = [], []
+        for _, _, st in items:
+            t = int(st["step"]) + 1
+            st["step"] = t
+            bc1.append(1.0 - b1 ** t)
+            bc2.append((1.0 - b2 ** t) ** 0.5)
         key = self._key(items)
         if self._plan is None or self._plan["key"] != key:
             self._build(items)
         pl = self._plan
         n = len(items)
-        dyn = self._upload(items, lrs, wds)
-        for _, _, st in items:
-            st["step"] = t
+        dyn = self._upload(items, lrs, wds, bc1, bc2)
         ops.call("trid_adam_multi_f32", ops._p(pl["p"]), ops._p(dyn), ops._p(pl["m"]), ops._p(pl["v"]),
                  ops._p(pl["sizes"]), ops._p(dyn) + 8 * n, ops._p(dyn) + 12 * n, ops._p(pl["ct"]), ops._p(pl["co"]), pl["n"],
-                 ADAM_CHUNK, float(b1), float(b2), float(eps), 1.0 - b1 ** t, (1.0 - b2 ** t) ** 0.5,
+                 ADAM_CHUNK, float(b1), float(b2), float(eps), ops._p(dyn) + 16 * n, ops._p(dyn) + 20 * n,
                  1 if self.decoupled else 0, ops.stream())
+        ops.note_parameter_write()  # raw-pointer write: torch's tensor._version does not move
         return loss
 
 
