@@ -99,9 +99,27 @@ def is_param(name):
 
 def _relu(x, taps):
     """F.relu; with a taps dict also tracks the smallest |pre-activation| seen ("relu_min"): the
-    fixtures' ReLU decision margin (tests/golden/make_golden.py keeps it far above fp32 rounding)."""
+    fixtures' ReLU decision margin (tests/golden/make_golden.py keeps it far above fp32 rounding).
+
+    taps["force_masks"] (a list of bool tensors, consumed in call order): the ReLU DECISIONS are taken from the
+    list instead of from the sign of x (relu(x) := x * mask).  A ReLU network is piecewise linear; two fp32
+    evaluations with different summation orders disagree on the side of a few pre-activations that sit within
+    rounding distance of zero, and past such a flip the two results are on different linear pieces.  Imposing the
+    implementation-under-test's decisions puts the oracle on the SAME piece, where the comparison is a pure
+    rounding-error comparison again; the disagreements themselves are counted ("flips") and their largest
+    |pre-activation| recorded relative to the tensor's largest ("flip_max_rel") so a test can bound both."""
     if taps is not None:
         taps["relu_min"] = min(taps.get("relu_min", float("inf")), float(x.detach().abs().min()))
+        if taps.get("force_masks"):
+            m = taps["force_masks"].pop(0)
+            xd = x.detach()
+            dis = (xd > 0) != m
+            n = int(dis.sum())
+            taps["flips"] = taps.get("flips", 0) + n
+            taps["relu_elems"] = taps.get("relu_elems", 0) + xd.numel()
+            if n:
+                taps["flip_max_rel"] = max(taps.get("flip_max_rel", 0.0), float(xd[dis].abs().max() / xd.abs().max()))
+            return x * m.to(x.dtype)
     return F.relu(x)
 
 

@@ -6,12 +6,19 @@ fp16-split GEMM variants at bench tile shapes seeing only trivial masks.  Here O
 stay countable) and the stem run at B = 128 on every distinct RN50 block shape with He-style weights and post-ReLU
 style inputs - random, unstructured masks - through the model's own code path (`block_forward` / `block_backward`,
 fp16 two-plane split convolutions with producer-side amax scalars, weight gradients on the side stream), against the
-CPU oracle (`oracle/visual.py:bottleneck`, reference `m_resnet.py:54-67,198-217`) evaluated in fp64 (truth) and in
-fp32 (the reference's arithmetic):
+CPU oracle (`oracle/visual.py:bottleneck`, reference `m_resnet.py:54-67,198-217`) evaluated in fp64.
 
-  * forward output, every weight / BatchNorm gradient, BatchNorm running statistics: flat 1e-3 of the tensor maximum;
-  * dx (the only quantity a flipped ReLU changes pointwise): q99.9 of |err| / max|ref| <= 1e-3, and its maximum bounded
-    by what the reference's OWN fp32 evaluation deviates from fp64 (x4, floor 1e-3).
+At M = B*H*W = 393 216 pixels a ReLU sees 25 M pre-activations; ~1e-6 of them lie within fp32 rounding distance of
+zero, where two correct evaluations with different summation orders decide differently, and ONE flipped decision moves
+a bias-like gradient (a random-sign sum over M pixels) by ~1/sqrt(M) = 1.6e-3 of its value - the oracle's own fp32
+evaluation deviates from its fp64 evaluation by that much (measured on the first run of this test: layer1.0 dx max
+3.9e-2, bias gradients 1-2e-3).  So the comparison is split into the two statements that ARE sharp:
+
+  1. decisions: the HIP path's ReLU masks equal the fp64 oracle's except at pre-activations within 1e-5 of the
+     tensor's largest (rounding distance), and at most 1e-5 of all decisions differ;
+  2. arithmetic: with the HIP path's decisions imposed on the oracle (`taps["force_masks"]`: same linear piece),
+     forward output, EVERY weight / BatchNorm gradient, dx (worst entry, not a quantile) and the BatchNorm running
+     statistics hold the flat 1e-3 of the tensor maximum (measured ~1e-6).
 """
 
 import pytest
@@ -44,14 +51,6 @@ def relmax(a, b):
     return float((a - b).abs().max() / (b.abs().max() + 1e-30))
 
 
-def quantile_err(a, b, q=0.999):
-    """(q-quantile, max) of |a - b| / max|b| (kthvalue: exact, any size)."""
-    a, b = torch.as_tensor(a).detach().cpu().double().reshape(-1), torch.as_tensor(b).detach().cpu().double().reshape(-1)
-    e = ((a - b).abs() / (b.abs().max() + 1e-30)).float()
-    k = max(1, int(q * e.numel()))
-    return float(e.kthvalue(k)[0]), float(e.max())
-
-
 # (name, inplanes, planes, stride, H, W): every distinct Bottleneck shape of CLIP-RN50 at 384x128 (block_plan(RN50))
 RN50_BLOCKS = [
     ("layer1.0", 64, 64, 1, 96, 32),
@@ -65,15 +64,20 @@ RN50_BLOCKS = [
 ]
 
 
-def _oracle_block(st, name, x, gout, stride, has_down, dtype):
+def _oracle_block(st, name, x, gout, stride, has_down, dtype, masks):
     s = {k: (v.to(dtype).clone() if v.dtype.is_floating_point else v.clone()) for k, v in st.items()}
     for k in s:
         if OV.is_param(k):
             s[k].requires_grad_(True)
     xr = x.to(dtype).clone().requires_grad_(True)
-    out = OV.bottleneck(s, name, xr, stride, has_down, True)
+    taps = {"force_masks": list(masks)}
+    out = OV.bottleneck(s, name, xr, stride, has_down, True, taps)
     out.backward(gout.to(dtype))
-    return out.detach(), xr.grad, {k: v.grad for k, v in s.items() if OV.is_param(k)}, s
+    return out.detach(), xr.grad, {k: v.grad for k, v in s.items() if OV.is_param(k)}, s, taps
+
+
+FLIP_FRACTION = 1e-5  # at most this share of the ReLU decisions may differ from the fp64 oracle's ...
+FLIP_MAGNITUDE = 1e-5  # ... and only at |pre-activation| <= this share of the tensor's largest
 
 
 @pytest.mark.parametrize("name,inpl,planes,stride,H,W", RN50_BLOCKS, ids=[b[0] for b in RN50_BLOCKS])
@@ -104,19 +108,19 @@ def test_bottleneck_b128_unstructured_masks(gpu, name, inpl, planes, stride, H, 
     gd = gout.permute(0, 2, 3, 1).contiguous().to(gpu)
     ar = M.ConvArith(gpu, M.weight_amax(blk))
     ax = ops.amax(xd)
-    nbt = []
-    out, a_out, rec = M.block_forward(blk, xd, ax, ar, True, True, nbt)
+    nbt, masks = [], []
+    out, a_out, rec = M.block_forward(blk, xd, ax, ar, True, True, nbt, masks)
     ws = M._WgradStream(gpu)
     G = {}
     dx = M.block_backward(blk, rec, gd, ar, ws, G)
     ws.join()
     torch.cuda.synchronize()
-    assert len(nbt) == (4 if has_down else 3)
+    assert len(nbt) == (4 if has_down else 3) and len(masks) == 3
 
-    o64, dx64, g64, s64 = _oracle_block(st, name, x, gout, stride, has_down, torch.float64)
-    o32, dx32, g32, _ = _oracle_block(st, name, x, gout, stride, has_down, torch.float32)
+    o64, dx64, g64, s64, taps = _oracle_block(st, name, x, gout, stride, has_down, torch.float64,
+                                              [m_.permute(0, 3, 1, 2).cpu() for m_ in masks])
 
-    errs = {"out": relmax(out.permute(0, 3, 1, 2), o64)}
+    errs = {"out": relmax(out.permute(0, 3, 1, 2), o64), "dx": relmax(dx.permute(0, 3, 1, 2), dx64)}
     named = dict(blk.named_parameters())
     for k, p in named.items():
         errs["grad:" + k] = relmax(G[id(p)].reshape(p.shape), g64[name + "." + k])
@@ -124,15 +128,15 @@ def test_bottleneck_b128_unstructured_masks(gpu, name, inpl, planes, stride, H, 
     for k in sd:
         if k.endswith(("running_mean", "running_var")):
             errs["state:" + k] = relmax(sd[k], s64[name + "." + k])
-    q, mx = quantile_err(dx.permute(0, 3, 1, 2), dx64)
-    ref_q, ref_mx = quantile_err(dx32, dx64)
     amax_err = relmax(a_out, o64.abs().max())
-    print("%s B=%d: worst flat %.1e; dx q99.9 %.1e max %.1e (oracle fp32 vs fp64: q99.9 %.1e max %.1e); amax(out) %.1e" % (
-        name, B, max(errs.values()), q, mx, ref_q, ref_mx, amax_err))
+    flips, total, fmax = taps.get("flips", 0), taps["relu_elems"], taps.get("flip_max_rel", 0.0)
+    worst = max(errs, key=errs.get)
+    print("%s B=%d: %d of %d ReLU decisions differ from the fp64 oracle (largest |pre-activation| there %.1e of the tensor's); "
+          "same decisions: worst of %d quantities %.1e (%s), dx %.1e; amax(out) %.1e" % (
+              name, B, flips, total, fmax, len(errs), errs[worst], worst, errs["dx"], amax_err))
+    assert flips <= FLIP_FRACTION * total and fmax <= FLIP_MAGNITUDE, (flips, total, fmax)
     bad = {k: v for k, v in errs.items() if not v <= TOL}
     assert not bad, bad
-    assert q <= TOL, (q, mx)
-    assert mx <= max(TOL, 4.0 * ref_mx), (mx, ref_mx)
     assert amax_err <= 1e-4  # the producer-side amax scalar the NEXT block's GEMM would scale by
 
 
@@ -153,8 +157,8 @@ def test_stem_b128_unstructured_masks(gpu):
     images = _randn((B, 3, spec.height, spec.in_width), seed)
     gout = _randn((B, spec.width, spec.height // 4, spec.in_width // 4), seed + 1)
     ar = M.ConvArith(gpu, M.weight_amax(m))
-    nbt = []
-    x, ax, rec = M.stem_forward(m, images.to(gpu), ar, True, nbt)
+    nbt, masks = [], []
+    x, ax, rec = M.stem_forward(m, images.to(gpu), ar, True, nbt, masks)
     ws = M._WgradStream(gpu)
     G = {}
     M.stem_backward(m, rec, gout.permute(0, 2, 3, 1).contiguous().to(gpu), ar, ws, G)
@@ -166,15 +170,16 @@ def test_stem_b128_unstructured_masks(gpu):
         for k in s:
             if OV.is_param(k):
                 s[k].requires_grad_(True)
+        taps = {"force_masks": [m_.permute(0, 3, 1, 2).cpu() for m_ in masks]}
         y = images.to(dtype)
-        y = F.relu(OV._bn(s, "bn1", F.conv2d(y, s["conv1.weight"], stride=2, padding=1), True))
-        y = F.relu(OV._bn(s, "bn2", F.conv2d(y, s["conv2.weight"], padding=1), True))
-        y = F.relu(OV._bn(s, "bn3", F.conv2d(y, s["conv3.weight"], padding=1), True))
+        y = OV._relu(OV._bn(s, "bn1", F.conv2d(y, s["conv1.weight"], stride=2, padding=1), True), taps)
+        y = OV._relu(OV._bn(s, "bn2", F.conv2d(y, s["conv2.weight"], padding=1), True), taps)
+        y = OV._relu(OV._bn(s, "bn3", F.conv2d(y, s["conv3.weight"], padding=1), True), taps)
         y = F.avg_pool2d(y, 2)
         y.backward(gout.to(dtype))
-        return y.detach(), s
+        return y.detach(), s, taps
 
-    o64, s64 = oracle(torch.float64)
+    o64, s64, taps = oracle(torch.float64)
     errs = {"out": relmax(x.permute(0, 3, 1, 2), o64)}
     named = dict(m.named_parameters())
     for k in keys:
@@ -182,6 +187,8 @@ def test_stem_b128_unstructured_masks(gpu):
             errs["grad:" + k] = relmax(G[id(named[k])].reshape(named[k].shape), s64[k].grad)
         elif k.endswith(("running_mean", "running_var")):
             errs["state:" + k] = relmax(m.state_dict()[k], s64[k])
-    print("stem B=%d:" % B, {k: "%.1e" % v for k, v in errs.items()})
+    flips, total, fmax = taps.get("flips", 0), taps["relu_elems"], taps.get("flip_max_rel", 0.0)
+    print("stem B=%d: %d of %d ReLU decisions differ (|pre-activation| <= %.1e of max);" % (B, flips, total, fmax), {k: "%.1e" % v for k, v in errs.items()})
+    assert flips <= FLIP_FRACTION * total and fmax <= FLIP_MAGNITUDE, (flips, total, fmax)
     bad = {k: v for k, v in errs.items() if not v <= TOL}
     assert not bad, bad

@@ -423,22 +423,18 @@ def test_full_size_step_vs_oracle(gpu):
     assert_within(errs, TOL)
 
 
-def _quantile_err(a, b, floor, q=0.999):
-    """(q-quantile, max) over the elements of |a - b| / max(max|b|, floor)."""
-    a, b = a.detach().cpu().double().reshape(-1), b.detach().cpu().double().reshape(-1)
-    e = ((a - b).abs() / max(float(b.abs().max()), floor)).float()
-    return float(e.kthvalue(max(1, int(q * e.numel())))[0]), float(e.max())
-
-
 def test_full_size_step_he_style_unstructured_masks(gpu):
-    """The configs[1] model (CLIP-RN50 + BiGRU, 384x128) with He-style weights: ReLU masks are unstructured through all
-    16 blocks, so two fp32 evaluations with different summation orders disagree on a handful of mask bits and each
-    flipped bit moves a few gradient entries (the reference's own fp32 result is 1-8 % of a tensor's maximum from fp64 in
-    the worst ENTRY).  What is held here:
-      * forward: every stage activation, both features, the three losses - FLAT 1e-3 against the oracle;
-      * all 183 gradients: the q99.9 quantile of |err| / max|ref| <= 1e-3 (a flip touches < 0.1 % of a tensor), and the
-        worst entry bounded by 4x what the oracle's OWN fp32 evaluation deviates from its fp64 evaluation on that tensor
-        (floor 1e-3): the HIP path is as close to the truth as the reference arithmetic is."""
+    """The configs[1] model (CLIP-RN50 + BiGRU, 384x128, B=16) with He-style weights: the ReLU masks are unstructured
+    through the stem and all 16 blocks (9.5e7 decisions).  Two correct fp32 evaluations with different summation orders
+    decide a few of the pre-activations that sit within rounding distance of zero differently, and past a flipped
+    decision they are on different linear pieces of the network (the reference's own fp32 result is 1-8 % of a
+    gradient tensor's maximum from fp64 in its worst entry).  The comparison is therefore split into two sharp
+    statements:
+      1. decisions: the HIP path's 51 ReLU masks equal the fp64 oracle's except at pre-activations inside the forward
+         tolerance (1e-3 of the layer's largest), and at most 1e-4 of all decisions differ;
+      2. arithmetic: with the HIP path's decisions imposed on the fp64 oracle (`taps["force_masks"]`), every stage
+         activation, both features, the three losses and ALL 183 gradients hold the FLAT 1e-3."""
+    from fixture_check import assert_within
     from textreid_amd.caption import CaptionBatch
     from textreid_amd.config import moco_cfg
     from textreid_amd.model import build_model
@@ -449,48 +445,39 @@ def test_full_size_step_he_style_unstructured_masks(gpu):
     head = model.embed_model
     head.load_state_dict({k: v.clone() for k, v in st.items()})
     model.to(gpu).train()
-    head.v_encoder_q._debug_taps = {}
+    enc = head.v_encoder_q
+    enc._debug_taps, enc._debug_masks = {}, []
     ld = model(images.to(gpu), CaptionBatch(tokens.to(gpu), lengths.to(gpu), ids.to(gpu)))
-    taps = {k: v.permute(0, 3, 1, 2) for k, v in head.v_encoder_q._debug_taps.items()}
-    head.v_encoder_q._debug_taps = None
+    taps = {k: v.permute(0, 3, 1, 2) for k, v in enc._debug_taps.items()}
+    masks = [m_.permute(0, 3, 1, 2).cpu() for m_ in enc._debug_masks]
+    enc._debug_taps = enc._debug_masks = None
+    assert len(taps) == 17 and len(masks) == 3 + 3 * 16
     sum(ld.values()).backward()
     tr = OH.trainable_names(st)
-
-    def oracle(dtype):
-        s = {k: (v.to(dtype).clone() if v.dtype.is_floating_point else v.clone()) for k, v in st.items()}
-        for k in tr:
-            s[k].requires_grad_(True)
-        tp = {}
-        out = OH.train_forward(s, spec, table.to(dtype), images.to(dtype), tokens, lengths, ids, m=0.999, epsilon=0.1, taps=tp)
-        sum(out.values()).backward()
-        return out, tp, {k: s[k].grad for k in tr}
-
-    o32, t32, g32 = oracle(torch.float32)
-    o64, t64, g64 = oracle(torch.float64)
+    dt = torch.float64
+    s64 = {k: (v.to(dt).clone() if v.dtype.is_floating_point else v.clone()) for k, v in st.items()}
+    for k in tr:
+        s64[k].requires_grad_(True)
+    tp = {"visual_q": {"force_masks": masks}}
+    o64 = OH.train_forward(s64, spec, table.to(dt), images.to(dt), tokens, lengths, ids, m=0.999, epsilon=0.1, taps=tp)
+    sum(o64.values()).backward()
+    vt = tp["visual_q"]
+    flips, total, fmax = vt.get("flips", 0), vt["relu_elems"], vt.get("flip_max_rel", 0.0)
     errs = {"loss:" + k: rel(ld[k], o64[k]) for k in o64}
     for k, v in taps.items():
-        errs["act:" + k] = rel(v, t64["visual_q"][k])
-    assert len(taps) == 17
-    print("he-style forward:", {k: "%.1e" % v for k, v in sorted(errs.items(), key=lambda kv: -kv[1])[:4]},
-          "relu_min %.1e" % t32["visual_q"]["relu_min"])
-    from fixture_check import assert_within
-
-    assert_within(errs, TOL)
+        errs["act:" + k] = rel(v, vt[k])
     named = dict(head.named_parameters())
-    gfl = 1e-3 * max(float(g64[k].abs().max()) for k in tr)
-    bad, worst_q, worst_m = {}, (0.0, None), (0.0, None, 0.0)
+    gfl = 1e-3 * max(float(s64[k].grad.abs().max()) for k in tr)
     for k in tr:
-        fl = gfl * (100.0 if k.endswith("attnpool.k_proj.bias") else 1.0)
-        q, mx = _quantile_err(named[k].grad, g64[k], fl)
-        rq, rmx = _quantile_err(g32[k], g64[k], fl)
-        if q > worst_q[0]:
-            worst_q = (q, k)
-        if mx > worst_m[0]:
-            worst_m = (mx, k, rmx)
-        if not (q <= TOL and mx <= max(TOL, 4.0 * rmx)):
-            bad[k] = (q, mx, rq, rmx)
-    print("he-style gradients: worst q99.9 %.1e (%s); worst entry %.1e (%s; oracle fp32 vs fp64 there %.1e)" % (worst_q + worst_m))
-    assert not bad, "%d of %d gradients: %s" % (len(bad), len(tr), sorted(bad.items(), key=lambda kv: -kv[1][0])[:6])
+        ref = s64[k].grad
+        fl = gfl * (100.0 if k.endswith("attnpool.k_proj.bias") else 1.0)  # analytically zero gradient, see fixture_check
+        errs["grad:" + k] = float((named[k].grad.detach().cpu().double() - ref).abs().max() / max(float(ref.abs().max()), fl))
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+    print("he-style RN50 step: %d of %d ReLU decisions differ from the fp64 oracle (largest |pre-activation| there %.1e of its layer's); "
+          "same decisions: %d quantities, worst %s" % (flips, total, fmax, len(errs), [(k, "%.1e" % v) for k, v in worst]))
+    assert sum(k.startswith("grad:") for k in errs) == 183
+    assert flips <= 1e-4 * total and fmax <= TOL, (flips, total, fmax)  # a decision may differ only where |pre-activation| is inside the forward tolerance
+    assert_within(errs, TOL)
 
 
 def test_config3_rn101_k65536_bf16(gpu):

@@ -167,9 +167,16 @@ def weight_amax(mod):
     return {id(w): out[i : i + 1] for i, w in enumerate(convs)}
 
 
-def stem_forward(mod, images, ar, training, nbt):
+def _pre_mask(y, st):
+    """bool [..., C]: the ReLU decision of relu(bn(y)) where only the pooled activation is kept, taken by the SAME
+    kernel arithmetic as the forward / backward passes (parity tests only)."""
+    return ops.bn_apply(y, st, relu=True) > 0
+
+
+def stem_forward(mod, images, ar, training, nbt, masks=None):
     """Three conv -> BatchNorm -> ReLU units + 2x2 average pool (m_resnet.py:199-207).  Returns
-    (x NHWC, its amax scalar, record for stem_backward)."""
+    (x NHWC, its amax scalar, record for stem_backward).  masks (a list, parity tests): receives the three ReLU
+    decision masks in execution order."""
     B = images.shape[0]
     P = ar.P
     col, Ho, Wo = ops.stem_im2col(images)
@@ -193,6 +200,8 @@ def stem_forward(mod, images, ar, training, nbt):
     st3 = _bn_coeffs(mod.bn3, p3, B * Ho * Wo, training, nbt)
     ax = ar.slot()
     x = ops.bn_apply_pool2(y3, st3, relu=True, amax=ax)
+    if masks is not None:
+        masks.extend([a1 > 0, a2 > 0, _pre_mask(y3, st3)])
     return x, ax, (col, y1, st1, a1, y2, st2, a2, y3, st3, a_a2, a_a1)
 
 
@@ -221,9 +230,10 @@ def stem_backward(mod, rec, g, ar, ws, G):
     G[id(c1)] = dw1[:, : c1[0].numel()].reshape(c1.shape)
 
 
-def block_forward(blk, x, ax, ar, training, save, nbt):
+def block_forward(blk, x, ax, ar, training, save, nbt, masks=None):
     """One Bottleneck (m_resnet.py:54-67) on NHWC activations.  x: block input, ax: its amax scalar (or None).
-    Returns (out, amax scalar of out, record for block_backward or None)."""
+    Returns (out, amax scalar of out, record for block_backward or None).  masks (a list, parity tests): receives
+    the block's three ReLU decision masks in execution order."""
     P = ar.P
     stride = blk.stride
     wa = blk.conv1.weight.view(blk.conv1.out_channels, -1)
@@ -260,6 +270,8 @@ def block_forward(blk, x, ax, ar, training, save, nbt):
     if save:
         out, rmask = out  # 1-bit ReLU mask of the block output for the backward pass
         rec = (x, ya, sta, aa, yb, stb, ab, yc, stc, xd, yd, std, rmask, (ax, a_aa, a_ab, a_xd))
+    if masks is not None:
+        masks.extend([aa > 0, _pre_mask(yb, stb) if stride > 1 else ab > 0, out > 0])
     return out, a_out, rec
 
 
@@ -460,7 +472,8 @@ class ModifiedResNet(nn.Module):
         ar = ConvArith(images.device, weight_amax(self) if ops.conv_precision() == 16 else {})
         nbt = []  # num_batches_tracked buffers, incremented together at the end of the pass
         # ---- stem (m_resnet.py:199-207)
-        x, ax, srec = stem_forward(self, images, ar, training, nbt)
+        masks = getattr(self, "_debug_masks", None)  # parity tests: every ReLU decision of the pass, in execution order
+        x, ax, srec = stem_forward(self, images, ar, training, nbt, masks)
         if save:
             S["stem"] = srec
             S["wamax"] = ar.WA
@@ -473,7 +486,7 @@ class ModifiedResNet(nn.Module):
             names = {id(blk): "layer%d.%d" % (li + 1, bi) for li, layer in enumerate((self.layer1, self.layer2, self.layer3, self.layer4))
                      for bi, blk in enumerate(layer)}
         for blk in self.blocks():
-            x, ax, rec = block_forward(blk, x, ax, ar, training, save, nbt)
+            x, ax, rec = block_forward(blk, x, ax, ar, training, save, nbt, masks)
             if save:
                 S["blocks"].append(rec)
             if taps is not None:
