@@ -87,6 +87,25 @@ typedef struct trid_gemm_desc {
 
 int trid_gemm_f32(const trid_gemm_desc* d, void* stream);
 
+/* ------------------------------------------------------------------------- *
+ * P16: pre-split GEMM operands (no reference counterpart: PyTorch's fp32 convolutions need no operand format).
+ * A [R rows][K] tensor (K % 32 == 0) in P16 holds x * 2^s (s from the tensor's amax, as precision 16 above) as TWO
+ * fp16 planes, 4 bytes per element: row r, K group g -> 128 bytes at r*K*4 + g*128 = [hi(32 k) | lo(32 k)].
+ * The kernel that PRODUCES an operand writes it split once; trid_gemm_p16 stages it with LDS-DMA (pure copies) and
+ * evaluates hi*hi + hi*lo + lo*hi on the fp16 MFMA exactly as precision 16 does (same error bound).
+ * ------------------------------------------------------------------------- */
+/* fp32 [rows][K] (row pitch ldx elements) -> P16; amax: device scalar max|x| (NULL: unscaled) */
+int trid_p16_pack_f32(const float* x, long long rows, int K, long long ldx, const float* amax, void* out, void* stream);
+/* P16 -> fp32 [rows][K]: (hi + lo) / 2^s */
+int trid_p16_unpack_f32(const void* in, long long rows, int K, const float* amax, float* out, void* stream);
+/* w [N][T][C] fp32 -> P16 [C rows][K = T*N], k = t'*N + n, t' = flip ? T-1-t : t: the data-gradient operand of a
+ * conv (autograd of nn.Conv2d, m_resnet.py:18-26): trid_weight_transpose_f32 + pack in one pass */
+int trid_p16_pack_wt_f32(const float* w, int N, int T, int C, int flip, const float* amax, void* out, void* stream);
+/* C = alpha * A . B^T (+ epilogues of trid_gemm_f32: bias, accumulate, residual, relu, split-K slabs, BatchNorm
+ * partials) with A ([M][K], or an NHWC image for a_mode TRID_A_CONV) and B ([N][K]) in P16; lda / ldb = row pitch
+ * in elements; a_amax / b_amax = the scalars the operands were packed with.  variant: tile shape (0 = default). */
+int trid_gemm_p16(const trid_gemm_desc* d, int variant, void* stream);
+
 /* C[i] (+)= sum_s slab[s*strideSplit + i], i < n (n % 4 == 0) */
 int trid_slab_reduce_f32(const float* slab, float* C, long long n, int splits, long long strideSplit,
                          int accumulate, void* stream);

@@ -1,0 +1,467 @@
+// GEMM / implicit-GEMM on PRE-SPLIT operands ("P16" tensors), LDS-DMA staged.
+//
+// The fp16 two-plane arithmetic of gemm_bf16.hip (x' = x * 2^s, hi = fp16(x'), lo = fp16(x' - hi), product =
+// hi*hi + hi*lo + lo*hi in one fp32 MFMA accumulator: <= 3 * 2^-22 per product, fp32-class) with the split moved
+// OUT of the GEMM: the kernel that PRODUCES an operand (BatchNorm apply / backward, the per-step weight pass) writes
+// it already split, once, instead of every GEMM tile re-splitting every element it stages (nine times per
+// activation for a 3x3 convolution, once per column tile on top).
+//
+// P16 layout of a [R rows][K] operand (K % 32 == 0), 4 bytes per element like fp32:
+//     row r, 32-wide K group g:  128 bytes at r*K*4 + g*128 = [ hi(k = 32g .. 32g+31) : 64 B | lo(same k) : 64 B ]
+// so one row of one 32-deep K tile is ONE full 128-byte line, and a loader lane moves 16 bytes = 8 consecutive k of
+// one plane = exactly one MFMA 32x32x16 operand fragment.  Loaders are pure copies: `buffer_load_dwordx4 ... lds`
+// (LDS-DMA, no VGPR staging, no VALU, no ds_write), eight lanes per 128-byte row, 8 rows per wave instruction.
+//
+// LDS image of a tile: [rows][8 slots of 16 B], slot s of row r stored at position s ^ ((r >> 1) & 7).  LDS-DMA
+// writes lane-linear (wave base + 16*lane), so the permutation is applied to the SOURCE address of each lane; the
+// MFMA fragment reads (32 consecutive rows, one slot, ds_read_b128 in 16-lane groups {0-3,12-15,20-27} / {4-11,
+// 16-19,28-31}) then hit 16 distinct 16-byte bank groups: conflict-free.
+//
+// Pipeline: STAGES LDS buffers, DMA issued STAGES-1 tiles ahead, ONE barrier per K tile, counted s_waitcnt vmcnt
+// (never 0 in steady state for STAGES >= 3), raw s_barrier so in-flight DMA survives the barrier.
+
+#include <mutex>
+
+#include "split_common.h"
+
+namespace trid {
+
+constexpr int P16_BK = 32;
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// one LDS-DMA instruction: every lane copies 16 bytes from its own source offset to (wave-uniform LDS base) + 16 * lane
+__device__ __forceinline__ void dma16(const __amdgpu_buffer_rsrc_t& rs, uint4* lds_base, unsigned voffset, unsigned soffset) {
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)lds_base, 16, voffset, soffset, 0, 0);
+}
+
+// AMODE: A_KC (rows = GEMM rows) or A_CONV (rows = pixels of an NHWC image, K = 9 taps x Cin, 3x3 / stride 1 / pad 1)
+template <int AMODE, int BM, int BN, int WM, int WN, int STAGES>
+__global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 && STAGES == 2) ? 2 : (WM * WN == 8 && (BM + BN) * 128 * STAGES <= 80 * 1024 ? 4 : 2)) void gemm_p16_kernel(GemmParams p) {
+    constexpr int NW = WM * WN;
+    constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
+    constexpr int A_CH = BM / 8, B_CH = BN / 8;                          // 1-KB DMA chunks (8 rows x 128 B)
+    constexpr int A_PW = (A_CH + NW - 1) / NW, B_PW = (B_CH + NW - 1) / NW;  // chunks per wave
+    constexpr int PER_TILE = A_PW + B_PW;                                // DMA instructions per wave and K tile
+    constexpr int STAGE_SLOTS = (BM + BN) * 8;
+    extern __shared__ __attribute__((aligned(16))) uint4 smem[];
+
+    const float scaleA = p.a_amax != nullptr ? f16_scale_of(*p.a_amax) : 1.f;
+    const float scaleB = p.b_amax != nullptr ? f16_scale_of(*p.b_amax) : 1.f;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int khalf = lane >> 5;
+
+    const uint32_t nwg = (uint32_t)p.mblocks * (uint32_t)p.nblocks;
+    const uint32_t lid = xcd_remap(blockIdx.x, nwg);
+    const int mb = lid / p.nblocks, nb = lid % p.nblocks;
+    const int m0 = mb * BM, n0 = nb * BN;
+    const int z = blockIdx.z;
+    const int bz = z / p.splits, sz = z % p.splits;
+    const int kt_begin = sz * (p.k_chunk / P16_BK);
+    const int kt_end = min(p.K / P16_BK, kt_begin + p.k_chunk / P16_BK);
+    const int nk = kt_end - kt_begin;
+
+    const char* A = reinterpret_cast<const char*>(p.A + (long long)bz * p.sA);
+    const char* Bp = reinterpret_cast<const char*>(p.B + (long long)bz * p.sB);
+    float* __restrict__ C = p.C + (long long)bz * p.sC + (long long)sz * p.sSplit;
+    const float* __restrict__ bias = p.bias ? p.bias + (long long)bz * p.sBias : nullptr;
+
+    // ---- loader lanes: chunk c covers tile rows 8c .. 8c+7; lane -> (row 8c + lane/8, stored slot lane%8)
+    constexpr unsigned OOB = 0x80000000u;
+    const long long a_ld_bytes = (AMODE == A_CONV ? (long long)p.Cin : p.lda) * 4;
+    const long long a_rows = (AMODE == A_CONV) ? (long long)p.M + 2 * p.W + 2 : p.M;
+    const char* a_base = (AMODE == A_CONV) ? A - (long long)(p.W + 1) * a_ld_bytes : A;  // tap offsets stay >= 0
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a_base, 0, (unsigned)(a_rows * a_ld_bytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)Bp, 0, (unsigned)((long long)p.N * p.ldb * 4), 0x00020000);
+
+    unsigned voA[A_PW], voB[B_PW], amask[A_PW];
+#pragma unroll
+    for (int j = 0; j < A_PW; ++j) {
+        const int c = j * NW + wave;
+        const int r = 8 * c + (lane >> 3);
+        const int s = (lane & 7) ^ ((r >> 1) & 7);
+        const int m = m0 + r;
+        voA[j] = (c < A_CH && m < p.M) ? (unsigned)((long long)m * a_ld_bytes + 16 * s) : OOB;
+        amask[j] = 0x1ffu;
+        if (AMODE == A_CONV) {
+            const uint32_t q = fdiv((uint32_t)m, p.fdW);
+            const int x = m - (int)q * p.W;
+            const uint32_t b = fdiv(q, p.fdH);
+            const int y = (int)q - (int)b * p.H;
+            unsigned mk = 0;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+                if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) mk |= 1u << t;
+            }
+            amask[j] = mk;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < B_PW; ++j) {
+        const int c = j * NW + wave;
+        const int r = 8 * c + (lane >> 3);
+        const int s = (lane & 7) ^ ((r >> 1) & 7);
+        const int n = n0 + r;
+        voB[j] = (c < B_CH && n < p.N) ? (unsigned)((long long)n * p.ldb * 4 + 16 * s) : OOB;
+    }
+    const int cgroups = (AMODE == A_CONV) ? p.Cin / P16_BK : 1;
+
+    auto issue = [&](int kt, int stage) {
+        uint4* sA = smem + stage * STAGE_SLOTS;
+        uint4* sB = sA + BM * 8;
+        unsigned soA, soB;
+        int tap = 0;
+        if (AMODE == A_CONV) {
+            // channel-group-major K order: all 9 taps of one 32-channel slab back to back (the nine shifted re-reads
+            // of an activation slab are adjacent in time: L1/L2 hits); the weights' K index is (tap, channel)
+            tap = kt % 9;
+            const int cg = kt / 9;
+            soA = (unsigned)((((tap / 3) * p.W + (tap % 3)) * (long long)p.Cin * 4) + cg * 128);
+            soB = (unsigned)((tap * cgroups + cg) * 128);
+        } else {
+            soA = soB = (unsigned)(kt * 128);
+        }
+#pragma unroll
+        for (int j = 0; j < A_PW; ++j) {
+            const int c = j * NW + wave;
+            if (A_CH % NW != 0 && c >= A_CH) break;
+            unsigned vo = voA[j];
+            if (AMODE == A_CONV) vo = ((amask[j] >> tap) & 1u) ? vo : OOB;
+            dma16(rsA, sA + c * 64, vo, soA);
+        }
+#pragma unroll
+        for (int j = 0; j < B_PW; ++j) {
+            const int c = j * NW + wave;
+            if (B_CH % NW != 0 && c >= B_CH) break;
+            dma16(rsB, sB + c * 64, voB[j], soB);
+        }
+    };
+
+    v16f acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int xs = (lane >> 1) & 7;
+    const int a_row = wm * (32 * TM) + (lane & 31);
+    const int b_row = wn * (32 * TN) + (lane & 31);
+
+    auto compute = [&](int stage) {
+        const uint4* sA = smem + stage * STAGE_SLOTS;
+        const uint4* sB = sA + BM * 8;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            f16x8 a[2][TM], b[2][TN];
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+                const int s = (4 * pl + 2 * ks + khalf) ^ xs;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[pl][i] = __builtin_bit_cast(f16x8, sA[(a_row + 32 * i) * 8 + s]);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[pl][j] = __builtin_bit_cast(f16x8, sB[(b_row + 32 * j) * 8 + s]);
+            }
+            // small terms first; consecutive MFMAs hit different accumulators
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][i], b[1][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][i], b[0][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][i], b[0][j], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    // ---- main loop
+    {
+#pragma unroll
+        for (int s = 0; s < STAGES - 1; ++s)
+            if (s < nk) issue(kt_begin + s, s);
+        int stage = 0, istage = (STAGES - 1) % STAGES;
+        for (int t = 0; t < nk; ++t) {
+            // tile t has landed once at most `ahead` later tiles are still in flight
+            const int ahead = min(STAGES - 2, nk - 1 - t);
+            if (STAGES >= 4 && ahead == 2) wait_vmcnt<2 * PER_TILE>();
+            else if (STAGES >= 3 && ahead >= 1) wait_vmcnt<PER_TILE>();
+            else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();  // every wave's share of tile t is in LDS; every wave is done with stage (t-1)
+            asm volatile("" ::: "memory");
+            if (t + STAGES - 1 < nk) issue(kt_begin + t + STAGES - 1, istage);
+            compute(stage);
+            stage = (stage + 1 == STAGES) ? 0 : stage + 1;
+            istage = (istage + 1 == STAGES) ? 0 : istage + 1;
+        }
+    }
+
+    // ---- epilogue (same contract as gemm_bf16.hip)
+    const float unscale = 1.f / (scaleA * scaleB);
+    const int row_base = m0 + wm * (32 * TM) + 4 * khalf;
+    const int col_base = n0 + wn * (32 * TN) + (lane & 31);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = col_base + 32 * j;
+        const float bv = (bias != nullptr && col < p.N) ? bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            float oldv[16];
+            if (p.accumulate) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = row_base + i * 32 + (r & 3) + 8 * (r >> 2);
+                    oldv[r] = (row < p.M && col < p.N) ? C[(long long)row * p.ldc + col] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row_base + i * 32 + (r & 3) + 8 * (r >> 2);
+                float v = p.alpha * unscale * acc[i][j][r] + bv;
+                if (p.accumulate) v += oldv[r];
+                if (p.res != nullptr && row < p.M && col < p.N) v += p.res[(long long)row * p.ldres + col];
+                if (p.relu) v = fmaxf(v, 0.f);
+                if (row < p.M && col < p.N) C[(long long)row * p.ldc + col] = v;
+                acc[i][j][r] = v;
+            }
+        }
+    }
+
+    if (p.stats != nullptr) {
+        // BatchNorm partials per 128-row slab of the tile: column (mean, M2) over the slab's rows < M
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);  // [WM][BN]
+        constexpr int WPS = 128 / (32 * TM);            // waves (along M) per slab
+        const int slab = wm / WPS;
+        const int rows_left = p.M - (m0 + 128 * slab);
+        const int cnt = rows_left < 128 ? rows_left : 128;
+        const float inv = cnt > 0 ? 1.f / (float)cnt : 0.f;
+        auto column_total = [&](float s, int cl) {  // sum over the slab's 128 rows of a per-lane partial
+            s += __shfl_xor(s, 32, 64);
+            if (khalf == 0) red[wm * BN + cl] = s;
+            __syncthreads();
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < WPS; ++w) t += red[(slab * WPS + w) * BN + cl];
+            __syncthreads();
+            return t;
+        };
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int cl = wn * (32 * TN) + 32 * j + (lane & 31);
+            const int col = n0 + cl;
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = row_base + i * 32 + (r & 3) + 8 * (r >> 2);
+                    if (row < p.M) s += acc[i][j][r];
+                }
+            const float mean = column_total(s, cl) * inv;
+            s = 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = row_base + i * 32 + (r & 3) + 8 * (r >> 2);
+                    const float d = acc[i][j][r] - mean;
+                    if (row < p.M) s += d * d;
+                }
+            const float m2 = column_total(s, cl);
+            if ((wm % WPS) == 0 && khalf == 0 && col < p.N && cnt > 0) {
+                float* dst = p.stats + (((long long)mb * (BM / 128) + slab) * p.N + col) * 2;
+                dst[0] = mean;
+                dst[1] = m2;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------- producers
+// fp32 [rows][K] (row pitch ldx) -> P16.  One thread = 8 consecutive k of one row.
+__global__ __launch_bounds__(256) void p16_pack_kernel(const float* __restrict__ x, long long rows, int K, long long ldx,
+                                                       const float* __restrict__ amax, uint4* __restrict__ out) {
+    const float scale = amax != nullptr ? f16_scale_of(*amax) : 1.f;
+    const int K8 = K / 8;
+    const long long total = rows * K8;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const long long row = idx / K8;
+        const int kg = (int)(idx - row * K8);
+        const float4 u = *reinterpret_cast<const float4*>(x + row * ldx + 8 * kg);
+        const float4 v = *reinterpret_cast<const float4*>(x + row * ldx + 8 * kg + 4);
+        unsigned h[4], l[4];
+        f16_split2(u.x * scale, u.y * scale, h[0], l[0]);
+        f16_split2(u.z * scale, u.w * scale, h[1], l[1]);
+        f16_split2(v.x * scale, v.y * scale, h[2], l[2]);
+        f16_split2(v.z * scale, v.w * scale, h[3], l[3]);
+        uint4* dst = out + row * (K / 4) + (kg >> 2) * 8 + (kg & 3);
+        dst[0] = make_uint4(h[0], h[1], h[2], h[3]);
+        dst[4] = make_uint4(l[0], l[1], l[2], l[3]);
+    }
+}
+
+// P16 -> fp32 (tests, consumers that need values): (hi + lo) / scale
+__global__ __launch_bounds__(256) void p16_unpack_kernel(const uint4* __restrict__ in, long long rows, int K,
+                                                         const float* __restrict__ amax, float* __restrict__ out) {
+    const float inv = 1.f / (amax != nullptr ? f16_scale_of(*amax) : 1.f);
+    const int K8 = K / 8;
+    const long long total = rows * K8;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const long long row = idx / K8;
+        const int kg = (int)(idx - row * K8);
+        const uint4* src = in + row * (K / 4) + (kg >> 2) * 8 + (kg & 3);
+        const uint4 h = src[0], l = src[4];
+        const unsigned hw[4] = {h.x, h.y, h.z, h.w}, lw[4] = {l.x, l.y, l.z, l.w};
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f16x2 a = __builtin_bit_cast(f16x2, hw[q]), b = __builtin_bit_cast(f16x2, lw[q]);
+            v[2 * q] = ((float)a.x + (float)b.x) * inv;
+            v[2 * q + 1] = ((float)a.y + (float)b.y) * inv;
+        }
+        float* dst = out + row * K + 8 * kg;
+        *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    }
+}
+
+// w [N][T][C] fp32 -> P16 [C rows][K = T*N], k = t'*N + n with t' = flip ? T-1-t : t: the data-gradient operand of a
+// convolution (3x3: 180-degree rotated, transposed filters; 1x1: the transposed matrix), packed in one pass.
+__global__ __launch_bounds__(256) void p16_pack_wt_kernel(const float* __restrict__ w, int N, int T, int C, int flip,
+                                                          const float* __restrict__ amax, uint4* __restrict__ out) {
+    const float scale = amax != nullptr ? f16_scale_of(*amax) : 1.f;
+    const int K = T * N, K8 = K / 8;
+    const long long total = (long long)C * K8;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        // consecutive threads take consecutive c (the contiguous direction of w) for one 8-wide k group
+        const int kg = (int)(idx / C);
+        const int c = (int)(idx - (long long)kg * C);
+        const int k0 = 8 * kg;
+        const int tp = k0 / N, n0 = k0 - tp * N;
+        const int t = flip ? T - 1 - tp : tp;
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = w[((long long)(n0 + i) * T + t) * C + c] * scale;
+        unsigned h[4], l[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) f16_split2(v[2 * q], v[2 * q + 1], h[q], l[q]);
+        uint4* dst = out + (long long)c * (K / 4) + (kg >> 2) * 8 + (kg & 3);
+        dst[0] = make_uint4(h[0], h[1], h[2], h[3]);
+        dst[4] = make_uint4(l[0], l[1], l[2], l[3]);
+    }
+}
+
+template <int AMODE, int BM, int BN, int WM, int WN, int STAGES>
+static int launch_p16(GemmParams& p, hipStream_t stream) {
+    p.mblocks = (p.M + BM - 1) / BM;
+    p.nblocks = (p.N + BN - 1) / BN;
+    dim3 grid((unsigned)(p.mblocks * p.nblocks), 1, (unsigned)(p.batch * p.splits));
+    constexpr size_t lds = (size_t)STAGES * (BM + BN) * 128;
+    static std::once_flag once;
+    static hipError_t attr_err = hipSuccess;
+    std::call_once(once, [] {
+        if (lds > 48 * 1024)
+            attr_err = hipFuncSetAttribute((const void*)gemm_p16_kernel<AMODE, BM, BN, WM, WN, STAGES>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    });
+    if (attr_err != hipSuccess) {
+        set_error("trid_gemm_p16: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(attr_err));
+        return (int)attr_err;
+    }
+    hipLaunchKernelGGL((gemm_p16_kernel<AMODE, BM, BN, WM, WN, STAGES>), grid, dim3(WM * WN * 64), lds, stream, p);
+    return check_launch("trid_gemm_p16");
+}
+
+template <int AMODE>
+static int pick_p16(GemmParams& p, int variant, hipStream_t stream) {
+    if (p.N <= 32) return launch_p16<AMODE, 256, 32, 4, 1, 3>(p, stream);
+    if (p.N <= 64) return launch_p16<AMODE, 128, 64, 2, 2, 3>(p, stream);
+    switch (variant) {
+        case 1: return launch_p16<AMODE, 128, 128, 2, 2, 3>(p, stream);   // 4 waves of 64x64, 3 stages (96 KB): 1 WG / CU
+        case 2: return launch_p16<AMODE, 256, 128, 4, 2, 3>(p, stream);   // 8 waves of 64x64, 3 stages (144 KB)
+        case 3: return launch_p16<AMODE, 128, 128, 2, 4, 2>(p, stream);   // 8 waves of 64x32, 2 stages (64 KB): 2 WG / CU
+        case 4: return launch_p16<AMODE, 256, 128, 4, 2, 2>(p, stream);   // 8 waves of 64x64, 2 stages (96 KB)
+        case 5: return launch_p16<AMODE, 128, 128, 2, 4, 3>(p, stream);   // 8 waves of 64x32, 3 stages (96 KB)
+        default: return launch_p16<AMODE, 128, 128, 2, 2, 2>(p, stream);  // 4 waves of 64x64, 2 stages (64 KB): 2 WG / CU
+    }
+}
+
+}  // namespace trid
+
+using namespace trid;
+
+extern "C" int trid_p16_pack_f32(const float* x, long long rows, int K, long long ldx, const float* amax, void* out,
+                                 void* stream) {
+    TRID_REQUIRE(x && out && rows > 0 && K > 0 && K % 32 == 0 && ldx % 4 == 0 && aligned16(x) && aligned16(out),
+                 "trid_p16_pack_f32: needs K %% 32 == 0 and 16-byte aligned rows (K=%d)", K);
+    hipLaunchKernelGGL(p16_pack_kernel, dim3(grid_for(rows * (K / 8), 256, 8192)), dim3(256), 0, (hipStream_t)stream, x, rows, K,
+                       ldx, amax, (uint4*)out);
+    return check_launch("trid_p16_pack_f32");
+}
+
+extern "C" int trid_p16_unpack_f32(const void* in, long long rows, int K, const float* amax, float* out, void* stream) {
+    TRID_REQUIRE(in && out && rows > 0 && K > 0 && K % 32 == 0 && aligned16(in) && aligned16(out), "trid_p16_unpack_f32: bad arguments");
+    hipLaunchKernelGGL(p16_unpack_kernel, dim3(grid_for(rows * (K / 8), 256, 8192)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint4*)in, rows, K, amax, out);
+    return check_launch("trid_p16_unpack_f32");
+}
+
+extern "C" int trid_p16_pack_wt_f32(const float* w, int N, int T, int C, int flip, const float* amax, void* out, void* stream) {
+    TRID_REQUIRE(w && out && N > 0 && T > 0 && C > 0 && N % 8 == 0 && (T * N) % 32 == 0 && aligned16(out),
+                 "trid_p16_pack_wt_f32: needs N %% 8 == 0 and T*N %% 32 == 0 (N=%d T=%d)", N, T);
+    hipLaunchKernelGGL(p16_pack_wt_kernel, dim3(grid_for((long long)C * (T * N / 8), 256, 8192)), dim3(256), 0, (hipStream_t)stream,
+                       w, N, T, C, flip, amax, (uint4*)out);
+    return check_launch("trid_p16_pack_wt_f32");
+}
+
+extern "C" int trid_gemm_p16(const trid_gemm_desc* d, int variant, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    TRID_REQUIRE(d != nullptr && d->A && d->B && d->C, "trid_gemm_p16: null operand");
+    TRID_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0 && d->K % 32 == 0, "trid_gemm_p16: K must be a positive multiple of 32 (K=%d)", d->K);
+    TRID_REQUIRE((d->a_mode == A_KC || d->a_mode == A_CONV) && d->b_mode == B_KC, "trid_gemm_p16: loader modes A_KC / A_CONV x B_KC only");
+    TRID_REQUIRE(aligned16(d->A) && aligned16(d->B) && aligned16(d->C), "trid_gemm_p16: operands must be 16-byte aligned");
+    TRID_REQUIRE(d->batch >= 1 && d->splits >= 1, "trid_gemm_p16: batch/splits must be >= 1");
+    TRID_REQUIRE(d->lda % 32 == 0 && d->ldb % 32 == 0, "trid_gemm_p16: row pitches must be multiples of 32 elements");
+    GemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.A = d->A; p.B = d->B; p.C = d->C;
+    p.M = d->M; p.N = d->N; p.K = d->K;
+    p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc;
+    p.sA = d->strideA; p.sB = d->strideB; p.sC = d->strideC;
+    p.batch = d->batch; p.splits = d->splits;
+    p.alpha = d->alpha; p.accumulate = d->accumulate;
+    p.bias = d->bias; p.sBias = d->strideBias; p.stats = d->stats;
+    p.res = d->residual; p.ldres = d->ldres; p.relu = d->relu;
+    p.H = d->H; p.W = d->W; p.Cin = d->Cin;
+    p.a_amax = d->a_amax; p.b_amax = d->b_amax;
+    if (d->a_mode == A_CONV) {
+        TRID_REQUIRE(d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cin % 32 == 0 && d->K == 9 * d->Cin && d->M % (d->H * d->W) == 0 && d->splits == 1,
+                     "trid_gemm_p16: A_CONV needs Cin %% 32 == 0, K == 9*Cin, M a multiple of H*W, splits == 1");
+        p.fdW = make_fastdiv((uint32_t)d->W);
+        p.fdH = make_fastdiv((uint32_t)d->H);
+    }
+    TRID_REQUIRE(!(d->stats && (d->splits != 1 || d->batch != 1)), "trid_gemm_p16: stats epilogue needs splits==1, batch==1");
+    TRID_REQUIRE(!(d->splits > 1 && (d->accumulate || d->bias || d->residual || d->relu)), "trid_gemm_p16: split-K writes raw slabs");
+    const long long a_bytes = (d->a_mode == A_CONV ? (long long)(d->M + 2 * d->W + 2) * d->Cin : (long long)d->M * d->lda) * 4;
+    TRID_REQUIRE(a_bytes < (1ll << 31) && (long long)d->N * d->ldb * 4 < (1ll << 31), "trid_gemm_p16: operands must stay below 2 GB (31-bit buffer offsets)");
+    int kc = (d->K + d->splits - 1) / d->splits;
+    kc = (kc + P16_BK - 1) / P16_BK * P16_BK;
+    p.k_chunk = kc;
+    p.sSplit = d->strideSplit;
+    if (d->a_mode == A_CONV) return pick_p16<A_CONV>(p, variant, stream);
+    return pick_p16<A_KC>(p, variant, stream);
+}

@@ -169,6 +169,73 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, a_mode=A_KC, b_mode=B_KC, alpha=1.0, a
     call("trid_gemm_f32", ctypes.addressof(d), stream())
 
 
+# --------------------------------------------------------------------------- P16 (pre-split) operands
+class P16:
+    """A GEMM operand stored pre-split (csrc/gemm_p16.hip): `data` holds, per row and 32-wide K group, 32 fp16 high parts
+    then 32 fp16 low parts of x * 2^s (4 bytes per element, same shape / dtype as the fp32 tensor it replaces so it
+    travels through the allocator unchanged); `amax` is the device scalar the scale s was derived from."""
+
+    __slots__ = ("data", "amax")
+
+    def __init__(self, data, amax):
+        self.data, self.amax = data, amax
+
+    @property
+    def shape(self):
+        return self.data.shape
+
+    def unpack(self):
+        K = self.data.shape[-1]
+        out = torch.empty_like(self.data)
+        call("trid_p16_unpack_f32", _p(self.data), self.data.numel() // K, K, _p(self.amax), _p(out), stream())
+        return out
+
+
+P16_VARIANT = int(__import__("os").environ.get("TRID_P16_VARIANT", "0"))  # tile shape of trid_gemm_p16 (experiments)
+
+
+def p16_pack(x, amax_=None):
+    """fp32 [..., K] (K % 32 == 0, rows contiguous) -> P16 with the same shape."""
+    K = x.shape[-1]
+    if amax_ is None:
+        amax_ = amax(x)
+    out = torch.empty_like(x)
+    call("trid_p16_pack_f32", _p(x), x.numel() // K, K, K, _p(amax_), _p(out), stream())
+    return P16(out, amax_)
+
+
+def p16_pack_wt(w, N, T, C, flip, amax_):
+    """w [N][T][C] fp32 -> P16 [C][T*N] (taps reversed when flip): the data-gradient operand of a conv."""
+    out = empty((C, T * N), w)
+    call("trid_p16_pack_wt_f32", _p(w), N, T, C, 1 if flip else 0, _p(amax_), _p(out), stream())
+    return P16(out, amax_)
+
+
+def gemm_p16(A, B, C, M, N, K, ldc, conv=None, alpha=1.0, accumulate=False, bias=None, stats=None, residual=None, ldres=0,
+             relu=False, splits=1, strideSplit=0, variant=None):
+    """C[M,N] = alpha * A . B^T with both operands P16: A [M][K] (or an NHWC image [B,H,W,Cin] with conv=(H,W,Cin),
+    K = 9*Cin), B [N][K]."""
+    d = GemmDesc()
+    d.A, d.B, d.C = _p(A.data), _p(B.data), _p(C)
+    d.M, d.N, d.K = M, N, K
+    d.lda = conv[2] if conv is not None else K
+    d.ldb, d.ldc = K, ldc
+    d.batch, d.splits, d.strideSplit = 1, splits, strideSplit
+    d.a_mode, d.b_mode = (A_CONV if conv is not None else A_KC), B_KC
+    d.alpha = alpha
+    d.accumulate = 1 if accumulate else 0
+    d.bias = _p(bias)
+    d.stats = _p(stats)
+    if conv is not None:
+        d.H, d.W, d.Cin = conv
+    d.precision = 16
+    d.a_amax, d.b_amax = _p(A.amax), _p(B.amax)
+    d.residual = _p(residual)
+    d.ldres = ldres
+    d.relu = 1 if relu else 0
+    call("trid_gemm_p16", ctypes.addressof(d), P16_VARIANT if variant is None else variant, stream())
+
+
 def linear(x, w, bias=None, out=None, alpha=1.0, accumulate=False, prec=None, aa=None, ba=None, relu=False):
     """y[M,N] = alpha * x[M,K] @ w[N,K]^T + bias.  x may be a strided row view.
     prec / aa / ba (here and below): GEMM arithmetic override and the two operands' amax device scalars."""
