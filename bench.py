@@ -286,9 +286,20 @@ def main():
     if world > 1:  # global ids so positives match across ranks' queue pushes
         batches = [(im, tk, ln, ids + rank * (B // 4) + s * (B // 4) * (world - 1)) for s, (im, tk, ln, ids) in enumerate(batches)]
 
-    def step(i):
+    # single process: the whole step (four streams, ~1100 launches) is recorded once as a hipGraph and replayed
+    # (engine/graph.py); data parallel: eager (RCCL collectives are issued from inside backward)
+    runner = None
+    if world == 1 and os.environ.get("TRID_CAPTURE", "1") != "0":
+        from textreid_amd.engine.graph import CapturedTrainStep
+
+        runner = CapturedTrainStep(model, opt, warmup=2, caption_bound=64)  # 64-token captions (padded to 105)
+
+    def batch(i):
         images, tokens, lengths, ids = batches[i % len(batches)]
-        cb = CaptionBatch(tokens, lengths, (ids + (i // len(batches)) * len(batches) * (B // 4) * world) % 11003, max_len=64)
+        return images, CaptionBatch(tokens, lengths, (ids + (i // len(batches)) * len(batches) * (B // 4) * world) % 11003, max_len=64)
+
+    def eager_step(i):
+        images, cb = batch(i)
         loss_dict = model(images, cb)
         losses = sum(loss_dict.values())
         opt.zero_grad()
@@ -297,10 +308,22 @@ def main():
             reducer.reduce(pre_gather)
             reducer.wait()
         opt.step()
-        return losses
+        return loss_dict
 
+    def step(i):
+        if runner is None:
+            return eager_step(i)
+        return runner(*batch(i))
+
+    n_prep = 0
+    if runner is not None:  # set-up, untimed and not counted as warm-up: two eager steps build every cached table, the third call records
+        while runner.graph is None:
+            step(n_prep)
+            n_prep += 1
+        torch.cuda.synchronize()
+        log("train step captured after %d set-up steps" % n_prep)
     for i in range(args.warmup):
-        step(i)
+        step(n_prep + i)
         torch.cuda.synchronize()
         log("warmup step %d done" % i)
     # live roofline of the dominant kernel: 3x3 implicit-GEMM conv, 128x128 tiles
@@ -308,20 +331,31 @@ def main():
     dom = (ops.A_CONV, ops.B_KC, 128, 128, split)
     dom2 = (ops.A_KC, ops.B_KC, 128, 128, split)  # 1x1 convs / linears: the largest TOTAL time of any kernel
     labels = {dom: "conv3x3", dom2: "gemm1x1"}
-    ops.PROFILE = {"match": labels.get, "events": []}
+    if runner is None:  # eager steps: events bracket every launch of the two kernels inside the timed region
+        ops.PROFILE = {"match": labels.get, "events": []}
     reducer.reset_stats()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        last = step(args.warmup + i)
+        last = step(n_prep + args.warmup + i)
     t_host = time.perf_counter() - t0
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
     log("timed region: %.3fs for %d steps (host enqueue time %.3fs)" % (dt, args.steps, t_host))
+    last = {k: v.detach().clone() for k, v in last.items()}
+    profiled_eager = 0
+    if runner is not None:
+        # events cannot bracket individual nodes of a replayed graph: the per-launch timing of the dominant kernels comes
+        # from eager re-runs of the SAME step (all four streams active) right after the timed region
+        ops.PROFILE = {"match": labels.get, "events": []}
+        profiled_eager = 3
+        for i in range(profiled_eager):
+            runner._eager(*batch(n_prep + args.warmup + args.steps + i))
+        torch.cuda.synchronize()
     prof, ops.PROFILE = ops.PROFILE, None
     tmax = torch.tensor([dt], device=device)
     if world > 1:
@@ -332,7 +366,7 @@ def main():
         else:
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
-    loss_val = float(last.item())
+    loss_val = float(sum(last.values()).item())
 
     def live(label):
         ev = [e for e in prof["events"] if e[0] == label]
@@ -420,7 +454,7 @@ def main():
         "traffic_note": traffic_note,
         "achieved_isolated": achieved_isolated,
         "frac_isolated": achieved_isolated / peak,
-        "note": "achieved/frac: events around every launch of this kernel during the timed steps, while the text / key-encoder / weight-gradient streams share the CUs; *_isolated: the same kernel on the five layer2-4 3x3 shapes with the GPU to itself",
+        "note": ("achieved/frac: events around every launch of this kernel " + ("in %d eager re-runs of the step right after the timed region (the timed steps are hipGraph replays: events cannot bracket graph nodes; rocprofv3 --kernel-trace of this command gives the in-graph durations, profiles/)" % profiled_eager if profiled_eager else "during the timed steps") + ", while the text / key-encoder / weight-gradient streams share the CUs; *_isolated: the same kernel on the five layer2-4 3x3 shapes with the GPU to itself"),
         "peak_note": peak_note,
         "launches": nlaunch,
         "avg_launch_ms": ms / max(nlaunch, 1),
@@ -469,6 +503,8 @@ def main():
                 "global_batch": B * world,
                 "parallelism": "dp%d" % world,
                 "optimizer": "Adam (fused multi-tensor)",
+                "step_launch": "hipGraph replay (one launch per step)" if runner is not None else "eager (%d ranks: RCCL collectives inside backward)" % world,
+                "host_enqueue_ms_per_step": t_host / args.steps * 1e3,
                 "gemm_arithmetic": arith,
                 "final_loss": loss_val,
             },

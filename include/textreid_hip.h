@@ -198,8 +198,10 @@ int trid_embedding_gather_f32(const float* table, const int64_t* tokens, float* 
 int trid_gru_cell_fwd_f32(const float* gi, const float* gh, float* h, const int64_t* lengths, float* gates,
                           float* hprev, float* maxv, int32_t* argt, int s, int Lmax, int L, int B, int Hd,
                           long long gates_dstride, long long hprev_dstride, void* stream);
-/* maxv/argt init: 0/-1 when length < Lmax (a zero pad row enters the max, gru.py:63) else -inf/-1 */
-int trid_gru_max_init_f32(float* maxv, int32_t* argt, const int64_t* lengths, int Lmax, int B, int Hd, void* stream);
+/* maxv/argt init: 0/-1 when length < batch maximum (a zero pad row enters the max, gru.py:63) else -inf/-1; the batch
+ * maximum is Lmax, or lmax_dev[0] (device scalar) when that pointer is not NULL and Lmax is only an upper bound */
+int trid_gru_max_init_f32(float* maxv, int32_t* argt, const int64_t* lengths, int Lmax, const int64_t* lmax_dev, int B,
+                          int Hd, void* stream);
 /* Backward of one step (reverse order of s).  dh [2,B,H] carries dL/dh; adds the
  * max-pool gradient dout[b, d*H+j] where argt == t; writes dgi rows into dGi
  * [B*L, 2*3H], dgh [2,B,3H]; dh <- dh*z (+ pass-through when inactive). */

@@ -412,6 +412,58 @@ def test_train_step_is_deterministic(gpu):
     assert outs[0] == outs[1]
 
 
+def test_captured_train_step_equals_eager_bitwise(gpu):
+    """engine.graph.CapturedTrainStep: the hipGraph replay of the train step (forward on four streams, three losses,
+    queue push, backward, FusedAdam with per-group lr that an LR scheduler changes between steps) produces the SAME BITS
+    as the eager step - losses every step, every parameter / moment / queue entry / BatchNorm buffer at the end - and a
+    batch of another shape falls back to the eager step (loudly) without corrupting the recording."""
+    import bench
+    from textreid_amd.caption import CaptionBatch
+    from textreid_amd.config import moco_cfg
+    from textreid_amd.engine.graph import CapturedTrainStep
+    from textreid_amd.model import build_model
+    from textreid_amd.solver import make_optimizer
+
+    B, K, steps = 8, 64, 7
+    cfg = moco_cfg("m_resnet50", K=K)
+    table = torch.randn(3000, 512, generator=torch.Generator().manual_seed(1)) * 0.02
+    batches = [bench.synth_batch(B, s, gpu, 5, vocab=3000) for s in range(steps)]
+    small = bench.synth_batch(4, 99, gpu, 5, vocab=3000)
+    runs = {}
+    for mode in ("eager", "graph"):
+        torch.manual_seed(0)
+        model = build_model(cfg, vocab_dict=table).to(gpu).train()
+        opt = make_optimizer(cfg, model)
+        runner = CapturedTrainStep(model, opt, warmup=2, caption_bound=64)
+        losses = []
+        for i in range(steps):
+            images, tokens, lengths, ids = batches[i]
+            cb = CaptionBatch(tokens, lengths, ids % 11003, max_len=64)
+            if i == 4:  # an LR scheduler step between two training steps
+                for grp in opt.param_groups:
+                    grp["lr"] *= 0.5
+            if i == 5:  # a ragged last batch of an epoch: other shape
+                im2, tk2, ln2, id2 = small
+                cb2 = CaptionBatch(tk2, ln2, id2 % 11003, max_len=64)
+                ld = runner._eager(im2, cb2) if mode == "eager" else runner(im2, cb2)
+                losses.append(torch.stack([v.detach().clone() for v in ld.values()]))
+            ld = runner._eager(images, cb) if mode == "eager" else runner(images, cb)
+            losses.append(torch.stack([v.detach().clone() for v in ld.values()]))
+        torch.cuda.synchronize()
+        if mode == "graph":
+            assert runner.graph is not None
+        runs[mode] = (torch.stack(losses), {k: v.detach().clone() for k, v in model.state_dict().items()},
+                      [opt.state[p]["exp_avg_sq"].clone() for g_ in opt.param_groups for p in g_["params"]],
+                      [int(opt.state[p]["step"]) for g_ in opt.param_groups for p in g_["params"]])
+        del model, opt, runner
+    assert torch.equal(runs["eager"][0], runs["graph"][0]), (runs["eager"][0] - runs["graph"][0]).abs().max()
+    for k, v in runs["eager"][1].items():
+        assert torch.equal(v, runs["graph"][1][k]), k
+    for a, b in zip(runs["eager"][2], runs["graph"][2]):
+        assert torch.equal(a, b)
+    assert runs["eager"][3] == runs["graph"][3] and set(runs["graph"][3]) == {steps + 1}
+
+
 def test_k_reciprocal_rerank_matches_reference_golden(gpu, golden_dir):
     """evaluation.py:40-65,122-124,144-163: Jaccard re-rank matrices and re-ranked CMC/mAP."""
     from textreid_amd.evaluation import k_reciprocal, l2_normalize_rows, rank

@@ -370,7 +370,7 @@ def full_step_case(spec, B, K, vocab, seed, style="margin"):
     return st, table, images, tokens, lengths, ids
 
 
-def _full_step_vs_oracle(gpu, arch, spec, B, K, vocab, seed):
+def _full_step_vs_oracle(gpu, arch, spec, B, K, vocab, seed, captured=False):
     """One MoCo train step of the full-size model on the HIP path and on the CPU oracle from the same
     `margin`-style state and seeded batch.  Returns {name: relative error} over the three losses, EVERY
     trainable gradient (full tensors, against max(max|ref|, gradient floor)), both queues, every
@@ -384,8 +384,24 @@ def _full_step_vs_oracle(gpu, arch, spec, B, K, vocab, seed):
     head = model.embed_model
     head.load_state_dict({k: v.clone() for k, v in st.items()})
     model.to(gpu).train()
-    ld = model(images.to(gpu), CaptionBatch(tokens.to(gpu), lengths.to(gpu), ids.to(gpu)))
-    sum(ld.values()).backward()
+    cb = CaptionBatch(tokens.to(gpu), lengths.to(gpu), ids.to(gpu))
+    if captured:
+        # the SAME step through the hipGraph path: two eager steps + the capture advance the state (queues, key encoders,
+        # BatchNorm statistics), so it is put back before the one replay that is compared
+        from textreid_amd.engine.graph import CapturedTrainStep
+
+        runner = CapturedTrainStep(model, None, warmup=2)
+        other = CaptionBatch(cb.tokens.roll(1, 0), cb.lengths.roll(1, 0), cb.ids + 1, max_len=cb.max_len)
+        for _ in range(2):
+            runner(images.to(gpu).flip(0), other)
+        runner._capture(images.to(gpu).flip(0), other)
+        head.load_state_dict({k: v.clone() for k, v in st.items()})
+        ld = runner(images.to(gpu), cb)
+        assert runner.graph is not None and runner.calls == 3
+        ld = {k: v.clone() for k, v in ld.items()}
+    else:
+        ld = model(images.to(gpu), cb)
+        sum(ld.values()).backward()
     tr = OH.trainable_names(st)
     for k in tr:
         st[k].requires_grad_(True)
@@ -419,6 +435,18 @@ def test_full_size_step_vs_oracle(gpu):
     errs = _full_step_vs_oracle(gpu, "m_resnet50", OV.RN50, B=16, K=64, vocab=3000, seed=30)  # seed: tools/pick_fullstep_seed.py
     worst = sorted(errs.items(), key=lambda kv: -kv[1])[:5]
     print(len(errs), "quantities; worst:", [(k, "%.1e" % v) for k, v in worst])
+    assert sum(k.startswith("grad:") for k in errs) == 183
+    assert_within(errs, TOL)
+
+
+def test_full_size_step_vs_oracle_through_the_captured_graph(gpu):
+    """The same full-size step, REPLAYED from the hipGraph recorded by engine.graph.CapturedTrainStep (the path bench.py
+    and do_train run): identical quantities, identical flat 1e-3."""
+    from fixture_check import assert_within
+
+    errs = _full_step_vs_oracle(gpu, "m_resnet50", OV.RN50, B=16, K=64, vocab=3000, seed=30, captured=True)
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+    print("captured:", len(errs), "quantities; worst:", [(k, "%.1e" % v) for k, v in worst])
     assert sum(k.startswith("grad:") for k in errs) == 183
     assert_within(errs, TOL)
 

@@ -33,7 +33,7 @@ FUSED_GRU_STEP = os.environ.get("TRID_FUSED_GRU", "1") != "0"  # A/B switch: 0 =
 
 class _GRUFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, mod, tokens, lengths, lmax, save, w_ih_f, w_hh_f, w_ih_r, w_hh_r):
+    def forward(ctx, mod, tokens, lengths, lmax, lmax_dev, save, w_ih_f, w_hh_f, w_ih_r, w_hh_r):
         # `save` comes from the caller: ctx.needs_input_grad ignores torch.no_grad()
         B = tokens.shape[0]
         H = w_hh_f.shape[1]
@@ -60,7 +60,7 @@ class _GRUFn(torch.autograd.Function):
         h = torch.zeros(2, B, H, device=table.device)
         maxv = ops.empty((B, 2 * H), table)
         argt = torch.empty(B, 2 * H, dtype=torch.int32, device=table.device)
-        ops.call("trid_gru_max_init_f32", ops._p(maxv), ops._p(argt), ops._p(lengths), L, B, H, st)
+        ops.call("trid_gru_max_init_f32", ops._p(maxv), ops._p(argt), ops._p(lengths), L, ops._p(lmax_dev), B, H, st)
         gates = ops.empty((2, L, B, 4 * H), table) if save else None
         hprev = ops.empty((2, L, B, H), table) if save else None
         img_bytes = ops.L.load().trid_gru_whh_image_bytes(H) if FUSED_GRU_STEP else 0
@@ -152,7 +152,7 @@ class _GRUFn(torch.autograd.Function):
             ops.gemm(dGi, x, slab, 3 * H, E, KK, 6 * H, E, E, a_mode=ops.A_MC, b_mode=ops.B_NC, batch=2,
                      strideA=3 * H, strideB=0, strideC=3 * H * E, splits=splits, strideSplit=n, **kw_ih)
             ops.call("trid_slab_reduce_f32", ops._p(slab), ops._p(dwih), n, splits, n, 0, st)
-        return None, None, None, None, None, dwih[0], dwhh[0], dwih[1], dwhh[1]
+        return None, None, None, None, None, None, dwih[0], dwhh[0], dwih[1], dwhh[1]
 
 
 class GRU(nn.Module):
@@ -182,7 +182,10 @@ class GRU(nn.Module):
         g = self.gru
         ws = (g.weight_ih_l0, g.weight_hh_l0, g.weight_ih_l0_reverse, g.weight_hh_l0_reverse)
         save = torch.is_grad_enabled() and any(w.requires_grad for w in ws)
-        return _GRUFn.apply(self, cb.tokens.contiguous(), cb.lengths.contiguous(), cb.max_len, save, *ws)
+        # cb.max_len is the time-loop length; when it is only an upper BOUND of the batch maximum (bound_only: a recorded
+        # step replayed on other captions) the zero-pad quirk of gru.py:63 takes the true maximum from the device
+        lmax_dev = cb.lengths.max().reshape(1) if getattr(cb, "bound_only", False) else None
+        return _GRUFn.apply(self, cb.tokens.contiguous(), cb.lengths.contiguous(), cb.max_len, lmax_dev, save, *ws)
 
 
 def build_gru(cfg, bidirectional, vocab_dict=None):

@@ -94,11 +94,15 @@ class Caption:
 class CaptionBatch:
     """tokens [B,L] i64, lengths [B] i64, ids [B] i64 (or None), max_len: host int."""
 
-    def __init__(self, tokens, lengths, ids=None, max_len=None):
+    def __init__(self, tokens, lengths, ids=None, max_len=None, bound_only=False):
+        """max_len: the batch-maximum token count when the host knows it (else one device read); bound_only: max_len
+        is merely an upper bound of it (the recorded train step, engine/graph.py) - the text encoder then loops max_len
+        steps and takes the true maximum, which the reference's padding semantics depend on, from the device."""
         self.tokens = tokens
         self.lengths = lengths.view(-1)
         self.ids = ids.view(-1) if ids is not None else None
         self.max_len = int(max_len) if max_len is not None else int(self.lengths.max())
+        self.bound_only = bool(bound_only)
 
     @classmethod
     def from_list(cls, captions):
@@ -119,7 +123,7 @@ class CaptionBatch:
 
     def to(self, device):
         return CaptionBatch(self.tokens.to(device), self.lengths.to(device),
-                            self.ids.to(device) if self.ids is not None else None, self.max_len)
+                            self.ids.to(device) if self.ids is not None else None, self.max_len, self.bound_only)
 
     def __len__(self):
         return self.tokens.shape[0]

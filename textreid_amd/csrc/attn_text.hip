@@ -123,11 +123,15 @@ __global__ void embedding_gather_kernel(const float4* __restrict__ table, const 
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-v)); }
 
 __global__ void gru_max_init_kernel(float* __restrict__ maxv, int32_t* __restrict__ argt,
-                                    const int64_t* __restrict__ lengths, int Lmax, int B, int Hd) {
+                                    const int64_t* __restrict__ lengths, int Lmax, const int64_t* __restrict__ lmax_dev,
+                                    int B, int Hd) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B * 2 * Hd) return;
     const int b = i / (2 * Hd);
-    maxv[i] = lengths[b] < Lmax ? 0.f : -INFINITY;
+    // pad_packed_sequence pads to the BATCH maximum (gru.py:78-79): that maximum is the host's Lmax, or - when the
+    // host only knows an upper bound (a recorded step replayed on other captions) - the device scalar
+    const long long batch_max = lmax_dev != nullptr ? lmax_dev[0] : (long long)Lmax;
+    maxv[i] = lengths[b] < batch_max ? 0.f : -INFINITY;
     argt[i] = -1;
 }
 
@@ -257,12 +261,12 @@ extern "C" int trid_embedding_gather_f32(const float* table, const int64_t* toke
     return check_launch("trid_embedding_gather_f32");
 }
 
-extern "C" int trid_gru_max_init_f32(float* maxv, int32_t* argt, const int64_t* lengths, int Lmax, int B, int Hd,
-                                     void* stream) {
+extern "C" int trid_gru_max_init_f32(float* maxv, int32_t* argt, const int64_t* lengths, int Lmax, const int64_t* lmax_dev,
+                                     int B, int Hd, void* stream) {
     TRID_REQUIRE(maxv && argt && lengths && B > 0 && Hd > 0 && Lmax > 0, "trid_gru_max_init_f32: bad arguments");
     const int n = B * 2 * Hd;
     hipLaunchKernelGGL(gru_max_init_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, maxv, argt, lengths,
-                       Lmax, B, Hd);
+                       Lmax, lmax_dev, B, Hd);
     return check_launch("trid_gru_max_init_f32");
 }
 

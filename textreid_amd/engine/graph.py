@@ -1,0 +1,116 @@
+"""The training step as ONE hipGraph (counterpart of the loop body ``lib/engine/trainer.py:72-91``:
+``model(images, captions)`` -> sum of the losses -> ``zero_grad`` -> ``backward`` -> ``optimizer.step``).
+
+A step is ~1 100 kernel launches on four HIP streams issued from Python through ctypes: ~40 ms of host work per
+50 ms step.  With zero host-device synchronisations and a flat allocation profile per step (both pinned by tests)
+the whole launch sequence - the side streams included, they fork from and join the capturing stream through events -
+is recorded once with ``torch.cuda.graph`` and replayed: one host call per step.
+
+What varies between steps lives in device memory that the replay reads:
+  * inputs: copied into static buffers (stream-ordered, before the replay);
+  * MoCo queue pointer, BatchNorm counters, amax scalars: device-resident already;
+  * optimizer hyper-parameters and bias corrections: ``FusedAdam.advance_for_replay()``.
+
+Shapes are part of the recording: a batch of another shape (or another caption length bound) runs EAGERLY, with a
+warning - never silently through a graph recorded for different sizes.
+"""
+
+import logging
+
+import torch
+
+from ..caption import CaptionBatch
+from ..parallel import dp_active
+
+
+class CapturedTrainStep:
+    def __init__(self, model, optimizer, warmup=2, caption_bound=None):
+        """warmup: eager steps before the capture (they build every cached pointer table / workspace / side stream the
+        step uses; they are REAL training steps).  optimizer=None: forward + backward only (parity tests).
+        caption_bound: number of recurrence steps the recorded text encoder runs (None: the token tensor's width, i.e.
+        any caption fits); batches whose longest caption exceeds it run eagerly."""
+        self.model, self.optimizer = model, optimizer
+        self.caption_bound = caption_bound
+        self.warmup = max(int(warmup), 1)
+        self.calls = 0
+        self.graph = None
+        self.static = None
+        self.out = None
+        self.signature = None
+        self.log = logging.getLogger("PersonSearch.trainer")
+        if dp_active():
+            raise RuntimeError("CapturedTrainStep covers the single-process step; under data parallelism the step runs eagerly "
+                               "(its RCCL collectives are issued from inside backward)")
+
+    # ------------------------------------------------------------------ eager form (also the fall-back)
+    def _eager(self, images, cb):
+        loss_dict = self.model(images, cb)
+        losses = sum(loss_dict.values())
+        if self.optimizer is not None:
+            self.optimizer.zero_grad()
+        else:
+            for p in self.model.parameters():
+                p.grad = None
+        losses.backward()
+        if self.optimizer is not None:
+            self.optimizer.step()
+        return loss_dict
+
+    @staticmethod
+    def _sig(images, cb):
+        return (tuple(images.shape), tuple(cb.tokens.shape), cb.ids is not None)
+
+    def _capture(self, images, cb):
+        from ..solver import FusedAdam
+
+        self.static = {
+            "images": images.clone(),
+            "tokens": cb.tokens.clone(),
+            "lengths": cb.lengths.clone(),
+            "ids": cb.ids.clone() if cb.ids is not None else None,
+        }
+        self.bound = int(self.caption_bound) if self.caption_bound is not None else int(cb.tokens.shape[1])
+        scb = CaptionBatch(self.static["tokens"], self.static["lengths"], self.static["ids"], max_len=self.bound, bound_only=True)
+        if isinstance(self.optimizer, FusedAdam):
+            self.optimizer.prepare_capture()
+        elif self.optimizer is not None:
+            raise RuntimeError("CapturedTrainStep needs textreid_amd.solver.FusedAdam (or optimizer=None)")
+        for p in self.model.parameters():
+            p.grad = None  # the captured backward allocates its gradients inside the graph's pool
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            loss_dict = self.model(self.static["images"], scb)
+            losses = sum(loss_dict.values())
+            losses.backward()
+            if self.optimizer is not None:
+                self.optimizer.step()
+        self.graph, self.out = g, loss_dict
+        self.grads = [(p, p.grad) for p in self.model.parameters() if p.grad is not None]  # live in the graph's pool
+        self.signature = self._sig(images, cb)
+        self.log.info("train step captured: one graph launch per step from here on")
+
+    def __call__(self, images, captions):
+        cb = CaptionBatch.from_list(captions)
+        self.calls += 1
+        if self.graph is None:
+            if self.calls <= self.warmup:
+                return self._eager(images, cb)
+            self._capture(images, cb)
+        if self._sig(images, cb) != self.signature or cb.max_len > self.bound:
+            self.log.warning("train step: batch signature %s (longest caption %d) does not fit the captured one %s (bound %d) - running this step eagerly",
+                             self._sig(images, cb), cb.max_len, self.signature, self.bound)
+            return self._eager(images, cb)
+        st = self.static
+        st["images"].copy_(images, non_blocking=True)
+        st["tokens"].copy_(cb.tokens, non_blocking=True)
+        st["lengths"].copy_(cb.lengths, non_blocking=True)
+        if st["ids"] is not None:
+            st["ids"].copy_(cb.ids, non_blocking=True)
+        for p, g in self.grads:  # (an eager fall-back step in between re-bound .grad)
+            if p.grad is not g:
+                p.grad = g
+        if self.optimizer is not None:
+            self.optimizer.advance_for_replay()
+        self.graph.replay()
+        return self.out

@@ -29,11 +29,20 @@ def train_step(model, optimizer, images, captions, reducer=None, pre_gather=None
 
 
 def do_train(model, data_loader, data_loader_val, optimizer, scheduler, checkpointer, meters, device,
-             checkpoint_period, evaluate_period, arguments, log_period=20):
+             checkpoint_period, evaluate_period, arguments, log_period=20, capture=True):
+    """capture: record the step as one hipGraph after two eager steps (engine/graph.py) when the optimizer is the fused
+    Adam, the model runs on a GPU and there is one process; batches of another shape run eagerly."""
     logger = logging.getLogger("PersonSearch.trainer")
     logger.info("Start training")
     max_epoch, epoch, iteration = arguments["max_epoch"], arguments["epoch"], arguments["iteration"]
     reducer = GradReducer()
+    runner = None
+    if capture and not dp_active() and torch.device(device).type == "cuda":
+        from ..solver import FusedAdam
+        from .graph import CapturedTrainStep
+
+        if isinstance(optimizer, FusedAdam):
+            runner = CapturedTrainStep(model, optimizer, warmup=2)
     pre_gather = [p for n, p in model.named_parameters() if p.requires_grad and "loss_evaluator" not in n][::-1]
     if dp_active() and hasattr(getattr(model, "embed_model", None), "v_encoder_q"):
         model.embed_model.v_encoder_q.grad_sync = reducer  # conv gradients all-reduced from inside backward
@@ -62,7 +71,11 @@ def do_train(model, data_loader, data_loader_val, optimizer, scheduler, checkpoi
             arguments["iteration"] = iteration
             images = images.to(device)
             captions = captions.to(device) if hasattr(captions, "to") else [c.to(device) for c in captions]
-            loss_dict, losses = train_step(model, optimizer, images, captions, reducer, pre_gather)
+            if runner is not None:
+                loss_dict = runner(images, captions)
+                losses = sum(loss_dict.values())
+            else:
+                loss_dict, losses = train_step(model, optimizer, images, captions, reducer, pre_gather)
             if meters is not None:
                 # every step counts (trainer.py:92-93 updates the meters per step): kept on device, one read per period
                 with torch.no_grad():

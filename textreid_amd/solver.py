@@ -106,6 +106,70 @@ class FusedAdam(torch.optim.Optimizer):
             pl["done"][k] = ev
         return dyn
 
+    # ---- hipGraph capture (engine/graph.py): the step's kernel launch is recorded once and replayed.  Gradient tensors of
+    # a captured backward live at fixed addresses, so their pointer table is written by ONE captured copy from a pinned
+    # buffer that never changes afterwards; what changes from replay to replay - lr / weight decay of every group (LR
+    # schedulers), the per-parameter bias corrections - lives in the tail of the same device table and is refreshed by
+    # `advance_for_replay()` with a stream-ordered copy from a small ring of pinned buffers right before each replay
+    # (no host sync, no captured host memory that changes).
+    def prepare_capture(self):
+        """OUTSIDE capture (pinned allocations are not capturable), after at least one eager step built the static
+        pointer tables: the device / pinned tables of the captured step."""
+        if self._plan is None:
+            raise RuntimeError("FusedAdam.prepare_capture(): run one eager step first (static pointer tables)")
+        pl = self._plan
+        n = len(pl["sizes"])
+        pl["graph_n"] = n
+        pl["graph_dyn"] = torch.empty(3 * n + 1, dtype=torch.int64, device=pl["sizes"].device)
+        pl["graph_gptr_host"] = torch.empty(n, dtype=torch.int64).pin_memory()
+        pl["graph_ring"] = [torch.empty(2 * n + 1, dtype=torch.int64).pin_memory() for _ in range(4)]
+        pl["graph_ring_ev"] = [None] * 4
+        pl["graph_turn"] = 0
+
+    def _capture_tables(self, items):
+        """INSIDE the capture: the captured gradients' addresses -> the static table (a captured copy node)."""
+        pl = self._plan
+        n = len(items)
+        if pl.get("graph_n") != n:
+            raise RuntimeError("FusedAdam.step() inside a stream capture needs prepare_capture() first (engine.graph.CapturedTrainStep "
+                               "does it) and the same set of parameters with gradients as the eager steps")
+        pl["graph_gptr_host"].numpy()[:] = np.array([g.data_ptr() for _, g, _ in items], dtype=np.uint64).view(np.int64)
+        pl["graph_dyn"][:n].copy_(pl["graph_gptr_host"], non_blocking=True)
+        return pl["graph_dyn"]
+
+    def advance_for_replay(self):
+        """Host side of one replayed step: per-parameter step counts, bias corrections, the groups' CURRENT lr / weight
+        decay -> the device table, stream-ordered."""
+        pl = self._plan
+        n = pl["graph_n"]
+        lrs, wds, bc1, bc2 = [], [], [], []
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                st = self.state[p]
+                t = int(st["step"]) + 1
+                st["step"] = t
+                lrs.append(group["lr"])
+                wds.append(group["weight_decay"])
+                bc1.append(1.0 - b1 ** t)
+                bc2.append((1.0 - b2 ** t) ** 0.5)
+        k = pl["graph_turn"]
+        pl["graph_turn"] = (k + 1) % len(pl["graph_ring"])
+        if pl["graph_ring_ev"][k] is not None:
+            pl["graph_ring_ev"][k].synchronize()  # the copy issued four steps ago (long finished)
+        f = pl["graph_ring"][k].numpy().view(np.float32)
+        f[:n] = np.asarray(lrs, dtype=np.float32)
+        f[n : 2 * n] = np.asarray(wds, dtype=np.float32)
+        f[2 * n : 3 * n] = np.asarray(bc1, dtype=np.float32)
+        f[3 * n : 4 * n] = np.asarray(bc2, dtype=np.float32)
+        pl["graph_dyn"][n:].copy_(pl["graph_ring"][k], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        pl["graph_ring_ev"][k] = ev
+        ops.note_parameter_write()
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = closure() if closure is not None else None
@@ -134,20 +198,27 @@ class FusedAdam(torch.optim.Optimizer):
                     raise RuntimeError("FusedAdam: betas/eps must be shared by all groups")
         if not items:
             return loss
-        # one step count PER PARAMETER, as torch.optim.Adam keeps it (a parameter that starts receiving gradients later,
-        # or a resumed state with unequal counts, gets its own bias correction)
-        bc1, bc2 = [], []
-        for _, _, st in items:
-            t = int(st["step"]) + 1
-            st["step"] = t
-            bc1.append(1.0 - b1 ** t)
-            bc2.append((1.0 - b2 ** t) ** 0.5)
+        capturing = items[0][0].is_cuda and torch.cuda.is_current_stream_capturing()
         key = self._key(items)
         if self._plan is None or self._plan["key"] != key:
+            if capturing:
+                raise RuntimeError("FusedAdam: parameter / moment tensors moved since the eager warm-up steps; cannot build tables inside a capture")
             self._build(items)
         pl = self._plan
         n = len(items)
-        dyn = self._upload(items, lrs, wds, bc1, bc2)
+        if capturing:
+            # nothing executes during a capture: step counts and hyper-parameters are advanced per REPLAY (advance_for_replay)
+            dyn = self._capture_tables(items)
+        else:
+            # one step count PER PARAMETER, as torch.optim.Adam keeps it (a parameter that starts receiving gradients
+            # later, or a resumed state with unequal counts, gets its own bias correction)
+            bc1, bc2 = [], []
+            for _, _, st in items:
+                t = int(st["step"]) + 1
+                st["step"] = t
+                bc1.append(1.0 - b1 ** t)
+                bc2.append((1.0 - b2 ** t) ** 0.5)
+            dyn = self._upload(items, lrs, wds, bc1, bc2)
         ops.call("trid_adam_multi_f32", ops._p(pl["p"]), ops._p(dyn), ops._p(pl["m"]), ops._p(pl["v"]),
                  ops._p(pl["sizes"]), ops._p(dyn) + 8 * n, ops._p(dyn) + 12 * n, ops._p(pl["ct"]), ops._p(pl["co"]), pl["n"],
                  ADAM_CHUNK, float(b1), float(b2), float(eps), ops._p(dyn) + 16 * n, ops._p(dyn) + 20 * n,
