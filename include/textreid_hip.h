@@ -83,6 +83,7 @@ typedef struct trid_gemm_desc {
     int32_t relu;          /* != 0: C = max(C, 0) last (eval: BatchNorm folded into weights + bias, ReLU here) */
     const float* a_amax;   /* precision 16 only: DEVICE scalars holding max|A| and max|B| over the whole operand */
     const float* b_amax;   /* (trid_amax_f32); NULL = operand used unscaled (must then lie in fp16's range)      */
+    int32_t stats_minmax;  /* trid_gemm_p16 only, with stats: partials are [..][N][4] = (mean, M2, min, max) per column */
 } trid_gemm_desc;
 
 int trid_gemm_f32(const trid_gemm_desc* d, void* stream);
@@ -101,10 +102,18 @@ int trid_p16_unpack_f32(const void* in, long long rows, int K, const float* amax
 /* w [N][T][C] fp32 -> P16 [C rows][K = T*N], k = t'*N + n, t' = flip ? T-1-t : t: the data-gradient operand of a
  * conv (autograd of nn.Conv2d, m_resnet.py:18-26): trid_weight_transpose_f32 + pack in one pass */
 int trid_p16_pack_wt_f32(const float* w, int N, int T, int C, int flip, const float* amax, void* out, void* stream);
+/* All conv filters of an encoder in one launch: table (device) = n_tensors x {src, dst, N, T, C, a} (int64), amax[a] =
+ * max|tensor|; transposed == 0: trid_p16_pack_f32 of [N][T*C]; != 0: trid_p16_pack_wt_f32 (taps reversed for T > 1) */
+int trid_p16_pack_multi_f32(const long long* table, const float* amax, int n_tensors, int transposed, void* stream);
 /* C = alpha * A . B^T (+ epilogues of trid_gemm_f32: bias, accumulate, residual, relu, split-K slabs, BatchNorm
  * partials) with A ([M][K], or an NHWC image for a_mode TRID_A_CONV) and B ([N][K]) in P16; lda / ldb = row pitch
  * in elements; a_amax / b_amax = the scalars the operands were packed with.  variant: tile shape (0 = default). */
 int trid_gemm_p16(const trid_gemm_desc* d, int variant, void* stream);
+/* Weight gradients on P16 operands: C[M][N] = alpha * sum_k A[k][m] * B[k][n] with A = dL/dy [K pixels][M] and
+ * B = the layer input [K pixels][N] (b_mode TRID_B_NC) or its 3x3 gather (TRID_B_CONV: N = 9*Cin, the NHWC image
+ * [K pixels][Cin]); the K-major operands are transposed by the LDS read (ds_read_b64_tr_b16).  splits > 1 writes
+ * split-K slabs (trid_slab_reduce_f32 folds them).  autograd of nn.Conv2d (m_resnet.py:18-26). */
+int trid_gemm_p16_wgrad(const trid_gemm_desc* d, void* stream);
 
 /* C[i] (+)= sum_s slab[s*strideSplit + i], i < n (n % 4 == 0) */
 int trid_slab_reduce_f32(const float* slab, float* C, long long n, int splits, long long strideSplit,
@@ -145,6 +154,24 @@ int trid_bn_apply_f32(const float* y, const float* scale, const float* shift, co
  * the producer of a GEMM operand hands the consumer its precision-16 scale without another pass. */
 int trid_bn_apply_pool2_f32(const float* y, const float* scale, const float* shift, float* out, int B, int H,
                             int W, int C, int relu, float* amax, void* stream);
+/* ---- the same passes PRODUCING / CONSUMING P16 tensors (pre-split GEMM operands, see trid_gemm_p16).  A P16 output
+ * needs its scale before the pass runs: `bound*` are device scalars holding an upper bound of max|out| - exact for
+ * act(BatchNorm(y)) from the column extremes of the conv epilogue (trid_bn_finalize_minmax_f32), a sum of two bounds
+ * for a residual block output, a triangle-inequality bound for BatchNorm backward (trid_bn_bwd_reduce_bound_f32). */
+/* trid_bn_finalize_f32 on (mean, M2, min, max) partials ([nparts][C][4], stats_minmax of trid_gemm_p16);
+ * amax_out[0] = max(amax_out[0], max_c max|act(y_c*scale_c+shift_c)|) (relu != 0: act = ReLU), amax_out zeroed by the caller */
+int trid_bn_finalize_minmax_f32(const float* partials, int nparts, int rows_per_part, long long M, int C,
+                                const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                float momentum, float eps, float* mean, float* invstd, float* scale, float* shift,
+                                int relu, float* amax_out, void* stream);
+/* trid_bn_apply_f32 with a P16 output scaled for the bound bound_a[0] (+ bound_b[0] if not NULL); bound_sum (may be
+ * NULL) receives that sum.  res_amax != NULL: `res` is a P16 tensor (identity residual) with that amax. */
+int trid_bn_apply_p16_f32(const float* y, const float* scale, const float* shift, const void* res, const float* rscale,
+                          const float* rshift, const float* res_amax, void* out, long long M, int C, int relu,
+                          uint64_t* relu_mask, const float* bound_a, const float* bound_b, float* bound_sum, void* stream);
+/* trid_bn_apply_pool2_f32 with a P16 output (scale from bound[0]); in_amax != NULL: y itself is a P16 tensor */
+int trid_bn_apply_pool2_p16_f32(const void* y, const float* scale, const float* shift, const float* in_amax, void* out,
+                                int B, int H, int W, int C, int relu, const float* bound, void* stream);
 /* dx[b,y,x,c] (+)= 0.25*g[b,y/2,x/2,c] */
 int trid_avgpool2_bwd_f32(const float* g, float* dx, int B, int H, int W, int C, int accumulate, void* stream);
 
@@ -163,6 +190,17 @@ int trid_bn_bwd_apply_f32(const float* g, const float* y, const float* act, cons
                           const float* invstd, const float* scale, const float* shift, const float* dgamma,
                           const float* dbeta, int mask_mode, int pooled, int B, int H, int W, int C, float* dy,
                           float* dres, float* amax, void* stream);
+/* trid_bn_bwd_reduce_f32 that also folds a bound of max|dy| into bound[0] (zeroed by the caller); ws as sized by
+ * trid_bn_bwd_ws_floats */
+int trid_bn_bwd_reduce_bound_f32(const float* g, const float* y, const float* act, const float* mean,
+                                 const float* invstd, const float* scale, const float* shift, int mask_mode, int pooled,
+                                 int B, int H, int W, int C, float* dgamma, float* dbeta, float* ws, float* bound,
+                                 void* stream);
+/* trid_bn_bwd_apply_f32 with dy written as a P16 tensor scaled for bound[0] */
+int trid_bn_bwd_apply_p16_f32(const float* g, const float* y, const float* act, const float* mean, const float* invstd,
+                              const float* scale, const float* shift, const float* dgamma, const float* dbeta,
+                              int mask_mode, int pooled, int B, int H, int W, int C, void* dy, float* dres,
+                              const float* bound, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Attention pool (m_resnet.py:103-135), token-0 query only.

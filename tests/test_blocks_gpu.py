@@ -80,8 +80,12 @@ FLIP_FRACTION = 1e-5  # at most this share of the ReLU decisions may differ from
 FLIP_MAGNITUDE = 1e-5  # ... and only at |pre-activation| <= this share of the tensor's largest
 
 
+@pytest.mark.parametrize("path", ["p16", "split"])
 @pytest.mark.parametrize("name,inpl,planes,stride,H,W", RN50_BLOCKS, ids=[b[0] for b in RN50_BLOCKS])
-def test_bottleneck_b128_unstructured_masks(gpu, name, inpl, planes, stride, H, W):
+def test_bottleneck_b128_unstructured_masks(gpu, name, inpl, planes, stride, H, W, path):
+    """path "p16": the production path - pre-split operands written by the BatchNorm passes (scales from the conv
+    epilogue's column extremes / the backward bound), LDS-DMA staged GEMMs, transposing weight-gradient kernel;
+    "split": the on-the-fly fp16 split (the path of encoders whose channel counts are not multiples of 32)."""
     from textreid_amd import ops
     from textreid_amd.backbones import m_resnet as M
 
@@ -106,13 +110,20 @@ def test_bottleneck_b128_unstructured_masks(gpu, name, inpl, planes, stride, H, 
 
     xd = x.permute(0, 2, 3, 1).contiguous().to(gpu)
     gd = gout.permute(0, 2, 3, 1).contiguous().to(gpu)
-    ar = M.ConvArith(gpu, M.weight_amax(blk))
+    WA = M.weight_amax(blk)
+    ar = M.ConvArith(gpu, WA)
     ax = ops.amax(xd)
     nbt, masks = [], []
-    out, a_out, rec = M.block_forward(blk, xd, ax, ar, True, True, nbt, masks)
     ws = M._WgradStream(gpu)
     G = {}
-    dx = M.block_backward(blk, rec, gd, ar, ws, G)
+    if path == "p16":
+        assert M.p16_eligible(type("One", (), {"blocks": lambda self: [blk]})())
+        outp, rec = M.block_forward_p16(blk, ops.p16_pack(xd, ax), M.p16_weights(blk, WA, False), gpu, True, True, nbt, masks)
+        out, a_out = outp.unpack(), outp.amax
+        dx = M.block_backward_p16(blk, rec, gd, M.p16_weights(blk, WA, True), ws, G)
+    else:
+        out, a_out, rec = M.block_forward(blk, xd, ax, ar, True, True, nbt, masks)
+        dx = M.block_backward(blk, rec, gd, ar, ws, G)
     ws.join()
     torch.cuda.synchronize()
     assert len(nbt) == (4 if has_down else 3) and len(masks) == 3
@@ -137,7 +148,10 @@ def test_bottleneck_b128_unstructured_masks(gpu, name, inpl, planes, stride, H, 
     assert flips <= FLIP_FRACTION * total and fmax <= FLIP_MAGNITUDE, (flips, total, fmax)
     bad = {k: v for k, v in errs.items() if not v <= TOL}
     assert not bad, bad
-    assert amax_err <= 1e-4  # the producer-side amax scalar the NEXT block's GEMM would scale by
+    # the scalar the NEXT block's GEMM scales by: the exact maximum on the split path, an upper bound within 2x on the
+    # P16 path (bound of the BatchNorm branch + bound of the residual; a looser scale costs one bit of the low plane)
+    a, true = float(a_out), float(o64.abs().max())
+    assert (true * (1 - 1e-6) <= a <= 2.0 * true) if path == "p16" else amax_err <= 1e-4, (a, true)
 
 
 def test_stem_b128_unstructured_masks(gpu):

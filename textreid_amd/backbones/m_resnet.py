@@ -164,7 +164,47 @@ def weight_amax(mod):
         mod._wamax_plan = plan
     out = torch.zeros(len(convs), dtype=torch.float32, device=convs[0].device)
     ops.call("trid_amax_multi_f32", ops._p(plan[1]), ops._p(plan[2]), len(convs), ops._p(out), ops.stream())
-    return {id(w): out[i : i + 1] for i, w in enumerate(convs)}
+    WA = {id(w): out[i : i + 1] for i, w in enumerate(convs)}
+    WA["all"] = out  # the scalars as one array, in module order of the conv filters (p16_weights)
+    return WA
+
+
+def p16_eligible(mod):
+    """The residual blocks run on pre-split (P16) operands when every block channel count is a multiple of the 32-wide
+    K group (all CLIP ModifiedResNets at width 64; not the width-16 test encoders)."""
+    ok = getattr(mod, "_p16_ok", None)
+    if ok is None:
+        ok = all(isinstance(m, nn.Conv2d) is False or (m.in_channels % 32 == 0 and m.out_channels % 32 == 0)
+                 for blk in mod.blocks() for m in blk.modules())
+        mod._p16_ok = ok
+    return ok
+
+
+def p16_weights(mod, WA, transposed):
+    """{id(conv weight): ops.P16} for every residual-block filter of `mod`, ONE multi-tensor launch: the forward
+    operands [N][taps*C] (filters as stored: 3x3 in OHWI) or, transposed, the data-gradient operands [C][taps*N] with
+    the taps reversed.  Destination buffers and the pointer table are persistent per module."""
+    convs = [m.weight for m in mod.modules() if isinstance(m, nn.Conv2d)]  # weight_amax's order
+    index = {id(w): i for i, w in enumerate(convs)}
+    blocks = mod.blocks() if hasattr(mod, "blocks") else [mod]  # (a single Bottleneck: per-block parity tests)
+    mine = [m.weight for blk in blocks for m in blk.modules() if isinstance(m, nn.Conv2d)]
+    key = tuple(w.data_ptr() for w in mine)
+    plans = mod.__dict__.setdefault("_p16_plans", {})
+    plan = plans.get(transposed)
+    if plan is None or plan[0] != key:
+        dev = mine[0].device
+        dsts, rows = [], []
+        for w in mine:
+            N, C, T = w.shape[0], w.shape[1], w.shape[2] * w.shape[3]
+            if T > 1 and not w.is_contiguous(memory_format=torch.channels_last):
+                raise RuntimeError("3x3 filters must live in channels_last (OHWI) memory")
+            d = torch.empty((C, T * N) if transposed else (N, T * C), dtype=torch.float32, device=dev)
+            dsts.append(d)
+            rows.append([w.data_ptr(), d.data_ptr(), N, T, C, index[id(w)]])
+        plan = (key, torch.tensor(rows, dtype=torch.int64, device=dev), dsts)
+        plans[transposed] = plan
+    ops.call("trid_p16_pack_multi_f32", ops._p(plan[1]), ops._p(WA["all"]), len(mine), 1 if transposed else 0, ops.stream())
+    return {id(w): ops.P16(d, WA[id(w)]) for w, d in zip(mine, plan[2])}
 
 
 def _pre_mask(y, st):
@@ -312,6 +352,95 @@ def block_backward(blk, rec, g, ar, ws, G):
         dx = dres
     ops.matmul_nn(dya.view(-1, dya.shape[-1]), wa, out=dx.view(-1, dx.shape[-1]), accumulate=True, prec=P, aa=a_dya, ba=ar.wam(blk.conv1))
     G[id(blk.conv1.weight)] = ws.run(lambda d_, x_: ops.conv1x1_wgrad(d_, x_, prec=P, aa=a_dya, ba=ax), dya, x, keep=(a_dya, ax)).view_as(blk.conv1.weight)
+    return dx
+
+
+def block_forward_p16(blk, x, WP, dev, training, save, nbt, masks=None):
+    """block_forward on pre-split operands: x and every GEMM operand are ops.P16 tensors written by their producers
+    (BatchNorm apply passes, whose output magnitude is known from the conv epilogue's column extremes before they
+    run), the convolutions stage them with LDS-DMA (csrc/gemm_p16.hip).  Same arithmetic as the fp16-split path."""
+    assert training
+    stride = blk.stride
+    slot = lambda: ops.amax_slot(dev)
+    fin = lambda bn, parts, M, relu, bound: _finalize_minmax(bn, parts, M, relu, bound, nbt)
+    ya, pa = ops.conv_p16(x, WP[id(blk.conv1.weight)])
+    Ma = ya.numel() // ya.shape[-1]
+    a_aa = slot()
+    sta = fin(blk.bn1, pa, Ma, True, a_aa)
+    aa = ops.bn_apply_p16(ya, sta, a_aa, relu=True)
+    yb, pb = ops.conv_p16(aa, WP[id(blk.conv2.weight)], conv3=True)
+    a_ab = slot()
+    stb = fin(blk.bn2, pb, Ma, True, a_ab)
+    ab = ops.bn_apply_pool2_p16(yb, stb, a_ab, relu=True) if stride > 1 else ops.bn_apply_p16(yb, stb, a_ab, relu=True)
+    yc, pc = ops.conv_p16(ab, WP[id(blk.conv3.weight)])
+    Mc = yc.numel() // yc.shape[-1]
+    a_c = slot()
+    stc = fin(blk.bn3, pc, Mc, False, a_c)
+    xd = yd = std = None
+    if blk.downsample is not None:
+        xd = ops.bn_apply_pool2_p16(x, None, x.amax) if stride > 1 else x
+        yd, pd = ops.conv_p16(xd, WP[id(blk.downsample[1].weight)])
+        a_d = slot()
+        std = fin(blk.downsample[2], pd, Mc, False, a_d)
+        out = ops.bn_apply_p16(yc, stc, a_c, relu=True, res=yd, res_st=std, bound_res=a_d, want_mask=save)
+    else:
+        out = ops.bn_apply_p16(yc, stc, a_c, relu=True, res=x, bound_res=x.amax, want_mask=save)
+    rec = None
+    if save:
+        out, rmask = out
+        rec = (x, ya, sta, aa, yb, stb, ab, yc, stc, xd, yd, std, rmask)
+    if masks is not None:
+        masks.extend([aa.unpack() > 0, (ops.bn_apply(yb, stb, relu=True) if stride > 1 else ab.unpack()) > 0, out.unpack() > 0])
+    return out, rec
+
+
+def _finalize_minmax(bn, partials, M, relu, bound, counters):
+    st = ops.bn_finalize_minmax(partials, M, bn.weight, bn.bias, bn.running_mean, bn.running_var, relu, bound)
+    counters.append(bn.num_batches_tracked)
+    return st
+
+
+def block_backward_p16(blk, rec, g, WPT, ws, G):
+    """Backward of block_forward_p16.  g: dL/d(out) fp32.  The BatchNorm-backward passes write their outputs as P16
+    tensors (bound of max|dy| from the reduce pass); data gradients on gemm_p16, weight gradients on the transposing
+    P16 kernel (side stream)."""
+    x, ya, sta, aa, yb, stb, ab, yc, stc, xd, yd, std, rmask = rec
+    stride = blk.stride
+    has_down = blk.downsample is not None
+
+    def wgrad(dy, act, conv=None):
+        return ws.run(lambda d_, x_: ops.wgrad_p16(ops.P16(d_, dy.amax), ops.P16(x_, act.amax), conv=conv), dy.data, act.data,
+                      keep=(dy.amax, act.amax))
+
+    dyc, dg, db, dres = ops.bn_bwd_p16(g, yc, stc, 3, act=rmask, want_dres=not has_down)
+    G[id(blk.bn3.weight)], G[id(blk.bn3.bias)] = dg, db
+    if has_down:
+        dyd, dg, db, _ = ops.bn_bwd_p16(g, yd, std, 3, act=rmask)
+        G[id(blk.downsample[2].weight)], G[id(blk.downsample[2].bias)] = dg, db
+    planes = blk.conv2.out_channels
+    Mc = dyc.data.numel() // dyc.shape[-1]
+    dab = ops.empty(tuple(ab.shape), g)
+    ops.gemm_p16(dyc, WPT[id(blk.conv3.weight)], dab, Mc, planes, dyc.shape[-1], planes)
+    G[id(blk.conv3.weight)] = wgrad(dyc, ab).view_as(blk.conv3.weight)
+    dyb, dg, db, _ = ops.bn_bwd_p16(dab, yb, stb, 1, pooled=stride > 1)
+    G[id(blk.bn2.weight)], G[id(blk.bn2.bias)] = dg, db
+    Bi, H, W, _ = yb.shape
+    Ma = Bi * H * W
+    daa = ops.empty(tuple(aa.shape), g)
+    ops.gemm_p16(dyb, WPT[id(blk.conv2.weight)], daa, Ma, planes, 9 * planes, planes, conv=(H, W, planes))
+    G[id(blk.conv2.weight)] = _g3x3(wgrad(dyb, aa, conv=(H, W, planes)), planes, planes)
+    dya, dg, db, _ = ops.bn_bwd_p16(daa, ya, sta, 1)
+    G[id(blk.bn1.weight)], G[id(blk.bn1.bias)] = dg, db
+    cin = blk.conv1.in_channels
+    if has_down:
+        dxd = ops.empty(tuple(xd.shape), g)
+        ops.gemm_p16(dyd, WPT[id(blk.downsample[1].weight)], dxd, Mc, cin, dyd.shape[-1], cin)
+        G[id(blk.downsample[1].weight)] = wgrad(dyd, xd).view_as(blk.downsample[1].weight)
+        dx = ops.avgpool2_bwd(dxd) if stride > 1 else dxd
+    else:
+        dx = dres
+    ops.gemm_p16(dya, WPT[id(blk.conv1.weight)], dx, Ma, cin, planes, cin, accumulate=True)
+    G[id(blk.conv1.weight)] = wgrad(dya, x).view_as(blk.conv1.weight)
     return dx
 
 
@@ -485,12 +614,28 @@ class ModifiedResNet(nn.Module):
             taps["stem"] = x
             names = {id(blk): "layer%d.%d" % (li + 1, bi) for li, layer in enumerate((self.layer1, self.layer2, self.layer3, self.layer4))
                      for bi, blk in enumerate(layer)}
-        for blk in self.blocks():
-            x, ax, rec = block_forward(blk, x, ax, ar, training, save, nbt, masks)
+        p16 = ops.USE_P16 and training and bool(ar.WA) and p16_eligible(self)
+        if p16:
+            # residual blocks on pre-split operands: filters packed once per pass, activations written split by the
+            # BatchNorm passes; the stem stays on the fp32 path (32-channel tiles) and hands over one packed tensor
+            WP = p16_weights(self, ar.WA, False)
+            x = ops.p16_pack(x, ax)
+            for blk in self.blocks():
+                x, rec = block_forward_p16(blk, x, WP, images.device, training, save, nbt, masks)
+                if save:
+                    S["blocks"].append(rec)
+                if taps is not None:
+                    taps[names[id(blk)]] = x.unpack()
+            x = x.unpack()
             if save:
-                S["blocks"].append(rec)
-            if taps is not None:
-                taps[names[id(blk)]] = x
+                S["p16"] = True
+        else:
+            for blk in self.blocks():
+                x, ax, rec = block_forward(blk, x, ax, ar, training, save, nbt, masks)
+                if save:
+                    S["blocks"].append(rec)
+                if taps is not None:
+                    taps[names[id(blk)]] = x
         if nbt:
             torch._foreach_add_(nbt, 1)  # one launch instead of one per BatchNorm layer
         # ---- attention pool (m_resnet.py:103-135), token-0 query only
@@ -613,10 +758,12 @@ class ModifiedResNet(nn.Module):
 
         first_of_layer = {id(layer[0]) for layer in (self.layer1, self.layer2, self.layer3, self.layer4)}
         dbg = getattr(self, "_debug_grads", None)
+        p16 = S.get("p16", False)
+        WPT = p16_weights(self, ar.WA, True) if p16 else None
         for blk, rec in zip(reversed(blocks), reversed(S["blocks"])):
             if dbg is not None:
                 dbg.append(g)
-            g = block_backward(blk, rec, g, ar, ws, G)
+            g = block_backward_p16(blk, rec, g, WPT, ws, G) if p16 else block_backward(blk, rec, g, ar, ws, G)
             if id(blk) in first_of_layer:  # a whole residual layer (and, the first time, the attention pool) is done
                 stage_ready()
         S["blocks"] = None

@@ -4,9 +4,41 @@
 // index = element index mod C so loads are fully coalesced.
 // Reference: m_resnet.py:19-29,38-49,57-66,161-171 (+ their autograd).
 
-#include "common.h"
+#include "split_common.h"
 
 namespace trid {
+
+// ---------------------------------------------------------------- P16 (pre-split GEMM operand) element access
+// A [rows][C] tensor in P16 (gemm_p16.hip): per row and 32-channel group 128 bytes = [hi x 32 | lo x 32] fp16 of
+// x * 2^s.  These kernels work on channel QUADS (float4): quad cq of a row lives at 8-byte unit
+// row * (C/2) + (cq / 8) * 16 + (cq % 8) (high parts) and 8 units further (low parts): a wave writes whole
+// 64-byte plane halves, fully coalesced.
+__device__ __forceinline__ void p16_store4(uint2* __restrict__ base, long long i, int CQ, float4 v, float scale) {
+    const long long row = i / CQ;
+    const int cq = (int)(i - row * CQ);
+    unsigned h0, l0, h1, l1;
+    f16_split2(v.x * scale, v.y * scale, h0, l0);
+    f16_split2(v.z * scale, v.w * scale, h1, l1);
+    uint2* dst = base + row * (2 * CQ) + (cq >> 3) * 16 + (cq & 7);
+    dst[0] = make_uint2(h0, h1);
+    dst[8] = make_uint2(l0, l1);
+}
+__device__ __forceinline__ float4 p16_load4(const uint2* __restrict__ base, long long i, int CQ, float inv) {
+    const long long row = i / CQ;
+    const int cq = (int)(i - row * CQ);
+    const uint2* src = base + row * (2 * CQ) + (cq >> 3) * 16 + (cq & 7);
+    const uint2 h = src[0], l = src[8];
+    const f16x2 h0 = __builtin_bit_cast(f16x2, h.x), h1 = __builtin_bit_cast(f16x2, h.y);
+    const f16x2 l0 = __builtin_bit_cast(f16x2, l.x), l1 = __builtin_bit_cast(f16x2, l.y);
+    return make_float4(((float)h0.x + (float)l0.x) * inv, ((float)h0.y + (float)l0.y) * inv,
+                       ((float)h1.x + (float)l1.x) * inv, ((float)h1.y + (float)l1.y) * inv);
+}
+// scale of a P16 tensor whose largest magnitude is bounded by *a (+ *b): the bound is also published for the consumers
+__device__ __forceinline__ float p16_out_scale(const float* a, const float* b, float* sum_out) {
+    const float bound = (a != nullptr ? *a : 0.f) + (b != nullptr ? *b : 0.f);
+    if (sum_out != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *sum_out = bound;
+    return f16_scale_of(bound);
+}
 
 // ---------------------------------------------------------------- weight transform
 __global__ void weight_transpose_kernel(const float* __restrict__ w, float* __restrict__ wt, int N, int T, int C,
@@ -55,15 +87,25 @@ __global__ void bn_finalize_kernel(const float* __restrict__ partials, int npart
                                    int C, const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* __restrict__ running_mean, float* __restrict__ running_var, float momentum,
                                    float eps, float* __restrict__ mean_out, float* __restrict__ invstd_out,
-                                   float* __restrict__ scale_out, float* __restrict__ shift_out) {
+                                   float* __restrict__ scale_out, float* __restrict__ shift_out, int pw, int relu,
+                                   float* __restrict__ amax_out) {
+    // pw: floats per (part, channel): 2 = (mean, M2), 4 = (mean, M2, min, max).  With the extremes the largest
+    // magnitude of act(y * scale + shift) over the channel is known exactly before the apply pass (an affine map
+    // takes extremes to extremes): folded over the channels into amax_out (zeroed by the caller; integer atomicMax on
+    // the bit pattern of a non-negative float: order-independent).
     const int c = blockIdx.x;
     const int tid = threadIdx.x;
     double n = 0.0, mean = 0.0, m2 = 0.0;
+    float lo = INFINITY, hi = -INFINITY;
     for (int p = tid; p < nparts; p += blockDim.x) {
         const long long rows_left = M - (long long)p * rows_per_part;
         const double nb = (double)(rows_left < rows_per_part ? rows_left : rows_per_part);
-        const double mb = partials[((long long)p * C + c) * 2 + 0];
-        const double qb = partials[((long long)p * C + c) * 2 + 1];
+        const double mb = partials[((long long)p * C + c) * pw + 0];
+        const double qb = partials[((long long)p * C + c) * pw + 1];
+        if (pw == 4) {
+            lo = fminf(lo, partials[((long long)p * C + c) * pw + 2]);
+            hi = fmaxf(hi, partials[((long long)p * C + c) * pw + 3]);
+        }
         const double nt = n + nb;
         const double d = mb - mean;
         mean += d * (nb / nt);
@@ -71,7 +113,16 @@ __global__ void bn_finalize_kernel(const float* __restrict__ partials, int npart
         n = nt;
     }
     __shared__ double sn[256], sm[256], sq[256];
+    __shared__ float slo[4], shi[4];
     sn[tid] = n; sm[tid] = mean; sq[tid] = m2;
+    if (pw == 4) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            lo = fminf(lo, __shfl_xor(lo, o, 64));
+            hi = fmaxf(hi, __shfl_xor(hi, o, 64));
+        }
+        if ((tid & 63) == 0) { slo[tid >> 6] = lo; shi[tid >> 6] = hi; }
+    }
     __syncthreads();
     for (int off = 128; off > 0; off >>= 1) {
         if (tid < off) {
@@ -96,7 +147,14 @@ __global__ void bn_finalize_kernel(const float* __restrict__ partials, int npart
         mean_out[c] = (float)mu;
         invstd_out[c] = invstd;
         scale_out[c] = sc;
-        shift_out[c] = b - (float)mu * sc;
+        const float sh = b - (float)mu * sc;
+        shift_out[c] = sh;
+        if (pw == 4 && amax_out != nullptr) {
+            const float l = fminf(fminf(slo[0], slo[1]), fminf(slo[2], slo[3])), h = fmaxf(fmaxf(shi[0], shi[1]), fmaxf(shi[2], shi[3]));
+            const float zl = fmaf(l, sc, sh), zh = fmaf(h, sc, sh);  // the apply pass's own arithmetic
+            const float bound = relu ? fmaxf(fmaxf(zl, zh), 0.f) : fmaxf(fabsf(zl), fabsf(zh));
+            atomicMax(reinterpret_cast<unsigned*>(amax_out), __builtin_bit_cast(unsigned, bound));
+        }
         if (running_mean != nullptr) {
             const double unb = nt > 1.0 ? sq[0] / (nt - 1.0) : var;
             running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
@@ -152,18 +210,26 @@ __device__ __forceinline__ float4 relu4(float4 v) {
     return make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
 }
 
+// P16OUT: `out` is written as a P16 tensor whose scale comes from the bound *oa (+ *ob), known BEFORE this pass
+// (bn_finalize's extremes; a residual adds its own bound); the sum is published in *osum for the consumers.
+// P16RES: the identity residual `res` is a P16 tensor (scale from *res_amax): decoded on the fly.
+template <bool P16OUT, bool P16RES>
 __global__ void bn_apply_kernel(const float4* __restrict__ y, const float4* __restrict__ scale,
                                 const float4* __restrict__ shift, const float4* __restrict__ res,
                                 const float4* __restrict__ rscale, const float4* __restrict__ rshift,
                                 float4* __restrict__ out, long long total4, int CQ, int relu,
-                                unsigned long long* __restrict__ mask, float* __restrict__ amax) {
+                                unsigned long long* __restrict__ mask, float* __restrict__ amax,
+                                const float* __restrict__ oa, const float* __restrict__ ob, float* __restrict__ osum,
+                                const float* __restrict__ res_amax) {
     unsigned am = 0;
+    const float oscale = P16OUT ? p16_out_scale(oa, ob, osum) : 1.f;
+    const float rinv = P16RES ? 1.f / f16_scale_of(*res_amax) : 1.f;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4;
          i += (long long)gridDim.x * blockDim.x) {
         const int cq = (int)(i % CQ);
         float4 v = affine4(y[i], scale[cq], shift[cq]);
         if (res != nullptr) {
-            float4 r = res[i];
+            float4 r = P16RES ? p16_load4(reinterpret_cast<const uint2*>(res), i, CQ, rinv) : res[i];
             if (rscale != nullptr) r = affine4(r, rscale[cq], rshift[cq]);
             v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
         }
@@ -178,17 +244,27 @@ __global__ void bn_apply_kernel(const float4* __restrict__ y, const float4* __re
             }
         }
         if (relu) v = relu4(v);
-        out[i] = v;
-        am = amax4(am, v);
+        if (P16OUT) {
+            p16_store4(reinterpret_cast<uint2*>(out), i, CQ, v, oscale);
+        } else {
+            out[i] = v;
+            am = amax4(am, v);
+        }
     }
-    if (amax != nullptr) amax_commit(am, amax);
+    if (!P16OUT && amax != nullptr) amax_commit(am, amax);
 }
 
+// P16OUT as above (scale from *oa); P16IN: `y` is a P16 tensor (scale from *in_amax) - the plain pooling of a block
+// input on its way to the downsample convolution keeps the input's scale (an average never exceeds the maximum)
+template <bool P16OUT, bool P16IN>
 __global__ void bn_apply_pool2_kernel(const float4* __restrict__ y, const float4* __restrict__ scale,
                                       const float4* __restrict__ shift, float4* __restrict__ out, int B, int H, int W,
-                                      int CQ, int relu, long long total4, float* __restrict__ amax) {
+                                      int CQ, int relu, long long total4, float* __restrict__ amax,
+                                      const float* __restrict__ oa, const float* __restrict__ in_amax) {
     const int Ho = H / 2, Wo = W / 2;
     unsigned am = 0;
+    const float oscale = P16OUT ? f16_scale_of(*oa) : 1.f;
+    const float iinv = P16IN ? 1.f / f16_scale_of(*in_amax) : 1.f;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4;
          i += (long long)gridDim.x * blockDim.x) {
         const int cq = (int)(i % CQ);
@@ -204,16 +280,21 @@ __global__ void bn_apply_pool2_kernel(const float4* __restrict__ y, const float4
         for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
             for (int dx = 0; dx < 2; ++dx) {
-                float4 v = y[(((long long)b * H + 2 * yo + dy) * W + 2 * xo + dx) * CQ + cq];
+                const long long src = (((long long)b * H + 2 * yo + dy) * W + 2 * xo + dx) * CQ + cq;
+                float4 v = P16IN ? p16_load4(reinterpret_cast<const uint2*>(y), src, CQ, iinv) : y[src];
                 v = affine4(v, s, t);
                 if (relu) v = relu4(v);
                 acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
             }
         const float4 o = make_float4(acc.x * 0.25f, acc.y * 0.25f, acc.z * 0.25f, acc.w * 0.25f);
-        out[i] = o;
-        am = amax4(am, o);
+        if (P16OUT) {
+            p16_store4(reinterpret_cast<uint2*>(out), i, CQ, o, oscale);
+        } else {
+            out[i] = o;
+            am = amax4(am, o);
+        }
     }
-    if (amax != nullptr) amax_commit(am, amax);
+    if (!P16OUT && amax != nullptr) amax_commit(am, amax);
 }
 
 __global__ void avgpool2_bwd_kernel(const float4* __restrict__ g, float4* __restrict__ dx, int B, int H, int W, int CQ,
@@ -288,18 +369,25 @@ __device__ __forceinline__ void bn_bwd_elem(const BnBwdArgs& a, long long i, int
 
 // grid*256 is a multiple of CQ, so a thread always sees the same channel quad.
 // ws layout: [grid][CW][8] with CW = min(CQ,256) quads covered by a block.
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a, float* __restrict__ ws) {
+// BOUND: also the per-channel maxima of |masked g| and |xhat| (ws2 [grid][CW][8]) - with dgamma / dbeta they bound
+// |dy| BEFORE the apply pass, which then writes dy as a P16 tensor (bn_bwd_reduce_final_kernel).
+template <bool BOUND>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a, float* __restrict__ ws, float* __restrict__ ws2) {
     const int tid = threadIdx.x;
     const long long T = (long long)gridDim.x * 256;
     const long long t0 = (long long)blockIdx.x * 256 + tid;
     const int cq = (int)(t0 % a.CQ);
-    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1, mg = s1, mx = s1;
     for (long long i = t0; i < a.total4; i += T) {
         float4 gm, xh;
         bn_bwd_elem(a, i, cq, gm, xh);
         s1.x += gm.x; s1.y += gm.y; s1.z += gm.z; s1.w += gm.w;
         s2.x = fmaf(gm.x, xh.x, s2.x); s2.y = fmaf(gm.y, xh.y, s2.y);
         s2.z = fmaf(gm.z, xh.z, s2.z); s2.w = fmaf(gm.w, xh.w, s2.w);
+        if (BOUND) {
+            mg.x = fmaxf(mg.x, fabsf(gm.x)); mg.y = fmaxf(mg.y, fabsf(gm.y)); mg.z = fmaxf(mg.z, fabsf(gm.z)); mg.w = fmaxf(mg.w, fabsf(gm.w));
+            mx.x = fmaxf(mx.x, fabsf(xh.x)); mx.y = fmaxf(mx.y, fabsf(xh.y)); mx.z = fmaxf(mx.z, fabsf(xh.z)); mx.w = fmaxf(mx.w, fabsf(xh.w));
+        }
     }
     __shared__ float red[256][9];
     red[tid][0] = s1.x; red[tid][1] = s1.y; red[tid][2] = s1.z; red[tid][3] = s1.w;
@@ -317,31 +405,64 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a, float* 
 #pragma unroll
         for (int k = 0; k < 8; ++k) dst[k] = acc[k];
     }
+    if (BOUND) {
+        __syncthreads();
+        red[tid][0] = mg.x; red[tid][1] = mg.y; red[tid][2] = mg.z; red[tid][3] = mg.w;
+        red[tid][4] = mx.x; red[tid][5] = mx.y; red[tid][6] = mx.z; red[tid][7] = mx.w;
+        __syncthreads();
+        if (tid < CW) {
+            float acc[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+            for (int r = tid; r < 256; r += CW)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc[k] = fmaxf(acc[k], red[r][k]);
+            float* dst = ws2 + ((long long)blockIdx.x * CW + tid) * 8;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) dst[k] = acc[k];
+        }
+    }
 }
 
 // one workgroup per channel quad: sum the block partials that cover it
+// ws2 / scale / bound (all or none): |dy_c| <= |scale_c| * (max|g_c| + (|dbeta_c| + max|xhat_c| * |dgamma_c|) / M), folded
+// over the channels into *bound (zeroed by the caller; integer atomicMax on a non-negative float's bit pattern)
 __global__ __launch_bounds__(256) void bn_bwd_reduce_final_kernel(const float* __restrict__ ws, int nblk, int CQ,
                                                                   float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                                  int C) {
+                                                                  int C, const float* __restrict__ ws2,
+                                                                  const float* __restrict__ scale, float invM,
+                                                                  float* __restrict__ bound) {
     const int q = blockIdx.x;
     const int CW = CQ < 256 ? CQ : 256;
     const int S = CQ / CW;  // channel-quad slices; block b covers slice b % S
     const int slice = q / CW, ql = q % CW;
-    float acc[8];
+    float acc[8], mxv[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+    for (int k = 0; k < 8; ++k) acc[k] = mxv[k] = 0.f;
     for (int b = slice + S * threadIdx.x; b < nblk; b += S * 256) {
         const float4* src = reinterpret_cast<const float4*>(ws + ((long long)b * CW + ql) * 8);
         const float4 u = src[0], v = src[1];
         acc[0] += u.x; acc[1] += u.y; acc[2] += u.z; acc[3] += u.w;
         acc[4] += v.x; acc[5] += v.y; acc[6] += v.z; acc[7] += v.w;
+        if (ws2 != nullptr) {
+            const float4* s2 = reinterpret_cast<const float4*>(ws2 + ((long long)b * CW + ql) * 8);
+            const float4 a = s2[0], c = s2[1];
+            mxv[0] = fmaxf(mxv[0], a.x); mxv[1] = fmaxf(mxv[1], a.y); mxv[2] = fmaxf(mxv[2], a.z); mxv[3] = fmaxf(mxv[3], a.w);
+            mxv[4] = fmaxf(mxv[4], c.x); mxv[5] = fmaxf(mxv[5], c.y); mxv[6] = fmaxf(mxv[6], c.z); mxv[7] = fmaxf(mxv[7], c.w);
+        }
     }
-    __shared__ float red[4][8];
+    __shared__ float red[4][8], redm[4][8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) acc[k] = wave_sum(acc[k]);
+    for (int k = 0; k < 8; ++k) {
+        acc[k] = wave_sum(acc[k]);
+        mxv[k] = wave_max(mxv[k]);
+    }
     if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) red[threadIdx.x >> 6][k] = acc[k];
+        for (int k = 0; k < 8; ++k) {
+            red[threadIdx.x >> 6][k] = acc[k];
+            redm[threadIdx.x >> 6][k] = mxv[k];
+        }
     }
     __syncthreads();
     if (threadIdx.x < 8) {
@@ -351,13 +472,28 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_final_kernel(const float* _
             if (threadIdx.x < 4) dbeta[c] = s; else dgamma[c] = s;
         }
     }
+    if (ws2 != nullptr && threadIdx.x < 4) {
+        const int k = threadIdx.x, c = 4 * q + k;
+        if (c < C) {
+            const float db = red[0][k] + red[1][k] + red[2][k] + red[3][k];
+            const float dg = red[0][4 + k] + red[1][4 + k] + red[2][4 + k] + red[3][4 + k];
+            const float mg = fmaxf(fmaxf(redm[0][k], redm[1][k]), fmaxf(redm[2][k], redm[3][k]));
+            const float mx = fmaxf(fmaxf(redm[0][4 + k], redm[1][4 + k]), fmaxf(redm[2][4 + k], redm[3][4 + k]));
+            // 1.0001: the apply pass rounds its three-term expression differently from this bound
+            const float b = 1.0001f * fabsf(scale[c]) * (mg + (fabsf(db) + mx * fabsf(dg)) * invM);
+            atomicMax(reinterpret_cast<unsigned*>(bound), __builtin_bit_cast(unsigned, b));
+        }
+    }
 }
 
+// P16OUT: dy is written as a P16 tensor, scale from the bound *oa of the reduce pass
+template <bool P16OUT>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a, const float4* __restrict__ dgamma,
                                                            const float4* __restrict__ dbeta, float invM,
                                                            float4* __restrict__ dy, float4* __restrict__ dres,
-                                                           float* __restrict__ amax) {
+                                                           float* __restrict__ amax, const float* __restrict__ oa) {
     unsigned am = 0;
+    const float oscale = P16OUT ? f16_scale_of(*oa) : 1.f;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < a.total4; i += (long long)gridDim.x * 256) {
         const int cq = (int)(i % a.CQ);
         float4 gm, xh;
@@ -368,11 +504,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a, const fl
         o.y = sc.y * (gm.y - db.y * invM - xh.y * dg.y * invM);
         o.z = sc.z * (gm.z - db.z * invM - xh.z * dg.z * invM);
         o.w = sc.w * (gm.w - db.w * invM - xh.w * dg.w * invM);
-        dy[i] = o;
-        am = amax4(am, o);
+        if (P16OUT) {
+            p16_store4(reinterpret_cast<uint2*>(dy), i, a.CQ, o, oscale);
+        } else {
+            dy[i] = o;
+            am = amax4(am, o);
+        }
         if (dres != nullptr) dres[i] = gm;
     }
-    if (amax != nullptr) amax_commit(am, amax);
+    if (!P16OUT && amax != nullptr) amax_commit(am, amax);
 }
 
 static int bn_bwd_grid(long long total4, int CQ) {
@@ -417,8 +557,22 @@ extern "C" int trid_bn_finalize_f32(const float* partials, int nparts, int rows_
                  "trid_bn_finalize_f32: nparts=%d rows_per_part=%d inconsistent with M=%lld", nparts, rows_per_part, M);
     TRID_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "trid_bn_finalize_f32: running stats both or none");
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, partials, nparts, rows_per_part, M,
-                       C, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift);
+                       C, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift, 2, 0, (float*)nullptr);
     return check_launch("trid_bn_finalize_f32");
+}
+
+extern "C" int trid_bn_finalize_minmax_f32(const float* partials, int nparts, int rows_per_part, long long M, int C,
+                                           const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                           float momentum, float eps, float* mean, float* invstd, float* scale, float* shift,
+                                           int relu, float* amax_out, void* stream) {
+    TRID_REQUIRE(partials && gamma && beta && mean && invstd && scale && shift && amax_out, "trid_bn_finalize_minmax_f32: null pointer");
+    TRID_REQUIRE(nparts > 0 && rows_per_part > 0 && C > 0 && M > (long long)(nparts - 1) * rows_per_part &&
+                     M <= (long long)nparts * rows_per_part,
+                 "trid_bn_finalize_minmax_f32: nparts=%d rows_per_part=%d inconsistent with M=%lld", nparts, rows_per_part, M);
+    TRID_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "trid_bn_finalize_minmax_f32: running stats both or none");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, partials, nparts, rows_per_part, M,
+                       C, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift, 4, relu, amax_out);
+    return check_launch("trid_bn_finalize_minmax_f32");
 }
 
 extern "C" int trid_bn_eval_coeffs_f32(const float* gamma, const float* beta, const float* running_mean,
@@ -437,11 +591,32 @@ extern "C" int trid_bn_apply_f32(const float* y, const float* scale, const float
     TRID_REQUIRE((rscale == nullptr) == (rshift == nullptr), "trid_bn_apply_f32: rscale/rshift both or none");
     TRID_REQUIRE(aligned16(y) && aligned16(out) && aligned16(scale) && aligned16(shift) && (!res || aligned16(res)), "trid_bn_apply_f32: 16-byte alignment");
     const long long total4 = M * (C / 4);
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(total4, 256 * 4)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL((bn_apply_kernel<false, false>), dim3(grid_for(total4, 256 * 4)), dim3(256), 0, (hipStream_t)stream,
                        (const float4*)y, (const float4*)scale, (const float4*)shift, (const float4*)res,
                        (const float4*)rscale, (const float4*)rshift, (float4*)out, total4, C / 4, relu,
-                       (unsigned long long*)relu_mask, amax);
+                       (unsigned long long*)relu_mask, amax, (const float*)nullptr, (const float*)nullptr, (float*)nullptr,
+                       (const float*)nullptr);
     return check_launch("trid_bn_apply_f32");
+}
+
+extern "C" int trid_bn_apply_p16_f32(const float* y, const float* scale, const float* shift, const void* res,
+                                     const float* rscale, const float* rshift, const float* res_amax, void* out,
+                                     long long M, int C, int relu, uint64_t* relu_mask, const float* bound_a,
+                                     const float* bound_b, float* bound_sum, void* stream) {
+    TRID_REQUIRE(y && scale && shift && out && bound_a && M > 0 && C > 0 && C % 32 == 0, "trid_bn_apply_p16_f32: bad arguments (C%%32)");
+    TRID_REQUIRE((rscale == nullptr) == (rshift == nullptr), "trid_bn_apply_p16_f32: rscale/rshift both or none");
+    TRID_REQUIRE(!(res_amax && rscale), "trid_bn_apply_p16_f32: a P16 residual is an identity residual (no BatchNorm on it)");
+    TRID_REQUIRE(aligned16(y) && aligned16(out) && aligned16(scale) && aligned16(shift) && (!res || aligned16(res)), "trid_bn_apply_p16_f32: 16-byte alignment");
+    const long long total4 = M * (C / 4);
+    const dim3 grid(grid_for(total4, 256 * 4));
+#define TRID_BN_APPLY_P16(RES)                                                                                              \
+    hipLaunchKernelGGL((bn_apply_kernel<true, RES>), grid, dim3(256), 0, (hipStream_t)stream, (const float4*)y,           \
+                       (const float4*)scale, (const float4*)shift, (const float4*)res, (const float4*)rscale,              \
+                       (const float4*)rshift, (float4*)out, total4, C / 4, relu, (unsigned long long*)relu_mask,           \
+                       (float*)nullptr, bound_a, bound_b, bound_sum, res_amax)
+    if (res_amax != nullptr) TRID_BN_APPLY_P16(true); else TRID_BN_APPLY_P16(false);
+#undef TRID_BN_APPLY_P16
+    return check_launch("trid_bn_apply_p16_f32");
 }
 
 extern "C" int trid_bn_apply_pool2_f32(const float* y, const float* scale, const float* shift, float* out, int B, int H,
@@ -449,10 +624,28 @@ extern "C" int trid_bn_apply_pool2_f32(const float* y, const float* scale, const
     TRID_REQUIRE(y && out && B > 0 && H % 2 == 0 && W % 2 == 0 && C % 4 == 0, "trid_bn_apply_pool2_f32: bad arguments");
     TRID_REQUIRE((scale == nullptr) == (shift == nullptr), "trid_bn_apply_pool2_f32: scale/shift both or none");
     const long long total4 = (long long)B * (H / 2) * (W / 2) * (C / 4);
-    hipLaunchKernelGGL(bn_apply_pool2_kernel, dim3(grid_for(total4, 256 * 2)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL((bn_apply_pool2_kernel<false, false>), dim3(grid_for(total4, 256 * 2)), dim3(256), 0, (hipStream_t)stream,
                        (const float4*)y, (const float4*)scale, (const float4*)shift, (float4*)out, B, H, W, C / 4, relu,
-                       total4, amax);
+                       total4, amax, (const float*)nullptr, (const float*)nullptr);
     return check_launch("trid_bn_apply_pool2_f32");
+}
+
+extern "C" int trid_bn_apply_pool2_p16_f32(const void* y, const float* scale, const float* shift, const float* in_amax,
+                                           void* out, int B, int H, int W, int C, int relu, const float* bound,
+                                           void* stream) {
+    TRID_REQUIRE(y && out && bound && B > 0 && H % 2 == 0 && W % 2 == 0 && C % 32 == 0, "trid_bn_apply_pool2_p16_f32: bad arguments (C%%32)");
+    TRID_REQUIRE((scale == nullptr) == (shift == nullptr), "trid_bn_apply_pool2_p16_f32: scale/shift both or none");
+    const long long total4 = (long long)B * (H / 2) * (W / 2) * (C / 4);
+    const dim3 grid(grid_for(total4, 256 * 2));
+    if (in_amax != nullptr)
+        hipLaunchKernelGGL((bn_apply_pool2_kernel<true, true>), grid, dim3(256), 0, (hipStream_t)stream, (const float4*)y,
+                           (const float4*)scale, (const float4*)shift, (float4*)out, B, H, W, C / 4, relu, total4,
+                           (float*)nullptr, bound, in_amax);
+    else
+        hipLaunchKernelGGL((bn_apply_pool2_kernel<true, false>), grid, dim3(256), 0, (hipStream_t)stream, (const float4*)y,
+                           (const float4*)scale, (const float4*)shift, (float4*)out, B, H, W, C / 4, relu, total4,
+                           (float*)nullptr, bound, in_amax);
+    return check_launch("trid_bn_apply_pool2_p16_f32");
 }
 
 extern "C" int trid_avgpool2_bwd_f32(const float* g, float* dx, int B, int H, int W, int C, int accumulate,
@@ -467,7 +660,7 @@ extern "C" int trid_avgpool2_bwd_f32(const float* g, float* dx, int B, int H, in
 extern "C" long long trid_bn_bwd_ws_floats(int C) {
     const int CQ = C / 4;
     const int CW = CQ < 256 ? CQ : 256;
-    return (long long)(1024 + 8) * CW * 8;
+    return 2 * (long long)(1024 + 8) * CW * 8;  // sums + (trid_bn_bwd_reduce_bound_f32) maxima
 }
 
 static int bn_bwd_fill(BnBwdArgs& a, const float* g, const float* y, const float* act, const float* mean,
@@ -500,10 +693,28 @@ extern "C" int trid_bn_bwd_reduce_f32(const float* g, const float* y, const floa
     if (rc) return rc;
     TRID_REQUIRE(dgamma && dbeta && ws, "trid_bn_bwd_reduce_f32: null output");
     const int grid = bn_bwd_grid(a.total4, a.CQ);
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, ws);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, ws, (float*)nullptr);
     hipLaunchKernelGGL(bn_bwd_reduce_final_kernel, dim3(a.CQ), dim3(256), 0, (hipStream_t)stream, ws, grid, a.CQ, dgamma,
-                       dbeta, C);
+                       dbeta, C, (const float*)nullptr, (const float*)nullptr, 0.f, (float*)nullptr);
     return check_launch("trid_bn_bwd_reduce_f32");
+}
+
+extern "C" int trid_bn_bwd_reduce_bound_f32(const float* g, const float* y, const float* act, const float* mean,
+                                            const float* invstd, const float* scale, const float* shift, int mask_mode,
+                                            int pooled, int B, int H, int W, int C, float* dgamma, float* dbeta, float* ws,
+                                            float* bound, void* stream) {
+    BnBwdArgs a;
+    int rc = bn_bwd_fill(a, g, y, act, mean, invstd, scale, shift, mask_mode, pooled, B, H, W, C);
+    if (rc) return rc;
+    TRID_REQUIRE(dgamma && dbeta && ws && bound, "trid_bn_bwd_reduce_bound_f32: null output");
+    const int grid = bn_bwd_grid(a.total4, a.CQ);
+    const int CW = a.CQ < 256 ? a.CQ : 256;
+    float* ws2 = ws + (long long)(1024 + 8) * CW * 8;
+    const float invM = 1.f / (float)((long long)B * H * W);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, ws, ws2);
+    hipLaunchKernelGGL(bn_bwd_reduce_final_kernel, dim3(a.CQ), dim3(256), 0, (hipStream_t)stream, ws, grid, a.CQ, dgamma,
+                       dbeta, C, (const float*)ws2, scale, invM, bound);
+    return check_launch("trid_bn_bwd_reduce_bound_f32");
 }
 
 extern "C" int trid_bn_bwd_apply_f32(const float* g, const float* y, const float* act, const float* mean,
@@ -515,7 +726,21 @@ extern "C" int trid_bn_bwd_apply_f32(const float* g, const float* y, const float
     if (rc) return rc;
     TRID_REQUIRE(dgamma && dbeta && dy, "trid_bn_bwd_apply_f32: null pointer");
     const float invM = 1.f / (float)((long long)B * H * W);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(a.total4, 256 * 4)), dim3(256), 0, (hipStream_t)stream, a,
-                       (const float4*)dgamma, (const float4*)dbeta, invM, (float4*)dy, (float4*)dres, amax);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(grid_for(a.total4, 256 * 4)), dim3(256), 0, (hipStream_t)stream, a,
+                       (const float4*)dgamma, (const float4*)dbeta, invM, (float4*)dy, (float4*)dres, amax, (const float*)nullptr);
     return check_launch("trid_bn_bwd_apply_f32");
+}
+
+extern "C" int trid_bn_bwd_apply_p16_f32(const float* g, const float* y, const float* act, const float* mean,
+                                         const float* invstd, const float* scale, const float* shift, const float* dgamma,
+                                         const float* dbeta, int mask_mode, int pooled, int B, int H, int W, int C,
+                                         void* dy, float* dres, const float* bound, void* stream) {
+    BnBwdArgs a;
+    int rc = bn_bwd_fill(a, g, y, act, mean, invstd, scale, shift, mask_mode, pooled, B, H, W, C);
+    if (rc) return rc;
+    TRID_REQUIRE(dgamma && dbeta && dy && bound && C % 32 == 0, "trid_bn_bwd_apply_p16_f32: null pointer or C %% 32 != 0");
+    const float invM = 1.f / (float)((long long)B * H * W);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(grid_for(a.total4, 256 * 4)), dim3(256), 0, (hipStream_t)stream, a,
+                       (const float4*)dgamma, (const float4*)dbeta, invM, (float4*)dy, (float4*)dres, (float*)nullptr, bound);
+    return check_launch("trid_bn_bwd_apply_p16_f32");
 }

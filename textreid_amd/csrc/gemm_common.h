@@ -47,6 +47,7 @@ struct GemmParams {
     const int* gate;   // optional device flag: the whole launch is a no-op when *gate == 0
     const float* a_amax;  // f16x3 arithmetic: device scalars holding max|A| / max|B| (null: operand used unscaled)
     const float* b_amax;
+    int stats_w;          // floats per column in `stats`: 2 (mean, M2) or 4 (+ min, max: gemm_p16.hip)
 };
 
 constexpr int BK = 32;

@@ -241,9 +241,11 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 && STAGES == 2) ? 2 : (W
     }
 
     if (p.stats != nullptr) {
-        // BatchNorm partials per 128-row slab of the tile: column (mean, M2) over the slab's rows < M
+        // BatchNorm partials per 128-row slab of the tile: column (mean, M2) over the slab's rows < M; with
+        // stats_w == 4 also the column (min, max): the consumer derives max|BatchNorm(y)| - the fp16 scale of the
+        // NEXT operand - from them before the apply pass runs (an affine map takes extremes to extremes)
         __syncthreads();
-        float* red = reinterpret_cast<float*>(smem);  // [WM][BN]
+        float* red = reinterpret_cast<float*>(smem);  // [WM][BN] (+ [WM][BN] for the second value of a pair)
         constexpr int WPS = 128 / (32 * TM);            // waves (along M) per slab
         const int slab = wm / WPS;
         const int rows_left = p.M - (m0 + 128 * slab);
@@ -263,13 +265,17 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 && STAGES == 2) ? 2 : (W
         for (int j = 0; j < TN; ++j) {
             const int cl = wn * (32 * TN) + 32 * j + (lane & 31);
             const int col = n0 + cl;
-            float s = 0.f;
+            float s = 0.f, lo = INFINITY, hi = -INFINITY;
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = row_base + i * 32 + (r & 3) + 8 * (r >> 2);
-                    if (row < p.M) s += acc[i][j][r];
+                    if (row < p.M) {
+                        s += acc[i][j][r];
+                        lo = fminf(lo, acc[i][j][r]);
+                        hi = fmaxf(hi, acc[i][j][r]);
+                    }
                 }
             const float mean = column_total(s, cl) * inv;
             s = 0.f;
@@ -282,13 +288,220 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 && STAGES == 2) ? 2 : (W
                     if (row < p.M) s += d * d;
                 }
             const float m2 = column_total(s, cl);
+            if (p.stats_w == 4) {
+                lo = fminf(lo, __shfl_xor(lo, 32, 64));
+                hi = fmaxf(hi, __shfl_xor(hi, 32, 64));
+                if (khalf == 0) {
+                    red[wm * BN + cl] = lo;
+                    red[(WM + wm) * BN + cl] = hi;
+                }
+                __syncthreads();
+#pragma unroll
+                for (int w = 0; w < WPS; ++w) {
+                    lo = fminf(lo, red[(slab * WPS + w) * BN + cl]);
+                    hi = fmaxf(hi, red[(WM + slab * WPS + w) * BN + cl]);
+                }
+                __syncthreads();
+            }
             if ((wm % WPS) == 0 && khalf == 0 && col < p.N && cnt > 0) {
-                float* dst = p.stats + (((long long)mb * (BM / 128) + slab) * p.N + col) * 2;
+                float* dst = p.stats + (((long long)mb * (BM / 128) + slab) * p.N + col) * p.stats_w;
                 dst[0] = mean;
                 dst[1] = m2;
+                if (p.stats_w == 4) {
+                    dst[2] = lo;
+                    dst[3] = hi;
+                }
             }
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------------- weight gradients
+// dW[n][j] = sum over pixels m of dy[m][n] * X[m][j]: both operands are P16 tensors whose rows are PIXELS, i.e. the
+// reduction index runs DOWN the rows while the MFMA wants 8 consecutive reduction indices per lane.  The tiles are
+// staged exactly as they lie in HBM (LDS-DMA, one 128-byte (pixel, 32-channel group) piece per 8 lanes) and the
+// transposition happens in the LDS READ: ds_read_b64_tr_b16 hands lane i of a 16-lane group column i of a 4 x 16 tile
+// of 16-bit elements whose rows are 4 consecutive pixels (row pitch 128 B here) - two such reads are one MFMA
+// 32x32x16 operand fragment (8 pixels of one channel).  No VALU, no ds_write, no register transposes.
+//
+// LDS image of an operand stage: [32-channel group][32 pixels][128 B]; inside a piece the 16-byte slot s is stored at
+// s ^ (4 * ((pixel >> 1) & 1)) (source-side permutation of the DMA), so the 32 lanes of a transpose read (4 pixels x
+// 2 sixteen-channel halves x 4 eight-byte chunks) cover 256 distinct bytes of the 64 banks: conflict-free.
+//
+// B_NC: X = the layer input [pixels][C] (1x1 convolution);  B_CONV: X[m][(tap, c)] = x[m + tap offset][c] with
+// zero padding (3x3 / stride 1 / pad 1): the DMA source row is shifted per 32-column group, invalid (pixel, tap)
+// pairs read out of range = zeros.
+typedef __fp16 h4v __attribute__((__vector_size__(4 * sizeof(__fp16))));
+
+__device__ __forceinline__ f16x8 tr_frag(const char* lds_addr) {
+    typedef __attribute__((address_space(3))) h4v* lp;
+    const h4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lp)(lds_addr));
+    const h4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lp)(lds_addr + 512));  // 4 pixels further (128 B each)
+    f16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+}
+
+template <int BMODE, int BM, int STAGES>
+__global__ __launch_bounds__(512, 4) void gemm_p16_wgrad_kernel(GemmParams p) {
+    constexpr int BN = 128, NW = 8, WN = 4, WM = 2;
+    constexpr int TM = BM / (32 * WM);           // 2 (BM = 128) or 1 (BM = 64)
+    constexpr int A_CH = (BM / 32) * 4, B_CH = (BN / 32) * 4;  // 1-KB DMA chunks: 8 pixels of one channel group
+    constexpr int A_PW = (A_CH + NW - 1) / NW, B_PW = B_CH / NW;
+    constexpr int PER_TILE = A_PW + B_PW;
+    constexpr int A_BYTES = (BM / 32) * 32 * 128, STAGE_BYTES = A_BYTES + (BN / 32) * 32 * 128;
+    extern __shared__ __attribute__((aligned(16))) uint4 smem[];
+    char* const sbase = reinterpret_cast<char*>(smem);
+
+    const float scaleA = p.a_amax != nullptr ? f16_scale_of(*p.a_amax) : 1.f;
+    const float scaleB = p.b_amax != nullptr ? f16_scale_of(*p.b_amax) : 1.f;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+
+    const uint32_t nwg = (uint32_t)p.mblocks * (uint32_t)p.nblocks;
+    const uint32_t lid = xcd_remap(blockIdx.x, nwg);
+    const int mb = lid / p.nblocks, nb = lid % p.nblocks;
+    const int m0 = mb * BM, n0 = nb * BN;
+    const int sz = blockIdx.z;
+    const int k_begin = sz * p.k_chunk;
+    const int k_end = min(p.K, k_begin + p.k_chunk);
+    const int nk = (k_end - k_begin + P16_BK - 1) / P16_BK;
+    float* __restrict__ C = p.C + (long long)sz * p.sSplit;
+
+    constexpr unsigned OOB = 0x80000000u;
+    const char* A = reinterpret_cast<const char*>(p.A);
+    const char* Bp = reinterpret_cast<const char*>(p.B);
+    const long long a_ld = p.lda * 4, b_ld = (BMODE == B_CONV ? (long long)p.Cin : p.ldb) * 4;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (unsigned)((long long)p.K * a_ld), 0x00020000);
+    const char* b_base = (BMODE == B_CONV) ? Bp - (long long)(p.W + 1) * b_ld : Bp;
+    const long long b_rows = (BMODE == B_CONV) ? (long long)p.K + 2 * p.W + 2 : p.K;
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)b_base, 0, (unsigned)(b_rows * b_ld), 0x00020000);
+
+    // loader lanes: chunk c -> channel group c / 4, pixels 8 * (c % 4) + lane / 8, stored slot lane % 8
+    unsigned voA[A_PW], voB[B_PW];
+    int b_pp[B_PW], b_dy[B_PW], b_dx[B_PW];
+#pragma unroll
+    for (int j = 0; j < A_PW; ++j) {
+        const int c = j * NW + wave;
+        const int gi = c >> 2, pp = 8 * (c & 3) + (lane >> 3);
+        const int s = (lane & 7) ^ (((pp >> 1) & 1) << 2);
+        voA[j] = (c < A_CH && m0 + 32 * gi < p.M) ? (unsigned)((long long)pp * a_ld + (m0 + 32 * gi) * 4 + 16 * s) : OOB;
+    }
+#pragma unroll
+    for (int j = 0; j < B_PW; ++j) {
+        const int c = j * NW + wave;
+        const int gi = c >> 2, pp = 8 * (c & 3) + (lane >> 3);
+        const int s = (lane & 7) ^ (((pp >> 1) & 1) << 2);
+        const int col = n0 + 32 * gi;
+        b_pp[j] = pp;
+        b_dy[j] = b_dx[j] = 0;
+        if (BMODE == B_CONV) {
+            const int tap = col / p.Cin, c0 = col - tap * p.Cin;
+            b_dy[j] = tap / 3 - 1;
+            b_dx[j] = tap % 3 - 1;
+            // byte offset of (pixel pp + tap shift, channel group c0, slot s) from the shifted base
+            voB[j] = col < p.N ? (unsigned)((long long)(pp + (b_dy[j] + 1) * p.W + (b_dx[j] + 1)) * b_ld + c0 * 4 + 16 * s) : OOB;
+        } else {
+            voB[j] = col < p.N ? (unsigned)((long long)pp * b_ld + col * 4 + 16 * s) : OOB;
+        }
+    }
+
+    auto issue = [&](int kt, int stage) {
+        char* sA = sbase + stage * STAGE_BYTES;
+        char* sB = sA + A_BYTES;
+        const int k0 = k_begin + kt * P16_BK;
+        const unsigned soA = (unsigned)((long long)k0 * a_ld), soB = (unsigned)((long long)k0 * b_ld);
+#pragma unroll
+        for (int j = 0; j < A_PW; ++j) {
+            const int c = j * NW + wave;
+            if (A_CH % NW != 0 && c >= A_CH) break;
+            // rows beyond the split's range must not leak into it: the buffer only clips at K
+            const unsigned vo = (k0 + 8 * (c & 3) + (lane >> 3) < k_end) ? voA[j] : OOB;
+            dma16(rsA, reinterpret_cast<uint4*>(sA + c * 1024), vo, soA);
+        }
+#pragma unroll
+        for (int j = 0; j < B_PW; ++j) {
+            const int c = j * NW + wave;
+            unsigned vo = voB[j];
+            const int m = k0 + b_pp[j];
+            bool ok = m < k_end;
+            if (BMODE == B_CONV) {
+                const uint32_t q = fdiv((uint32_t)m, p.fdW);
+                const int x = m - (int)q * p.W;
+                const uint32_t b = fdiv(q, p.fdH);
+                const int y = (int)q - (int)b * p.H;
+                const int yy = y + b_dy[j], xx = x + b_dx[j];
+                ok = ok && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
+            }
+            dma16(rsB, reinterpret_cast<uint4*>(sB + c * 1024), ok ? vo : OOB, soB);
+        }
+    };
+
+    v16f acc[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    // transpose-read lane constants: 16-channel half h, pixel row r of the 4 x 16 tile, 8-byte chunk c8, k half kh
+    const int h = (lane >> 4) & 1, r4 = (lane & 15) >> 2, c8 = lane & 3, kh = lane >> 5;
+    const int swz = (r4 >> 1) << 2;
+    // byte offset inside a channel group's [32 pixels][128 B] block for plane pl, k step ks: pixel = 16 ks + 8 kh + r4 (+4)
+    auto frag_off = [&](int pl, int ks) { return (16 * ks + 8 * kh + r4) * 128 + (((pl * 4 + h * 2 + (c8 >> 1)) ^ swz) << 4) + 8 * (c8 & 1); };
+
+    auto compute = [&](int stage) {
+        const char* sA = sbase + stage * STAGE_BYTES + (wm * TM) * 4096;
+        const char* sB = sbase + stage * STAGE_BYTES + A_BYTES + wn * 4096;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            f16x8 a[2][TM], b[2];
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+                const int off = frag_off(pl, ks);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[pl][i] = tr_frag(sA + i * 4096 + off);
+                b[pl] = tr_frag(sB + off);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][i], b[1], acc[i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][i], b[0], acc[i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][i], b[0], acc[i], 0, 0, 0);
+        }
+    };
+
+    {
+#pragma unroll
+        for (int s = 0; s < STAGES - 1; ++s)
+            if (s < nk) issue(s, s);
+        int stage = 0, istage = (STAGES - 1) % STAGES;
+        for (int t = 0; t < nk; ++t) {
+            const int ahead = min(STAGES - 2, nk - 1 - t);
+            if (STAGES >= 3 && ahead >= 1) wait_vmcnt<PER_TILE>();
+            else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (t + STAGES - 1 < nk) issue(t + STAGES - 1, istage);
+            compute(stage);
+            stage = (stage + 1 == STAGES) ? 0 : stage + 1;
+            istage = (istage + 1 == STAGES) ? 0 : istage + 1;
+        }
+    }
+
+    const float f = p.alpha / (scaleA * scaleB);
+    const int row_base = m0 + wm * (32 * TM) + 4 * kh;
+    const int col = n0 + wn * 32 + (lane & 31);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = row_base + i * 32 + (r & 3) + 8 * (r >> 2);
+            if (row < p.M && col < p.N) C[(long long)row * p.ldc + col] = f * acc[i][r];
+        }
 }
 
 // ---------------------------------------------------------------------------------------------------- producers
@@ -365,6 +578,55 @@ __global__ __launch_bounds__(256) void p16_pack_wt_kernel(const float* __restric
     }
 }
 
+// Every conv filter of an encoder in ONE launch: table[t] = {src, dst, N, T, C, a} (device, 6 x int64 per tensor), amax[a]
+// the tensor's largest magnitude.  transposed == 0: dst = P16 [N][K = T*C] (the forward operand, filters as stored);
+// transposed != 0: dst = P16 [C][K = T*N] with the taps reversed for T > 1 (the data-gradient operand).
+__global__ __launch_bounds__(256) void p16_pack_multi_kernel(const long long* __restrict__ table, const float* __restrict__ amax,
+                                                             int transposed) {
+    const long long* e = table + 6 * (long long)blockIdx.y;
+    const float* __restrict__ w = reinterpret_cast<const float*>(e[0]);
+    uint4* __restrict__ out = reinterpret_cast<uint4*>(e[1]);
+    const int N = (int)e[2], T = (int)e[3], C = (int)e[4];
+    const float scale = f16_scale_of(amax[e[5]]);
+    if (!transposed) {
+        const int K = T * C, K8 = K / 8;
+        const long long total = (long long)N * K8;
+        for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+            const long long row = idx / K8;
+            const int kg = (int)(idx - row * K8);
+            const float4 u = *reinterpret_cast<const float4*>(w + row * K + 8 * kg);
+            const float4 v = *reinterpret_cast<const float4*>(w + row * K + 8 * kg + 4);
+            unsigned h[4], l[4];
+            f16_split2(u.x * scale, u.y * scale, h[0], l[0]);
+            f16_split2(u.z * scale, u.w * scale, h[1], l[1]);
+            f16_split2(v.x * scale, v.y * scale, h[2], l[2]);
+            f16_split2(v.z * scale, v.w * scale, h[3], l[3]);
+            uint4* dst = out + row * (K / 4) + (kg >> 2) * 8 + (kg & 3);
+            dst[0] = make_uint4(h[0], h[1], h[2], h[3]);
+            dst[4] = make_uint4(l[0], l[1], l[2], l[3]);
+        }
+    } else {
+        const int K = T * N, K8 = K / 8;
+        const long long total = (long long)C * K8;
+        for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+            const int kg = (int)(idx / C);
+            const int c = (int)(idx - (long long)kg * C);
+            const int k0 = 8 * kg;
+            const int tp = k0 / N, n0 = k0 - tp * N;
+            const int t = T - 1 - tp;
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = w[((long long)(n0 + i) * T + t) * C + c] * scale;
+            unsigned h[4], l[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) f16_split2(v[2 * q], v[2 * q + 1], h[q], l[q]);
+            uint4* dst = out + (long long)c * (K / 4) + (kg >> 2) * 8 + (kg & 3);
+            dst[0] = make_uint4(h[0], h[1], h[2], h[3]);
+            dst[4] = make_uint4(l[0], l[1], l[2], l[3]);
+        }
+    }
+}
+
 template <int AMODE, int BM, int BN, int WM, int WN, int STAGES>
 static int launch_p16(GemmParams& p, hipStream_t stream) {
     p.mblocks = (p.M + BM - 1) / BM;
@@ -428,6 +690,69 @@ extern "C" int trid_p16_pack_wt_f32(const float* w, int N, int T, int C, int fli
     return check_launch("trid_p16_pack_wt_f32");
 }
 
+template <int BMODE, int BM>
+static int launch_p16_wgrad(GemmParams& p, hipStream_t stream) {
+    constexpr int STAGES = 2;
+    p.mblocks = (p.M + BM - 1) / BM;
+    p.nblocks = (p.N + 127) / 128;
+    dim3 grid((unsigned)(p.mblocks * p.nblocks), 1, (unsigned)p.splits);
+    constexpr size_t lds = (size_t)STAGES * ((BM / 32) + 4) * 4096;
+    static std::once_flag once;
+    static hipError_t attr_err = hipSuccess;
+    std::call_once(once, [] {
+        if (lds > 48 * 1024)
+            attr_err = hipFuncSetAttribute((const void*)gemm_p16_wgrad_kernel<BMODE, BM, STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    });
+    if (attr_err != hipSuccess) {
+        set_error("trid_gemm_p16_wgrad: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(attr_err));
+        return (int)attr_err;
+    }
+    hipLaunchKernelGGL((gemm_p16_wgrad_kernel<BMODE, BM, STAGES>), grid, dim3(512), lds, stream, p);
+    return check_launch("trid_gemm_p16_wgrad");
+}
+
+extern "C" int trid_gemm_p16_wgrad(const trid_gemm_desc* d, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    TRID_REQUIRE(d != nullptr && d->A && d->B && d->C, "trid_gemm_p16_wgrad: null operand");
+    TRID_REQUIRE(d->a_mode == A_MC && (d->b_mode == B_NC || d->b_mode == B_CONV), "trid_gemm_p16_wgrad: loader modes A_MC x B_NC / B_CONV only");
+    TRID_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0 && d->M % 32 == 0 && d->N % 32 == 0 && d->lda % 32 == 0,
+                 "trid_gemm_p16_wgrad: M, N and the row pitches must be multiples of 32 (M=%d N=%d)", d->M, d->N);
+    TRID_REQUIRE(d->batch == 1 && d->splits >= 1 && !d->accumulate && !d->bias && !d->residual && !d->relu && !d->stats,
+                 "trid_gemm_p16_wgrad: plain or split-K output only");
+    TRID_REQUIRE(aligned16(d->A) && aligned16(d->B) && aligned16(d->C), "trid_gemm_p16_wgrad: operands must be 16-byte aligned");
+    GemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.A = d->A; p.B = d->B; p.C = d->C;
+    p.M = d->M; p.N = d->N; p.K = d->K;
+    p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc;
+    p.batch = 1; p.splits = d->splits;
+    p.alpha = d->alpha;
+    p.H = d->H; p.W = d->W; p.Cin = d->Cin;
+    p.a_amax = d->a_amax; p.b_amax = d->b_amax;
+    if (d->b_mode == B_CONV) {
+        TRID_REQUIRE(d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cin % 32 == 0 && d->N == 9 * d->Cin && d->K % (d->H * d->W) == 0,
+                     "trid_gemm_p16_wgrad: B_CONV needs Cin %% 32 == 0, N == 9*Cin, K a multiple of H*W");
+        p.fdW = make_fastdiv((uint32_t)d->W);
+        p.fdH = make_fastdiv((uint32_t)d->H);
+        TRID_REQUIRE((long long)(d->K + 2 * d->W + 2) * d->Cin * 4 < (1ll << 31), "trid_gemm_p16_wgrad: operands must stay below 2 GB");
+    } else {
+        TRID_REQUIRE(d->ldb % 32 == 0 && (long long)d->K * d->ldb * 4 < (1ll << 31), "trid_gemm_p16_wgrad: ldb %% 32 and B below 2 GB");
+    }
+    TRID_REQUIRE((long long)d->K * d->lda * 4 < (1ll << 31), "trid_gemm_p16_wgrad: operands must stay below 2 GB");
+    int kc = (d->K + d->splits - 1) / d->splits;
+    kc = (kc + P16_BK - 1) / P16_BK * P16_BK;
+    p.k_chunk = kc;
+    p.sSplit = d->strideSplit;
+    if (d->b_mode == B_CONV) return d->M <= 64 ? launch_p16_wgrad<B_CONV, 64>(p, stream) : launch_p16_wgrad<B_CONV, 128>(p, stream);
+    return d->M <= 64 ? launch_p16_wgrad<B_NC, 64>(p, stream) : launch_p16_wgrad<B_NC, 128>(p, stream);
+}
+
+extern "C" int trid_p16_pack_multi_f32(const long long* table, const float* amax, int n_tensors, int transposed, void* stream) {
+    TRID_REQUIRE(table && amax && n_tensors > 0, "trid_p16_pack_multi_f32: bad arguments");
+    hipLaunchKernelGGL(p16_pack_multi_kernel, dim3(64, (unsigned)n_tensors), dim3(256), 0, (hipStream_t)stream, table, amax, transposed);
+    return check_launch("trid_p16_pack_multi_f32");
+}
+
 extern "C" int trid_gemm_p16(const trid_gemm_desc* d, int variant, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     TRID_REQUIRE(d != nullptr && d->A && d->B && d->C, "trid_gemm_p16: null operand");
@@ -448,6 +773,7 @@ extern "C" int trid_gemm_p16(const trid_gemm_desc* d, int variant, void* stream_
     p.res = d->residual; p.ldres = d->ldres; p.relu = d->relu;
     p.H = d->H; p.W = d->W; p.Cin = d->Cin;
     p.a_amax = d->a_amax; p.b_amax = d->b_amax;
+    p.stats_w = d->stats_minmax ? 4 : 2;
     if (d->a_mode == A_CONV) {
         TRID_REQUIRE(d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cin % 32 == 0 && d->K == 9 * d->Cin && d->M % (d->H * d->W) == 0 && d->splits == 1,
                      "trid_gemm_p16: A_CONV needs Cin %% 32 == 0, K == 9*Cin, M a multiple of H*W, splits == 1");

@@ -54,7 +54,10 @@ class CapturedTrainStep:
         losses.backward()
         if self.optimizer is not None:
             self.optimizer.step()
-        return loss_dict
+        # detached: a caller that keeps the returned losses must not keep the autograd graph (and its AccumulateGrad
+        # nodes, bound to THIS call's stream) alive into the next call - a stale node inside a capture drags the
+        # stream it was created on into the recording
+        return {k: v.detach() for k, v in loss_dict.items()}
 
     @staticmethod
     def _sig(images, cb):
@@ -77,6 +80,9 @@ class CapturedTrainStep:
             raise RuntimeError("CapturedTrainStep needs textreid_amd.solver.FusedAdam (or optimizer=None)")
         for p in self.model.parameters():
             p.grad = None  # the captured backward allocates its gradients inside the graph's pool
+        from .. import ops
+
+        ops.begin_capture()
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
@@ -85,7 +91,8 @@ class CapturedTrainStep:
             losses.backward()
             if self.optimizer is not None:
                 self.optimizer.step()
-        self.graph, self.out = g, loss_dict
+        self.graph, self.out = g, {k: v.detach() for k, v in loss_dict.items()}
+        del loss_dict, losses
         self.grads = [(p, p.grad) for p in self.model.parameters() if p.grad is not None]  # live in the graph's pool
         self.signature = self._sig(images, cb)
         self.log.info("train step captured: one graph launch per step from here on")

@@ -49,6 +49,7 @@ class GemmDesc(ctypes.Structure):
         ("relu", ctypes.c_int32),
         ("a_amax", ctypes.c_void_p),
         ("b_amax", ctypes.c_void_p),
+        ("stats_minmax", ctypes.c_int32),
     ]
 
 

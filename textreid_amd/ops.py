@@ -97,6 +97,14 @@ def empty(shape, like=None, dtype=torch.float32, device=None):
 
 # --------------------------------------------------------------------------- GEMM
 _amax_pool = {}
+_amax_pool_capture = {}
+
+
+def begin_capture():
+    """engine.graph.CapturedTrainStep, right before a stream capture: slots handed out INSIDE the capture come from
+    pools that are allocated (and zero-filled: a recorded fill, re-executed by every replay) inside that capture -
+    a pool filled once in eager mode would hand the replays slots that still hold the previous replay's maxima."""
+    _amax_pool_capture.clear()
 
 
 def amax_slot(device):
@@ -104,10 +112,11 @@ def amax_slot(device):
     zero-filled pool per (device, stream) and are written once, so there is no per-call memset; the view keeps its
     pool buffer alive."""
     key = (device, torch.cuda.current_stream(device).cuda_stream)
-    ent = _amax_pool.get(key)
+    pools = _amax_pool_capture if torch.cuda.is_current_stream_capturing() else _amax_pool
+    ent = pools.get(key)
     if ent is None or ent[1] >= ent[0].numel():
         ent = [torch.zeros(4096, dtype=torch.float32, device=device), 0]
-        _amax_pool[key] = ent
+        pools[key] = ent
     slot = ent[0][ent[1] : ent[1] + 1]
     ent[1] += 1
     return slot
@@ -191,7 +200,7 @@ class P16:
         return out
 
 
-P16_VARIANT = int(__import__("os").environ.get("TRID_P16_VARIANT", "0"))  # tile shape of trid_gemm_p16 (experiments)
+P16_VARIANT = int(__import__("os").environ.get("TRID_P16_VARIANT", "3"))  # tile shape of trid_gemm_p16 (experiments)
 
 
 def p16_pack(x, amax_=None):
@@ -212,9 +221,9 @@ def p16_pack_wt(w, N, T, C, flip, amax_):
 
 
 def gemm_p16(A, B, C, M, N, K, ldc, conv=None, alpha=1.0, accumulate=False, bias=None, stats=None, residual=None, ldres=0,
-             relu=False, splits=1, strideSplit=0, variant=None):
+             relu=False, splits=1, strideSplit=0, variant=None, minmax=False):
     """C[M,N] = alpha * A . B^T with both operands P16: A [M][K] (or an NHWC image [B,H,W,Cin] with conv=(H,W,Cin),
-    K = 9*Cin), B [N][K]."""
+    K = 9*Cin), B [N][K].  minmax: the BatchNorm partials `stats` are [tiles][N][4] = (mean, M2, min, max)."""
     d = GemmDesc()
     d.A, d.B, d.C = _p(A.data), _p(B.data), _p(C)
     d.M, d.N, d.K = M, N, K
@@ -233,7 +242,126 @@ def gemm_p16(A, B, C, M, N, K, ldc, conv=None, alpha=1.0, accumulate=False, bias
     d.residual = _p(residual)
     d.ldres = ldres
     d.relu = 1 if relu else 0
-    call("trid_gemm_p16", ctypes.addressof(d), P16_VARIANT if variant is None else variant, stream())
+    d.stats_minmax = 1 if minmax else 0
+    v = P16_VARIANT if variant is None else variant
+    prof = PROFILE
+    if prof is not None and N > 64:
+        label = prof["match"]((A_CONV if conv is not None else A_KC, B_KC, 128, 128, True))
+        if label:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            call("trid_gemm_p16", ctypes.addressof(d), v, stream())
+            e1.record()
+            prof["events"].append((label, 2.0 * M * N * K, e0, e1))
+            return
+    call("trid_gemm_p16", ctypes.addressof(d), v, stream())
+
+
+USE_P16 = __import__("os").environ.get("TRID_P16", "1") != "0"  # residual blocks on pre-split operands (csrc/gemm_p16.hip)
+
+
+def conv_p16(x, w, conv3=False, stats=True):
+    """x: P16 [B,H,W,C] (or [M,C]); w: P16 [N, K] -> raw conv output y fp32 [.., N] (+ (mean, M2, min, max) partials)."""
+    C = x.shape[-1]
+    M = x.data.numel() // C
+    N = w.shape[0]
+    y = empty(tuple(x.shape[:-1]) + (N,), x.data)
+    st = empty(((M + STATS_ROWS - 1) // STATS_ROWS, N, 4), x.data) if stats else None
+    if conv3:
+        gemm_p16(x, w, y, M, N, 9 * C, N, conv=(x.shape[1], x.shape[2], C), stats=st, minmax=stats)
+    else:
+        gemm_p16(x, w, y, M, N, C, N, stats=st, minmax=stats)
+    return (y, st) if stats else y
+
+
+def bn_finalize_minmax(partials, M, gamma, beta, running_mean, running_var, relu, bound, momentum=BN_MOMENTUM, eps=BN_EPS):
+    """bn_finalize on (mean, M2, min, max) partials; `bound` (a zeroed amax_slot) receives max|act(BatchNorm(y))|."""
+    C = gamma.numel()
+    st = BNState(C, gamma)
+    call("trid_bn_finalize_minmax_f32", _p(partials), partials.shape[0], STATS_ROWS, M, C, _p(gamma), _p(beta),
+         _p(running_mean), _p(running_var), momentum, eps, _p(st.mean), _p(st.invstd), _p(st.scale), _p(st.shift),
+         1 if relu else 0, _p(bound), stream())
+    if running_mean is not None:
+        note_parameter_write()
+    return st
+
+
+def bn_apply_p16(y, st, bound, relu=True, res=None, res_st=None, bound_res=None, want_mask=False):
+    """act(bn(y) (+ res | bn(res))) written as a P16 tensor.  bound: device scalar >= max|bn(y)| (bn_finalize_minmax);
+    with a residual, bound_res bounds the residual term and the output's amax scalar is their sum.  res: fp32 raw
+    conv output (with res_st) or a P16 tensor (identity)."""
+    C = y.shape[-1]
+    M = y.numel() // C
+    out = torch.empty_like(y)
+    mask = torch.empty(((M * C // 4 + 63) // 64) * 4, dtype=torch.int64, device=y.device) if want_mask else None
+    res_p16 = isinstance(res, P16)
+    osum = amax_slot(y.device) if res is not None else None
+    call("trid_bn_apply_p16_f32", _p(y), _p(st.scale), _p(st.shift), _p(res.data if res_p16 else res),
+         _p(res_st.scale) if res_st else None, _p(res_st.shift) if res_st else None, _p(res.amax) if res_p16 else None,
+         _p(out), M, C, 1 if relu else 0, _p(mask), _p(bound), _p(bound_res), _p(osum), stream())
+    o = P16(out, osum if res is not None else bound)
+    return (o, mask) if want_mask else o
+
+
+def bn_apply_pool2_p16(y, st, bound, relu=True):
+    """avgpool2(act(bn(y))) -> P16; y: raw conv output fp32 (st given) or a P16 tensor (st None: plain pooling, the
+    output keeps the input's scale)."""
+    src = y.data if isinstance(y, P16) else y
+    Bi, H, W, C = src.shape
+    out = empty((Bi, H // 2, W // 2, C), src)
+    call("trid_bn_apply_pool2_p16_f32", _p(src), _p(st.scale) if st else None, _p(st.shift) if st else None,
+         _p(y.amax) if isinstance(y, P16) else None, _p(out), Bi, H, W, C, 1 if (relu and st is not None) else 0,
+         _p(bound), stream())
+    return P16(out, bound)
+
+
+def bn_bwd_p16(g, y, st, mask_mode, act=None, pooled=False, want_dres=False):
+    """BatchNorm backward with dy written as a P16 tensor: the reduce pass also bounds max|dy| (triangle inequality
+    over per-channel maxima), the apply pass scales by that bound.  Returns (dy P16, dgamma, dbeta, dres)."""
+    Bi, H, W, C = y.shape
+    dg = empty((2, C), y)
+    dgamma, dbeta = dg[0], dg[1]
+    ws = _bn_ws(C, y)
+    bound = amax_slot(y.device)
+    call("trid_bn_bwd_reduce_bound_f32", _p(g), _p(y), _p(act), _p(st.mean), _p(st.invstd), _p(st.scale), _p(st.shift),
+         mask_mode, 1 if pooled else 0, Bi, H, W, C, _p(dgamma), _p(dbeta), _p(ws), _p(bound), stream())
+    dy = torch.empty_like(y)
+    dres = torch.empty_like(y) if want_dres else None
+    call("trid_bn_bwd_apply_p16_f32", _p(g), _p(y), _p(act), _p(st.mean), _p(st.invstd), _p(st.scale), _p(st.shift),
+         _p(dgamma), _p(dbeta), mask_mode, 1 if pooled else 0, Bi, H, W, C, _p(dy), _p(dres), _p(bound), stream())
+    return P16(dy, bound), dgamma, dbeta, dres
+
+
+def wgrad_p16(dy, x, conv=None, alpha=1.0):
+    """Weight gradient on P16 operands: dW [N, J] = dy[M,N]^T @ X[M,J] with X = x [M, C] (1x1) or the 3x3 gather of the
+    NHWC image x [B,H,W,C] (conv=(H,W,C), J = 9*C).  Split over the pixels, slabs folded by trid_slab_reduce_f32."""
+    N = dy.shape[-1]
+    M = dy.data.numel() // N
+    C = x.shape[-1]
+    J = 9 * C if conv is not None else C
+    out = empty((N, J), dy.data)
+    tiles = ((N + 127) // 128) * ((J + 127) // 128)
+    splits = _wgrad_splits(tiles, M)
+    d = GemmDesc()
+    d.A, d.B = _p(dy.data), _p(x.data)
+    d.M, d.N, d.K = N, J, M
+    d.lda, d.ldb, d.ldc = N, C, J
+    d.batch, d.splits = 1, splits
+    d.a_mode, d.b_mode = A_MC, (B_CONV if conv is not None else B_NC)
+    d.alpha = alpha
+    if conv is not None:
+        d.H, d.W, d.Cin = conv
+    d.precision = 16
+    d.a_amax, d.b_amax = _p(dy.amax), _p(x.amax)
+    if splits == 1:
+        d.C = _p(out)
+        call("trid_gemm_p16_wgrad", ctypes.addressof(d), stream())
+        return out
+    slab = empty((splits, N, J), dy.data)
+    d.C, d.strideSplit = _p(slab), N * J
+    call("trid_gemm_p16_wgrad", ctypes.addressof(d), stream())
+    call("trid_slab_reduce_f32", _p(slab), _p(out), N * J, splits, N * J, 0, stream())
+    return out
 
 
 def linear(x, w, bias=None, out=None, alpha=1.0, accumulate=False, prec=None, aa=None, ba=None, relu=False):

@@ -55,6 +55,42 @@ def conv1(name, P, Ci, Co, count=1):
         tot[v] += ms * count
         out += "  %5.3f/%3.0f (%.0e,%.0e)" % (ms, fl / ms / 1e9, rel(y, y0), rel(st, st0))
     print(out, flush=True)
+def wg3(name, H, W, Ci, Co, count=1):
+    x, dy = torch.randn(B, H, W, Ci, device=dev).relu_(), torch.randn(B, H, W, Co, device=dev)
+    ax, ady = ops.amax(x), ops.amax(dy)
+    fl = 2.0 * B * H * W * Ci * Co * 9
+    g0 = ops.conv3x3_wgrad(dy, x, prec=16, aa=ady, ba=ax)
+    ms0 = t(lambda: ops.conv3x3_wgrad(dy, x, prec=16, aa=ady, ba=ax))
+    xp, dyp = ops.p16_pack(x, ax), ops.p16_pack(dy, ady)
+    g1 = ops.wgrad_p16(dyp, xp, conv=(H, W, Ci))
+    ms1 = t(lambda: ops.wgrad_p16(dyp, xp, conv=(H, W, Ci)))
+    print("wgrad %-28s old %6.3f ms %4.0f TF | p16 %6.3f ms %4.0f TF  (err %.0e)" % (name, ms0, fl / ms0 / 1e9, ms1, fl / ms1 / 1e9, rel(g1, g0)), flush=True)
+    return ms0 * count, ms1 * count
+def wg1(name, P, Ci, Co, count=1):
+    M = B * P
+    x, dy = torch.randn(M, Ci, device=dev).relu_(), torch.randn(M, Co, device=dev)
+    ax, ady = ops.amax(x), ops.amax(dy)
+    fl = 2.0 * M * Ci * Co
+    g0 = ops.conv1x1_wgrad(dy, x, prec=16, aa=ady, ba=ax)
+    ms0 = t(lambda: ops.conv1x1_wgrad(dy, x, prec=16, aa=ady, ba=ax))
+    xp, dyp = ops.p16_pack(x, ax), ops.p16_pack(dy, ady)
+    g1 = ops.wgrad_p16(dyp, xp)
+    ms1 = t(lambda: ops.wgrad_p16(dyp, xp))
+    print("wgrad %-28s old %6.3f ms %4.0f TF | p16 %6.3f ms %4.0f TF  (err %.0e)" % (name, ms0, fl / ms0 / 1e9, ms1, fl / ms1 / 1e9, rel(g1, g0)), flush=True)
+    return ms0 * count, ms1 * count
+if os.environ.get("P16_WGRAD", "1") == "1":
+    tw = [0.0, 0.0]
+    for r in (wg3("l1 3x3 64 @96x32", 96, 32, 64, 64, 3), wg1("l1 conv3 64->256", 3072, 64, 256, 4), wg1("l1 conv1 256->64", 3072, 256, 64, 2),
+              wg1("l2.0 conv1 256->128", 3072, 256, 128), wg3("l2.0 3x3 128 @96x32", 96, 32, 128, 128), wg1("l2 conv3 128->512", 768, 128, 512, 4),
+              wg1("l2.0 down 256->512", 768, 256, 512), wg1("l2 conv1 512->128", 768, 512, 128, 3), wg3("l2 3x3 128 @48x16", 48, 16, 128, 128, 3),
+              wg1("l3.0 conv1 512->256", 768, 512, 256), wg3("l3.0 3x3 256 @48x16", 48, 16, 256, 256), wg1("l3 conv3 256->1024", 192, 256, 1024, 6),
+              wg1("l3.0 down 512->1024", 192, 512, 1024), wg1("l3 conv1 1024->256", 192, 1024, 256, 5), wg3("l3 3x3 256 @24x8", 24, 8, 256, 256, 5),
+              wg1("l4.0 conv1 1024->512", 192, 1024, 512), wg3("l4 3x3 512 @24x8", 24, 8, 512, 512, 3), wg1("l4 conv3 512->2048", 192, 512, 2048, 3),
+              wg1("l4.0 down 1024->2048", 192, 1024, 2048), wg1("l4 conv1 2048->512", 192, 2048, 512, 2)):
+        tw[0] += r[0]; tw[1] += r[1]
+    print("weight-gradient GEMM total per encoder pass: old %.2f ms, p16 %.2f ms" % tuple(tw))
+if os.environ.get("P16_FWD", "1") != "1":
+    sys.exit(0)
 # pack / unpack round trip
 z = torch.randn(1000, 96, device=dev) * 3
 zp = ops.p16_pack(z)
