@@ -381,17 +381,23 @@ def main():
 
     # the same kernel alone on the GPU (no side-stream work sharing the CUs): the 3x3 layers of layer2-4
     iso_fl, iso_ms = 0.0, 0.0
+    p16 = ops.USE_P16 and ops.conv_precision() == 16  # the residual blocks' convolutions run on pre-split operands
     for (Hh, Ww, Cc) in ((96, 32, 128), (48, 16, 128), (48, 16, 256), (24, 8, 256), (24, 8, 512)):
         xx = torch.randn(B, Hh, Ww, Cc, device=device)
         ww = torch.randn(Cc, 9 * Cc, device=device)
         cp = ops.conv_precision()
-        kw = dict(prec=cp, aa=ops.amax(xx), ba=ops.amax(ww)) if cp == 16 else {}  # the model's conv arithmetic
-        ops.conv3x3(xx, ww, stats=True, **kw)
+        if p16:
+            xp, wp = ops.p16_pack(xx), ops.p16_pack(ww)
+            run = lambda: ops.conv_p16(xp, wp, conv3=True)
+        else:
+            kw = dict(prec=cp, aa=ops.amax(xx), ba=ops.amax(ww)) if cp == 16 else {}  # the model's conv arithmetic
+            run = lambda: ops.conv3x3(xx, ww, stats=True, **kw)
+        run()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(3):
-            ops.conv3x3(xx, ww, stats=True, **kw)
+            run()
         e1.record()
         torch.cuda.synchronize()
         iso_ms += e0.elapsed_time(e1) / 3
@@ -401,7 +407,12 @@ def main():
 
     prec = ops.GEMM_PRECISION
     cprec = ops.conv_precision()
-    if cprec == 16:
+    if cprec == 16 and p16:
+        peak = BF16_MFMA_PEAK_TFLOPS / 3
+        kname = "trid::gemm_p16_kernel<A_CONV,128,128,2,4,2> (3x3 implicit-GEMM conv fwd+dgrad on PRE-SPLIT operands: activations / filters live in HBM as two fp16 planes of x*2^s (4 B per element, written split by their producers), LDS-DMA staged, 3 fp16 MFMA 32x32x16 products per multiply-add in one fp32 accumulator)"
+        peak_note = "dense bf16/fp16 MFMA peak 2500 TFLOP/s / 3 products = fp32-equivalent peak; SQ counters of this kernel: MFMA pipe busy 58 % of the elapsed cycles at the ~1.95 GHz the chip sustains under this load (profiles/r03e_pmc_sq_p16.txt)"
+        arith = "fp32-class: conv products evaluated as 3 fp16 MFMA terms of a scaled 2-way fp16 split (representation + dropped term <= 3*2^-22 per product), operands split ONCE by their producers (P16 tensors); everything else as 6 bf16 MFMA terms of a 3-way bf16 split (<= 2^-26); fp32 accumulation, BatchNorm, losses, optimizer"
+    elif cprec == 16:
         # the image encoder's convolutions run the fp16 two-plane split: 3 fp16 MFMA products per fp32 multiply-add
         peak = BF16_MFMA_PEAK_TFLOPS / 3
         kname = "trid::gemm_bf16s_kernel<A_CONV,B_KC,16,128> (3x3 implicit-GEMM conv fwd+dgrad; fp32 operands scaled per tensor by a power of two and split into 2 fp16 planes (11+11 significand bits), 3 fp16 MFMA 32x32x16 products per multiply-add in one fp32 accumulator)"
@@ -428,12 +439,13 @@ def main():
     # measurement of the committed build, not a counter read of this run: `traffic_source` names the file.
     traffic, traffic_note, traffic_src = None, None, None
     here = os.path.dirname(os.path.abspath(__file__))
-    for fn in ("r02d_pmc_hbm_traffic.txt", "r02c_pmc_hbm_traffic.txt", "r02a_pmc_hbm_traffic.txt", "r01j_pmc_hbm_traffic.txt"):
+    for fn in ("r03_pmc_hbm_traffic.txt", "r02d_pmc_hbm_traffic.txt", "r02c_pmc_hbm_traffic.txt", "r02a_pmc_hbm_traffic.txt", "r01j_pmc_hbm_traffic.txt"):
         try:
             for line in open(os.path.join(here, "profiles", fn)):
                 f = line.split()
                 want = "0, 16, 128>(trid::GemmParams)" if cprec == 16 else "0, 3, 128>(trid::GemmParams)"
-                if prec == 6 and len(f) > 5 and "gemm_bf16s_kernel<2," in line and line.rstrip().endswith(want):
+                hit = ("gemm_p16_kernel<2, 128, 128, 2, 4, 2>" in line) if p16 else ("gemm_bf16s_kernel<2," in line and line.rstrip().endswith(want))
+                if prec == 6 and len(f) > 5 and hit:
                     traffic = (float(f[2]) + float(f[3])) * 1e6
                     traffic_src = "profiles/" + fn
                     traffic_note = "read %s MB + write %s MB per launch (separate --pmc passes, stored; average over all launches of this kernel incl. layer1); algorithmic input + weights + output of the layer2-4 shapes ~ 58 + 9 + 58 MB" % (f[2], f[3])
