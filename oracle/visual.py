@@ -16,6 +16,58 @@ import torch.nn.functional as F
 BN_EPS = 1e-5  # nn.BatchNorm2d default used at m_resnet.py:19
 BN_MOMENTUM = 0.1
 
+# configs[3]'s "bf16" (BASELINE.json; the reference itself has no reduced-precision path: its DTYPE key is unread,
+# lib/config/defaults.py:142-144): every convolution of the image encoder's 16 / 33 RESIDUAL BLOCKS (97 % of its
+# FLOPs) takes its operands in bf16 - activations, filters and, in backward, the incoming gradient are rounded to bf16
+# (round-to-nearest-even) where the convolution reads them; products are exact, accumulation / BatchNorm / the 3-conv
+# stem / the attention pool / everything else stays fp32.  `with bf16_conv():` switches
+# the oracle to that arithmetic: the comparator of the HIP path's TRID_CONV_PRECISION=1 mode.
+BF16_CONV = False
+
+
+class bf16_conv:
+    def __enter__(self):
+        global BF16_CONV
+        self.old, BF16_CONV = BF16_CONV, True
+
+    def __exit__(self, *a):
+        global BF16_CONV
+        BF16_CONV = self.old
+
+
+def _to_bf16(t):
+    return t.to(torch.bfloat16).to(t.dtype)
+
+
+class _RoundOperand(torch.autograd.Function):
+    """operand -> bf16 value (straight-through: the rounding is where the conv READS the tensor, not a layer)"""
+
+    @staticmethod
+    def forward(ctx, x):
+        return _to_bf16(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+class _RoundIncomingGrad(torch.autograd.Function):
+    """identity whose backward rounds: the gradient arriving at a conv output is an operand of its two backward convs"""
+
+    @staticmethod
+    def forward(ctx, y):
+        return y.view_as(y)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _to_bf16(g)
+
+
+def _conv(x, w, **kw):
+    if BF16_CONV:
+        return _RoundIncomingGrad.apply(F.conv2d(_RoundOperand.apply(x), _RoundOperand.apply(w), **kw))
+    return F.conv2d(x, w, **kw)
+
 
 @dataclass(frozen=True)
 class VisualSpec:
@@ -135,16 +187,16 @@ def _bn(st, p, x, training):
 
 def bottleneck(st, p, x, stride, has_down, training, taps=None):
     # m_resnet.py:54-67
-    out = _relu(_bn(st, p + ".bn1", F.conv2d(x, st[p + ".conv1.weight"]), training), taps)
-    out = _relu(_bn(st, p + ".bn2", F.conv2d(out, st[p + ".conv2.weight"], padding=1), training), taps)
+    out = _relu(_bn(st, p + ".bn1", _conv(x, st[p + ".conv1.weight"]), training), taps)
+    out = _relu(_bn(st, p + ".bn2", _conv(out, st[p + ".conv2.weight"], padding=1), training), taps)
     if stride > 1:
         out = F.avg_pool2d(out, stride)
-    out = _bn(st, p + ".bn3", F.conv2d(out, st[p + ".conv3.weight"]), training)
+    out = _bn(st, p + ".bn3", _conv(out, st[p + ".conv3.weight"]), training)
     idn = x
     if has_down:
         if stride > 1:
             idn = F.avg_pool2d(idn, stride)
-        idn = _bn(st, p + ".downsample.1", F.conv2d(idn, st[p + ".downsample.0.weight"]), training)
+        idn = _bn(st, p + ".downsample.1", _conv(idn, st[p + ".downsample.0.weight"]), training)
     return _relu(out + idn, taps)
 
 

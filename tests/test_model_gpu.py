@@ -508,28 +508,77 @@ def test_full_size_step_he_style_unstructured_masks(gpu):
     assert_within(errs, TOL)
 
 
-def test_config3_rn101_k65536_bf16(gpu):
-    """configs[3] on one GPU: CLIP-RN101 + BiGRU, MoCo queue 65536, bf16 arithmetic (TRID_GEMM_PRECISION=1:
-    GEMM operands rounded to bf16, fp32 accumulation and tensors), one train step against the fp32 CPU oracle.
-    This mode is OUTSIDE the fp32 parity contract by construction; the bounds below are what bf16 operand
-    rounding (2^-9 per product, ~100 layers and 64 recurrent steps deep, random weights) leaves: losses within
-    2 % (measured 5e-4), every gradient / key parameter / queue entry within 3e-1 of its tensor's maximum
-    (measured: GRU input weights 2.0e-1, stem filters 1.4e-1, median 2e-2).  The same model and queue in
-    the default fp32-class arithmetic is held to the flat 1e-3 by the next test."""
-    from fixture_check import assert_within
-    from textreid_amd import ops
+def _oracle_full_step(spec, st0, table, images, tokens, lengths, ids, dtype):
+    """One oracle train step from state st0 in `dtype`: (losses, {name: gradient}, state after the step)."""
+    st = {k: (v.to(dtype).clone() if v.dtype.is_floating_point else v.clone()) for k, v in st0.items()}
+    tr = OH.trainable_names(st)
+    for k in tr:
+        st[k].requires_grad_(True)
+    ld = OH.train_forward(st, spec, table.to(dtype), images.to(dtype), tokens, lengths, ids, m=0.999, epsilon=0.1)
+    sum(ld.values()).backward()
+    return {k: v.detach() for k, v in ld.items()}, {k: st[k].grad for k in tr}, {k: v.detach() for k, v in st.items()}
 
-    old = ops.GEMM_PRECISION
+
+def _step_errors(losses, grad_of, state, ref):
+    """{name: relative error} of (losses, gradients, post-step state) against the reference triple `ref`."""
+    rl, rg, rs = ref
+    errs = {"loss:" + k: rel(losses[k], rl[k]) for k in rl}
+    gfl = 1e-3 * max(float(g.abs().max()) for g in rg.values())
+    for k, g in rg.items():
+        fl = gfl * (100.0 if k.endswith("attnpool.k_proj.bias") else 1.0)
+        errs["grad:" + k] = float((grad_of(k).detach().cpu().double() - g.double()).abs().max() / max(float(g.abs().max()), fl))
+    for k, v in rs.items():
+        if k.startswith(("v_encoder_k.", "t_encoder_k.")) and v.dtype.is_floating_point or k.endswith(("running_mean", "running_var")) or k in ("v_queue", "t_queue"):
+            errs["state:" + k] = rel(state[k], v)
+    return errs
+
+
+def test_config3_rn101_k65536_bf16(gpu):
+    """configs[3] on one GPU: CLIP-RN101 + BiGRU, MoCo queue 65536, bf16 convolution operands (TRID_CONV_PRECISION=1:
+    the residual blocks' convolutions - 97 % of the image encoder's FLOPs - read activations, filters and incoming
+    gradients rounded to bf16; fp32 accumulation, BatchNorm, stem, attention pool, text encoder, losses).
+
+    The comparator is the oracle evaluated in THAT arithmetic (`oracle.visual.bf16_conv`: the same roundings at the
+    same points, exact products).  Rounding to bf16 is a step function with 2^-8 jumps: two evaluations whose fp32
+    intermediates differ in the last bit round a fraction ~2e-4 of the operands to different neighbours, and every
+    output depends on hundreds of operands - so this arithmetic is only DEFINED up to ~1e-3 (forward) / ~1e-1 (worst
+    gradient entry): the oracle's own fp32 evaluation is that far from its fp64 evaluation (measured here, per
+    quantity).  The bound is therefore relative to that spread: every one of the 1096 quantities of the HIP path is
+    within 3x of what the reference arithmetic's fp32 evaluation deviates from the fp64 one (floor 1e-3), and the three
+    losses hold 2e-3 outright.  (Round 2 compared this mode with the fp32 oracle and could only bound it at 3e-1.)"""
+    from textreid_amd import ops
+    from textreid_amd.caption import CaptionBatch
+    from textreid_amd.config import moco_cfg
+    from textreid_amd.model import build_model
+
+    spec, B, K, vocab, seed = OV.RN101, 16, 65536, 3000, 43  # seed: tools/pick_fullstep_seed.py
+    st, table, images, tokens, lengths, ids = full_step_case(spec, B, K, vocab, seed)
+    model = build_model(moco_cfg("m_resnet101", K=K), vocab_dict=table)
+    head = model.embed_model
+    head.load_state_dict({k: v.clone() for k, v in st.items()})
+    model.to(gpu).train()
+    old = ops.CONV_PRECISION
     try:
-        ops.GEMM_PRECISION = 1
-        errs = _full_step_vs_oracle(gpu, "m_resnet101", OV.RN101, B=16, K=65536, vocab=3000, seed=43)  # seed: tools/pick_fullstep_seed.py
+        ops.CONV_PRECISION = 1
+        ld = model(images.to(gpu), CaptionBatch(tokens.to(gpu), lengths.to(gpu), ids.to(gpu)))
+        sum(ld.values()).backward()
     finally:
-        ops.GEMM_PRECISION = old
-    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:5]
-    losses = {k: v for k, v in errs.items() if k.startswith("loss:")}
-    print("bf16:", len(errs), "quantities; losses", {k: "%.1e" % v for k, v in losses.items()}, "worst:", [(k, "%.1e" % v) for k, v in worst])
-    assert_within(losses, 2e-2)
-    assert_within({k: v for k, v in errs.items() if not k.startswith("loss:")}, 3e-1)
+        ops.CONV_PRECISION = old
+    with OV.bf16_conv():
+        ref64 = _oracle_full_step(spec, st, table, images, tokens, lengths, ids, torch.float64)
+        ref32 = _oracle_full_step(spec, st, table, images, tokens, lengths, ids, torch.float32)
+    named = dict(head.named_parameters())
+    hip = _step_errors(ld, lambda k: named[k].grad, head.state_dict(), ref64)
+    spread = _step_errors(ref32[0], lambda k: ref32[1][k], ref32[2], ref64)
+    assert sum(k.startswith("grad:") for k in hip) == 336
+    ratio = sorted(hip[k] / max(spread[k], 1e-3 / 3) for k in hip)
+    worst = sorted(hip, key=lambda k: -hip[k] / max(spread[k], 1e-3 / 3))[:4]
+    print("bf16 conv operands: %d quantities; losses %s; HIP error / oracle-fp32 spread: median %.2f, max %.2f (%s)" % (
+        len(hip), {k: "%.1e" % v for k, v in hip.items() if k.startswith("loss:")}, ratio[len(ratio) // 2], ratio[-1],
+        [(k, "%.1e vs %.1e" % (hip[k], spread[k])) for k in worst]))
+    bad = {k: (hip[k], spread[k]) for k in hip if not hip[k] <= max(TOL, 3.0 * spread[k])}
+    assert not bad, "%d of %d quantities beyond 3x the oracle's own fp32-vs-fp64 spread: %s" % (len(bad), len(hip), sorted(bad.items(), key=lambda kv: -kv[1][0])[:6])
+    assert all(v <= 2e-3 for k, v in hip.items() if k.startswith("loss:")), hip
 
 
 def test_config3_rn101_k65536_fp32_class(gpu):

@@ -139,9 +139,13 @@ class ConvArith:
     operand travels with its largest magnitude as a device scalar: `WA` maps id(conv weight) -> max|w| (weight_amax),
     `slot()` hands out zeroed scalars for the amax side outputs of the BatchNorm kernels that produce activations."""
 
-    def __init__(self, device, WA):
+    def __init__(self, device, WA, PB=None):
         self.device, self.WA = device, WA
+        # P: arithmetic of the stem convolutions - 16 (fp16 two-plane split, needs WA) or None (the library's default);
+        # PB: arithmetic of the residual blocks' convolutions - the same, or 1: operands rounded to bf16 where the conv
+        # reads them (configs[3]'s arithmetic, TRID_CONV_PRECISION=1; oracle: oracle.visual.bf16_conv)
         self.P = 16 if WA else None
+        self.PB = self.P if PB is None else PB
 
     def slot(self):
         return ops.amax_slot(self.device) if self.WA else None
@@ -274,7 +278,7 @@ def block_forward(blk, x, ax, ar, training, save, nbt, masks=None):
     """One Bottleneck (m_resnet.py:54-67) on NHWC activations.  x: block input, ax: its amax scalar (or None).
     Returns (out, amax scalar of out, record for block_backward or None).  masks (a list, parity tests): receives
     the block's three ReLU decision masks in execution order."""
-    P = ar.P
+    P = ar.PB
     stride = blk.stride
     wa = blk.conv1.weight.view(blk.conv1.out_channels, -1)
     kwa = dict(prec=P, aa=ax, ba=ar.wam(blk.conv1))
@@ -319,7 +323,7 @@ def block_backward(blk, rec, g, ar, ws, G):
     """Backward of block_forward.  g: dL/d(out).  Fills G[id(param)] for the block's parameters (weight gradients on
     the side stream `ws`) and returns dL/d(x)."""
     x, ya, sta, aa, yb, stb, ab, yc, stc, xd, yd, std, rmask, (ax, a_aa, a_ab, a_xd) = rec
-    P = ar.P
+    P = ar.PB
     stride = blk.stride
     has_down = blk.downsample is not None
     a_dyc = ar.slot()
@@ -598,7 +602,8 @@ class ModifiedResNet(nn.Module):
         B = images.shape[0]
         S = {"B": B} if save else None
         # fp16-split conv arithmetic: every GEMM operand comes with its largest magnitude as a device scalar
-        ar = ConvArith(images.device, weight_amax(self) if ops.conv_precision() == 16 else {})
+        cp = ops.conv_precision()
+        ar = ConvArith(images.device, weight_amax(self) if cp in (16, 1) else {}, 1 if cp == 1 else None)
         nbt = []  # num_batches_tracked buffers, incremented together at the end of the pass
         # ---- stem (m_resnet.py:199-207)
         masks = getattr(self, "_debug_masks", None)  # parity tests: every ReLU decision of the pass, in execution order
@@ -606,6 +611,7 @@ class ModifiedResNet(nn.Module):
         if save:
             S["stem"] = srec
             S["wamax"] = ar.WA
+            S["prec"] = ar.PB
         # ---- residual layers (m_resnet.py:54-67)
         if save:
             S["blocks"] = []
@@ -614,7 +620,7 @@ class ModifiedResNet(nn.Module):
             taps["stem"] = x
             names = {id(blk): "layer%d.%d" % (li + 1, bi) for li, layer in enumerate((self.layer1, self.layer2, self.layer3, self.layer4))
                      for bi, blk in enumerate(layer)}
-        p16 = ops.USE_P16 and training and bool(ar.WA) and p16_eligible(self)
+        p16 = ops.USE_P16 and training and ar.PB == 16 and p16_eligible(self)
         if p16:
             # residual blocks on pre-split operands: filters packed once per pass, activations written split by the
             # BatchNorm passes; the stem stays on the fp32 path (32-channel tiles) and hands over one packed tensor
@@ -739,7 +745,7 @@ class ModifiedResNet(nn.Module):
     def _run_backward(self, S, gout):
         G = {}
         ws = _WgradStream(gout.device)
-        ar = ConvArith(gout.device, S.get("wamax", {}))  # the forward's conv arithmetic (its weight / activation amax scalars are reused here)
+        ar = ConvArith(gout.device, S.get("wamax", {}), S.get("prec"))  # the forward's conv arithmetic (its weight / activation amax scalars are reused here)
         g = self._attnpool_backward(S["attn"], gout, G)
         S["attn"] = None
         blocks = list(self.blocks())
