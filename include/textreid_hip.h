@@ -95,16 +95,18 @@ int trid_gemm_f32(const trid_gemm_desc* d, void* stream);
  * The kernel that PRODUCES an operand writes it split once; trid_gemm_p16 stages it with LDS-DMA (pure copies) and
  * evaluates hi*hi + hi*lo + lo*hi on the fp16 MFMA exactly as precision 16 does (same error bound).
  * ------------------------------------------------------------------------- */
-/* fp32 [rows][K] (row pitch ldx elements) -> P16; amax: device scalar max|x| (NULL: unscaled) */
-int trid_p16_pack_f32(const float* x, long long rows, int K, long long ldx, const float* amax, void* out, void* stream);
+/* fp32 [rows][K] (row pitch ldx elements) -> fmt 1: P16 (amax: device scalar max|x|, NULL: unscaled); fmt 2: plain
+ * bf16 rows (round-to-nearest-even) */
+int trid_p16_pack_f32(const float* x, long long rows, int K, long long ldx, const float* amax, void* out, int fmt, void* stream);
 /* P16 -> fp32 [rows][K]: (hi + lo) / 2^s */
 int trid_p16_unpack_f32(const void* in, long long rows, int K, const float* amax, float* out, void* stream);
 /* w [N][T][C] fp32 -> P16 [C rows][K = T*N], k = t'*N + n, t' = flip ? T-1-t : t: the data-gradient operand of a
  * conv (autograd of nn.Conv2d, m_resnet.py:18-26): trid_weight_transpose_f32 + pack in one pass */
 int trid_p16_pack_wt_f32(const float* w, int N, int T, int C, int flip, const float* amax, void* out, void* stream);
 /* All conv filters of an encoder in one launch: table (device) = n_tensors x {src, dst, N, T, C, a} (int64), amax[a] =
- * max|tensor|; transposed == 0: trid_p16_pack_f32 of [N][T*C]; != 0: trid_p16_pack_wt_f32 (taps reversed for T > 1) */
-int trid_p16_pack_multi_f32(const long long* table, const float* amax, int n_tensors, int transposed, void* stream);
+ * max|tensor|; transposed == 0: trid_p16_pack_f32 of [N][T*C]; != 0: trid_p16_pack_wt_f32 (taps reversed for T > 1);
+ * fmt 1: P16, fmt 2: plain bf16 rows (the operands of trid_gemm_p16 with precision 1; amax unused) */
+int trid_p16_pack_multi_f32(const long long* table, const float* amax, int n_tensors, int transposed, int fmt, void* stream);
 /* C = alpha * A . B^T (+ epilogues of trid_gemm_f32: bias, accumulate, residual, relu, split-K slabs, BatchNorm
  * partials) with A ([M][K], or an NHWC image for a_mode TRID_A_CONV) and B ([N][K]) in P16; lda / ldb = row pitch
  * in elements; a_amax / b_amax = the scalars the operands were packed with.  variant: tile shape (0 = default). */
@@ -164,14 +166,19 @@ int trid_bn_finalize_minmax_f32(const float* partials, int nparts, int rows_per_
                                 const float* gamma, const float* beta, float* running_mean, float* running_var,
                                 float momentum, float eps, float* mean, float* invstd, float* scale, float* shift,
                                 int relu, float* amax_out, void* stream);
-/* trid_bn_apply_f32 with a P16 output scaled for the bound bound_a[0] (+ bound_b[0] if not NULL); bound_sum (may be
- * NULL) receives that sum.  res_amax != NULL: `res` is a P16 tensor (identity residual) with that amax. */
+/* Tensor formats of these entry points: 0 = fp32, 1 = P16, 2 = plain bf16 (configs[3]'s arithmetic: the convolutions
+ * of the residual blocks read bf16 operands; written here with round-to-nearest-even, no scale, bounds unused). */
+/* trid_bn_apply_f32 with the output in format fmt (1 / 2): P16 scaled for the bound bound_a[0] (+ bound_b[0] if not
+ * NULL), bound_sum (may be NULL) receives that sum.  res_fmt: format of `res` (1 / 2: an identity residual; 1 needs
+ * res_amax). */
 int trid_bn_apply_p16_f32(const float* y, const float* scale, const float* shift, const void* res, const float* rscale,
-                          const float* rshift, const float* res_amax, void* out, long long M, int C, int relu,
-                          uint64_t* relu_mask, const float* bound_a, const float* bound_b, float* bound_sum, void* stream);
-/* trid_bn_apply_pool2_f32 with a P16 output (scale from bound[0]); in_amax != NULL: y itself is a P16 tensor */
-int trid_bn_apply_pool2_p16_f32(const void* y, const float* scale, const float* shift, const float* in_amax, void* out,
-                                int B, int H, int W, int C, int relu, const float* bound, void* stream);
+                          const float* rshift, int res_fmt, const float* res_amax, void* out, int fmt, long long M, int C,
+                          int relu, uint64_t* relu_mask, const float* bound_a, const float* bound_b, float* bound_sum,
+                          void* stream);
+/* trid_bn_apply_pool2_f32 with the output in format fmt (P16: scale from bound[0]); in_fmt != 0: y itself is a tensor
+ * of that format (plain pooling of a block input) */
+int trid_bn_apply_pool2_p16_f32(const void* y, const float* scale, const float* shift, int in_fmt, const float* in_amax,
+                                void* out, int fmt, int B, int H, int W, int C, int relu, const float* bound, void* stream);
 /* dx[b,y,x,c] (+)= 0.25*g[b,y/2,x/2,c] */
 int trid_avgpool2_bwd_f32(const float* g, float* dx, int B, int H, int W, int C, int accumulate, void* stream);
 
@@ -196,10 +203,10 @@ int trid_bn_bwd_reduce_bound_f32(const float* g, const float* y, const float* ac
                                  const float* invstd, const float* scale, const float* shift, int mask_mode, int pooled,
                                  int B, int H, int W, int C, float* dgamma, float* dbeta, float* ws, float* bound,
                                  void* stream);
-/* trid_bn_bwd_apply_f32 with dy written as a P16 tensor scaled for bound[0] */
+/* trid_bn_bwd_apply_f32 with dy written in format fmt (1: P16 scaled for bound[0]; 2: bf16) */
 int trid_bn_bwd_apply_p16_f32(const float* g, const float* y, const float* act, const float* mean, const float* invstd,
                               const float* scale, const float* shift, const float* dgamma, const float* dbeta,
-                              int mask_mode, int pooled, int B, int H, int W, int C, void* dy, float* dres,
+                              int mask_mode, int pooled, int B, int H, int W, int C, void* dy, int fmt, float* dres,
                               const float* bound, void* stream);
 
 /* ------------------------------------------------------------------------- *

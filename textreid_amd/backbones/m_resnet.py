@@ -173,28 +173,28 @@ def weight_amax(mod):
     return WA
 
 
-def p16_eligible(mod):
+def p16_eligible(mod, mult=32):
     """The residual blocks run on pre-split (P16) operands when every block channel count is a multiple of the 32-wide
-    K group (all CLIP ModifiedResNets at width 64; not the width-16 test encoders)."""
-    ok = getattr(mod, "_p16_ok", None)
-    if ok is None:
-        ok = all(isinstance(m, nn.Conv2d) is False or (m.in_channels % 32 == 0 and m.out_channels % 32 == 0)
-                 for blk in mod.blocks() for m in blk.modules())
-        mod._p16_ok = ok
-    return ok
+    K group - 64 for the bf16 form - (all CLIP ModifiedResNets at width 64; not the width-16 test encoders)."""
+    cache = mod.__dict__.setdefault("_p16_ok", {})
+    if mult not in cache:
+        cache[mult] = all(isinstance(m, nn.Conv2d) is False or (m.in_channels % mult == 0 and m.out_channels % mult == 0)
+                          for blk in mod.blocks() for m in blk.modules())
+    return cache[mult]
 
 
-def p16_weights(mod, WA, transposed):
+def p16_weights(mod, WA, transposed, fmt=1):
     """{id(conv weight): ops.P16} for every residual-block filter of `mod`, ONE multi-tensor launch: the forward
     operands [N][taps*C] (filters as stored: 3x3 in OHWI) or, transposed, the data-gradient operands [C][taps*N] with
-    the taps reversed.  Destination buffers and the pointer table are persistent per module."""
+    the taps reversed.  fmt 1: P16 (scaled by WA's amax scalars); fmt 2: plain bf16.  Destination buffers and the
+    pointer table are persistent per module."""
     convs = [m.weight for m in mod.modules() if isinstance(m, nn.Conv2d)]  # weight_amax's order
     index = {id(w): i for i, w in enumerate(convs)}
     blocks = mod.blocks() if hasattr(mod, "blocks") else [mod]  # (a single Bottleneck: per-block parity tests)
     mine = [m.weight for blk in blocks for m in blk.modules() if isinstance(m, nn.Conv2d)]
     key = tuple(w.data_ptr() for w in mine)
     plans = mod.__dict__.setdefault("_p16_plans", {})
-    plan = plans.get(transposed)
+    plan = plans.get((transposed, fmt))
     if plan is None or plan[0] != key:
         dev = mine[0].device
         dsts, rows = [], []
@@ -202,13 +202,13 @@ def p16_weights(mod, WA, transposed):
             N, C, T = w.shape[0], w.shape[1], w.shape[2] * w.shape[3]
             if T > 1 and not w.is_contiguous(memory_format=torch.channels_last):
                 raise RuntimeError("3x3 filters must live in channels_last (OHWI) memory")
-            d = torch.empty((C, T * N) if transposed else (N, T * C), dtype=torch.float32, device=dev)
+            d = ops.p16_empty((C, T * N) if transposed else (N, T * C), w, fmt)
             dsts.append(d)
             rows.append([w.data_ptr(), d.data_ptr(), N, T, C, index[id(w)]])
         plan = (key, torch.tensor(rows, dtype=torch.int64, device=dev), dsts)
-        plans[transposed] = plan
-    ops.call("trid_p16_pack_multi_f32", ops._p(plan[1]), ops._p(WA["all"]), len(mine), 1 if transposed else 0, ops.stream())
-    return {id(w): ops.P16(d, WA[id(w)]) for w, d in zip(mine, plan[2])}
+        plans[(transposed, fmt)] = plan
+    ops.call("trid_p16_pack_multi_f32", ops._p(plan[1]), ops._p(WA["all"]), len(mine), 1 if transposed else 0, fmt, ops.stream())
+    return {id(w): ops.P16(d, WA[id(w)] if fmt == 1 else None, fmt) for w, d in zip(mine, plan[2])}
 
 
 def _pre_mask(y, st):
@@ -362,33 +362,37 @@ def block_backward(blk, rec, g, ar, ws, G):
 def block_forward_p16(blk, x, WP, dev, training, save, nbt, masks=None):
     """block_forward on pre-split operands: x and every GEMM operand are ops.P16 tensors written by their producers
     (BatchNorm apply passes, whose output magnitude is known from the conv epilogue's column extremes before they
-    run), the convolutions stage them with LDS-DMA (csrc/gemm_p16.hip).  Same arithmetic as the fp16-split path."""
+    run), the convolutions stage them with LDS-DMA (csrc/gemm_p16.hip).  Same arithmetic as the fp16-split path.
+    With x.fmt == 2 the same data flow runs on plain bf16 tensors (configs[3]'s arithmetic; no scales / bounds)."""
     assert training
     stride = blk.stride
-    slot = lambda: ops.amax_slot(dev)
-    fin = lambda bn, parts, M, relu, bound: _finalize_minmax(bn, parts, M, relu, bound, nbt)
+    fmt = x.fmt
+
+    def fin(bn, parts, M, relu):
+        """(BatchNorm coefficients, bound of max|act(bn(y))| or None)"""
+        if fmt == 2:
+            return _bn_coeffs(bn, parts, M, True, nbt), None
+        bound = ops.amax_slot(dev)
+        return _finalize_minmax(bn, parts, M, relu, bound, nbt), bound
+
     ya, pa = ops.conv_p16(x, WP[id(blk.conv1.weight)])
     Ma = ya.numel() // ya.shape[-1]
-    a_aa = slot()
-    sta = fin(blk.bn1, pa, Ma, True, a_aa)
-    aa = ops.bn_apply_p16(ya, sta, a_aa, relu=True)
+    sta, a_aa = fin(blk.bn1, pa, Ma, True)
+    aa = ops.bn_apply_p16(ya, sta, a_aa, relu=True, fmt=fmt)
     yb, pb = ops.conv_p16(aa, WP[id(blk.conv2.weight)], conv3=True)
-    a_ab = slot()
-    stb = fin(blk.bn2, pb, Ma, True, a_ab)
-    ab = ops.bn_apply_pool2_p16(yb, stb, a_ab, relu=True) if stride > 1 else ops.bn_apply_p16(yb, stb, a_ab, relu=True)
+    stb, a_ab = fin(blk.bn2, pb, Ma, True)
+    ab = ops.bn_apply_pool2_p16(yb, stb, a_ab, relu=True, fmt=fmt) if stride > 1 else ops.bn_apply_p16(yb, stb, a_ab, relu=True, fmt=fmt)
     yc, pc = ops.conv_p16(ab, WP[id(blk.conv3.weight)])
     Mc = yc.numel() // yc.shape[-1]
-    a_c = slot()
-    stc = fin(blk.bn3, pc, Mc, False, a_c)
+    stc, a_c = fin(blk.bn3, pc, Mc, False)
     xd = yd = std = None
     if blk.downsample is not None:
-        xd = ops.bn_apply_pool2_p16(x, None, x.amax) if stride > 1 else x
+        xd = ops.bn_apply_pool2_p16(x, None, x.amax, fmt=fmt) if stride > 1 else x
         yd, pd = ops.conv_p16(xd, WP[id(blk.downsample[1].weight)])
-        a_d = slot()
-        std = fin(blk.downsample[2], pd, Mc, False, a_d)
-        out = ops.bn_apply_p16(yc, stc, a_c, relu=True, res=yd, res_st=std, bound_res=a_d, want_mask=save)
+        std, a_d = fin(blk.downsample[2], pd, Mc, False)
+        out = ops.bn_apply_p16(yc, stc, a_c, relu=True, res=yd, res_st=std, bound_res=a_d, want_mask=save, fmt=fmt)
     else:
-        out = ops.bn_apply_p16(yc, stc, a_c, relu=True, res=x, bound_res=x.amax, want_mask=save)
+        out = ops.bn_apply_p16(yc, stc, a_c, relu=True, res=x, bound_res=x.amax, want_mask=save, fmt=fmt)
     rec = None
     if save:
         out, rmask = out
@@ -412,28 +416,30 @@ def block_backward_p16(blk, rec, g, WPT, ws, G):
     stride = blk.stride
     has_down = blk.downsample is not None
 
+    fmt = x.fmt
+
     def wgrad(dy, act, conv=None):
-        return ws.run(lambda d_, x_: ops.wgrad_p16(ops.P16(d_, dy.amax), ops.P16(x_, act.amax), conv=conv), dy.data, act.data,
+        return ws.run(lambda d_, x_: ops.wgrad_p16(ops.P16(d_, dy.amax, fmt), ops.P16(x_, act.amax, fmt), conv=conv), dy.data, act.data,
                       keep=(dy.amax, act.amax))
 
-    dyc, dg, db, dres = ops.bn_bwd_p16(g, yc, stc, 3, act=rmask, want_dres=not has_down)
+    dyc, dg, db, dres = ops.bn_bwd_p16(g, yc, stc, 3, act=rmask, want_dres=not has_down, fmt=fmt)
     G[id(blk.bn3.weight)], G[id(blk.bn3.bias)] = dg, db
     if has_down:
-        dyd, dg, db, _ = ops.bn_bwd_p16(g, yd, std, 3, act=rmask)
+        dyd, dg, db, _ = ops.bn_bwd_p16(g, yd, std, 3, act=rmask, fmt=fmt)
         G[id(blk.downsample[2].weight)], G[id(blk.downsample[2].bias)] = dg, db
     planes = blk.conv2.out_channels
     Mc = dyc.data.numel() // dyc.shape[-1]
     dab = ops.empty(tuple(ab.shape), g)
     ops.gemm_p16(dyc, WPT[id(blk.conv3.weight)], dab, Mc, planes, dyc.shape[-1], planes)
     G[id(blk.conv3.weight)] = wgrad(dyc, ab).view_as(blk.conv3.weight)
-    dyb, dg, db, _ = ops.bn_bwd_p16(dab, yb, stb, 1, pooled=stride > 1)
+    dyb, dg, db, _ = ops.bn_bwd_p16(dab, yb, stb, 1, pooled=stride > 1, fmt=fmt)
     G[id(blk.bn2.weight)], G[id(blk.bn2.bias)] = dg, db
     Bi, H, W, _ = yb.shape
     Ma = Bi * H * W
     daa = ops.empty(tuple(aa.shape), g)
     ops.gemm_p16(dyb, WPT[id(blk.conv2.weight)], daa, Ma, planes, 9 * planes, planes, conv=(H, W, planes))
     G[id(blk.conv2.weight)] = _g3x3(wgrad(dyb, aa, conv=(H, W, planes)), planes, planes)
-    dya, dg, db, _ = ops.bn_bwd_p16(daa, ya, sta, 1)
+    dya, dg, db, _ = ops.bn_bwd_p16(daa, ya, sta, 1, fmt=fmt)
     G[id(blk.bn1.weight)], G[id(blk.bn1.bias)] = dg, db
     cin = blk.conv1.in_channels
     if has_down:
@@ -620,12 +626,14 @@ class ModifiedResNet(nn.Module):
             taps["stem"] = x
             names = {id(blk): "layer%d.%d" % (li + 1, bi) for li, layer in enumerate((self.layer1, self.layer2, self.layer3, self.layer4))
                      for bi, blk in enumerate(layer)}
-        p16 = ops.USE_P16 and training and ar.PB == 16 and p16_eligible(self)
+        p16 = ops.USE_P16 and training and ar.PB in (16, 1) and p16_eligible(self, 32 if ar.PB == 16 else 64)
         if p16:
             # residual blocks on pre-split operands: filters packed once per pass, activations written split by the
-            # BatchNorm passes; the stem stays on the fp32 path (32-channel tiles) and hands over one packed tensor
-            WP = p16_weights(self, ar.WA, False)
-            x = ops.p16_pack(x, ax)
+            # BatchNorm passes; the stem stays on the fp32 path (32-channel tiles) and hands over one packed tensor.
+            # PB == 1 (configs[3]): the same data flow on plain bf16 tensors
+            fmt = 1 if ar.PB == 16 else 2
+            WP = p16_weights(self, ar.WA, False, fmt)
+            x = ops.p16_pack(x, ax, fmt)
             for blk in self.blocks():
                 x, rec = block_forward_p16(blk, x, WP, images.device, training, save, nbt, masks)
                 if save:
@@ -634,7 +642,7 @@ class ModifiedResNet(nn.Module):
                     taps[names[id(blk)]] = x.unpack()
             x = x.unpack()
             if save:
-                S["p16"] = True
+                S["p16"] = fmt
         else:
             for blk in self.blocks():
                 x, ax, rec = block_forward(blk, x, ax, ar, training, save, nbt, masks)
@@ -764,8 +772,8 @@ class ModifiedResNet(nn.Module):
 
         first_of_layer = {id(layer[0]) for layer in (self.layer1, self.layer2, self.layer3, self.layer4)}
         dbg = getattr(self, "_debug_grads", None)
-        p16 = S.get("p16", False)
-        WPT = p16_weights(self, ar.WA, True) if p16 else None
+        p16 = S.get("p16", 0)
+        WPT = p16_weights(self, ar.WA, True, p16) if p16 else None
         for blk, rec in zip(reversed(blocks), reversed(S["blocks"])):
             if dbg is not None:
                 dbg.append(g)

@@ -33,6 +33,16 @@ __device__ __forceinline__ float4 p16_load4(const uint2* __restrict__ base, long
     return make_float4(((float)h0.x + (float)l0.x) * inv, ((float)h0.y + (float)l0.y) * inv,
                        ((float)h1.x + (float)l1.x) * inv, ((float)h1.y + (float)l1.y) * inv);
 }
+// the same tensors as plain bf16 (configs[3]'s arithmetic: the convolutions read bf16 operands; round-to-nearest-even
+// here = the rounding the GEMM loader would apply): quad i = 8 bytes at 8 * i, no scale
+__device__ __forceinline__ void bf16_store4(uint2* __restrict__ base, long long i, float4 v) {
+    base[i] = make_uint2(cvt_pk_bf16(v.x, v.y), cvt_pk_bf16(v.z, v.w));
+}
+__device__ __forceinline__ float4 bf16_load4(const uint2* __restrict__ base, long long i) {
+    const uint2 u = base[i];
+    return make_float4(__builtin_bit_cast(float, u.x << 16), __builtin_bit_cast(float, u.x & 0xffff0000u),
+                       __builtin_bit_cast(float, u.y << 16), __builtin_bit_cast(float, u.y & 0xffff0000u));
+}
 // scale of a P16 tensor whose largest magnitude is bounded by *a (+ *b): the bound is also published for the consumers
 __device__ __forceinline__ float p16_out_scale(const float* a, const float* b, float* sum_out) {
     const float bound = (a != nullptr ? *a : 0.f) + (b != nullptr ? *b : 0.f);
@@ -213,7 +223,8 @@ __device__ __forceinline__ float4 relu4(float4 v) {
 // P16OUT: `out` is written as a P16 tensor whose scale comes from the bound *oa (+ *ob), known BEFORE this pass
 // (bn_finalize's extremes; a residual adds its own bound); the sum is published in *osum for the consumers.
 // P16RES: the identity residual `res` is a P16 tensor (scale from *res_amax): decoded on the fly.
-template <bool P16OUT, bool P16RES>
+// (formats: 0 = fp32, 1 = P16, 2 = plain bf16)
+template <int OFMT, int RFMT>
 __global__ void bn_apply_kernel(const float4* __restrict__ y, const float4* __restrict__ scale,
                                 const float4* __restrict__ shift, const float4* __restrict__ res,
                                 const float4* __restrict__ rscale, const float4* __restrict__ rshift,
@@ -222,14 +233,16 @@ __global__ void bn_apply_kernel(const float4* __restrict__ y, const float4* __re
                                 const float* __restrict__ oa, const float* __restrict__ ob, float* __restrict__ osum,
                                 const float* __restrict__ res_amax) {
     unsigned am = 0;
+    constexpr bool P16OUT = OFMT == 1;
     const float oscale = P16OUT ? p16_out_scale(oa, ob, osum) : 1.f;
-    const float rinv = P16RES ? 1.f / f16_scale_of(*res_amax) : 1.f;
+    const float rinv = RFMT == 1 ? 1.f / f16_scale_of(*res_amax) : 1.f;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4;
          i += (long long)gridDim.x * blockDim.x) {
         const int cq = (int)(i % CQ);
         float4 v = affine4(y[i], scale[cq], shift[cq]);
         if (res != nullptr) {
-            float4 r = P16RES ? p16_load4(reinterpret_cast<const uint2*>(res), i, CQ, rinv) : res[i];
+            float4 r = RFMT == 1 ? p16_load4(reinterpret_cast<const uint2*>(res), i, CQ, rinv)
+                     : RFMT == 2 ? bf16_load4(reinterpret_cast<const uint2*>(res), i) : res[i];
             if (rscale != nullptr) r = affine4(r, rscale[cq], rshift[cq]);
             v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
         }
@@ -244,27 +257,29 @@ __global__ void bn_apply_kernel(const float4* __restrict__ y, const float4* __re
             }
         }
         if (relu) v = relu4(v);
-        if (P16OUT) {
+        if (OFMT == 1) {
             p16_store4(reinterpret_cast<uint2*>(out), i, CQ, v, oscale);
+        } else if (OFMT == 2) {
+            bf16_store4(reinterpret_cast<uint2*>(out), i, v);
         } else {
             out[i] = v;
             am = amax4(am, v);
         }
     }
-    if (!P16OUT && amax != nullptr) amax_commit(am, amax);
+    if (OFMT == 0 && amax != nullptr) amax_commit(am, amax);
 }
 
 // P16OUT as above (scale from *oa); P16IN: `y` is a P16 tensor (scale from *in_amax) - the plain pooling of a block
 // input on its way to the downsample convolution keeps the input's scale (an average never exceeds the maximum)
-template <bool P16OUT, bool P16IN>
+template <int OFMT, int IFMT>
 __global__ void bn_apply_pool2_kernel(const float4* __restrict__ y, const float4* __restrict__ scale,
                                       const float4* __restrict__ shift, float4* __restrict__ out, int B, int H, int W,
                                       int CQ, int relu, long long total4, float* __restrict__ amax,
                                       const float* __restrict__ oa, const float* __restrict__ in_amax) {
     const int Ho = H / 2, Wo = W / 2;
     unsigned am = 0;
-    const float oscale = P16OUT ? f16_scale_of(*oa) : 1.f;
-    const float iinv = P16IN ? 1.f / f16_scale_of(*in_amax) : 1.f;
+    const float oscale = OFMT == 1 ? f16_scale_of(*oa) : 1.f;
+    const float iinv = IFMT == 1 ? 1.f / f16_scale_of(*in_amax) : 1.f;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4;
          i += (long long)gridDim.x * blockDim.x) {
         const int cq = (int)(i % CQ);
@@ -281,20 +296,23 @@ __global__ void bn_apply_pool2_kernel(const float4* __restrict__ y, const float4
 #pragma unroll
             for (int dx = 0; dx < 2; ++dx) {
                 const long long src = (((long long)b * H + 2 * yo + dy) * W + 2 * xo + dx) * CQ + cq;
-                float4 v = P16IN ? p16_load4(reinterpret_cast<const uint2*>(y), src, CQ, iinv) : y[src];
+                float4 v = IFMT == 1 ? p16_load4(reinterpret_cast<const uint2*>(y), src, CQ, iinv)
+                         : IFMT == 2 ? bf16_load4(reinterpret_cast<const uint2*>(y), src) : y[src];
                 v = affine4(v, s, t);
                 if (relu) v = relu4(v);
                 acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
             }
         const float4 o = make_float4(acc.x * 0.25f, acc.y * 0.25f, acc.z * 0.25f, acc.w * 0.25f);
-        if (P16OUT) {
+        if (OFMT == 1) {
             p16_store4(reinterpret_cast<uint2*>(out), i, CQ, o, oscale);
+        } else if (OFMT == 2) {
+            bf16_store4(reinterpret_cast<uint2*>(out), i, o);
         } else {
             out[i] = o;
             am = amax4(am, o);
         }
     }
-    if (!P16OUT && amax != nullptr) amax_commit(am, amax);
+    if (OFMT == 0 && amax != nullptr) amax_commit(am, amax);
 }
 
 __global__ void avgpool2_bwd_kernel(const float4* __restrict__ g, float4* __restrict__ dx, int B, int H, int W, int CQ,
@@ -487,13 +505,13 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_final_kernel(const float* _
 }
 
 // P16OUT: dy is written as a P16 tensor, scale from the bound *oa of the reduce pass
-template <bool P16OUT>
+template <int OFMT>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a, const float4* __restrict__ dgamma,
                                                            const float4* __restrict__ dbeta, float invM,
                                                            float4* __restrict__ dy, float4* __restrict__ dres,
                                                            float* __restrict__ amax, const float* __restrict__ oa) {
     unsigned am = 0;
-    const float oscale = P16OUT ? f16_scale_of(*oa) : 1.f;
+    const float oscale = OFMT == 1 ? f16_scale_of(*oa) : 1.f;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < a.total4; i += (long long)gridDim.x * 256) {
         const int cq = (int)(i % a.CQ);
         float4 gm, xh;
@@ -504,15 +522,17 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a, const fl
         o.y = sc.y * (gm.y - db.y * invM - xh.y * dg.y * invM);
         o.z = sc.z * (gm.z - db.z * invM - xh.z * dg.z * invM);
         o.w = sc.w * (gm.w - db.w * invM - xh.w * dg.w * invM);
-        if (P16OUT) {
+        if (OFMT == 1) {
             p16_store4(reinterpret_cast<uint2*>(dy), i, a.CQ, o, oscale);
+        } else if (OFMT == 2) {
+            bf16_store4(reinterpret_cast<uint2*>(dy), i, o);
         } else {
             dy[i] = o;
             am = amax4(am, o);
         }
         if (dres != nullptr) dres[i] = gm;
     }
-    if (!P16OUT && amax != nullptr) amax_commit(am, amax);
+    if (OFMT == 0 && amax != nullptr) amax_commit(am, amax);
 }
 
 static int bn_bwd_grid(long long total4, int CQ) {
@@ -591,7 +611,7 @@ extern "C" int trid_bn_apply_f32(const float* y, const float* scale, const float
     TRID_REQUIRE((rscale == nullptr) == (rshift == nullptr), "trid_bn_apply_f32: rscale/rshift both or none");
     TRID_REQUIRE(aligned16(y) && aligned16(out) && aligned16(scale) && aligned16(shift) && (!res || aligned16(res)), "trid_bn_apply_f32: 16-byte alignment");
     const long long total4 = M * (C / 4);
-    hipLaunchKernelGGL((bn_apply_kernel<false, false>), dim3(grid_for(total4, 256 * 4)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL((bn_apply_kernel<0, 0>), dim3(grid_for(total4, 256 * 4)), dim3(256), 0, (hipStream_t)stream,
                        (const float4*)y, (const float4*)scale, (const float4*)shift, (const float4*)res,
                        (const float4*)rscale, (const float4*)rshift, (float4*)out, total4, C / 4, relu,
                        (unsigned long long*)relu_mask, amax, (const float*)nullptr, (const float*)nullptr, (float*)nullptr,
@@ -600,21 +620,27 @@ extern "C" int trid_bn_apply_f32(const float* y, const float* scale, const float
 }
 
 extern "C" int trid_bn_apply_p16_f32(const float* y, const float* scale, const float* shift, const void* res,
-                                     const float* rscale, const float* rshift, const float* res_amax, void* out,
-                                     long long M, int C, int relu, uint64_t* relu_mask, const float* bound_a,
+                                     const float* rscale, const float* rshift, int res_fmt, const float* res_amax, void* out,
+                                     int fmt, long long M, int C, int relu, uint64_t* relu_mask, const float* bound_a,
                                      const float* bound_b, float* bound_sum, void* stream) {
-    TRID_REQUIRE(y && scale && shift && out && bound_a && M > 0 && C > 0 && C % 32 == 0, "trid_bn_apply_p16_f32: bad arguments (C%%32)");
+    TRID_REQUIRE(y && scale && shift && out && (fmt == 2 || bound_a) && (fmt == 1 || fmt == 2) && M > 0 && C > 0 && C % 32 == 0,
+                 "trid_bn_apply_p16_f32: bad arguments (fmt 1 / 2, C%%32)");
+    TRID_REQUIRE(res_fmt >= 0 && res_fmt <= 2 && (res_fmt != 1 || res_amax), "trid_bn_apply_p16_f32: bad residual format");
     TRID_REQUIRE((rscale == nullptr) == (rshift == nullptr), "trid_bn_apply_p16_f32: rscale/rshift both or none");
-    TRID_REQUIRE(!(res_amax && rscale), "trid_bn_apply_p16_f32: a P16 residual is an identity residual (no BatchNorm on it)");
+    TRID_REQUIRE(!(res_fmt != 0 && rscale), "trid_bn_apply_p16_f32: a P16 / bf16 residual is an identity residual (no BatchNorm on it)");
     TRID_REQUIRE(aligned16(y) && aligned16(out) && aligned16(scale) && aligned16(shift) && (!res || aligned16(res)), "trid_bn_apply_p16_f32: 16-byte alignment");
     const long long total4 = M * (C / 4);
     const dim3 grid(grid_for(total4, 256 * 4));
-#define TRID_BN_APPLY_P16(RES)                                                                                              \
-    hipLaunchKernelGGL((bn_apply_kernel<true, RES>), grid, dim3(256), 0, (hipStream_t)stream, (const float4*)y,           \
+#define TRID_BN_APPLY_P16(OF, RF)                                                                                           \
+    hipLaunchKernelGGL((bn_apply_kernel<OF, RF>), grid, dim3(256), 0, (hipStream_t)stream, (const float4*)y,              \
                        (const float4*)scale, (const float4*)shift, (const float4*)res, (const float4*)rscale,              \
                        (const float4*)rshift, (float4*)out, total4, C / 4, relu, (unsigned long long*)relu_mask,           \
                        (float*)nullptr, bound_a, bound_b, bound_sum, res_amax)
-    if (res_amax != nullptr) TRID_BN_APPLY_P16(true); else TRID_BN_APPLY_P16(false);
+    if (fmt == 1) {
+        if (res_fmt == 1) TRID_BN_APPLY_P16(1, 1); else TRID_BN_APPLY_P16(1, 0);
+    } else {
+        if (res_fmt == 2) TRID_BN_APPLY_P16(2, 2); else TRID_BN_APPLY_P16(2, 0);
+    }
 #undef TRID_BN_APPLY_P16
     return check_launch("trid_bn_apply_p16_f32");
 }
@@ -624,27 +650,31 @@ extern "C" int trid_bn_apply_pool2_f32(const float* y, const float* scale, const
     TRID_REQUIRE(y && out && B > 0 && H % 2 == 0 && W % 2 == 0 && C % 4 == 0, "trid_bn_apply_pool2_f32: bad arguments");
     TRID_REQUIRE((scale == nullptr) == (shift == nullptr), "trid_bn_apply_pool2_f32: scale/shift both or none");
     const long long total4 = (long long)B * (H / 2) * (W / 2) * (C / 4);
-    hipLaunchKernelGGL((bn_apply_pool2_kernel<false, false>), dim3(grid_for(total4, 256 * 2)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL((bn_apply_pool2_kernel<0, 0>), dim3(grid_for(total4, 256 * 2)), dim3(256), 0, (hipStream_t)stream,
                        (const float4*)y, (const float4*)scale, (const float4*)shift, (float4*)out, B, H, W, C / 4, relu,
                        total4, amax, (const float*)nullptr, (const float*)nullptr);
     return check_launch("trid_bn_apply_pool2_f32");
 }
 
-extern "C" int trid_bn_apply_pool2_p16_f32(const void* y, const float* scale, const float* shift, const float* in_amax,
-                                           void* out, int B, int H, int W, int C, int relu, const float* bound,
+extern "C" int trid_bn_apply_pool2_p16_f32(const void* y, const float* scale, const float* shift, int in_fmt, const float* in_amax,
+                                           void* out, int fmt, int B, int H, int W, int C, int relu, const float* bound,
                                            void* stream) {
-    TRID_REQUIRE(y && out && bound && B > 0 && H % 2 == 0 && W % 2 == 0 && C % 32 == 0, "trid_bn_apply_pool2_p16_f32: bad arguments (C%%32)");
+    TRID_REQUIRE(y && out && (fmt == 2 || bound) && (fmt == 1 || fmt == 2) && (in_fmt == 0 || in_fmt == fmt) && (in_fmt != 1 || in_amax) &&
+                     B > 0 && H % 2 == 0 && W % 2 == 0 && C % 32 == 0,
+                 "trid_bn_apply_pool2_p16_f32: bad arguments (fmt 1 / 2, C%%32)");
     TRID_REQUIRE((scale == nullptr) == (shift == nullptr), "trid_bn_apply_pool2_p16_f32: scale/shift both or none");
     const long long total4 = (long long)B * (H / 2) * (W / 2) * (C / 4);
     const dim3 grid(grid_for(total4, 256 * 2));
-    if (in_amax != nullptr)
-        hipLaunchKernelGGL((bn_apply_pool2_kernel<true, true>), grid, dim3(256), 0, (hipStream_t)stream, (const float4*)y,
-                           (const float4*)scale, (const float4*)shift, (float4*)out, B, H, W, C / 4, relu, total4,
-                           (float*)nullptr, bound, in_amax);
-    else
-        hipLaunchKernelGGL((bn_apply_pool2_kernel<true, false>), grid, dim3(256), 0, (hipStream_t)stream, (const float4*)y,
-                           (const float4*)scale, (const float4*)shift, (float4*)out, B, H, W, C / 4, relu, total4,
-                           (float*)nullptr, bound, in_amax);
+#define TRID_BN_POOL_P16(OF, IF)                                                                                            \
+    hipLaunchKernelGGL((bn_apply_pool2_kernel<OF, IF>), grid, dim3(256), 0, (hipStream_t)stream, (const float4*)y,        \
+                       (const float4*)scale, (const float4*)shift, (float4*)out, B, H, W, C / 4, relu, total4,             \
+                       (float*)nullptr, bound, in_amax)
+    if (fmt == 1) {
+        if (in_fmt == 1) TRID_BN_POOL_P16(1, 1); else TRID_BN_POOL_P16(1, 0);
+    } else {
+        if (in_fmt == 2) TRID_BN_POOL_P16(2, 2); else TRID_BN_POOL_P16(2, 0);
+    }
+#undef TRID_BN_POOL_P16
     return check_launch("trid_bn_apply_pool2_p16_f32");
 }
 
@@ -726,7 +756,7 @@ extern "C" int trid_bn_bwd_apply_f32(const float* g, const float* y, const float
     if (rc) return rc;
     TRID_REQUIRE(dgamma && dbeta && dy, "trid_bn_bwd_apply_f32: null pointer");
     const float invM = 1.f / (float)((long long)B * H * W);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(grid_for(a.total4, 256 * 4)), dim3(256), 0, (hipStream_t)stream, a,
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<0>, dim3(grid_for(a.total4, 256 * 4)), dim3(256), 0, (hipStream_t)stream, a,
                        (const float4*)dgamma, (const float4*)dbeta, invM, (float4*)dy, (float4*)dres, amax, (const float*)nullptr);
     return check_launch("trid_bn_bwd_apply_f32");
 }
@@ -734,13 +764,18 @@ extern "C" int trid_bn_bwd_apply_f32(const float* g, const float* y, const float
 extern "C" int trid_bn_bwd_apply_p16_f32(const float* g, const float* y, const float* act, const float* mean,
                                          const float* invstd, const float* scale, const float* shift, const float* dgamma,
                                          const float* dbeta, int mask_mode, int pooled, int B, int H, int W, int C,
-                                         void* dy, float* dres, const float* bound, void* stream) {
+                                         void* dy, int fmt, float* dres, const float* bound, void* stream) {
     BnBwdArgs a;
     int rc = bn_bwd_fill(a, g, y, act, mean, invstd, scale, shift, mask_mode, pooled, B, H, W, C);
     if (rc) return rc;
-    TRID_REQUIRE(dgamma && dbeta && dy && bound && C % 32 == 0, "trid_bn_bwd_apply_p16_f32: null pointer or C %% 32 != 0");
+    TRID_REQUIRE(dgamma && dbeta && dy && (fmt == 2 || bound) && (fmt == 1 || fmt == 2) && C % 32 == 0,
+                 "trid_bn_bwd_apply_p16_f32: null pointer, fmt not 1 / 2 or C %% 32 != 0");
     const float invM = 1.f / (float)((long long)B * H * W);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(grid_for(a.total4, 256 * 4)), dim3(256), 0, (hipStream_t)stream, a,
-                       (const float4*)dgamma, (const float4*)dbeta, invM, (float4*)dy, (float4*)dres, (float*)nullptr, bound);
+    if (fmt == 1)
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, dim3(grid_for(a.total4, 256 * 4)), dim3(256), 0, (hipStream_t)stream, a,
+                           (const float4*)dgamma, (const float4*)dbeta, invM, (float4*)dy, (float4*)dres, (float*)nullptr, bound);
+    else
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<2>, dim3(grid_for(a.total4, 256 * 4)), dim3(256), 0, (hipStream_t)stream, a,
+                           (const float4*)dgamma, (const float4*)dbeta, invM, (float4*)dy, (float4*)dres, (float*)nullptr, bound);
     return check_launch("trid_bn_bwd_apply_p16_f32");
 }

@@ -40,9 +40,14 @@ __device__ __forceinline__ void dma16(const __amdgpu_buffer_rsrc_t& rs, uint4* l
 }
 
 // AMODE: A_KC (rows = GEMM rows) or A_CONV (rows = pixels of an NHWC image, K = 9 taps x Cin, 3x3 / stride 1 / pad 1)
-template <int AMODE, int BM, int BN, int WM, int WN, int STAGES>
+// PL = 2: P16 operands (two fp16 planes, 32 k per 128-byte row chunk, 3 MFMA products per multiply-add: fp32-class);
+// PL = 1: plain bf16 operands (64 k per 128-byte chunk, one bf16 MFMA per product): configs[3]'s bf16 arithmetic on
+// tensors their producers already wrote in bf16 - half the operand bytes, a third of the matrix work.
+template <int AMODE, int BM, int BN, int WM, int WN, int STAGES, int PL>
 __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 && STAGES == 2) ? 2 : (WM * WN == 8 && (BM + BN) * 128 * STAGES <= 80 * 1024 ? 4 : 2)) void gemm_p16_kernel(GemmParams p) {
     constexpr int NW = WM * WN;
+    constexpr int BKE = PL == 2 ? 32 : 64;  // K elements per 128-byte row chunk = per K tile
+    constexpr int EB = PL == 2 ? 4 : 2;     // bytes per element of a row
     constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
     constexpr int A_CH = BM / 8, B_CH = BN / 8;                          // 1-KB DMA chunks (8 rows x 128 B)
     constexpr int A_PW = (A_CH + NW - 1) / NW, B_PW = (B_CH + NW - 1) / NW;  // chunks per wave
@@ -50,8 +55,8 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 && STAGES == 2) ? 2 : (W
     constexpr int STAGE_SLOTS = (BM + BN) * 8;
     extern __shared__ __attribute__((aligned(16))) uint4 smem[];
 
-    const float scaleA = p.a_amax != nullptr ? f16_scale_of(*p.a_amax) : 1.f;
-    const float scaleB = p.b_amax != nullptr ? f16_scale_of(*p.b_amax) : 1.f;
+    const float scaleA = (PL == 2 && p.a_amax != nullptr) ? f16_scale_of(*p.a_amax) : 1.f;
+    const float scaleB = (PL == 2 && p.b_amax != nullptr) ? f16_scale_of(*p.b_amax) : 1.f;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -65,22 +70,22 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 && STAGES == 2) ? 2 : (W
     const int m0 = mb * BM, n0 = nb * BN;
     const int z = blockIdx.z;
     const int bz = z / p.splits, sz = z % p.splits;
-    const int kt_begin = sz * (p.k_chunk / P16_BK);
-    const int kt_end = min(p.K / P16_BK, kt_begin + p.k_chunk / P16_BK);
+    const int kt_begin = sz * (p.k_chunk / BKE);
+    const int kt_end = min(p.K / BKE, kt_begin + p.k_chunk / BKE);
     const int nk = kt_end - kt_begin;
 
-    const char* A = reinterpret_cast<const char*>(p.A + (long long)bz * p.sA);
-    const char* Bp = reinterpret_cast<const char*>(p.B + (long long)bz * p.sB);
+    const char* A = reinterpret_cast<const char*>(p.A) + (long long)bz * p.sA * EB;
+    const char* Bp = reinterpret_cast<const char*>(p.B) + (long long)bz * p.sB * EB;
     float* __restrict__ C = p.C + (long long)bz * p.sC + (long long)sz * p.sSplit;
     const float* __restrict__ bias = p.bias ? p.bias + (long long)bz * p.sBias : nullptr;
 
     // ---- loader lanes: chunk c covers tile rows 8c .. 8c+7; lane -> (row 8c + lane/8, stored slot lane%8)
     constexpr unsigned OOB = 0x80000000u;
-    const long long a_ld_bytes = (AMODE == A_CONV ? (long long)p.Cin : p.lda) * 4;
+    const long long a_ld_bytes = (AMODE == A_CONV ? (long long)p.Cin : p.lda) * EB;
     const long long a_rows = (AMODE == A_CONV) ? (long long)p.M + 2 * p.W + 2 : p.M;
     const char* a_base = (AMODE == A_CONV) ? A - (long long)(p.W + 1) * a_ld_bytes : A;  // tap offsets stay >= 0
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a_base, 0, (unsigned)(a_rows * a_ld_bytes), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)Bp, 0, (unsigned)((long long)p.N * p.ldb * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)Bp, 0, (unsigned)((long long)p.N * p.ldb * EB), 0x00020000);
 
     unsigned voA[A_PW], voB[B_PW], amask[A_PW];
 #pragma unroll
@@ -111,9 +116,9 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 && STAGES == 2) ? 2 : (W
         const int r = 8 * c + (lane >> 3);
         const int s = (lane & 7) ^ ((r >> 1) & 7);
         const int n = n0 + r;
-        voB[j] = (c < B_CH && n < p.N) ? (unsigned)((long long)n * p.ldb * 4 + 16 * s) : OOB;
+        voB[j] = (c < B_CH && n < p.N) ? (unsigned)((long long)n * p.ldb * EB + 16 * s) : OOB;
     }
-    const int cgroups = (AMODE == A_CONV) ? p.Cin / P16_BK : 1;
+    const int cgroups = (AMODE == A_CONV) ? p.Cin / BKE : 1;
 
     auto issue = [&](int kt, int stage) {
         uint4* sA = smem + stage * STAGE_SLOTS;
@@ -125,7 +130,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 && STAGES == 2) ? 2 : (W
             // of an activation slab are adjacent in time: L1/L2 hits); the weights' K index is (tap, channel)
             tap = kt % 9;
             const int cg = kt / 9;
-            soA = (unsigned)((((tap / 3) * p.W + (tap % 3)) * (long long)p.Cin * 4) + cg * 128);
+            soA = (unsigned)((((tap / 3) * p.W + (tap % 3)) * (long long)p.Cin * EB) + cg * 128);
             soB = (unsigned)((tap * cgroups + cg) * 128);
         } else {
             soA = soB = (unsigned)(kt * 128);
@@ -161,30 +166,46 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 && STAGES == 2) ? 2 : (W
     auto compute = [&](int stage) {
         const uint4* sA = smem + stage * STAGE_SLOTS;
         const uint4* sB = sA + BM * 8;
+        if constexpr (PL == 1) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            f16x8 a[2][TM], b[2][TN];
+            for (int ks = 0; ks < 4; ++ks) {
+                bf16x8 a[TM], b[TN];
+                const int s = (2 * ks + khalf) ^ xs;
 #pragma unroll
-            for (int pl = 0; pl < 2; ++pl) {
-                const int s = (4 * pl + 2 * ks + khalf) ^ xs;
+                for (int i = 0; i < TM; ++i) a[i] = __builtin_bit_cast(bf16x8, sA[(a_row + 32 * i) * 8 + s]);
 #pragma unroll
-                for (int i = 0; i < TM; ++i) a[pl][i] = __builtin_bit_cast(f16x8, sA[(a_row + 32 * i) * 8 + s]);
+                for (int j = 0; j < TN; ++j) b[j] = __builtin_bit_cast(bf16x8, sB[(b_row + 32 * j) * 8 + s]);
 #pragma unroll
-                for (int j = 0; j < TN; ++j) b[pl][j] = __builtin_bit_cast(f16x8, sB[(b_row + 32 * j) * 8 + s]);
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
             }
-            // small terms first; consecutive MFMAs hit different accumulators
+        } else {
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+            for (int ks = 0; ks < 2; ++ks) {
+                f16x8 a[2][TM], b[2][TN];
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][i], b[1][j], acc[i][j], 0, 0, 0);
+                for (int pl = 0; pl < 2; ++pl) {
+                    const int s = (4 * pl + 2 * ks + khalf) ^ xs;
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                    for (int i = 0; i < TM; ++i) a[pl][i] = __builtin_bit_cast(f16x8, sA[(a_row + 32 * i) * 8 + s]);
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][i], b[0][j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < TN; ++j) b[pl][j] = __builtin_bit_cast(f16x8, sB[(b_row + 32 * j) * 8 + s]);
+                }
+                // small terms first; consecutive MFMAs hit different accumulators
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][i], b[0][j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][i], b[1][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][i], b[0][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][i], b[0][j], acc[i][j], 0, 0, 0);
+            }
         }
     };
 
@@ -343,19 +364,26 @@ __device__ __forceinline__ f16x8 tr_frag(const char* lds_addr) {
     return r;
 }
 
-template <int BMODE, int BM, int STAGES>
+// PL = 2: P16 operands (pieces of 32 channels, 32-pixel K tiles); PL = 1: plain bf16 operands (pieces of 64 channels,
+// 64-pixel K tiles, one bf16 MFMA per product).
+template <int BMODE, int BM, int STAGES, int PL>
 __global__ __launch_bounds__(512, 4) void gemm_p16_wgrad_kernel(GemmParams p) {
     constexpr int BN = 128, NW = 8, WN = 4, WM = 2;
+    constexpr int GC = PL == 2 ? 32 : 64;        // channels per 128-byte piece
+    constexpr int PBK = PL == 2 ? 32 : 64;       // pixels per K tile
+    constexpr int EB = PL == 2 ? 4 : 2;          // bytes per element of a row
+    constexpr int CPG = PBK / 8;                 // DMA chunks (8 pixels) per channel group
     constexpr int TM = BM / (32 * WM);           // 2 (BM = 128) or 1 (BM = 64)
-    constexpr int A_CH = (BM / 32) * 4, B_CH = (BN / 32) * 4;  // 1-KB DMA chunks: 8 pixels of one channel group
+    constexpr int A_CH = (BM / GC) * CPG, B_CH = (BN / GC) * CPG;  // 1-KB DMA chunks
     constexpr int A_PW = (A_CH + NW - 1) / NW, B_PW = B_CH / NW;
     constexpr int PER_TILE = A_PW + B_PW;
-    constexpr int A_BYTES = (BM / 32) * 32 * 128, STAGE_BYTES = A_BYTES + (BN / 32) * 32 * 128;
+    constexpr int GBYTES = PBK * 128;            // one channel group's [pixels][128 B] block
+    constexpr int A_BYTES = (BM / GC) * GBYTES, STAGE_BYTES = A_BYTES + (BN / GC) * GBYTES;
     extern __shared__ __attribute__((aligned(16))) uint4 smem[];
     char* const sbase = reinterpret_cast<char*>(smem);
 
-    const float scaleA = p.a_amax != nullptr ? f16_scale_of(*p.a_amax) : 1.f;
-    const float scaleB = p.b_amax != nullptr ? f16_scale_of(*p.b_amax) : 1.f;
+    const float scaleA = (PL == 2 && p.a_amax != nullptr) ? f16_scale_of(*p.a_amax) : 1.f;
+    const float scaleB = (PL == 2 && p.b_amax != nullptr) ? f16_scale_of(*p.b_amax) : 1.f;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -368,34 +396,34 @@ __global__ __launch_bounds__(512, 4) void gemm_p16_wgrad_kernel(GemmParams p) {
     const int sz = blockIdx.z;
     const int k_begin = sz * p.k_chunk;
     const int k_end = min(p.K, k_begin + p.k_chunk);
-    const int nk = (k_end - k_begin + P16_BK - 1) / P16_BK;
+    const int nk = (k_end - k_begin + PBK - 1) / PBK;
     float* __restrict__ C = p.C + (long long)sz * p.sSplit;
 
     constexpr unsigned OOB = 0x80000000u;
     const char* A = reinterpret_cast<const char*>(p.A);
     const char* Bp = reinterpret_cast<const char*>(p.B);
-    const long long a_ld = p.lda * 4, b_ld = (BMODE == B_CONV ? (long long)p.Cin : p.ldb) * 4;
+    const long long a_ld = p.lda * EB, b_ld = (BMODE == B_CONV ? (long long)p.Cin : p.ldb) * EB;
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (unsigned)((long long)p.K * a_ld), 0x00020000);
     const char* b_base = (BMODE == B_CONV) ? Bp - (long long)(p.W + 1) * b_ld : Bp;
     const long long b_rows = (BMODE == B_CONV) ? (long long)p.K + 2 * p.W + 2 : p.K;
     const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)b_base, 0, (unsigned)(b_rows * b_ld), 0x00020000);
 
-    // loader lanes: chunk c -> channel group c / 4, pixels 8 * (c % 4) + lane / 8, stored slot lane % 8
+    // loader lanes: chunk c -> channel group c / CPG, pixels 8 * (c % CPG) + lane / 8, stored slot lane % 8
     unsigned voA[A_PW], voB[B_PW];
     int b_pp[B_PW], b_dy[B_PW], b_dx[B_PW];
 #pragma unroll
     for (int j = 0; j < A_PW; ++j) {
         const int c = j * NW + wave;
-        const int gi = c >> 2, pp = 8 * (c & 3) + (lane >> 3);
+        const int gi = c / CPG, pp = 8 * (c % CPG) + (lane >> 3);
         const int s = (lane & 7) ^ (((pp >> 1) & 1) << 2);
-        voA[j] = (c < A_CH && m0 + 32 * gi < p.M) ? (unsigned)((long long)pp * a_ld + (m0 + 32 * gi) * 4 + 16 * s) : OOB;
+        voA[j] = (c < A_CH && m0 + GC * gi < p.M) ? (unsigned)((long long)pp * a_ld + (m0 + GC * gi) * EB + 16 * s) : OOB;
     }
 #pragma unroll
     for (int j = 0; j < B_PW; ++j) {
         const int c = j * NW + wave;
-        const int gi = c >> 2, pp = 8 * (c & 3) + (lane >> 3);
+        const int gi = c / CPG, pp = 8 * (c % CPG) + (lane >> 3);
         const int s = (lane & 7) ^ (((pp >> 1) & 1) << 2);
-        const int col = n0 + 32 * gi;
+        const int col = n0 + GC * gi;
         b_pp[j] = pp;
         b_dy[j] = b_dx[j] = 0;
         if (BMODE == B_CONV) {
@@ -403,23 +431,23 @@ __global__ __launch_bounds__(512, 4) void gemm_p16_wgrad_kernel(GemmParams p) {
             b_dy[j] = tap / 3 - 1;
             b_dx[j] = tap % 3 - 1;
             // byte offset of (pixel pp + tap shift, channel group c0, slot s) from the shifted base
-            voB[j] = col < p.N ? (unsigned)((long long)(pp + (b_dy[j] + 1) * p.W + (b_dx[j] + 1)) * b_ld + c0 * 4 + 16 * s) : OOB;
+            voB[j] = col < p.N ? (unsigned)((long long)(pp + (b_dy[j] + 1) * p.W + (b_dx[j] + 1)) * b_ld + c0 * EB + 16 * s) : OOB;
         } else {
-            voB[j] = col < p.N ? (unsigned)((long long)pp * b_ld + col * 4 + 16 * s) : OOB;
+            voB[j] = col < p.N ? (unsigned)((long long)pp * b_ld + col * EB + 16 * s) : OOB;
         }
     }
 
     auto issue = [&](int kt, int stage) {
         char* sA = sbase + stage * STAGE_BYTES;
         char* sB = sA + A_BYTES;
-        const int k0 = k_begin + kt * P16_BK;
+        const int k0 = k_begin + kt * PBK;
         const unsigned soA = (unsigned)((long long)k0 * a_ld), soB = (unsigned)((long long)k0 * b_ld);
 #pragma unroll
         for (int j = 0; j < A_PW; ++j) {
             const int c = j * NW + wave;
             if (A_CH % NW != 0 && c >= A_CH) break;
             // rows beyond the split's range must not leak into it: the buffer only clips at K
-            const unsigned vo = (k0 + 8 * (c & 3) + (lane >> 3) < k_end) ? voA[j] : OOB;
+            const unsigned vo = (k0 + 8 * (c % CPG) + (lane >> 3) < k_end) ? voA[j] : OOB;
             dma16(rsA, reinterpret_cast<uint4*>(sA + c * 1024), vo, soA);
         }
 #pragma unroll
@@ -449,28 +477,44 @@ __global__ __launch_bounds__(512, 4) void gemm_p16_wgrad_kernel(GemmParams p) {
     // transpose-read lane constants: 16-channel half h, pixel row r of the 4 x 16 tile, 8-byte chunk c8, k half kh
     const int h = (lane >> 4) & 1, r4 = (lane & 15) >> 2, c8 = lane & 3, kh = lane >> 5;
     const int swz = (r4 >> 1) << 2;
-    // byte offset inside a channel group's [32 pixels][128 B] block for plane pl, k step ks: pixel = 16 ks + 8 kh + r4 (+4)
-    auto frag_off = [&](int pl, int ks) { return (16 * ks + 8 * kh + r4) * 128 + (((pl * 4 + h * 2 + (c8 >> 1)) ^ swz) << 4) + 8 * (c8 & 1); };
+    // byte offset inside a stage region of the fragment of 32-channel subtile `sub` (channels 32*sub .. +31 of the
+    // tile), plane pl, k step ks: piece = (channel group, pixel 16 ks + 8 kh + r4), then the 16-byte slot
+    auto frag_off = [&](int sub, int pl, int ks) {
+        const int gi = (32 * sub) / GC;
+        const int slot = PL == 2 ? (pl * 4 + h * 2 + (c8 >> 1)) : (((sub & 1) * 2 + h) * 2 + (c8 >> 1));
+        return gi * GBYTES + (16 * ks + 8 * kh + r4) * 128 + ((slot ^ swz) << 4) + 8 * (c8 & 1);
+    };
 
     auto compute = [&](int stage) {
-        const char* sA = sbase + stage * STAGE_BYTES + (wm * TM) * 4096;
-        const char* sB = sbase + stage * STAGE_BYTES + A_BYTES + wn * 4096;
+        const char* sA = sbase + stage * STAGE_BYTES;
+        const char* sB = sA + A_BYTES;
+        if constexpr (PL == 1) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            f16x8 a[2][TM], b[2];
+            for (int ks = 0; ks < 4; ++ks) {
+                bf16x8 a[TM], b;
 #pragma unroll
-            for (int pl = 0; pl < 2; ++pl) {
-                const int off = frag_off(pl, ks);
+                for (int i = 0; i < TM; ++i) a[i] = __builtin_bit_cast(bf16x8, tr_frag(sA + frag_off(wm * TM + i, 0, ks)));
+                b = __builtin_bit_cast(bf16x8, tr_frag(sB + frag_off(wn, 0, ks)));
 #pragma unroll
-                for (int i = 0; i < TM; ++i) a[pl][i] = tr_frag(sA + i * 4096 + off);
-                b[pl] = tr_frag(sB + off);
+                for (int i = 0; i < TM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b, acc[i], 0, 0, 0);
             }
+        } else {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][i], b[1], acc[i], 0, 0, 0);
+            for (int ks = 0; ks < 2; ++ks) {
+                f16x8 a[2][TM], b[2];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][i], b[0], acc[i], 0, 0, 0);
+                for (int pl = 0; pl < 2; ++pl) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][i], b[0], acc[i], 0, 0, 0);
+                    for (int i = 0; i < TM; ++i) a[pl][i] = tr_frag(sA + frag_off(wm * TM + i, pl, ks));
+                    b[pl] = tr_frag(sB + frag_off(wn, pl, ks));
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][i], b[1], acc[i], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][i], b[0], acc[i], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][i], b[0], acc[i], 0, 0, 0);
+            }
         }
     };
 
@@ -505,10 +549,24 @@ __global__ __launch_bounds__(512, 4) void gemm_p16_wgrad_kernel(GemmParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------------- producers
+// fmt 1: P16 (scaled fp16 planes); fmt 2: plain bf16 rows (round-to-nearest-even, no scale)
+__device__ __forceinline__ void pack8_store(uint4* __restrict__ out, long long row, int K, int kg, const float (&v)[8], float scale, int fmt) {
+    if (fmt == 2) {
+        out[row * (K / 8) + kg] = make_uint4(cvt_pk_bf16(v[0], v[1]), cvt_pk_bf16(v[2], v[3]), cvt_pk_bf16(v[4], v[5]), cvt_pk_bf16(v[6], v[7]));
+        return;
+    }
+    unsigned h[4], l[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) f16_split2(v[2 * q] * scale, v[2 * q + 1] * scale, h[q], l[q]);
+    uint4* dst = out + row * (K / 4) + (kg >> 2) * 8 + (kg & 3);
+    dst[0] = make_uint4(h[0], h[1], h[2], h[3]);
+    dst[4] = make_uint4(l[0], l[1], l[2], l[3]);
+}
+
 // fp32 [rows][K] (row pitch ldx) -> P16.  One thread = 8 consecutive k of one row.
 __global__ __launch_bounds__(256) void p16_pack_kernel(const float* __restrict__ x, long long rows, int K, long long ldx,
-                                                       const float* __restrict__ amax, uint4* __restrict__ out) {
-    const float scale = amax != nullptr ? f16_scale_of(*amax) : 1.f;
+                                                       const float* __restrict__ amax, uint4* __restrict__ out, int fmt) {
+    const float scale = (fmt == 1 && amax != nullptr) ? f16_scale_of(*amax) : 1.f;
     const int K8 = K / 8;
     const long long total = rows * K8;
     for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
@@ -516,14 +574,8 @@ __global__ __launch_bounds__(256) void p16_pack_kernel(const float* __restrict__
         const int kg = (int)(idx - row * K8);
         const float4 u = *reinterpret_cast<const float4*>(x + row * ldx + 8 * kg);
         const float4 v = *reinterpret_cast<const float4*>(x + row * ldx + 8 * kg + 4);
-        unsigned h[4], l[4];
-        f16_split2(u.x * scale, u.y * scale, h[0], l[0]);
-        f16_split2(u.z * scale, u.w * scale, h[1], l[1]);
-        f16_split2(v.x * scale, v.y * scale, h[2], l[2]);
-        f16_split2(v.z * scale, v.w * scale, h[3], l[3]);
-        uint4* dst = out + row * (K / 4) + (kg >> 2) * 8 + (kg & 3);
-        dst[0] = make_uint4(h[0], h[1], h[2], h[3]);
-        dst[4] = make_uint4(l[0], l[1], l[2], l[3]);
+        const float x8[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
+        pack8_store(out, row, K, kg, x8, scale, fmt);
     }
 }
 
@@ -582,12 +634,12 @@ __global__ __launch_bounds__(256) void p16_pack_wt_kernel(const float* __restric
 // the tensor's largest magnitude.  transposed == 0: dst = P16 [N][K = T*C] (the forward operand, filters as stored);
 // transposed != 0: dst = P16 [C][K = T*N] with the taps reversed for T > 1 (the data-gradient operand).
 __global__ __launch_bounds__(256) void p16_pack_multi_kernel(const long long* __restrict__ table, const float* __restrict__ amax,
-                                                             int transposed) {
+                                                             int transposed, int fmt) {
     const long long* e = table + 6 * (long long)blockIdx.y;
     const float* __restrict__ w = reinterpret_cast<const float*>(e[0]);
     uint4* __restrict__ out = reinterpret_cast<uint4*>(e[1]);
     const int N = (int)e[2], T = (int)e[3], C = (int)e[4];
-    const float scale = f16_scale_of(amax[e[5]]);
+    const float scale = fmt == 1 ? f16_scale_of(amax[e[5]]) : 1.f;
     if (!transposed) {
         const int K = T * C, K8 = K / 8;
         const long long total = (long long)N * K8;
@@ -596,14 +648,8 @@ __global__ __launch_bounds__(256) void p16_pack_multi_kernel(const long long* __
             const int kg = (int)(idx - row * K8);
             const float4 u = *reinterpret_cast<const float4*>(w + row * K + 8 * kg);
             const float4 v = *reinterpret_cast<const float4*>(w + row * K + 8 * kg + 4);
-            unsigned h[4], l[4];
-            f16_split2(u.x * scale, u.y * scale, h[0], l[0]);
-            f16_split2(u.z * scale, u.w * scale, h[1], l[1]);
-            f16_split2(v.x * scale, v.y * scale, h[2], l[2]);
-            f16_split2(v.z * scale, v.w * scale, h[3], l[3]);
-            uint4* dst = out + row * (K / 4) + (kg >> 2) * 8 + (kg & 3);
-            dst[0] = make_uint4(h[0], h[1], h[2], h[3]);
-            dst[4] = make_uint4(l[0], l[1], l[2], l[3]);
+            const float x8[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
+            pack8_store(out, row, K, kg, x8, scale, fmt);
         }
     } else {
         const int K = T * N, K8 = K / 8;
@@ -616,18 +662,13 @@ __global__ __launch_bounds__(256) void p16_pack_multi_kernel(const long long* __
             const int t = T - 1 - tp;
             float v[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = w[((long long)(n0 + i) * T + t) * C + c] * scale;
-            unsigned h[4], l[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) f16_split2(v[2 * q], v[2 * q + 1], h[q], l[q]);
-            uint4* dst = out + (long long)c * (K / 4) + (kg >> 2) * 8 + (kg & 3);
-            dst[0] = make_uint4(h[0], h[1], h[2], h[3]);
-            dst[4] = make_uint4(l[0], l[1], l[2], l[3]);
+            for (int i = 0; i < 8; ++i) v[i] = w[((long long)(n0 + i) * T + t) * C + c];
+            pack8_store(out, c, K, kg, v, scale, fmt);
         }
     }
 }
 
-template <int AMODE, int BM, int BN, int WM, int WN, int STAGES>
+template <int AMODE, int BM, int BN, int WM, int WN, int STAGES, int PL = 2>
 static int launch_p16(GemmParams& p, hipStream_t stream) {
     p.mblocks = (p.M + BM - 1) / BM;
     p.nblocks = (p.N + BN - 1) / BN;
@@ -637,19 +678,23 @@ static int launch_p16(GemmParams& p, hipStream_t stream) {
     static hipError_t attr_err = hipSuccess;
     std::call_once(once, [] {
         if (lds > 48 * 1024)
-            attr_err = hipFuncSetAttribute((const void*)gemm_p16_kernel<AMODE, BM, BN, WM, WN, STAGES>,
+            attr_err = hipFuncSetAttribute((const void*)gemm_p16_kernel<AMODE, BM, BN, WM, WN, STAGES, PL>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     });
     if (attr_err != hipSuccess) {
         set_error("trid_gemm_p16: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(attr_err));
         return (int)attr_err;
     }
-    hipLaunchKernelGGL((gemm_p16_kernel<AMODE, BM, BN, WM, WN, STAGES>), grid, dim3(WM * WN * 64), lds, stream, p);
+    hipLaunchKernelGGL((gemm_p16_kernel<AMODE, BM, BN, WM, WN, STAGES, PL>), grid, dim3(WM * WN * 64), lds, stream, p);
     return check_launch("trid_gemm_p16");
 }
 
 template <int AMODE>
-static int pick_p16(GemmParams& p, int variant, hipStream_t stream) {
+static int pick_p16(GemmParams& p, int variant, int planes, hipStream_t stream) {
+    if (planes == 1) {  // bf16 operands: the residual blocks only (N >= 64)
+        if (p.N <= 64) return launch_p16<AMODE, 128, 64, 2, 2, 3, 1>(p, stream);
+        return launch_p16<AMODE, 128, 128, 2, 4, 2, 1>(p, stream);
+    }
     if (p.N <= 32) return launch_p16<AMODE, 256, 32, 4, 1, 3>(p, stream);
     if (p.N <= 64) return launch_p16<AMODE, 128, 64, 2, 2, 3>(p, stream);
     switch (variant) {
@@ -666,12 +711,12 @@ static int pick_p16(GemmParams& p, int variant, hipStream_t stream) {
 
 using namespace trid;
 
-extern "C" int trid_p16_pack_f32(const float* x, long long rows, int K, long long ldx, const float* amax, void* out,
+extern "C" int trid_p16_pack_f32(const float* x, long long rows, int K, long long ldx, const float* amax, void* out, int fmt,
                                  void* stream) {
-    TRID_REQUIRE(x && out && rows > 0 && K > 0 && K % 32 == 0 && ldx % 4 == 0 && aligned16(x) && aligned16(out),
-                 "trid_p16_pack_f32: needs K %% 32 == 0 and 16-byte aligned rows (K=%d)", K);
+    TRID_REQUIRE(x && out && rows > 0 && K > 0 && K % 32 == 0 && ldx % 4 == 0 && aligned16(x) && aligned16(out) && (fmt == 1 || fmt == 2),
+                 "trid_p16_pack_f32: needs K %% 32 == 0, 16-byte aligned rows and fmt 1 / 2 (K=%d)", K);
     hipLaunchKernelGGL(p16_pack_kernel, dim3(grid_for(rows * (K / 8), 256, 8192)), dim3(256), 0, (hipStream_t)stream, x, rows, K,
-                       ldx, amax, (uint4*)out);
+                       ldx, amax, (uint4*)out, fmt);
     return check_launch("trid_p16_pack_f32");
 }
 
@@ -690,24 +735,24 @@ extern "C" int trid_p16_pack_wt_f32(const float* w, int N, int T, int C, int fli
     return check_launch("trid_p16_pack_wt_f32");
 }
 
-template <int BMODE, int BM>
+template <int BMODE, int BM, int PL>
 static int launch_p16_wgrad(GemmParams& p, hipStream_t stream) {
     constexpr int STAGES = 2;
     p.mblocks = (p.M + BM - 1) / BM;
     p.nblocks = (p.N + 127) / 128;
     dim3 grid((unsigned)(p.mblocks * p.nblocks), 1, (unsigned)p.splits);
-    constexpr size_t lds = (size_t)STAGES * ((BM / 32) + 4) * 4096;
+    constexpr size_t lds = (size_t)STAGES * ((BM / 32) + 4) * 4096;  // (same bytes for both operand formats)
     static std::once_flag once;
     static hipError_t attr_err = hipSuccess;
     std::call_once(once, [] {
         if (lds > 48 * 1024)
-            attr_err = hipFuncSetAttribute((const void*)gemm_p16_wgrad_kernel<BMODE, BM, STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_err = hipFuncSetAttribute((const void*)gemm_p16_wgrad_kernel<BMODE, BM, STAGES, PL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     });
     if (attr_err != hipSuccess) {
         set_error("trid_gemm_p16_wgrad: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(attr_err));
         return (int)attr_err;
     }
-    hipLaunchKernelGGL((gemm_p16_wgrad_kernel<BMODE, BM, STAGES>), grid, dim3(512), lds, stream, p);
+    hipLaunchKernelGGL((gemm_p16_wgrad_kernel<BMODE, BM, STAGES, PL>), grid, dim3(512), lds, stream, p);
     return check_launch("trid_gemm_p16_wgrad");
 }
 
@@ -715,8 +760,10 @@ extern "C" int trid_gemm_p16_wgrad(const trid_gemm_desc* d, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     TRID_REQUIRE(d != nullptr && d->A && d->B && d->C, "trid_gemm_p16_wgrad: null operand");
     TRID_REQUIRE(d->a_mode == A_MC && (d->b_mode == B_NC || d->b_mode == B_CONV), "trid_gemm_p16_wgrad: loader modes A_MC x B_NC / B_CONV only");
-    TRID_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0 && d->M % 32 == 0 && d->N % 32 == 0 && d->lda % 32 == 0,
-                 "trid_gemm_p16_wgrad: M, N and the row pitches must be multiples of 32 (M=%d N=%d)", d->M, d->N);
+    const int planes = d->precision == 1 ? 1 : 2;  // precision 1: plain bf16 operands; else P16
+    const int gc = planes == 1 ? 64 : 32;
+    TRID_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0 && d->M % gc == 0 && d->N % gc == 0 && d->lda % gc == 0,
+                 "trid_gemm_p16_wgrad: M, N and the row pitches must be multiples of %d (M=%d N=%d)", gc, d->M, d->N);
     TRID_REQUIRE(d->batch == 1 && d->splits >= 1 && !d->accumulate && !d->bias && !d->residual && !d->relu && !d->stats,
                  "trid_gemm_p16_wgrad: plain or split-K output only");
     TRID_REQUIRE(aligned16(d->A) && aligned16(d->B) && aligned16(d->C), "trid_gemm_p16_wgrad: operands must be 16-byte aligned");
@@ -730,8 +777,8 @@ extern "C" int trid_gemm_p16_wgrad(const trid_gemm_desc* d, void* stream_) {
     p.H = d->H; p.W = d->W; p.Cin = d->Cin;
     p.a_amax = d->a_amax; p.b_amax = d->b_amax;
     if (d->b_mode == B_CONV) {
-        TRID_REQUIRE(d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cin % 32 == 0 && d->N == 9 * d->Cin && d->K % (d->H * d->W) == 0,
-                     "trid_gemm_p16_wgrad: B_CONV needs Cin %% 32 == 0, N == 9*Cin, K a multiple of H*W");
+        TRID_REQUIRE(d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cin % gc == 0 && d->N == 9 * d->Cin && d->K % (d->H * d->W) == 0,
+                     "trid_gemm_p16_wgrad: B_CONV needs Cin %% %d == 0, N == 9*Cin, K a multiple of H*W", gc);
         p.fdW = make_fastdiv((uint32_t)d->W);
         p.fdH = make_fastdiv((uint32_t)d->H);
         TRID_REQUIRE((long long)(d->K + 2 * d->W + 2) * d->Cin * 4 < (1ll << 31), "trid_gemm_p16_wgrad: operands must stay below 2 GB");
@@ -739,28 +786,36 @@ extern "C" int trid_gemm_p16_wgrad(const trid_gemm_desc* d, void* stream_) {
         TRID_REQUIRE(d->ldb % 32 == 0 && (long long)d->K * d->ldb * 4 < (1ll << 31), "trid_gemm_p16_wgrad: ldb %% 32 and B below 2 GB");
     }
     TRID_REQUIRE((long long)d->K * d->lda * 4 < (1ll << 31), "trid_gemm_p16_wgrad: operands must stay below 2 GB");
+    const int pbk = planes == 1 ? 64 : 32;
     int kc = (d->K + d->splits - 1) / d->splits;
-    kc = (kc + P16_BK - 1) / P16_BK * P16_BK;
+    kc = (kc + pbk - 1) / pbk * pbk;
     p.k_chunk = kc;
     p.sSplit = d->strideSplit;
-    if (d->b_mode == B_CONV) return d->M <= 64 ? launch_p16_wgrad<B_CONV, 64>(p, stream) : launch_p16_wgrad<B_CONV, 128>(p, stream);
-    return d->M <= 64 ? launch_p16_wgrad<B_NC, 64>(p, stream) : launch_p16_wgrad<B_NC, 128>(p, stream);
+    if (planes == 1) {
+        if (d->b_mode == B_CONV) return d->M <= 64 ? launch_p16_wgrad<B_CONV, 64, 1>(p, stream) : launch_p16_wgrad<B_CONV, 128, 1>(p, stream);
+        return d->M <= 64 ? launch_p16_wgrad<B_NC, 64, 1>(p, stream) : launch_p16_wgrad<B_NC, 128, 1>(p, stream);
+    }
+    if (d->b_mode == B_CONV) return d->M <= 64 ? launch_p16_wgrad<B_CONV, 64, 2>(p, stream) : launch_p16_wgrad<B_CONV, 128, 2>(p, stream);
+    return d->M <= 64 ? launch_p16_wgrad<B_NC, 64, 2>(p, stream) : launch_p16_wgrad<B_NC, 128, 2>(p, stream);
 }
 
-extern "C" int trid_p16_pack_multi_f32(const long long* table, const float* amax, int n_tensors, int transposed, void* stream) {
-    TRID_REQUIRE(table && amax && n_tensors > 0, "trid_p16_pack_multi_f32: bad arguments");
-    hipLaunchKernelGGL(p16_pack_multi_kernel, dim3(64, (unsigned)n_tensors), dim3(256), 0, (hipStream_t)stream, table, amax, transposed);
+extern "C" int trid_p16_pack_multi_f32(const long long* table, const float* amax, int n_tensors, int transposed, int fmt, void* stream) {
+    TRID_REQUIRE(table && (amax || fmt == 2) && n_tensors > 0 && (fmt == 1 || fmt == 2), "trid_p16_pack_multi_f32: bad arguments");
+    hipLaunchKernelGGL(p16_pack_multi_kernel, dim3(64, (unsigned)n_tensors), dim3(256), 0, (hipStream_t)stream, table, amax, transposed, fmt);
     return check_launch("trid_p16_pack_multi_f32");
 }
 
 extern "C" int trid_gemm_p16(const trid_gemm_desc* d, int variant, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     TRID_REQUIRE(d != nullptr && d->A && d->B && d->C, "trid_gemm_p16: null operand");
-    TRID_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0 && d->K % 32 == 0, "trid_gemm_p16: K must be a positive multiple of 32 (K=%d)", d->K);
+    const int planes = d->precision == 1 ? 1 : 2;  // precision 1: plain bf16 operands (64-wide K tiles); else P16
+    const int bke = planes == 1 ? 64 : 32;
+    TRID_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0 && d->K % bke == 0, "trid_gemm_p16: K must be a positive multiple of %d (K=%d)", bke, d->K);
     TRID_REQUIRE((d->a_mode == A_KC || d->a_mode == A_CONV) && d->b_mode == B_KC, "trid_gemm_p16: loader modes A_KC / A_CONV x B_KC only");
     TRID_REQUIRE(aligned16(d->A) && aligned16(d->B) && aligned16(d->C), "trid_gemm_p16: operands must be 16-byte aligned");
     TRID_REQUIRE(d->batch >= 1 && d->splits >= 1, "trid_gemm_p16: batch/splits must be >= 1");
     TRID_REQUIRE(d->lda % 32 == 0 && d->ldb % 32 == 0, "trid_gemm_p16: row pitches must be multiples of 32 elements");
+    TRID_REQUIRE(planes == 2 || d->N >= 64, "trid_gemm_p16: bf16 operands need N >= 64");
     GemmParams p;
     memset(&p, 0, sizeof(p));
     p.A = d->A; p.B = d->B; p.C = d->C;
@@ -775,8 +830,8 @@ extern "C" int trid_gemm_p16(const trid_gemm_desc* d, int variant, void* stream_
     p.a_amax = d->a_amax; p.b_amax = d->b_amax;
     p.stats_w = d->stats_minmax ? 4 : 2;
     if (d->a_mode == A_CONV) {
-        TRID_REQUIRE(d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cin % 32 == 0 && d->K == 9 * d->Cin && d->M % (d->H * d->W) == 0 && d->splits == 1,
-                     "trid_gemm_p16: A_CONV needs Cin %% 32 == 0, K == 9*Cin, M a multiple of H*W, splits == 1");
+        TRID_REQUIRE(d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cin % bke == 0 && d->K == 9 * d->Cin && d->M % (d->H * d->W) == 0 && d->splits == 1,
+                     "trid_gemm_p16: A_CONV needs Cin %% %d == 0, K == 9*Cin, M a multiple of H*W, splits == 1", bke);
         p.fdW = make_fastdiv((uint32_t)d->W);
         p.fdH = make_fastdiv((uint32_t)d->H);
     }
@@ -785,9 +840,9 @@ extern "C" int trid_gemm_p16(const trid_gemm_desc* d, int variant, void* stream_
     const long long a_bytes = (d->a_mode == A_CONV ? (long long)(d->M + 2 * d->W + 2) * d->Cin : (long long)d->M * d->lda) * 4;
     TRID_REQUIRE(a_bytes < (1ll << 31) && (long long)d->N * d->ldb * 4 < (1ll << 31), "trid_gemm_p16: operands must stay below 2 GB (31-bit buffer offsets)");
     int kc = (d->K + d->splits - 1) / d->splits;
-    kc = (kc + P16_BK - 1) / P16_BK * P16_BK;
+    kc = (kc + bke - 1) / bke * bke;
     p.k_chunk = kc;
     p.sSplit = d->strideSplit;
-    if (d->a_mode == A_CONV) return pick_p16<A_CONV>(p, variant, stream);
-    return pick_p16<A_KC>(p, variant, stream);
+    if (d->a_mode == A_CONV) return pick_p16<A_CONV>(p, variant, planes, stream);
+    return pick_p16<A_KC>(p, variant, planes, stream);
 }

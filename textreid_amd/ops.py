@@ -184,16 +184,20 @@ class P16:
     then 32 fp16 low parts of x * 2^s (4 bytes per element, same shape / dtype as the fp32 tensor it replaces so it
     travels through the allocator unchanged); `amax` is the device scalar the scale s was derived from."""
 
-    __slots__ = ("data", "amax")
+    __slots__ = ("data", "amax", "fmt")
 
-    def __init__(self, data, amax):
-        self.data, self.amax = data, amax
+    def __init__(self, data, amax, fmt=1):
+        """fmt 1: P16 proper (fp32-class).  fmt 2: a plain bf16 tensor (configs[3]'s arithmetic: the residual blocks'
+        convolutions read bf16 operands) - same producers / consumers, no scale, half the bytes."""
+        self.data, self.amax, self.fmt = data, amax, fmt
 
     @property
     def shape(self):
         return self.data.shape
 
     def unpack(self):
+        if self.fmt == 2:
+            return self.data.float()  # (taps / masks of the parity tests)
         K = self.data.shape[-1]
         out = torch.empty_like(self.data)
         call("trid_p16_unpack_f32", _p(self.data), self.data.numel() // K, K, _p(self.amax), _p(out), stream())
@@ -203,14 +207,18 @@ class P16:
 P16_VARIANT = int(__import__("os").environ.get("TRID_P16_VARIANT", "3"))  # tile shape of trid_gemm_p16 (experiments)
 
 
-def p16_pack(x, amax_=None):
-    """fp32 [..., K] (K % 32 == 0, rows contiguous) -> P16 with the same shape."""
+def p16_empty(shape, like, fmt):
+    return torch.empty(shape, dtype=torch.float32 if fmt == 1 else torch.bfloat16, device=like.device)
+
+
+def p16_pack(x, amax_=None, fmt=1):
+    """fp32 [..., K] (K % 32 == 0, rows contiguous) -> P16 (fmt 1) / bf16 (fmt 2) with the same shape."""
     K = x.shape[-1]
-    if amax_ is None:
+    if amax_ is None and fmt == 1:
         amax_ = amax(x)
-    out = torch.empty_like(x)
-    call("trid_p16_pack_f32", _p(x), x.numel() // K, K, K, _p(amax_), _p(out), stream())
-    return P16(out, amax_)
+    out = p16_empty(x.shape, x, fmt)
+    call("trid_p16_pack_f32", _p(x), x.numel() // K, K, K, _p(amax_) if fmt == 1 else None, _p(out), fmt, stream())
+    return P16(out, amax_ if fmt == 1 else None, fmt)
 
 
 def p16_pack_wt(w, N, T, C, flip, amax_):
@@ -237,7 +245,8 @@ def gemm_p16(A, B, C, M, N, K, ldc, conv=None, alpha=1.0, accumulate=False, bias
     d.stats = _p(stats)
     if conv is not None:
         d.H, d.W, d.Cin = conv
-    d.precision = 16
+    assert A.fmt == B.fmt
+    d.precision = 16 if A.fmt == 1 else 1
     d.a_amax, d.b_amax = _p(A.amax), _p(B.amax)
     d.residual = _p(residual)
     d.ldres = ldres
@@ -266,11 +275,12 @@ def conv_p16(x, w, conv3=False, stats=True):
     M = x.data.numel() // C
     N = w.shape[0]
     y = empty(tuple(x.shape[:-1]) + (N,), x.data)
-    st = empty(((M + STATS_ROWS - 1) // STATS_ROWS, N, 4), x.data) if stats else None
+    mm = stats and x.fmt == 1  # bf16 operands need no scale, hence no extremes
+    st = empty(((M + STATS_ROWS - 1) // STATS_ROWS, N, 4 if mm else 2), x.data) if stats else None
     if conv3:
-        gemm_p16(x, w, y, M, N, 9 * C, N, conv=(x.shape[1], x.shape[2], C), stats=st, minmax=stats)
+        gemm_p16(x, w, y, M, N, 9 * C, N, conv=(x.shape[1], x.shape[2], C), stats=st, minmax=mm)
     else:
-        gemm_p16(x, w, y, M, N, C, N, stats=st, minmax=stats)
+        gemm_p16(x, w, y, M, N, C, N, stats=st, minmax=mm)
     return (y, st) if stats else y
 
 
@@ -286,50 +296,56 @@ def bn_finalize_minmax(partials, M, gamma, beta, running_mean, running_var, relu
     return st
 
 
-def bn_apply_p16(y, st, bound, relu=True, res=None, res_st=None, bound_res=None, want_mask=False):
+def bn_apply_p16(y, st, bound, relu=True, res=None, res_st=None, bound_res=None, want_mask=False, fmt=1):
     """act(bn(y) (+ res | bn(res))) written as a P16 tensor.  bound: device scalar >= max|bn(y)| (bn_finalize_minmax);
     with a residual, bound_res bounds the residual term and the output's amax scalar is their sum.  res: fp32 raw
     conv output (with res_st) or a P16 tensor (identity)."""
     C = y.shape[-1]
     M = y.numel() // C
-    out = torch.empty_like(y)
+    out = p16_empty(y.shape, y, fmt)
     mask = torch.empty(((M * C // 4 + 63) // 64) * 4, dtype=torch.int64, device=y.device) if want_mask else None
     res_p16 = isinstance(res, P16)
-    osum = amax_slot(y.device) if res is not None else None
+    osum = amax_slot(y.device) if (res is not None and fmt == 1) else None
     call("trid_bn_apply_p16_f32", _p(y), _p(st.scale), _p(st.shift), _p(res.data if res_p16 else res),
-         _p(res_st.scale) if res_st else None, _p(res_st.shift) if res_st else None, _p(res.amax) if res_p16 else None,
-         _p(out), M, C, 1 if relu else 0, _p(mask), _p(bound), _p(bound_res), _p(osum), stream())
-    o = P16(out, osum if res is not None else bound)
+         _p(res_st.scale) if res_st else None, _p(res_st.shift) if res_st else None, res.fmt if res_p16 else 0,
+         _p(res.amax) if res_p16 else None, _p(out), fmt, M, C, 1 if relu else 0, _p(mask), _p(bound), _p(bound_res), _p(osum),
+         stream())
+    o = P16(out, (osum if res is not None else bound) if fmt == 1 else None, fmt)
     return (o, mask) if want_mask else o
 
 
-def bn_apply_pool2_p16(y, st, bound, relu=True):
+def bn_apply_pool2_p16(y, st, bound, relu=True, fmt=1):
     """avgpool2(act(bn(y))) -> P16; y: raw conv output fp32 (st given) or a P16 tensor (st None: plain pooling, the
     output keeps the input's scale)."""
     src = y.data if isinstance(y, P16) else y
     Bi, H, W, C = src.shape
-    out = empty((Bi, H // 2, W // 2, C), src)
+    out = p16_empty((Bi, H // 2, W // 2, C), src, fmt)
     call("trid_bn_apply_pool2_p16_f32", _p(src), _p(st.scale) if st else None, _p(st.shift) if st else None,
-         _p(y.amax) if isinstance(y, P16) else None, _p(out), Bi, H, W, C, 1 if (relu and st is not None) else 0,
-         _p(bound), stream())
-    return P16(out, bound)
+         y.fmt if isinstance(y, P16) else 0, _p(y.amax) if isinstance(y, P16) else None, _p(out), fmt, Bi, H, W, C,
+         1 if (relu and st is not None) else 0, _p(bound), stream())
+    return P16(out, bound if fmt == 1 else None, fmt)
 
 
-def bn_bwd_p16(g, y, st, mask_mode, act=None, pooled=False, want_dres=False):
+def bn_bwd_p16(g, y, st, mask_mode, act=None, pooled=False, want_dres=False, fmt=1):
     """BatchNorm backward with dy written as a P16 tensor: the reduce pass also bounds max|dy| (triangle inequality
     over per-channel maxima), the apply pass scales by that bound.  Returns (dy P16, dgamma, dbeta, dres)."""
     Bi, H, W, C = y.shape
     dg = empty((2, C), y)
     dgamma, dbeta = dg[0], dg[1]
     ws = _bn_ws(C, y)
-    bound = amax_slot(y.device)
-    call("trid_bn_bwd_reduce_bound_f32", _p(g), _p(y), _p(act), _p(st.mean), _p(st.invstd), _p(st.scale), _p(st.shift),
-         mask_mode, 1 if pooled else 0, Bi, H, W, C, _p(dgamma), _p(dbeta), _p(ws), _p(bound), stream())
-    dy = torch.empty_like(y)
+    bound = None
+    if fmt == 1:
+        bound = amax_slot(y.device)
+        call("trid_bn_bwd_reduce_bound_f32", _p(g), _p(y), _p(act), _p(st.mean), _p(st.invstd), _p(st.scale), _p(st.shift),
+             mask_mode, 1 if pooled else 0, Bi, H, W, C, _p(dgamma), _p(dbeta), _p(ws), _p(bound), stream())
+    else:
+        call("trid_bn_bwd_reduce_f32", _p(g), _p(y), _p(act), _p(st.mean), _p(st.invstd), _p(st.scale), _p(st.shift),
+             mask_mode, 1 if pooled else 0, Bi, H, W, C, _p(dgamma), _p(dbeta), _p(ws), stream())
+    dy = p16_empty(y.shape, y, fmt)
     dres = torch.empty_like(y) if want_dres else None
     call("trid_bn_bwd_apply_p16_f32", _p(g), _p(y), _p(act), _p(st.mean), _p(st.invstd), _p(st.scale), _p(st.shift),
-         _p(dgamma), _p(dbeta), mask_mode, 1 if pooled else 0, Bi, H, W, C, _p(dy), _p(dres), _p(bound), stream())
-    return P16(dy, bound), dgamma, dbeta, dres
+         _p(dgamma), _p(dbeta), mask_mode, 1 if pooled else 0, Bi, H, W, C, _p(dy), fmt, _p(dres), _p(bound), stream())
+    return P16(dy, bound, fmt), dgamma, dbeta, dres
 
 
 def wgrad_p16(dy, x, conv=None, alpha=1.0):
@@ -351,7 +367,7 @@ def wgrad_p16(dy, x, conv=None, alpha=1.0):
     d.alpha = alpha
     if conv is not None:
         d.H, d.W, d.Cin = conv
-    d.precision = 16
+    d.precision = 16 if dy.fmt == 1 else 1
     d.a_amax, d.b_amax = _p(dy.amax), _p(x.amax)
     if splits == 1:
         d.C = _p(out)
