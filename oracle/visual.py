@@ -19,8 +19,9 @@ BN_MOMENTUM = 0.1
 # configs[3]'s "bf16" (BASELINE.json; the reference itself has no reduced-precision path: its DTYPE key is unread,
 # lib/config/defaults.py:142-144): every convolution of the image encoder's 16 / 33 RESIDUAL BLOCKS (97 % of its
 # FLOPs) takes its operands in bf16 - activations, filters and, in backward, the incoming gradient are rounded to bf16
-# (round-to-nearest-even) where the convolution reads them; products are exact, accumulation / BatchNorm / the 3-conv
-# stem / the attention pool / everything else stays fp32.  `with bf16_conv():` switches
+# (round-to-nearest-even) where the convolution reads them - and every block OUTPUT is a bf16 tensor (so the identity
+# residual of the next block reads the rounded value too); products are exact, accumulation / BatchNorm / gradients
+# w.r.t. block outputs / the 3-conv stem / the attention pool's own arithmetic / everything else stays fp32.  `with bf16_conv():` switches
 # the oracle to that arithmetic: the comparator of the HIP path's TRID_CONV_PRECISION=1 mode.
 BF16_CONV = False
 
@@ -197,7 +198,10 @@ def bottleneck(st, p, x, stride, has_down, training, taps=None):
         if stride > 1:
             idn = F.avg_pool2d(idn, stride)
         idn = _bn(st, p + ".downsample.1", _conv(idn, st[p + ".downsample.0.weight"]), training)
-    return _relu(out + idn, taps)
+    out = _relu(out + idn, taps)
+    # bf16 mode: a block's OUTPUT tensor is a bf16 tensor (it is the next block's conv operand AND its identity
+    # residual, the input of the downsample pooling, and - after the last block - of the attention pool)
+    return _RoundOperand.apply(out) if BF16_CONV else out
 
 
 def attention_pool(st, x, heads):
