@@ -132,6 +132,52 @@ def queue_similarity_bench(device, B=128, C=256, K=8192, reps=20):
             "note": "fused single pass over both queues (queue_nce.hip): ONE kernel for the batch-wide negative filter (hashed id set in LDS) + similarity + masked softmax + dL/dq of both modalities (no [B,K] matrix), partial fold, loss sum; fp32-class arithmetic = 6 fp16 MFMA products per (query, row, channel) (two-plane split, fixed scales), so the block is MFMA-issue-bound at B=128: HBM time of the algorithmic bytes at 8 TB/s would be %.1f us" % (nbytes / 8e12 * 1e6)}
 
 
+def configs3_bench(device, B=128, K=65536, steps=6, warmup=3):
+    """configs[3]'s per-GPU workload on this one GPU (CLIP-RN101 + BiGRU, B=128, MoCo queue 65536): the same train step
+    in the fp32-class default and with bf16 convolution operands (the residual blocks' activations, filters and
+    incoming gradients live in HBM as bf16 tensors, TRID_CONV_PRECISION=1; parity: tests/test_model_gpu.py::
+    test_config3_rn101_k65536_bf16 against the bf16-emulating oracle)."""
+    from textreid_amd import ops
+    from textreid_amd.caption import CaptionBatch
+    from textreid_amd.config import moco_cfg
+    from textreid_amd.model import build_model
+    from textreid_amd.solver import make_optimizer
+
+    torch.manual_seed(0)
+    cfg = moco_cfg("m_resnet101", K=K)
+    model = build_model(cfg, vocab_dict=torch.randn(49408, 512) * 0.02).to(device).train()
+    opt = make_optimizer(cfg, model)
+    batches = [synth_batch(B, s, device, 4321) for s in range(2)]
+    out = {"workload": "configs[3] per-GPU share: CLIP-RN101 + GRU, bs%d, MoCo queue %d, 1xMI355X, eager launches" % (B, K)}
+    old = ops.CONV_PRECISION
+
+    def step(i):
+        images, tokens, lengths, ids = batches[i % 2]
+        ld = model(images, CaptionBatch(tokens, lengths, (ids + i * (B // 4)) % 11003, max_len=64))
+        opt.zero_grad()
+        sum(ld.values()).backward()
+        opt.step()
+
+    try:
+        for name, prec in (("fp32_class", 16), ("bf16_conv_operands", 1)):
+            ops.CONV_PRECISION = prec
+            for i in range(warmup):
+                step(i)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(steps):
+                step(warmup + i)
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / steps * 1e3
+            out[name] = {"ms_per_step": ms, "pairs_per_s": B / ms * 1e3}
+    finally:
+        ops.CONV_PRECISION = old
+    out["bf16_speedup"] = out["fp32_class"]["ms_per_step"] / out["bf16_conv_operands"]["ms_per_step"]
+    del model, opt
+    torch.cuda.empty_cache()
+    return out
+
+
 def encode_bench(model, images, tokens, lengths, reps=5):
     """Eval-mode encode rates (test_net.py path: running-stat BatchNorm, no key encoders): gallery images/s
     and query captions/s of ONE GPU at the training batch size."""
@@ -235,6 +281,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--retrieval", action="store_true", help="(default on; kept for compatibility)")
     ap.add_argument("--no-retrieval", action="store_true", help="skip the configs[4] retrieval timing ('retrieval' object)")
+    ap.add_argument("--no-configs3", action="store_true", help="skip the secondary configs[3]-shape timing ('configs3_1gpu' object)")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -495,6 +542,12 @@ def main():
         retr.update(encode_bench(model, batches[0][0], batches[0][1], batches[0][2]))
         log("retrieval: %.1f M gallery imgs/s" % (retr["value"] / 1e6))
     qsim = [queue_similarity_bench(device, B=B, K=k) for k in sorted({args.queue, 65536})]
+    c3 = None
+    if world == 1 and not args.no_configs3 and ops.conv_precision() == 16 and args.model == "m_resnet50":
+        del model, opt, runner
+        torch.cuda.empty_cache()
+        c3 = configs3_bench(device)
+        log("configs[3] shape on one GPU: %.1f ms fp32-class, %.1f ms bf16 conv operands" % (c3["fp32_class"]["ms_per_step"], c3["bf16_conv_operands"]["ms_per_step"]))
     if rank == 0:
         out = {
             "metric": "image-text pairs/sec (train), CLIP-RN50 + BiGRU MoCo step, bs128/GPU",
@@ -530,6 +583,7 @@ def main():
                                         embedding_allgather_bytes_per_rank=B * (4 * 256 + 2) * 4)
         out["retrieval"] = retr
         out["queue_similarity"] = qsim
+        out["configs3_1gpu"] = c3
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
         else:
