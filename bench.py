@@ -542,6 +542,7 @@ def main():
         retr.update(encode_bench(model, batches[0][0], batches[0][1], batches[0][2]))
         log("retrieval: %.1f M gallery imgs/s" % (retr["value"] / 1e6))
     qsim = [queue_similarity_bench(device, B=B, K=k) for k in sorted({args.queue, 65536})]
+    step_launch = "hipGraph replay (one launch per step)" if runner is not None else "eager (%d rank(s)%s)" % (world, ": RCCL collectives inside backward" if world > 1 else "")
     c3 = None
     if world == 1 and not args.no_configs3 and ops.conv_precision() == 16 and args.model == "m_resnet50":
         del model, opt, runner
@@ -568,7 +569,7 @@ def main():
                 "global_batch": B * world,
                 "parallelism": "dp%d" % world,
                 "optimizer": "Adam (fused multi-tensor)",
-                "step_launch": "hipGraph replay (one launch per step)" if runner is not None else "eager (%d ranks: RCCL collectives inside backward)" % world,
+                "step_launch": step_launch,
                 "host_enqueue_ms_per_step": t_host / args.steps * 1e3,
                 "gemm_arithmetic": arith,
                 "final_loss": loss_val,

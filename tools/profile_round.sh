@@ -5,10 +5,10 @@ TAG=${1:-r02}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-retrieval"
+BENCH="python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-retrieval --no-configs3"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ks -- $BENCH > $OUT/bench_line_profiled.json 2> $OUT/ks.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/qs -- python3 $GRAFT_REPO_ROOT/tools/qsim_prof.py > $OUT/qsim.log 2>&1
-BENCH2="python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-retrieval"
+BENCH2="python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-retrieval --no-configs3"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- $BENCH2 > /dev/null 2> $OUT/fetch.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- $BENCH2 > /dev/null 2> $OUT/write.err
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/mfma -- $BENCH2 > /dev/null 2> $OUT/mfma.err
