@@ -93,38 +93,61 @@ __global__ void stem_im2col_kernel(const float* __restrict__ img, float* __restr
 
 // ---------------------------------------------------------------- BN finalize
 // One workgroup per channel: Chan-merge the per-tile (n, mean, M2) partials in fp64.
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// block-wide fp64 sum over 256 threads (4 waves), result in every thread
+__device__ __forceinline__ double block_sum_f64(double v, double* sh) {
+    v = wave_sum_f64(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
 __global__ void bn_finalize_kernel(const float* __restrict__ partials, int nparts, int rows_per_part, long long M,
                                    int C, const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* __restrict__ running_mean, float* __restrict__ running_var, float momentum,
                                    float eps, float* __restrict__ mean_out, float* __restrict__ invstd_out,
                                    float* __restrict__ scale_out, float* __restrict__ shift_out, int pw, int relu,
                                    float* __restrict__ amax_out) {
-    // pw: floats per (part, channel): 2 = (mean, M2), 4 = (mean, M2, min, max).  With the extremes the largest
-    // magnitude of act(y * scale + shift) over the channel is known exactly before the apply pass (an affine map
-    // takes extremes to extremes): folded over the channels into amax_out (zeroed by the caller; integer atomicMax on
-    // the bit pattern of a non-negative float: order-independent).
+    // One workgroup per channel.  The per-tile (mean_b, M2_b) partials (n_b rows each) combine exactly as
+    //     mean = sum n_b mean_b / N,   M2 = sum M2_b + sum n_b (mean_b - mean)^2        (Chan et al.)
+    // evaluated in fp64 in two sweeps over the (L2-resident, <= 3072) partials: no per-merge division chain, two block
+    // reductions by wave shuffles.  pw: floats per (part, channel): 2 = (mean, M2), 4 = (mean, M2, min, max).  With the
+    // extremes the largest magnitude of act(y * scale + shift) over the channel is known exactly before the apply pass
+    // (an affine map takes extremes to extremes): folded over the channels into amax_out (zeroed by the caller; integer
+    // atomicMax on the bit pattern of a non-negative float: order-independent).
+    __shared__ double sh[4];
+    __shared__ float slo[4], shi[4];
     const int c = blockIdx.x;
     const int tid = threadIdx.x;
-    double n = 0.0, mean = 0.0, m2 = 0.0;
+    double s1 = 0.0;
     float lo = INFINITY, hi = -INFINITY;
     for (int p = tid; p < nparts; p += blockDim.x) {
         const long long rows_left = M - (long long)p * rows_per_part;
         const double nb = (double)(rows_left < rows_per_part ? rows_left : rows_per_part);
-        const double mb = partials[((long long)p * C + c) * pw + 0];
-        const double qb = partials[((long long)p * C + c) * pw + 1];
+        const float* e = partials + ((long long)p * C + c) * pw;
+        s1 += nb * (double)e[0];
         if (pw == 4) {
-            lo = fminf(lo, partials[((long long)p * C + c) * pw + 2]);
-            hi = fmaxf(hi, partials[((long long)p * C + c) * pw + 3]);
+            lo = fminf(lo, e[2]);
+            hi = fmaxf(hi, e[3]);
         }
-        const double nt = n + nb;
-        const double d = mb - mean;
-        mean += d * (nb / nt);
-        m2 += qb + d * d * (n * nb / nt);
-        n = nt;
     }
-    __shared__ double sn[256], sm[256], sq[256];
-    __shared__ float slo[4], shi[4];
-    sn[tid] = n; sm[tid] = mean; sq[tid] = m2;
+    const double nt = (double)M;
+    const double mu = block_sum_f64(s1, sh) / nt;
+    double s2 = 0.0;
+    for (int p = tid; p < nparts; p += blockDim.x) {
+        const long long rows_left = M - (long long)p * rows_per_part;
+        const double nb = (double)(rows_left < rows_per_part ? rows_left : rows_per_part);
+        const float* e = partials + ((long long)p * C + c) * pw;
+        const double d = (double)e[0] - mu;
+        s2 += (double)e[1] + nb * d * d;
+    }
+    const double m2 = block_sum_f64(s2, sh);
     if (pw == 4) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
@@ -132,41 +155,26 @@ __global__ void bn_finalize_kernel(const float* __restrict__ partials, int npart
             hi = fmaxf(hi, __shfl_xor(hi, o, 64));
         }
         if ((tid & 63) == 0) { slo[tid >> 6] = lo; shi[tid >> 6] = hi; }
-    }
-    __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-        if (tid < off) {
-            const double na = sn[tid], nb = sn[tid + off];
-            const double nt = na + nb;
-            if (nt > 0.0) {
-                const double d = sm[tid + off] - sm[tid];
-                sm[tid] += d * (nb / nt);
-                sq[tid] += sq[tid + off] + d * d * (na * nb / nt);
-                sn[tid] = nt;
-            }
-        }
         __syncthreads();
     }
     if (tid == 0) {
-        const double nt = sn[0];
-        const double mu = sm[0];
-        const double var = sq[0] / nt;
+        const double var = m2 / nt;
         const float invstd = (float)(1.0 / sqrt(var + (double)eps));
         const float g = gamma[c], b = beta[c];
         const float sc = g * invstd;
         mean_out[c] = (float)mu;
         invstd_out[c] = invstd;
         scale_out[c] = sc;
-        const float sh = b - (float)mu * sc;
-        shift_out[c] = sh;
+        const float shf = b - (float)mu * sc;
+        shift_out[c] = shf;
         if (pw == 4 && amax_out != nullptr) {
             const float l = fminf(fminf(slo[0], slo[1]), fminf(slo[2], slo[3])), h = fmaxf(fmaxf(shi[0], shi[1]), fmaxf(shi[2], shi[3]));
-            const float zl = fmaf(l, sc, sh), zh = fmaf(h, sc, sh);  // the apply pass's own arithmetic
+            const float zl = fmaf(l, sc, shf), zh = fmaf(h, sc, shf);  // the apply pass's own arithmetic
             const float bound = relu ? fmaxf(fmaxf(zl, zh), 0.f) : fmaxf(fabsf(zl), fabsf(zh));
             atomicMax(reinterpret_cast<unsigned*>(amax_out), __builtin_bit_cast(unsigned, bound));
         }
         if (running_mean != nullptr) {
-            const double unb = nt > 1.0 ? sq[0] / (nt - 1.0) : var;
+            const double unb = nt > 1.0 ? m2 / (nt - 1.0) : var;
             running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
             running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
         }

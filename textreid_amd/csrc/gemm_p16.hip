@@ -121,6 +121,9 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 && STAGES == 2) ? 2 : (W
     const int cgroups = (AMODE == A_CONV) ? p.Cin / BKE : 1;
 
     auto issue = [&](int kt, int stage) {
+#ifdef P16_EXP_NODMA
+        return;
+#endif
         uint4* sA = smem + stage * STAGE_SLOTS;
         uint4* sB = sA + BM * 8;
         unsigned soA, soB;
@@ -187,11 +190,28 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 && STAGES == 2) ? 2 : (W
 #pragma unroll
                 for (int pl = 0; pl < 2; ++pl) {
                     const int s = (4 * pl + 2 * ks + khalf) ^ xs;
+#ifdef P16_EXP_NOLDS
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) a[pl][i] = __builtin_bit_cast(f16x8, uint4{(unsigned)lane, (unsigned)s, (unsigned)i, 1u});
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) b[pl][j] = __builtin_bit_cast(f16x8, uint4{(unsigned)lane, (unsigned)s, (unsigned)j, 2u});
+#else
 #pragma unroll
                     for (int i = 0; i < TM; ++i) a[pl][i] = __builtin_bit_cast(f16x8, sA[(a_row + 32 * i) * 8 + s]);
 #pragma unroll
                     for (int j = 0; j < TN; ++j) b[pl][j] = __builtin_bit_cast(f16x8, sB[(b_row + 32 * j) * 8 + s]);
+#endif
                 }
+#ifdef P16_EXP_NOMFMA
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) asm volatile("" ::"v"(a[pl][i]));
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(b[pl][j]));
+                }
+                continue;
+#endif
                 // small terms first; consecutive MFMAs hit different accumulators
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
@@ -390,10 +410,21 @@ __global__ __launch_bounds__(512, 4) void gemm_p16_wgrad_kernel(GemmParams p) {
     const int wm = wave / WN, wn = wave % WN;
 
     const uint32_t nwg = (uint32_t)p.mblocks * (uint32_t)p.nblocks;
-    const uint32_t lid = xcd_remap(blockIdx.x, nwg);
+    uint32_t lid;
+    int sz;
+    if (p.xcd_split) {
+        // workgroup L runs on XCD L % 8: every XCD takes whole K splits (split s on XCD s % 8), so the tiles of a split -
+        // which all read the same pixel range of dy and (shifted by their taps) of x - fetch it into ONE L2, once
+        const uint32_t slot = blockIdx.x >> 3;
+        sz = (int)((slot / nwg) * 8 + (blockIdx.x & 7));
+        lid = slot % nwg;
+        if (sz >= p.splits) return;
+    } else {
+        lid = xcd_remap(blockIdx.x, nwg);
+        sz = blockIdx.z;
+    }
     const int mb = lid / p.nblocks, nb = lid % p.nblocks;
     const int m0 = mb * BM, n0 = nb * BN;
-    const int sz = blockIdx.z;
     const int k_begin = sz * p.k_chunk;
     const int k_end = min(p.K, k_begin + p.k_chunk);
     const int nk = (k_end - k_begin + PBK - 1) / PBK;
@@ -740,7 +771,10 @@ static int launch_p16_wgrad(GemmParams& p, hipStream_t stream) {
     constexpr int STAGES = 2;
     p.mblocks = (p.M + BM - 1) / BM;
     p.nblocks = (p.N + 127) / 128;
+    static const int xcd_env = getenv("TRID_WGRAD_XCD") ? atoi(getenv("TRID_WGRAD_XCD")) : 1;  // (0: the plain tile-major grid, for A/B runs)
+    p.xcd_split = (xcd_env && p.splits >= 8) ? 1 : 0;
     dim3 grid((unsigned)(p.mblocks * p.nblocks), 1, (unsigned)p.splits);
+    if (p.xcd_split) grid = dim3((unsigned)(p.mblocks * p.nblocks) * 8u * (unsigned)((p.splits + 7) / 8), 1, 1);
     constexpr size_t lds = (size_t)STAGES * ((BM / 32) + 4) * 4096;  // (same bytes for both operand formats)
     static std::once_flag once;
     static hipError_t attr_err = hipSuccess;

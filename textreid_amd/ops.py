@@ -357,7 +357,7 @@ def wgrad_p16(dy, x, conv=None, alpha=1.0):
     J = 9 * C if conv is not None else C
     out = empty((N, J), dy.data)
     tiles = ((N + 127) // 128) * ((J + 127) // 128)
-    splits = _wgrad_splits(tiles, M)
+    splits = _wgrad_splits(tiles, M, slots=768 if N <= 64 else 512)
     d = GemmDesc()
     d.A, d.B = _p(dy.data), _p(x.data)
     d.M, d.N, d.K = N, J, M
@@ -413,13 +413,28 @@ def matmul_nn(a, b, out=None, alpha=1.0, accumulate=False, prec=None, aa=None, b
     return out
 
 
+_WGRAD_SPLITS_OVERRIDE = None  # kernel experiments
+
+
 def _wgrad_splits(tiles, K, slots=512):
-    """Split-K factor for a weight-gradient GEMM: fill the chip with whole waves of workgroups
-    (`slots` = 256 CUs x 2 resident workgroups): the largest split count whose grid is at most
-    two full waves, never leaving a nearly-empty tail wave, with >= 512 reduction rows per split."""
+    """Split-K factor for a weight-gradient GEMM (K = pixels of the batch): ONE full round of resident workgroups
+    (`slots` = 256 CUs x 2) when the tile count allows a >= 90 % full one, else two rounds; >= 512 reduction rows per
+    split.  Counts >= 8 are multiples of 8: the P16 kernels give every XCD whole splits (the tiles of a split then share
+    one L2), which balances only then.  Fewer, longer splits also mean fewer slabs to fold.  (Sweep on the RN50 layer
+    shapes at B=128: tools/exp/wgrad_splits.py, profiles/r03i_wgrad_split_sweep.txt.)"""
+    if _WGRAD_SPLITS_OVERRIDE is not None:
+        return _WGRAD_SPLITS_OVERRIDE
     tiles = max(tiles, 1)
     cap = max(1, K // 512)
-    return max(1, min(cap, (2 * slots) // tiles))
+
+    def fit(n):
+        s = min(cap, n // tiles)
+        return s - s % 8 if s >= 8 else s
+
+    s = fit(slots)
+    if s * tiles < 0.9 * slots:
+        s = max(s, fit(2 * slots))
+    return max(1, s)
 
 
 def matmul_tn(a, b, out=None, alpha=1.0, prec=None, aa=None, ba=None):
