@@ -137,11 +137,15 @@ int trid_stem_im2col_f32(const float* img, float* col, int B, int Cin, int H, in
  * ------------------------------------------------------------------------- */
 /* Merge per-tile (mean,M2) partials (rows_per_part rows each, last one ragged)
  * into batch mean / biased var; write mean, invstd, scale=gamma*invstd,
- * shift=beta-mean*scale; update running stats (unbiased var, momentum). */
+ * shift=beta-mean*scale; update running stats (unbiased var, momentum).
+ * ws: NULL, or trid_bn_finalize_ws_bytes() bytes of device scratch private to the stream: with it the layers with
+ * thousands of partials (>= 1024) run as two launches - range sums per channel octet over many workgroups, then a
+ * merge in range order - instead of one workgroup per channel. */
+long long trid_bn_finalize_ws_bytes(void);
 int trid_bn_finalize_f32(const float* partials, int nparts, int rows_per_part, long long M, int C,
                          const float* gamma, const float* beta, float* running_mean, float* running_var,
                          float momentum, float eps, float* mean, float* invstd, float* scale, float* shift,
-                         void* stream);
+                         void* ws, void* stream);
 /* eval mode: scale/shift from running statistics */
 int trid_bn_eval_coeffs_f32(const float* gamma, const float* beta, const float* running_mean,
                             const float* running_var, float eps, float* scale, float* shift, int C, void* stream);
@@ -165,7 +169,7 @@ int trid_bn_apply_pool2_f32(const float* y, const float* scale, const float* shi
 int trid_bn_finalize_minmax_f32(const float* partials, int nparts, int rows_per_part, long long M, int C,
                                 const float* gamma, const float* beta, float* running_mean, float* running_var,
                                 float momentum, float eps, float* mean, float* invstd, float* scale, float* shift,
-                                int relu, float* amax_out, void* stream);
+                                int relu, float* amax_out, void* ws, void* stream);
 /* Tensor formats of these entry points: 0 = fp32, 1 = P16, 2 = plain bf16 (configs[3]'s arithmetic: the convolutions
  * of the residual blocks read bf16 operands; written here with round-to-nearest-even, no scale, bounds unused). */
 /* trid_bn_apply_f32 with the output in format fmt (1 / 2): P16 scaled for the bound bound_a[0] (+ bound_b[0] if not

@@ -92,93 +92,155 @@ __global__ void stem_im2col_kernel(const float* __restrict__ img, float* __restr
 }
 
 // ---------------------------------------------------------------- BN finalize
-// One workgroup per channel: Chan-merge the per-tile (n, mean, M2) partials in fp64.
-__device__ __forceinline__ double wave_sum_f64(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
+// The per-tile (mean_b, M2_b) partials (n_b rows each) of a channel combine exactly as
+//     mean = sum n_b mean_b / N,      M2 = sum (M2_b + n_b mean_b^2) - N mean^2,
+// evaluated in fp64 in ONE sweep (the subtraction loses log2(N mean^2 / M2) of fp64's 53 bits: nothing next to the
+// fp32 partials).  pw: floats per (part, channel): 2 = (mean, M2), 4 = (mean, M2, min, max).  With the extremes the
+// largest magnitude of act(y * scale + shift) over the channel is known exactly before the apply pass (an affine map
+// takes extremes to extremes): folded over the channels into amax_out (zeroed by the caller; integer atomicMax on the
+// bit pattern of a non-negative float: order-independent).
+//   * up to ~1000 parts: one workgroup per channel (CH = 1), one launch.
+//   * the layers with thousands of parts (stem, layer1: M = 4e5..1.6e6 rows): a workgroup owns a channel OCTET (CH = 8:
+//     with 2 / 4 floats per (part, channel) a contiguous 64 / 128 bytes of every part - whole lines) and one of S ranges
+//     of the parts; the range sums go to `scratch` and a second small launch merges them in range order.  (A single
+//     launch with a last-arriver ticket was measured SLOWER: its device-scope release / acquire fences write back and
+//     invalidate the whole L2 of an XCD under the GEMMs running beside it.)
+struct BnFinalizeOut {
+    const float* gamma;
+    const float* beta;
+    float* running_mean;
+    float* running_var;
+    float momentum, eps;
+    float* mean;
+    float* invstd;
+    float* scale;
+    float* shift;
+    int relu;
+    float* amax_out;  // null: no bound
+};
 
-// block-wide fp64 sum over 256 threads (4 waves), result in every thread
-__device__ __forceinline__ double block_sum_f64(double v, double* sh) {
-    v = wave_sum_f64(v);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
-    __syncthreads();
-    return (sh[0] + sh[1]) + (sh[2] + sh[3]);
-}
-
-__global__ void bn_finalize_kernel(const float* __restrict__ partials, int nparts, int rows_per_part, long long M,
-                                   int C, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                   float* __restrict__ running_mean, float* __restrict__ running_var, float momentum,
-                                   float eps, float* __restrict__ mean_out, float* __restrict__ invstd_out,
-                                   float* __restrict__ scale_out, float* __restrict__ shift_out, int pw, int relu,
-                                   float* __restrict__ amax_out) {
-    // One workgroup per channel.  The per-tile (mean_b, M2_b) partials (n_b rows each) combine exactly as
-    //     mean = sum n_b mean_b / N,   M2 = sum M2_b + sum n_b (mean_b - mean)^2        (Chan et al.)
-    // evaluated in fp64 in two sweeps over the (L2-resident, <= 3072) partials: no per-merge division chain, two block
-    // reductions by wave shuffles.  pw: floats per (part, channel): 2 = (mean, M2), 4 = (mean, M2, min, max).  With the
-    // extremes the largest magnitude of act(y * scale + shift) over the channel is known exactly before the apply pass
-    // (an affine map takes extremes to extremes): folded over the channels into amax_out (zeroed by the caller; integer
-    // atomicMax on the bit pattern of a non-negative float: order-independent).
-    __shared__ double sh[4];
-    __shared__ float slo[4], shi[4];
-    const int c = blockIdx.x;
-    const int tid = threadIdx.x;
-    double s1 = 0.0;
-    float lo = INFINITY, hi = -INFINITY;
-    for (int p = tid; p < nparts; p += blockDim.x) {
-        const long long rows_left = M - (long long)p * rows_per_part;
-        const double nb = (double)(rows_left < rows_per_part ? rows_left : rows_per_part);
-        const float* e = partials + ((long long)p * C + c) * pw;
-        s1 += nb * (double)e[0];
-        if (pw == 4) {
-            lo = fminf(lo, e[2]);
-            hi = fmaxf(hi, e[3]);
-        }
-    }
+__device__ __forceinline__ void bn_finalize_channel(const BnFinalizeOut& f, int c, long long M, double s0, double s1, float lo,
+                                                    float hi) {
     const double nt = (double)M;
-    const double mu = block_sum_f64(s1, sh) / nt;
-    double s2 = 0.0;
-    for (int p = tid; p < nparts; p += blockDim.x) {
-        const long long rows_left = M - (long long)p * rows_per_part;
-        const double nb = (double)(rows_left < rows_per_part ? rows_left : rows_per_part);
-        const float* e = partials + ((long long)p * C + c) * pw;
-        const double d = (double)e[0] - mu;
-        s2 += (double)e[1] + nb * d * d;
+    const double mu = s0 / nt;
+    const double m2 = fmax(s1 - nt * mu * mu, 0.0);
+    const double var = m2 / nt;
+    const float invstd = (float)(1.0 / sqrt(var + (double)f.eps));
+    const float sc = f.gamma[c] * invstd;
+    const float shf = f.beta[c] - (float)mu * sc;
+    f.mean[c] = (float)mu;
+    f.invstd[c] = invstd;
+    f.scale[c] = sc;
+    f.shift[c] = shf;
+    if (f.amax_out != nullptr) {
+        const float zl = fmaf(lo, sc, shf), zh = fmaf(hi, sc, shf);  // the apply pass's own arithmetic
+        const float bound = f.relu ? fmaxf(fmaxf(zl, zh), 0.f) : fmaxf(fabsf(zl), fabsf(zh));
+        atomicMax(reinterpret_cast<unsigned*>(f.amax_out), __builtin_bit_cast(unsigned, bound));
     }
-    const double m2 = block_sum_f64(s2, sh);
-    if (pw == 4) {
+    if (f.running_mean != nullptr) {
+        const double unb = nt > 1.0 ? m2 / (nt - 1.0) : var;
+        f.running_mean[c] = (1.f - f.momentum) * f.running_mean[c] + f.momentum * (float)mu;
+        f.running_var[c] = (1.f - f.momentum) * f.running_var[c] + f.momentum * (float)unb;
+    }
+}
+
+// grid: ceil(C / CH) * S workgroups; S == 1: finalizes; S > 1: range sums to scratch [C groups][S][CH][4] doubles
+template <int CH>
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partials, int nparts, int rows_per_part,
+                                                          long long M, int C, int pw, int S, double* __restrict__ scratch,
+                                                          BnFinalizeOut f) {
+    __shared__ double sh0[4][CH], sh1[4][CH];
+    __shared__ float slo[4][CH], shi[4][CH];
+    const int O = (C + CH - 1) / CH;
+    const int o = blockIdx.x % O, r = blockIdx.x / O;
+    const int tid = threadIdx.x, cl = tid % CH, sl = tid / CH;
+    const int c = o * CH + cl;
+    const int per = (nparts + S - 1) / S;
+    const int begin = r * per, end = min(nparts, begin + per);
+    double s0 = 0.0, s1 = 0.0;
+    float lo = INFINITY, hi = -INFINITY;
+    if (c < C) {
+        for (int p = begin + sl; p < end; p += 256 / CH) {
+            const long long rows_left = M - (long long)p * rows_per_part;
+            const double nb = (double)(rows_left < rows_per_part ? rows_left : rows_per_part);
+            const float* e = partials + ((long long)p * C + c) * pw;
+            double mb, m2b;
+            if (pw == 4) {
+                const float4 v = *reinterpret_cast<const float4*>(e);
+                mb = (double)v.x; m2b = (double)v.y;
+                lo = fminf(lo, v.z);
+                hi = fmaxf(hi, v.w);
+            } else {
+                const float2 v = *reinterpret_cast<const float2*>(e);
+                mb = (double)v.x; m2b = (double)v.y;
+            }
+            s0 += nb * mb;
+            s1 += m2b + nb * mb * mb;
+        }
+    }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            lo = fminf(lo, __shfl_xor(lo, o, 64));
-            hi = fmaxf(hi, __shfl_xor(hi, o, 64));
-        }
-        if ((tid & 63) == 0) { slo[tid >> 6] = lo; shi[tid >> 6] = hi; }
-        __syncthreads();
+    for (int x = CH; x < 64; x <<= 1) {  // the lanes of a wave that hold the same channel
+        s0 += __shfl_xor(s0, x, 64);
+        s1 += __shfl_xor(s1, x, 64);
+        lo = fminf(lo, __shfl_xor(lo, x, 64));
+        hi = fmaxf(hi, __shfl_xor(hi, x, 64));
     }
-    if (tid == 0) {
-        const double var = m2 / nt;
-        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-        const float g = gamma[c], b = beta[c];
-        const float sc = g * invstd;
-        mean_out[c] = (float)mu;
-        invstd_out[c] = invstd;
-        scale_out[c] = sc;
-        const float shf = b - (float)mu * sc;
-        shift_out[c] = shf;
-        if (pw == 4 && amax_out != nullptr) {
-            const float l = fminf(fminf(slo[0], slo[1]), fminf(slo[2], slo[3])), h = fmaxf(fmaxf(shi[0], shi[1]), fmaxf(shi[2], shi[3]));
-            const float zl = fmaf(l, sc, shf), zh = fmaf(h, sc, shf);  // the apply pass's own arithmetic
-            const float bound = relu ? fmaxf(fmaxf(zl, zh), 0.f) : fmaxf(fabsf(zl), fabsf(zh));
-            atomicMax(reinterpret_cast<unsigned*>(amax_out), __builtin_bit_cast(unsigned, bound));
-        }
-        if (running_mean != nullptr) {
-            const double unb = nt > 1.0 ? m2 / (nt - 1.0) : var;
-            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
-            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+    if ((tid & 63) < CH) {
+        sh0[tid >> 6][cl] = s0; sh1[tid >> 6][cl] = s1;
+        slo[tid >> 6][cl] = lo; shi[tid >> 6][cl] = hi;
+    }
+    __syncthreads();
+    if (tid < CH && c < C) {
+        s0 = (sh0[0][tid] + sh0[1][tid]) + (sh0[2][tid] + sh0[3][tid]);
+        s1 = (sh1[0][tid] + sh1[1][tid]) + (sh1[2][tid] + sh1[3][tid]);
+        lo = fminf(fminf(slo[0][tid], slo[1][tid]), fminf(slo[2][tid], slo[3][tid]));
+        hi = fmaxf(fmaxf(shi[0][tid], shi[1][tid]), fmaxf(shi[2][tid], shi[3][tid]));
+        if (S == 1) {
+            bn_finalize_channel(f, c, M, s0, s1, lo, hi);
+        } else {
+            double* d = scratch + (((long long)o * S + r) * CH + tid) * 4;
+            d[0] = s0; d[1] = s1; d[2] = (double)lo; d[3] = (double)hi;
         }
     }
+}
+
+template <int CH>
+__global__ __launch_bounds__(64) void bn_finalize_merge_kernel(const double* __restrict__ scratch, int S, long long M, int C,
+                                                               BnFinalizeOut f) {
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= C) return;
+    const int o = c / CH, cl = c % CH;
+    double s0 = 0.0, s1 = 0.0;
+    float lo = INFINITY, hi = -INFINITY;
+    for (int r = 0; r < S; ++r) {
+        const double* d = scratch + (((long long)o * S + r) * CH + cl) * 4;
+        s0 += d[0];
+        s1 += d[1];
+        lo = fminf(lo, (float)d[2]);
+        hi = fmaxf(hi, (float)d[3]);
+    }
+    bn_finalize_channel(f, c, M, s0, s1, lo, hi);
+}
+
+constexpr int FIN_MAX_WG = 1024;  // octets x ranges of the two-launch form
+constexpr size_t FIN_WS_BYTES = (size_t)FIN_MAX_WG * 8 * 4 * sizeof(double);
+
+static int bn_finalize_launch(const float* partials, int nparts, int rows_per_part, long long M, int C, int pw, void* ws,
+                              const BnFinalizeOut& f, hipStream_t stream) {
+    const int O = (C + 7) / 8;
+    if (ws != nullptr && nparts >= 1024 && O <= FIN_MAX_WG / 2) {
+        int S = nparts / 64;  // >= 2 sweep steps of 32 parts per workgroup
+        if (S > 32) S = 32;
+        if (S > FIN_MAX_WG / O) S = FIN_MAX_WG / O;
+        double* scratch = reinterpret_cast<double*>(ws);
+        hipLaunchKernelGGL(bn_finalize_kernel<8>, dim3(O * S), dim3(256), 0, stream, partials, nparts, rows_per_part, M, C, pw, S,
+                           scratch, f);
+        hipLaunchKernelGGL(bn_finalize_merge_kernel<8>, dim3((C + 63) / 64), dim3(64), 0, stream, (const double*)scratch, S, M, C, f);
+        return 0;
+    }
+    hipLaunchKernelGGL(bn_finalize_kernel<1>, dim3(C), dim3(256), 0, stream, partials, nparts, rows_per_part, M, C, pw, 1,
+                       (double*)nullptr, f);
+    return 0;
 }
 
 __global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, const float* rm, const float* rv,
@@ -575,31 +637,35 @@ extern "C" int trid_stem_im2col_f32(const float* img, float* col, int B, int Cin
     return check_launch("trid_stem_im2col_f32");
 }
 
+extern "C" long long trid_bn_finalize_ws_bytes(void) { return (long long)FIN_WS_BYTES; }
+
 extern "C" int trid_bn_finalize_f32(const float* partials, int nparts, int rows_per_part, long long M, int C,
                                     const float* gamma, const float* beta, float* running_mean, float* running_var,
                                     float momentum, float eps, float* mean, float* invstd, float* scale, float* shift,
-                                    void* stream) {
+                                    void* ws, void* stream) {
     TRID_REQUIRE(partials && gamma && beta && mean && invstd && scale && shift, "trid_bn_finalize_f32: null pointer");
+    TRID_REQUIRE(aligned16(partials) && aligned16(ws), "trid_bn_finalize_f32: partials / ws must be 16-byte aligned");
     TRID_REQUIRE(nparts > 0 && rows_per_part > 0 && C > 0 && M > (long long)(nparts - 1) * rows_per_part &&
                      M <= (long long)nparts * rows_per_part,
                  "trid_bn_finalize_f32: nparts=%d rows_per_part=%d inconsistent with M=%lld", nparts, rows_per_part, M);
     TRID_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "trid_bn_finalize_f32: running stats both or none");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, partials, nparts, rows_per_part, M,
-                       C, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift, 2, 0, (float*)nullptr);
+    const BnFinalizeOut f{gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift, 0, nullptr};
+    bn_finalize_launch(partials, nparts, rows_per_part, M, C, 2, ws, f, (hipStream_t)stream);
     return check_launch("trid_bn_finalize_f32");
 }
 
 extern "C" int trid_bn_finalize_minmax_f32(const float* partials, int nparts, int rows_per_part, long long M, int C,
                                            const float* gamma, const float* beta, float* running_mean, float* running_var,
                                            float momentum, float eps, float* mean, float* invstd, float* scale, float* shift,
-                                           int relu, float* amax_out, void* stream) {
+                                           int relu, float* amax_out, void* ws, void* stream) {
     TRID_REQUIRE(partials && gamma && beta && mean && invstd && scale && shift && amax_out, "trid_bn_finalize_minmax_f32: null pointer");
+    TRID_REQUIRE(aligned16(partials) && aligned16(ws), "trid_bn_finalize_minmax_f32: partials / ws must be 16-byte aligned");
     TRID_REQUIRE(nparts > 0 && rows_per_part > 0 && C > 0 && M > (long long)(nparts - 1) * rows_per_part &&
                      M <= (long long)nparts * rows_per_part,
                  "trid_bn_finalize_minmax_f32: nparts=%d rows_per_part=%d inconsistent with M=%lld", nparts, rows_per_part, M);
     TRID_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "trid_bn_finalize_minmax_f32: running stats both or none");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, partials, nparts, rows_per_part, M,
-                       C, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift, 4, relu, amax_out);
+    const BnFinalizeOut f{gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift, relu, amax_out};
+    bn_finalize_launch(partials, nparts, rows_per_part, M, C, 4, ws, f, (hipStream_t)stream);
     return check_launch("trid_bn_finalize_minmax_f32");
 }
 

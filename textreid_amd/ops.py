@@ -7,6 +7,7 @@ with torch ops, and nothing falls back to the CPU: a CPU tensor raises.
 """
 
 import ctypes
+import os
 import math
 
 import torch
@@ -105,6 +106,26 @@ def begin_capture():
     pools that are allocated (and zero-filled: a recorded fill, re-executed by every replay) inside that capture -
     a pool filled once in eager mode would hand the replays slots that still hold the previous replay's maxima."""
     _amax_pool_capture.clear()
+    _finalize_ws_capture.clear()
+
+
+_finalize_ws = {}
+_finalize_ws_capture = {}
+_FINALIZE_SPLIT = os.environ.get("TRID_BN_FINALIZE_SPLIT", "1") != "0"  # (0: always one workgroup per channel, for A/B runs)
+
+
+def bn_finalize_ws(device):
+    """Scratch of trid_bn_finalize_* (range sums of its two-launch form), private to a (device, stream): kernels on one
+    stream are serial.  (Inside a capture it comes from the capture's pool, see begin_capture.)"""
+    if not _FINALIZE_SPLIT:
+        return None
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    cache = _finalize_ws_capture if torch.cuda.is_current_stream_capturing() else _finalize_ws
+    ws = cache.get(key)
+    if ws is None:
+        ws = torch.empty(int(L.load().trid_bn_finalize_ws_bytes()), dtype=torch.uint8, device=device)
+        cache[key] = ws
+    return ws
 
 
 def amax_slot(device):
@@ -290,7 +311,7 @@ def bn_finalize_minmax(partials, M, gamma, beta, running_mean, running_var, relu
     st = BNState(C, gamma)
     call("trid_bn_finalize_minmax_f32", _p(partials), partials.shape[0], STATS_ROWS, M, C, _p(gamma), _p(beta),
          _p(running_mean), _p(running_var), momentum, eps, _p(st.mean), _p(st.invstd), _p(st.scale), _p(st.shift),
-         1 if relu else 0, _p(bound), stream())
+         1 if relu else 0, _p(bound), _p(bn_finalize_ws(partials.device)), stream())
     if running_mean is not None:
         note_parameter_write()
     return st
@@ -547,7 +568,7 @@ def bn_finalize(partials, M, gamma, beta, running_mean, running_var, momentum=BN
     st = BNState(C, gamma)
     call("trid_bn_finalize_f32", _p(partials), partials.shape[0], STATS_ROWS, M, C, _p(gamma), _p(beta),
          _p(running_mean), _p(running_var), momentum, eps, _p(st.mean), _p(st.invstd), _p(st.scale), _p(st.shift),
-         stream())
+         _p(bn_finalize_ws(partials.device)), stream())
     if running_mean is not None:
         note_parameter_write()
     return st
