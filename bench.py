@@ -102,7 +102,7 @@ def cpu_baseline(sample_b=128, steps=3, warm_b=32):
     }
 
 
-def queue_similarity_bench(device, B=128, C=256, K=8192, reps=20):
+def queue_similarity_bench(device, B=128, C=256, K=8192, reps=20, bf16=False):
     """The batch x queue similarity / masked-InfoNCE block on its own (head.py:148-170 + losses.py:206-217),
     forward AND gradient: the fused single-pass kernel of csrc/queue_nce.hip.  Algorithmic HBM bytes = both
     queues + ids + queries + gradients (17.4 MB at K=8192); no [B,K] matrix exists."""
@@ -114,22 +114,36 @@ def queue_similarity_bench(device, B=128, C=256, K=8192, reps=20):
     tqueue, vqueue = nrm(torch.randn(K, C, generator=g)), nrm(torch.randn(K, C, generator=g))
     ids = torch.arange(B, device=device) // 4
     idq = torch.randint(0, 11003, (1, K), generator=g).to(device)
+    from textreid_amd import ops
+
     fn = lambda: losses.queue_infonce_loss(vq, tq, vk, tk, ids, tqueue, vqueue, idq)
-    fn()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
+    old_prec = ops.GEMM_PRECISION
+    if bf16:
+        ops.GEMM_PRECISION = 1  # one bf16 plane of everything (configs[3]'s autocast arithmetic)
+    try:
         fn()
-    e1.record()
-    torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+    finally:
+        ops.GEMM_PRECISION = old_prec
     ms = e0.elapsed_time(e1) / reps
     nbytes = 2 * C * K * 4 + 8 * K + 4 * B * C * 4 + 2 * B * C * 4
     flops = 2 * 2 * 2.0 * B * C * K  # similarity + gradient GEMMs, both modalities
+    products = 1 if bf16 else 3
+    if bf16:
+        return {"K": K, "arithmetic": "bf16 (one plane, 1 MFMA product per multiply-add)", "ms": ms, "algorithmic_MB": nbytes / 1e6,
+                "achieved_GB_per_s": nbytes / ms / 1e6, "achieved_TFLOP_per_s": flops / ms / 1e9, "launches": 4,
+                "note": "same single pass in bf16-autocast arithmetic (trid_queue_nce_f32 precision 1, the queues still fp32 in HBM): a third of the matrix work of the fp32-class kernel"}
     return {"K": K, "ms": ms, "algorithmic_MB": nbytes / 1e6, "achieved_GB_per_s": nbytes / ms / 1e6,
             "achieved_TFLOP_per_s": flops / ms / 1e9,
+            "mfma_issue_TFLOP_per_s": products * flops / ms / 1e9, "mfma_issue_frac_of_dense_peak": products * flops / ms / 1e9 / 2500.0,
             "launches": 3,
-            "note": "fused single pass over both queues (queue_nce.hip): ONE kernel for the batch-wide negative filter (hashed id set in LDS) + similarity + masked softmax + dL/dq of both modalities (no [B,K] matrix), partial fold, loss sum; fp32-class arithmetic = 6 fp16 MFMA products per (query, row, channel) (two-plane split, fixed scales), so the block is MFMA-issue-bound at B=128: HBM time of the algorithmic bytes at 8 TB/s would be %.1f us" % (nbytes / 8e12 * 1e6)}
+            "note": "fused single pass over both queues (queue_nce.hip): ONE kernel for the batch-wide negative filter (hashed id set in LDS) + similarity + masked softmax + dL/dq of both modalities (no [B,K] matrix), partial fold, loss sum; fp32-class arithmetic = 6 fp16 MFMA products per (query, row, channel) (two-plane split, fixed scales), so the block is MFMA-issue-bound at B=128 (mfma_issue_*: the matrix rate actually sustained; random-data MFMA kernels on this part are power-limited to ~0.5-0.6 of the dense peak, profiles/r03j_zero_vs_random.txt): HBM time of the algorithmic bytes at 8 TB/s would be %.1f us" % (nbytes / 8e12 * 1e6)}
 
 
 def configs3_bench(device, B=128, K=65536, steps=6, warmup=3):
@@ -427,30 +441,39 @@ def main():
     dp_stats = reducer.stats() if world > 1 else None
 
     # the same kernel alone on the GPU (no side-stream work sharing the CUs): the 3x3 layers of layer2-4
-    iso_fl, iso_ms = 0.0, 0.0
+    # ... and once more on ZERO-filled operands: MFMA timing does not depend on the data, the power drawn - hence the
+    # sustained clock - does; the gap between the two is the part of the distance to the nominal peak that no schedule
+    # can close on real data
+    iso_fl, iso_ms, iso_ms_zero = 0.0, 0.0, 0.0
     p16 = ops.USE_P16 and ops.conv_precision() == 16  # the residual blocks' convolutions run on pre-split operands
     for (Hh, Ww, Cc) in ((96, 32, 128), (48, 16, 128), (48, 16, 256), (24, 8, 256), (24, 8, 512)):
-        xx = torch.randn(B, Hh, Ww, Cc, device=device)
-        ww = torch.randn(Cc, 9 * Cc, device=device)
-        cp = ops.conv_precision()
-        if p16:
-            xp, wp = ops.p16_pack(xx), ops.p16_pack(ww)
-            run = lambda: ops.conv_p16(xp, wp, conv3=True)
-        else:
-            kw = dict(prec=cp, aa=ops.amax(xx), ba=ops.amax(ww)) if cp == 16 else {}  # the model's conv arithmetic
-            run = lambda: ops.conv3x3(xx, ww, stats=True, **kw)
-        run()
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(3):
+        for zero in (False, True):
+            xx = torch.zeros(B, Hh, Ww, Cc, device=device) if zero else torch.randn(B, Hh, Ww, Cc, device=device)
+            ww = torch.zeros(Cc, 9 * Cc, device=device) if zero else torch.randn(Cc, 9 * Cc, device=device)
+            cp = ops.conv_precision()
+            if p16:
+                one = torch.ones(1, device=device)
+                xp, wp = (ops.p16_pack(xx, one), ops.p16_pack(ww, one)) if zero else (ops.p16_pack(xx), ops.p16_pack(ww))
+                run = lambda: ops.conv_p16(xp, wp, conv3=True)
+            else:
+                kw = dict(prec=cp, aa=ops.amax(xx), ba=ops.amax(ww)) if cp == 16 else {}  # the model's conv arithmetic
+                run = lambda: ops.conv3x3(xx, ww, stats=True, **kw)
             run()
-        e1.record()
-        torch.cuda.synchronize()
-        iso_ms += e0.elapsed_time(e1) / 3
-        iso_fl += 2.0 * B * Hh * Ww * Cc * 9 * Cc
-        del xx, ww
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3):
+                run()
+            e1.record()
+            torch.cuda.synchronize()
+            if zero:
+                iso_ms_zero += e0.elapsed_time(e1) / 3
+            else:
+                iso_ms += e0.elapsed_time(e1) / 3
+                iso_fl += 2.0 * B * Hh * Ww * Cc * 9 * Cc
+            del xx, ww
     achieved_isolated = iso_fl / (iso_ms * 1e-3) / 1e12
+    achieved_isolated_zero = iso_fl / (iso_ms_zero * 1e-3) / 1e12
 
     prec = ops.GEMM_PRECISION
     cprec = ops.conv_precision()
@@ -486,7 +509,7 @@ def main():
     # measurement of the committed build, not a counter read of this run: `traffic_source` names the file.
     traffic, traffic_note, traffic_src = None, None, None
     here = os.path.dirname(os.path.abspath(__file__))
-    for fn in ("r03_pmc_hbm_traffic.txt", "r02d_pmc_hbm_traffic.txt", "r02c_pmc_hbm_traffic.txt", "r02a_pmc_hbm_traffic.txt", "r01j_pmc_hbm_traffic.txt"):
+    for fn in ("r03i_pmc_hbm_traffic.txt", "r03_pmc_hbm_traffic.txt", "r02d_pmc_hbm_traffic.txt", "r02c_pmc_hbm_traffic.txt", "r02a_pmc_hbm_traffic.txt", "r01j_pmc_hbm_traffic.txt"):
         try:
             for line in open(os.path.join(here, "profiles", fn)):
                 f = line.split()
@@ -513,6 +536,9 @@ def main():
         "traffic_note": traffic_note,
         "achieved_isolated": achieved_isolated,
         "frac_isolated": achieved_isolated / peak,
+        "achieved_isolated_zero_operands": achieved_isolated_zero,
+        "frac_isolated_zero_operands": achieved_isolated_zero / peak,
+        "power_note": "the *_zero_operands figures are the same launches on zero-filled tensors: identical instruction stream, lower switching power, higher sustained clock - the gap to *_isolated is set by the part's power limit under random fp16 operands, not by the kernel's schedule (profiles/r03j_zero_vs_random.txt; the guide's own best plain-HIP bf16 GEMM sustains 0.53-0.59 of the dense peak on random data)",
         "note": ("achieved/frac: events around every launch of this kernel " + ("in %d eager re-runs of the step right after the timed region (the timed steps are hipGraph replays: events cannot bracket graph nodes; rocprofv3 --kernel-trace of this command gives the in-graph durations, profiles/)" % profiled_eager if profiled_eager else "during the timed steps") + ", while the text / key-encoder / weight-gradient streams share the CUs; *_isolated: the same kernel on the five layer2-4 3x3 shapes with the GPU to itself"),
         "peak_note": peak_note,
         "launches": nlaunch,
@@ -542,6 +568,7 @@ def main():
         retr.update(encode_bench(model, batches[0][0], batches[0][1], batches[0][2]))
         log("retrieval: %.1f M gallery imgs/s" % (retr["value"] / 1e6))
     qsim = [queue_similarity_bench(device, B=B, K=k) for k in sorted({args.queue, 65536})]
+    qsim.append(queue_similarity_bench(device, B=B, K=65536, bf16=True))
     step_launch = "hipGraph replay (one launch per step)" if runner is not None else "eager (%d rank(s)%s)" % (world, ": RCCL collectives inside backward" if world > 1 else "")
     c3 = None
     if world == 1 and not args.no_configs3 and ops.conv_precision() == 16 and args.model == "m_resnet50":

@@ -43,7 +43,8 @@ __device__ __forceinline__ void dma16(const __amdgpu_buffer_rsrc_t& rs, uint4* l
 // PL = 2: P16 operands (two fp16 planes, 32 k per 128-byte row chunk, 3 MFMA products per multiply-add: fp32-class);
 // PL = 1: plain bf16 operands (64 k per 128-byte chunk, one bf16 MFMA per product): configs[3]'s bf16 arithmetic on
 // tensors their producers already wrote in bf16 - half the operand bytes, a third of the matrix work.
-template <int AMODE, int BM, int BN, int WM, int WN, int STAGES, int PL>
+// PP: the two wave halves of the workgroup run the K loop half a tile apart ("ping-pong", see the main loop).
+template <int AMODE, int BM, int BN, int WM, int WN, int STAGES, int PL, bool PP = false>
 __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 && STAGES == 2) ? 2 : (WM * WN == 8 && (BM + BN) * 128 * STAGES <= 80 * 1024 ? 4 : 2)) void gemm_p16_kernel(GemmParams p) {
     constexpr int NW = WM * WN;
     constexpr int BKE = PL == 2 ? 32 : 64;  // K elements per 128-byte row chunk = per K tile
@@ -230,7 +231,95 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 && STAGES == 2) ? 2 : (W
     };
 
     // ---- main loop
-    {
+    if constexpr (PP) {
+        // Ping-pong: waves [0, NW/2) ("A") and [NW/2, NW) ("B") - one of each per SIMD - alternate between a READ period
+        // (issue the next tile's LDS-DMA, pull the current tile's fragments LDS -> VGPRs) and an MFMA period (nothing but
+        // the tile's MFMAs, at raised priority), B one period behind A: in every period one half feeds the matrix pipe
+        // while the other half uses the LDS and the load path, instead of all waves doing the same thing at once.
+        //   period 2t:   A reads tile t   | B multiplies tile t-1      (both issue tile t+1 -> stage (t+1)&1 first)
+        //   period 2t+1: A multiplies t   | B reads tile t
+        // one barrier between periods.  Stage (t+1)&1 held tile t-1: read by A in period 2t-2, by B in period 2t-1 with
+        // its ds_reads retired (lgkmcnt(0)) before the barrier into period 2t.  Tile t+1 is first read in period 2t+2:
+        // every wave retires its DMA share (vmcnt(0)) before the barrier into that period.
+        static_assert(STAGES == 2 && NW % 2 == 0, "ping-pong schedule: two stages, an even number of waves");
+        constexpr int NKS = PL == 2 ? 2 : 4, NPL = PL == 2 ? 2 : 1;
+        uint4 fa[NKS][NPL][TM], fb[NKS][NPL][TN];
+        auto rd = [&](int stage) {
+            const uint4* sA = smem + stage * STAGE_SLOTS;
+            const uint4* sB = sA + BM * 8;
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+                for (int pl = 0; pl < NPL; ++pl) {
+                    const int s = ((PL == 2 ? 4 * pl : 0) + 2 * ks + khalf) ^ xs;
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) fa[ks][pl][i] = sA[(a_row + 32 * i) * 8 + s];
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) fb[ks][pl][j] = sB[(b_row + 32 * j) * 8 + s];
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        };
+        auto mm = [&]() {
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                if constexpr (PL == 1) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[ks][0][i]), __builtin_bit_cast(bf16x8, fb[ks][0][j]), acc[i][j], 0, 0, 0);
+                } else {
+                    // small terms first; consecutive MFMAs hit different accumulators
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[ks][0][i]), __builtin_bit_cast(f16x8, fb[ks][1][j]), acc[i][j], 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[ks][1][i]), __builtin_bit_cast(f16x8, fb[ks][0][j]), acc[i][j], 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[ks][0][i]), __builtin_bit_cast(f16x8, fb[ks][0][j]), acc[i][j], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_s_setprio(0);
+        };
+        auto bar = [&]() {
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        };
+        if (nk > 0) issue(kt_begin, 0);
+        wait_vmcnt<0>();
+        bar();  // tile 0 is in LDS
+        if (wave < NW / 2) {
+            for (int t = 0; t < nk; ++t) {
+                if (t + 1 < nk) issue(kt_begin + t + 1, (t + 1) & 1);
+                rd(t & 1);
+                bar();
+                mm();
+                wait_vmcnt<0>();
+                bar();
+            }
+            bar();
+        } else {
+            if (1 < nk) issue(kt_begin + 1, 1);
+            bar();
+            for (int t = 0; t < nk; ++t) {
+                rd(t & 1);
+                wait_vmcnt<0>();
+                bar();
+                if (t + 2 < nk) issue(kt_begin + t + 2, t & 1);
+                mm();
+                bar();
+            }
+        }
+    } else {
 #pragma unroll
         for (int s = 0; s < STAGES - 1; ++s)
             if (s < nk) issue(kt_begin + s, s);
@@ -699,7 +788,7 @@ __global__ __launch_bounds__(256) void p16_pack_multi_kernel(const long long* __
     }
 }
 
-template <int AMODE, int BM, int BN, int WM, int WN, int STAGES, int PL = 2>
+template <int AMODE, int BM, int BN, int WM, int WN, int STAGES, int PL = 2, bool PP = false>
 static int launch_p16(GemmParams& p, hipStream_t stream) {
     p.mblocks = (p.M + BM - 1) / BM;
     p.nblocks = (p.N + BN - 1) / BN;
@@ -709,14 +798,14 @@ static int launch_p16(GemmParams& p, hipStream_t stream) {
     static hipError_t attr_err = hipSuccess;
     std::call_once(once, [] {
         if (lds > 48 * 1024)
-            attr_err = hipFuncSetAttribute((const void*)gemm_p16_kernel<AMODE, BM, BN, WM, WN, STAGES, PL>,
+            attr_err = hipFuncSetAttribute((const void*)gemm_p16_kernel<AMODE, BM, BN, WM, WN, STAGES, PL, PP>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     });
     if (attr_err != hipSuccess) {
         set_error("trid_gemm_p16: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(attr_err));
         return (int)attr_err;
     }
-    hipLaunchKernelGGL((gemm_p16_kernel<AMODE, BM, BN, WM, WN, STAGES, PL>), grid, dim3(WM * WN * 64), lds, stream, p);
+    hipLaunchKernelGGL((gemm_p16_kernel<AMODE, BM, BN, WM, WN, STAGES, PL, PP>), grid, dim3(WM * WN * 64), lds, stream, p);
     return check_launch("trid_gemm_p16");
 }
 
@@ -734,6 +823,8 @@ static int pick_p16(GemmParams& p, int variant, int planes, hipStream_t stream) 
         case 3: return launch_p16<AMODE, 128, 128, 2, 4, 2>(p, stream);   // 8 waves of 64x32, 2 stages (64 KB): 2 WG / CU
         case 4: return launch_p16<AMODE, 256, 128, 4, 2, 2>(p, stream);   // 8 waves of 64x64, 2 stages (96 KB)
         case 5: return launch_p16<AMODE, 128, 128, 2, 4, 3>(p, stream);   // 8 waves of 64x32, 3 stages (96 KB)
+        case 6: return launch_p16<AMODE, 128, 128, 2, 4, 2, 2, true>(p, stream);  // variant 3 with the ping-pong schedule
+        case 7: return launch_p16<AMODE, 256, 128, 4, 2, 2, 2, true>(p, stream);  // variant 4 with the ping-pong schedule
         default: return launch_p16<AMODE, 128, 128, 2, 2, 2>(p, stream);  // 4 waves of 64x64, 2 stages (64 KB): 2 WG / CU
     }
 }
