@@ -84,6 +84,8 @@ typedef struct trid_gemm_desc {
     const float* a_amax;   /* precision 16 only: DEVICE scalars holding max|A| and max|B| over the whole operand */
     const float* b_amax;   /* (trid_amax_f32); NULL = operand used unscaled (must then lie in fp16's range)      */
     int32_t stats_minmax;  /* trid_gemm_p16 only, with stats: partials are [..][N][4] = (mean, M2, min, max) per column */
+    int32_t c_format;      /* trid_gemm_p16 only: 0 = C is fp32; 2 = C is a plain bf16 tensor (ldc in elements; read as such
+                            * with accumulate) - data gradients of the bf16 mode; needs batch == splits == 1, no stats */
 } trid_gemm_desc;
 
 int trid_gemm_f32(const trid_gemm_desc* d, void* stream);
@@ -183,8 +185,8 @@ int trid_bn_apply_p16_f32(const float* y, const float* scale, const float* shift
  * of that format (plain pooling of a block input) */
 int trid_bn_apply_pool2_p16_f32(const void* y, const float* scale, const float* shift, int in_fmt, const float* in_amax,
                                 void* out, int fmt, int B, int H, int W, int C, int relu, const float* bound, void* stream);
-/* dx[b,y,x,c] (+)= 0.25*g[b,y/2,x/2,c] */
-int trid_avgpool2_bwd_f32(const float* g, float* dx, int B, int H, int W, int C, int accumulate, void* stream);
+/* dx[b,y,x,c] (+)= 0.25*g[b,y/2,x/2,c]; fmt: 0 = fp32 tensors, 2 = both plain bf16 (gradient tensors of the bf16 mode) */
+int trid_avgpool2_bwd_f32(const void* g, void* dx, int B, int H, int W, int C, int accumulate, int fmt, void* stream);
 
 /* BatchNorm backward.  g is dL/d(out).  mask_mode: 0 none, 1 recompute
  * (y*scale+shift > 0), 2 from `act` (> 0), 3 from the bit mask of trid_bn_apply_f32 passed as `act`.  pooled != 0: g has shape
@@ -207,10 +209,17 @@ int trid_bn_bwd_reduce_bound_f32(const float* g, const float* y, const float* ac
                                  const float* invstd, const float* scale, const float* shift, int mask_mode, int pooled,
                                  int B, int H, int W, int C, float* dgamma, float* dbeta, float* ws, float* bound,
                                  void* stream);
-/* trid_bn_bwd_apply_f32 with dy written in format fmt (1: P16 scaled for bound[0]; 2: bf16) */
-int trid_bn_bwd_apply_p16_f32(const float* g, const float* y, const float* act, const float* mean, const float* invstd,
+/* trid_bn_bwd_reduce_f32 on an incoming gradient of format g_fmt: 0 = fp32, 2 = plain bf16 (configs[3]'s bf16 mode: the
+ * gradient of a bf16 tensor is a bf16 tensor - written so by trid_gemm_p16 with c_format 2) */
+int trid_bn_bwd_reduce_g_f32(const void* g, int g_fmt, const float* y, const float* act, const float* mean,
+                             const float* invstd, const float* scale, const float* shift, int mask_mode,
+                             int pooled, int B, int H, int W, int C, float* dgamma, float* dbeta, float* ws,
+                             void* stream);
+/* trid_bn_bwd_apply_f32 with dy written in format fmt (1: P16 scaled for bound[0]; 2: bf16); g - and dres, its masked
+ * copy - in format g_fmt (0 / 2) */
+int trid_bn_bwd_apply_p16_f32(const void* g, int g_fmt, const float* y, const float* act, const float* mean, const float* invstd,
                               const float* scale, const float* shift, const float* dgamma, const float* dbeta,
-                              int mask_mode, int pooled, int B, int H, int W, int C, void* dy, int fmt, float* dres,
+                              int mask_mode, int pooled, int B, int H, int W, int C, void* dy, int fmt, void* dres,
                               const float* bound, void* stream);
 
 /* ------------------------------------------------------------------------- *

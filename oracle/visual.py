@@ -20,8 +20,9 @@ BN_MOMENTUM = 0.1
 # lib/config/defaults.py:142-144): every convolution of the image encoder's 16 / 33 RESIDUAL BLOCKS (97 % of its
 # FLOPs) takes its operands in bf16 - activations, filters and, in backward, the incoming gradient are rounded to bf16
 # (round-to-nearest-even) where the convolution reads them - and every block OUTPUT is a bf16 tensor (so the identity
-# residual of the next block reads the rounded value too); products are exact, accumulation / BatchNorm / gradients
-# w.r.t. block outputs / the 3-conv stem / the attention pool's own arithmetic / everything else stays fp32.  `with bf16_conv():` switches
+# residual of the next block reads the rounded value too); the gradient w.r.t. such a bf16 ACTIVATION tensor (a conv
+# input, a block output) is a bf16 tensor as well (as under autocast); products are exact, accumulation / BatchNorm /
+# weight gradients / the 3-conv stem / the attention pool's own arithmetic / everything else stays fp32.  `with bf16_conv():` switches
 # the oracle to that arithmetic: the comparator of the HIP path's TRID_CONV_PRECISION=1 mode.
 BF16_CONV = False
 
@@ -52,6 +53,18 @@ class _RoundOperand(torch.autograd.Function):
         return g
 
 
+class _RoundActivation(torch.autograd.Function):
+    """activation -> bf16 value; the gradient w.r.t. a bf16 tensor is a bf16 tensor (rounded on its way back)"""
+
+    @staticmethod
+    def forward(ctx, x):
+        return _to_bf16(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _to_bf16(g)
+
+
 class _RoundIncomingGrad(torch.autograd.Function):
     """identity whose backward rounds: the gradient arriving at a conv output is an operand of its two backward convs"""
 
@@ -66,7 +79,7 @@ class _RoundIncomingGrad(torch.autograd.Function):
 
 def _conv(x, w, **kw):
     if BF16_CONV:
-        return _RoundIncomingGrad.apply(F.conv2d(_RoundOperand.apply(x), _RoundOperand.apply(w), **kw))
+        return _RoundIncomingGrad.apply(F.conv2d(_RoundActivation.apply(x), _RoundOperand.apply(w), **kw))
     return F.conv2d(x, w, **kw)
 
 
@@ -201,7 +214,7 @@ def bottleneck(st, p, x, stride, has_down, training, taps=None):
     out = _relu(out + idn, taps)
     # bf16 mode: a block's OUTPUT tensor is a bf16 tensor (it is the next block's conv operand AND its identity
     # residual, the input of the downsample pooling, and - after the last block - of the attention pool)
-    return _RoundOperand.apply(out) if BF16_CONV else out
+    return _RoundActivation.apply(out) if BF16_CONV else out
 
 
 def attention_pool(st, x, heads):

@@ -234,6 +234,53 @@ def test_bn_eval_and_pool(ops):
     assert rel(dx.permute(0, 3, 1, 2), yr.grad) < 1e-6
 
 
+def _bf(t):
+    return t.to(torch.bfloat16)
+
+
+def test_bf16_gradient_tensors(ops):
+    """configs[3]'s bf16 mode keeps the residual blocks' DATA gradients as bf16 tensors.  Each kernel that reads or
+    writes one is pinned to its fp32 form on the same (bf16-representable) values: reads are exact widenings, writes
+    are one round-to-nearest-even of the fp32 result - so the comparison is bit-exact."""
+    B, H, W, C, N = 4, 8, 6, 64, 128
+    # (1) data-gradient GEMM writing / accumulating a bf16 C
+    dy = ops.p16_pack(dev(R("bdy", B * H * W, N)), None, 2)
+    wt = ops.p16_pack(dev(R("bw", C, N, scale=0.05)), None, 2)
+    c32 = torch.empty(B * H * W, C, device="cuda")
+    ops.gemm_p16(dy, wt, c32, B * H * W, C, N, C)
+    c16 = torch.empty(B * H * W, C, device="cuda", dtype=torch.bfloat16)
+    ops.gemm_p16(dy, wt, c16, B * H * W, C, N, C)
+    assert torch.equal(c16, _bf(c32))
+    old = _bf(dev(R("bold", B * H * W, C)))
+    acc32 = old.float()
+    ops.gemm_p16(dy, wt, acc32, B * H * W, C, N, C, accumulate=True)
+    acc16 = old.clone()
+    ops.gemm_p16(dy, wt, acc16, B * H * W, C, N, C, accumulate=True)
+    assert torch.equal(acc16, _bf(acc32))
+    # (2) BatchNorm backward on a bf16 incoming gradient (plain, pooled, bit-mask + dres)
+    y = dev(nhwc(R("by", B, C, H, W)))
+    gamma, beta = dev(R("bg", C).abs() + 0.5), dev(R("bb", C))
+    yc, st = ops.conv1x1(y, torch.eye(C, device="cuda"), stats=True)
+    bst = ops.bn_finalize(st, B * H * W, gamma, beta, None, None)
+    out, mask = ops.bn_apply(yc, bst, relu=True, want_mask=True)
+    for pooled, mode, act, dres in ((False, 1, None, False), (True, 1, None, False), (False, 3, mask, True)):
+        g = _bf(dev(nhwc(R("bgr%d%d" % (pooled, mode), B, C, H // 2 if pooled else H, W // 2 if pooled else W))))
+        a = ops.bn_bwd_p16(g.float(), yc, bst, mode, act=act, pooled=pooled, want_dres=dres, fmt=2)
+        b = ops.bn_bwd_p16(g, yc, bst, mode, act=act, pooled=pooled, want_dres=dres, fmt=2)
+        assert torch.equal(a[0].data, b[0].data) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+        if dres:
+            assert b[3].dtype == torch.bfloat16 and torch.equal(b[3].float(), a[3])
+    # (3) AvgPool backward, plain and accumulating
+    g = _bf(dev(nhwc(R("bpg", B, C, H // 2, W // 2))))
+    d32 = ops.avgpool2_bwd(g.float())
+    d16 = ops.avgpool2_bwd(g)
+    assert d16.dtype == torch.bfloat16 and torch.equal(d16, _bf(d32))
+    base = _bf(dev(nhwc(R("bpb", B, C, H, W))))
+    e32 = ops.avgpool2_bwd(g.float(), dx=base.float(), accumulate=True)
+    e16 = ops.avgpool2_bwd(g, dx=base.clone(), accumulate=True)
+    assert torch.equal(e16, _bf(e32))
+
+
 def test_small_ops(ops):
     x = R("sx", 37, 256)
     y, inv = ops.l2norm_rows(dev(x))

@@ -429,21 +429,21 @@ def block_backward_p16(blk, rec, g, WPT, ws, G):
         G[id(blk.downsample[2].weight)], G[id(blk.downsample[2].bias)] = dg, db
     planes = blk.conv2.out_channels
     Mc = dyc.data.numel() // dyc.shape[-1]
-    dab = ops.empty(tuple(ab.shape), g)
+    dab = ops.empty(tuple(ab.shape), g, dtype=g.dtype)  # (bf16 mode: data gradients are bf16 tensors, like g)
     ops.gemm_p16(dyc, WPT[id(blk.conv3.weight)], dab, Mc, planes, dyc.shape[-1], planes)
     G[id(blk.conv3.weight)] = wgrad(dyc, ab).view_as(blk.conv3.weight)
     dyb, dg, db, _ = ops.bn_bwd_p16(dab, yb, stb, 1, pooled=stride > 1, fmt=fmt)
     G[id(blk.bn2.weight)], G[id(blk.bn2.bias)] = dg, db
     Bi, H, W, _ = yb.shape
     Ma = Bi * H * W
-    daa = ops.empty(tuple(aa.shape), g)
+    daa = ops.empty(tuple(aa.shape), g, dtype=g.dtype)
     ops.gemm_p16(dyb, WPT[id(blk.conv2.weight)], daa, Ma, planes, 9 * planes, planes, conv=(H, W, planes))
     G[id(blk.conv2.weight)] = _g3x3(wgrad(dyb, aa, conv=(H, W, planes)), planes, planes)
     dya, dg, db, _ = ops.bn_bwd_p16(daa, ya, sta, 1, fmt=fmt)
     G[id(blk.bn1.weight)], G[id(blk.bn1.bias)] = dg, db
     cin = blk.conv1.in_channels
     if has_down:
-        dxd = ops.empty(tuple(xd.shape), g)
+        dxd = ops.empty(tuple(xd.shape), g, dtype=g.dtype)
         ops.gemm_p16(dyd, WPT[id(blk.downsample[1].weight)], dxd, Mc, cin, dyd.shape[-1], cin)
         G[id(blk.downsample[1].weight)] = wgrad(dyd, xd).view_as(blk.downsample[1].weight)
         dx = ops.avgpool2_bwd(dxd) if stride > 1 else dxd
@@ -774,13 +774,16 @@ class ModifiedResNet(nn.Module):
         dbg = getattr(self, "_debug_grads", None)
         p16 = S.get("p16", 0)
         WPT = p16_weights(self, ar.WA, True, p16) if p16 else None
+        if p16 == 2 and ops.BF16_GRADS:
+            g = g.to(torch.bfloat16)  # bf16 mode: the gradient of a bf16 tensor (the block outputs) is a bf16 tensor
         for blk, rec in zip(reversed(blocks), reversed(S["blocks"])):
             if dbg is not None:
-                dbg.append(g)
+                dbg.append(g.float())
             g = block_backward_p16(blk, rec, g, WPT, ws, G) if p16 else block_backward(blk, rec, g, ar, ws, G)
             if id(blk) in first_of_layer:  # a whole residual layer (and, the first time, the attention pool) is done
                 stage_ready()
         S["blocks"] = None
+        g = g.float()  # the stem runs on fp32 tensors in every mode
         stem_backward(self, S["stem"], g, ar, ws, G)
         ws.join()
         if sync is not None:

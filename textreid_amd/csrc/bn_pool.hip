@@ -385,6 +385,8 @@ __global__ void bn_apply_pool2_kernel(const float4* __restrict__ y, const float4
     if (OFMT == 0 && amax != nullptr) amax_commit(am, amax);
 }
 
+// FMT 0: fp32 tensors; 2: plain bf16 (gradient tensors of configs[3]'s bf16 mode; 0.25 * a bf16 value is exact)
+template <int FMT>
 __global__ void avgpool2_bwd_kernel(const float4* __restrict__ g, float4* __restrict__ dx, int B, int H, int W, int CQ,
                                     int accumulate, long long total4) {
     const int Ho = H / 2, Wo = W / 2;
@@ -396,13 +398,15 @@ __global__ void avgpool2_bwd_kernel(const float4* __restrict__ g, float4* __rest
         p /= W;
         const int yy = (int)(p % H);
         const int b = (int)(p / H);
-        float4 v = g[(((long long)b * Ho + yy / 2) * Wo + x / 2) * CQ + cq];
+        const long long src = (((long long)b * Ho + yy / 2) * Wo + x / 2) * CQ + cq;
+        float4 v = FMT == 2 ? bf16_load4(reinterpret_cast<const uint2*>(g), src) : g[src];
         v.x *= 0.25f; v.y *= 0.25f; v.z *= 0.25f; v.w *= 0.25f;
         if (accumulate) {
-            float4 o = dx[i];
+            const float4 o = FMT == 2 ? bf16_load4(reinterpret_cast<const uint2*>(dx), i) : dx[i];
             v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
         }
-        dx[i] = v;
+        if (FMT == 2) bf16_store4(reinterpret_cast<uint2*>(dx), i, v);
+        else dx[i] = v;
     }
 }
 
@@ -416,6 +420,7 @@ struct BnBwdArgs {
     const float4* scale;
     const float4* shift;
     int mask_mode, pooled;
+    int g_fmt;  // 0: g (and dres) fp32; 2: plain bf16 (configs[3]: gradients of bf16 tensors are bf16 tensors)
     int B, H, W, CQ;
     long long total4;  // B*H*W*CQ
     FastDiv fdW, fdH;
@@ -430,10 +435,11 @@ __device__ __forceinline__ void bn_bwd_elem(const BnBwdArgs& a, long long i, int
         const int x = (int)(p - q * a.W);
         const uint32_t b = fdiv(q, a.fdH);
         const int yy = (int)(q - b * a.H);
-        g = a.g[(((long long)b * (a.H / 2) + yy / 2) * (a.W / 2) + x / 2) * a.CQ + cq];
+        const long long src = (((long long)b * (a.H / 2) + yy / 2) * (a.W / 2) + x / 2) * a.CQ + cq;
+        g = a.g_fmt == 2 ? bf16_load4(reinterpret_cast<const uint2*>(a.g), src) : a.g[src];
         g.x *= 0.25f; g.y *= 0.25f; g.z *= 0.25f; g.w *= 0.25f;
     } else {
-        g = a.g[i];
+        g = a.g_fmt == 2 ? bf16_load4(reinterpret_cast<const uint2*>(a.g), i) : a.g[i];
     }
     const float4 yv = a.y[i];
     const float4 mu = a.mean[cq], is = a.invstd[cq];
@@ -600,7 +606,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a, const fl
             dy[i] = o;
             am = amax4(am, o);
         }
-        if (dres != nullptr) dres[i] = gm;
+        if (dres != nullptr) {
+            if (a.g_fmt == 2) bf16_store4(reinterpret_cast<uint2*>(dres), i, gm);  // (a masked bf16 value: exact)
+            else dres[i] = gm;
+        }
     }
     if (OFMT == 0 && amax != nullptr) amax_commit(am, amax);
 }
@@ -752,12 +761,16 @@ extern "C" int trid_bn_apply_pool2_p16_f32(const void* y, const float* scale, co
     return check_launch("trid_bn_apply_pool2_p16_f32");
 }
 
-extern "C" int trid_avgpool2_bwd_f32(const float* g, float* dx, int B, int H, int W, int C, int accumulate,
+extern "C" int trid_avgpool2_bwd_f32(const void* g, void* dx, int B, int H, int W, int C, int accumulate, int fmt,
                                      void* stream) {
-    TRID_REQUIRE(g && dx && B > 0 && H % 2 == 0 && W % 2 == 0 && C % 4 == 0, "trid_avgpool2_bwd_f32: bad arguments");
+    TRID_REQUIRE(g && dx && B > 0 && H % 2 == 0 && W % 2 == 0 && C % 4 == 0 && (fmt == 0 || fmt == 2), "trid_avgpool2_bwd_f32: bad arguments");
     const long long total4 = (long long)B * H * W * (C / 4);
-    hipLaunchKernelGGL(avgpool2_bwd_kernel, dim3(grid_for(total4, 256 * 4)), dim3(256), 0, (hipStream_t)stream,
-                       (const float4*)g, (float4*)dx, B, H, W, C / 4, accumulate, total4);
+    if (fmt == 2)
+        hipLaunchKernelGGL(avgpool2_bwd_kernel<2>, dim3(grid_for(total4, 256 * 4)), dim3(256), 0, (hipStream_t)stream,
+                           (const float4*)g, (float4*)dx, B, H, W, C / 4, accumulate, total4);
+    else
+        hipLaunchKernelGGL(avgpool2_bwd_kernel<0>, dim3(grid_for(total4, 256 * 4)), dim3(256), 0, (hipStream_t)stream,
+                           (const float4*)g, (float4*)dx, B, H, W, C / 4, accumulate, total4);
     return check_launch("trid_avgpool2_bwd_f32");
 }
 
@@ -769,8 +782,9 @@ extern "C" long long trid_bn_bwd_ws_floats(int C) {
 
 static int bn_bwd_fill(BnBwdArgs& a, const float* g, const float* y, const float* act, const float* mean,
                        const float* invstd, const float* scale, const float* shift, int mask_mode, int pooled, int B,
-                       int H, int W, int C) {
+                       int H, int W, int C, int g_fmt = 0) {
     TRID_REQUIRE(g && y && mean && invstd && scale && shift, "bn_bwd: null pointer");
+    TRID_REQUIRE(g_fmt == 0 || g_fmt == 2, "bn_bwd: g_fmt must be 0 (fp32) or 2 (bf16)");
     TRID_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "bn_bwd: bad shape");
     const int CQ = C / 4;
     TRID_REQUIRE(256 % CQ == 0 || CQ % 256 == 0, "bn_bwd: C/4 must divide 256 or be a multiple of 256 (C=%d)", C);
@@ -781,6 +795,7 @@ static int bn_bwd_fill(BnBwdArgs& a, const float* g, const float* y, const float
     a.mean = (const float4*)mean; a.invstd = (const float4*)invstd;
     a.scale = (const float4*)scale; a.shift = (const float4*)shift;
     a.mask_mode = mask_mode; a.pooled = pooled;
+    a.g_fmt = g_fmt;
     a.B = B; a.H = H; a.W = W; a.CQ = CQ;
     a.total4 = (long long)B * H * W * CQ;
     a.fdW = make_fastdiv((uint32_t)W);
@@ -792,8 +807,15 @@ extern "C" int trid_bn_bwd_reduce_f32(const float* g, const float* y, const floa
                                       const float* invstd, const float* scale, const float* shift, int mask_mode,
                                       int pooled, int B, int H, int W, int C, float* dgamma, float* dbeta, float* ws,
                                       void* stream) {
+    return trid_bn_bwd_reduce_g_f32(g, 0, y, act, mean, invstd, scale, shift, mask_mode, pooled, B, H, W, C, dgamma, dbeta, ws, stream);
+}
+
+extern "C" int trid_bn_bwd_reduce_g_f32(const void* g, int g_fmt, const float* y, const float* act, const float* mean,
+                                        const float* invstd, const float* scale, const float* shift, int mask_mode,
+                                        int pooled, int B, int H, int W, int C, float* dgamma, float* dbeta, float* ws,
+                                        void* stream) {
     BnBwdArgs a;
-    int rc = bn_bwd_fill(a, g, y, act, mean, invstd, scale, shift, mask_mode, pooled, B, H, W, C);
+    int rc = bn_bwd_fill(a, (const float*)g, y, act, mean, invstd, scale, shift, mask_mode, pooled, B, H, W, C, g_fmt);
     if (rc) return rc;
     TRID_REQUIRE(dgamma && dbeta && ws, "trid_bn_bwd_reduce_f32: null output");
     const int grid = bn_bwd_grid(a.total4, a.CQ);
@@ -835,12 +857,12 @@ extern "C" int trid_bn_bwd_apply_f32(const float* g, const float* y, const float
     return check_launch("trid_bn_bwd_apply_f32");
 }
 
-extern "C" int trid_bn_bwd_apply_p16_f32(const float* g, const float* y, const float* act, const float* mean,
+extern "C" int trid_bn_bwd_apply_p16_f32(const void* g, int g_fmt, const float* y, const float* act, const float* mean,
                                          const float* invstd, const float* scale, const float* shift, const float* dgamma,
                                          const float* dbeta, int mask_mode, int pooled, int B, int H, int W, int C,
-                                         void* dy, int fmt, float* dres, const float* bound, void* stream) {
+                                         void* dy, int fmt, void* dres, const float* bound, void* stream) {
     BnBwdArgs a;
-    int rc = bn_bwd_fill(a, g, y, act, mean, invstd, scale, shift, mask_mode, pooled, B, H, W, C);
+    int rc = bn_bwd_fill(a, (const float*)g, y, act, mean, invstd, scale, shift, mask_mode, pooled, B, H, W, C, g_fmt);
     if (rc) return rc;
     TRID_REQUIRE(dgamma && dbeta && dy && (fmt == 2 || bound) && (fmt == 1 || fmt == 2) && C % 32 == 0,
                  "trid_bn_bwd_apply_p16_f32: null pointer, fmt not 1 / 2 or C %% 32 != 0");

@@ -48,6 +48,8 @@ struct GemmParams {
     const float* a_amax;  // f16x3 arithmetic: device scalars holding max|A| / max|B| (null: operand used unscaled)
     const float* b_amax;
     int stats_w;          // floats per column in `stats`: 2 (mean, M2) or 4 (+ min, max: gemm_p16.hip)
+    int c_fmt;            // gemm_p16.hip: 0 = C fp32, 2 = C plain bf16
+    int wide_epilogue;    // gemm_p16.hip: stores (and accumulate / res reads) as whole rows through LDS
     int xcd_split;        // weight gradients (gemm_p16.hip): 1-D grid, every XCD owns whole K splits
 };
 

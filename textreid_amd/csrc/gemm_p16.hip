@@ -343,34 +343,10 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 && STAGES == 2) ? 2 : (W
     const float unscale = 1.f / (scaleA * scaleB);
     const int row_base = m0 + wm * (32 * TM) + 4 * khalf;
     const int col_base = n0 + wn * (32 * TN) + (lane & 31);
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int col = col_base + 32 * j;
-        const float bv = (bias != nullptr && col < p.N) ? bias[col] : 0.f;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            float oldv[16];
-            if (p.accumulate) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = row_base + i * 32 + (r & 3) + 8 * (r >> 2);
-                    oldv[r] = (row < p.M && col < p.N) ? C[(long long)row * p.ldc + col] : 0.f;
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = row_base + i * 32 + (r & 3) + 8 * (r >> 2);
-                float v = p.alpha * unscale * acc[i][j][r] + bv;
-                if (p.accumulate) v += oldv[r];
-                if (p.res != nullptr && row < p.M && col < p.N) v += p.res[(long long)row * p.ldres + col];
-                if (p.relu) v = fmaxf(v, 0.f);
-                if (row < p.M && col < p.N) C[(long long)row * p.ldc + col] = v;
-                acc[i][j][r] = v;
-            }
-        }
-    }
+    unsigned short* __restrict__ Cb = reinterpret_cast<unsigned short*>(p.C);  // c_fmt 2: plain bf16 output (batch = splits = 1)
 
-    if (p.stats != nullptr) {
+    // BatchNorm partials from the FINAL values held in acc (accumulator layout)
+    auto emit_stats = [&]() {
         // BatchNorm partials per 128-row slab of the tile: column (mean, M2) over the slab's rows < M; with
         // stats_w == 4 also the column (min, max): the consumer derives max|BatchNorm(y)| - the fp16 scale of the
         // NEXT operand - from them before the apply pass runs (an affine map takes extremes to extremes)
@@ -443,7 +419,113 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 && STAGES == 2) ? 2 : (W
                 }
             }
         }
+    };
+
+    if constexpr (BM * BN * 4 <= STAGES * STAGE_SLOTS * 16) {
+        const bool pre = p.stats != nullptr;  // partials need the final values in the accumulator layout
+        if (p.wide_epilogue && (p.N & 3) == 0 && (p.ldc & 3) == 0 && (p.sC & 3) == 0 && (p.sSplit & 3) == 0 &&
+            (p.res == nullptr || (p.ldres & 3) == 0) && !(pre && (p.accumulate || p.res != nullptr))) {
+            // The tile goes through LDS so that a lane owns 4 consecutive columns and a wave stores whole rows of the tile
+            // (16-byte pieces of fp32, 8-byte pieces of bf16) and reads `accumulate` / `res` the same way - the accumulator
+            // layout itself has one column per lane: 4-byte (2-byte) stores, 128 (64) bytes per row and instruction.
+            if (pre) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int col = col_base + 32 * j;
+                    const float bv = (bias != nullptr && col < p.N) ? bias[col] : 0.f;
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const float v = p.alpha * unscale * acc[i][j][r] + bv;
+                            acc[i][j][r] = p.relu ? fmaxf(v, 0.f) : v;
+                        }
+                }
+                emit_stats();  // (ends with a barrier: the partial buffers in LDS are free again)
+            }
+            __syncthreads();  // every wave is done with the operand stages
+            float* Ct = reinterpret_cast<float*>(smem);  // [BM][BN]
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int rl = wm * (32 * TM) + 4 * khalf + i * 32 + (r & 3) + 8 * (r >> 2);
+                        Ct[rl * BN + wn * (32 * TN) + 32 * j + (lane & 31)] = pre ? acc[i][j][r] : p.alpha * unscale * acc[i][j][r];
+                    }
+            __syncthreads();
+            constexpr int C4 = BN / 4, RG = NW * 64 / C4;
+            const int c4 = tid % C4, rg = tid / C4;
+            const int col = n0 + 4 * c4;
+            float4 bv4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!pre && bias != nullptr && col < p.N) bv4 = *reinterpret_cast<const float4*>(bias + col);
+#pragma unroll
+            for (int ps = 0; ps < BM / RG; ++ps) {
+                const int rl = ps * RG + rg, row = m0 + rl;
+                if (row >= p.M || col >= p.N) continue;
+                float4 v = *reinterpret_cast<const float4*>(Ct + rl * BN + 4 * c4);
+                const long long at = (long long)row * p.ldc + col;
+                if (!pre) {
+                    v.x += bv4.x; v.y += bv4.y; v.z += bv4.z; v.w += bv4.w;
+                    if (p.accumulate) {
+                        if (p.c_fmt == 2) {
+                            const uint2 u = *reinterpret_cast<const uint2*>(Cb + at);
+                            v.x += __builtin_bit_cast(float, u.x << 16); v.y += __builtin_bit_cast(float, u.x & 0xffff0000u);
+                            v.z += __builtin_bit_cast(float, u.y << 16); v.w += __builtin_bit_cast(float, u.y & 0xffff0000u);
+                        } else {
+                            const float4 u = *reinterpret_cast<const float4*>(C + at);
+                            v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+                        }
+                    }
+                    if (p.res != nullptr) {
+                        const float4 rr = *reinterpret_cast<const float4*>(p.res + (long long)row * p.ldres + col);
+                        v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+                    }
+                    if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                }
+                if (p.c_fmt == 2) *reinterpret_cast<uint2*>(Cb + at) = make_uint2(cvt_pk_bf16(v.x, v.y), cvt_pk_bf16(v.z, v.w));
+                else *reinterpret_cast<float4*>(C + at) = v;
+            }
+            return;
+        }
     }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = col_base + 32 * j;
+        const float bv = (bias != nullptr && col < p.N) ? bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            float oldv[16];
+            if (p.accumulate) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = row_base + i * 32 + (r & 3) + 8 * (r >> 2);
+                    const long long at = (long long)row * p.ldc + col;
+                    if (row < p.M && col < p.N)
+                        oldv[r] = p.c_fmt == 2 ? __builtin_bit_cast(float, (unsigned)Cb[at] << 16) : C[at];
+                    else
+                        oldv[r] = 0.f;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row_base + i * 32 + (r & 3) + 8 * (r >> 2);
+                float v = p.alpha * unscale * acc[i][j][r] + bv;
+                if (p.accumulate) v += oldv[r];
+                if (p.res != nullptr && row < p.M && col < p.N) v += p.res[(long long)row * p.ldres + col];
+                if (p.relu) v = fmaxf(v, 0.f);
+                if (row < p.M && col < p.N) {
+                    const long long at = (long long)row * p.ldc + col;
+                    if (p.c_fmt == 2) Cb[at] = (unsigned short)(cvt_pk_bf16(v, 0.f) & 0xffffu);  // round to nearest even
+                    else C[at] = v;
+                }
+                acc[i][j][r] = v;
+            }
+        }
+    }
+
+    if (p.stats != nullptr) emit_stats();
 }
 
 // ---------------------------------------------------------------------------------------------------- weight gradients
@@ -954,6 +1036,11 @@ extern "C" int trid_gemm_p16(const trid_gemm_desc* d, int variant, void* stream_
     p.H = d->H; p.W = d->W; p.Cin = d->Cin;
     p.a_amax = d->a_amax; p.b_amax = d->b_amax;
     p.stats_w = d->stats_minmax ? 4 : 2;
+    p.c_fmt = d->c_format;
+    static const int wide_env = getenv("TRID_GEMM_WIDE_EPILOGUE") ? atoi(getenv("TRID_GEMM_WIDE_EPILOGUE")) : 1;  // (0: A/B runs)
+    p.wide_epilogue = wide_env;
+    TRID_REQUIRE(p.c_fmt == 0 || (p.c_fmt == 2 && d->batch == 1 && d->splits == 1 && !d->stats),
+                 "trid_gemm_p16: c_format must be 0, or 2 with batch == splits == 1 and no stats");
     if (d->a_mode == A_CONV) {
         TRID_REQUIRE(d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cin % bke == 0 && d->K == 9 * d->Cin && d->M % (d->H * d->W) == 0 && d->splits == 1,
                      "trid_gemm_p16: A_CONV needs Cin %% %d == 0, K == 9*Cin, M a multiple of H*W, splits == 1", bke);

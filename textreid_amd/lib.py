@@ -50,6 +50,7 @@ class GemmDesc(ctypes.Structure):
         ("a_amax", ctypes.c_void_p),
         ("b_amax", ctypes.c_void_p),
         ("stats_minmax", ctypes.c_int32),
+        ("c_format", ctypes.c_int32),
     ]
 
 

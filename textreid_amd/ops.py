@@ -111,6 +111,9 @@ def begin_capture():
 
 _finalize_ws = {}
 _finalize_ws_capture = {}
+# bf16 mode (conv precision 1): the residual blocks' DATA gradients (dL/d block output, dL/d conv input) are bf16 tensors,
+# as the gradients of bf16 tensors are under autocast; 0: fp32 gradient tensors, only the GEMM operands rounded (A/B runs)
+BF16_GRADS = os.environ.get("TRID_BF16_GRADS", "1") != "0"
 _FINALIZE_SPLIT = os.environ.get("TRID_BN_FINALIZE_SPLIT", "1") != "0"  # (0: always one workgroup per channel, for A/B runs)
 
 
@@ -273,6 +276,7 @@ def gemm_p16(A, B, C, M, N, K, ldc, conv=None, alpha=1.0, accumulate=False, bias
     d.ldres = ldres
     d.relu = 1 if relu else 0
     d.stats_minmax = 1 if minmax else 0
+    d.c_format = 2 if C.dtype == torch.bfloat16 else 0  # (data gradients of the bf16 mode are bf16 tensors)
     v = P16_VARIANT if variant is None else variant
     prof = PROFILE
     if prof is not None and N > 64:
@@ -349,22 +353,25 @@ def bn_apply_pool2_p16(y, st, bound, relu=True, fmt=1):
 
 def bn_bwd_p16(g, y, st, mask_mode, act=None, pooled=False, want_dres=False, fmt=1):
     """BatchNorm backward with dy written as a P16 tensor: the reduce pass also bounds max|dy| (triangle inequality
-    over per-channel maxima), the apply pass scales by that bound.  Returns (dy P16, dgamma, dbeta, dres)."""
+    over per-channel maxima), the apply pass scales by that bound.  Returns (dy P16, dgamma, dbeta, dres).
+    g: fp32, or (fmt 2) a bf16 tensor - dres, its masked copy, has g's dtype."""
     Bi, H, W, C = y.shape
     dg = empty((2, C), y)
     dgamma, dbeta = dg[0], dg[1]
     ws = _bn_ws(C, y)
     bound = None
+    g_fmt = 2 if g.dtype == torch.bfloat16 else 0
     if fmt == 1:
+        assert g_fmt == 0
         bound = amax_slot(y.device)
         call("trid_bn_bwd_reduce_bound_f32", _p(g), _p(y), _p(act), _p(st.mean), _p(st.invstd), _p(st.scale), _p(st.shift),
              mask_mode, 1 if pooled else 0, Bi, H, W, C, _p(dgamma), _p(dbeta), _p(ws), _p(bound), stream())
     else:
-        call("trid_bn_bwd_reduce_f32", _p(g), _p(y), _p(act), _p(st.mean), _p(st.invstd), _p(st.scale), _p(st.shift),
+        call("trid_bn_bwd_reduce_g_f32", _p(g), g_fmt, _p(y), _p(act), _p(st.mean), _p(st.invstd), _p(st.scale), _p(st.shift),
              mask_mode, 1 if pooled else 0, Bi, H, W, C, _p(dgamma), _p(dbeta), _p(ws), stream())
     dy = p16_empty(y.shape, y, fmt)
-    dres = torch.empty_like(y) if want_dres else None
-    call("trid_bn_bwd_apply_p16_f32", _p(g), _p(y), _p(act), _p(st.mean), _p(st.invstd), _p(st.scale), _p(st.shift),
+    dres = torch.empty(y.shape, dtype=g.dtype, device=y.device) if want_dres else None
+    call("trid_bn_bwd_apply_p16_f32", _p(g), g_fmt, _p(y), _p(act), _p(st.mean), _p(st.invstd), _p(st.scale), _p(st.shift),
          _p(dgamma), _p(dbeta), mask_mode, 1 if pooled else 0, Bi, H, W, C, _p(dy), fmt, _p(dres), _p(bound), stream())
     return P16(dy, bound, fmt), dgamma, dbeta, dres
 
@@ -606,10 +613,13 @@ def bn_apply_pool2(y, st, relu=True, amax=None):
 
 
 def avgpool2_bwd(g, dx=None, accumulate=False):
+    """g fp32 or bf16 (dx in the same dtype)."""
     Bi, Ho, Wo, C = g.shape
     if dx is None:
-        dx = empty((Bi, Ho * 2, Wo * 2, C), g)
-    call("trid_avgpool2_bwd_f32", _p(g), _p(dx), Bi, Ho * 2, Wo * 2, C, 1 if accumulate else 0, stream())
+        dx = empty((Bi, Ho * 2, Wo * 2, C), g, dtype=g.dtype)
+    assert dx.dtype == g.dtype
+    call("trid_avgpool2_bwd_f32", _p(g), _p(dx), Bi, Ho * 2, Wo * 2, C, 1 if accumulate else 0,
+         2 if g.dtype == torch.bfloat16 else 0, stream())
     return dx
 
 
