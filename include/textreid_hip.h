@@ -85,7 +85,8 @@ typedef struct trid_gemm_desc {
     const float* b_amax;   /* (trid_amax_f32); NULL = operand used unscaled (must then lie in fp16's range)      */
     int32_t stats_minmax;  /* trid_gemm_p16 only, with stats: partials are [..][N][4] = (mean, M2, min, max) per column */
     int32_t c_format;      /* trid_gemm_p16 only: 0 = C is fp32; 2 = C is a plain bf16 tensor (ldc in elements; read as such
-                            * with accumulate) - data gradients of the bf16 mode; needs batch == splits == 1, no stats */
+                            * with accumulate; BatchNorm partials are those of the ROUNDED values) - conv outputs and data
+                            * gradients of the bf16 mode; needs batch == splits == 1 */
 } trid_gemm_desc;
 
 int trid_gemm_f32(const trid_gemm_desc* d, void* stream);
@@ -175,9 +176,10 @@ int trid_bn_finalize_minmax_f32(const float* partials, int nparts, int rows_per_
 /* Tensor formats of these entry points: 0 = fp32, 1 = P16, 2 = plain bf16 (configs[3]'s arithmetic: the convolutions
  * of the residual blocks read bf16 operands; written here with round-to-nearest-even, no scale, bounds unused). */
 /* trid_bn_apply_f32 with the output in format fmt (1 / 2): P16 scaled for the bound bound_a[0] (+ bound_b[0] if not
- * NULL), bound_sum (may be NULL) receives that sum.  res_fmt: format of `res` (1 / 2: an identity residual; 1 needs
- * res_amax). */
-int trid_bn_apply_p16_f32(const float* y, const float* scale, const float* shift, const void* res, const float* rscale,
+ * NULL), bound_sum (may be NULL) receives that sum.  res_fmt: format of `res` (1: an identity residual, needs res_amax;
+ * 2: a bf16 identity residual, or with rscale / rshift the bf16 raw output of the downsample convolution).  y_fmt: 0, or
+ * 2 (bf16 mode: the conv output y is a bf16 tensor, written so by trid_gemm_p16 with c_format 2). */
+int trid_bn_apply_p16_f32(const void* y, int y_fmt, const float* scale, const float* shift, const void* res, const float* rscale,
                           const float* rshift, int res_fmt, const float* res_amax, void* out, int fmt, long long M, int C,
                           int relu, uint64_t* relu_mask, const float* bound_a, const float* bound_b, float* bound_sum,
                           void* stream);
@@ -210,14 +212,15 @@ int trid_bn_bwd_reduce_bound_f32(const float* g, const float* y, const float* ac
                                  int B, int H, int W, int C, float* dgamma, float* dbeta, float* ws, float* bound,
                                  void* stream);
 /* trid_bn_bwd_reduce_f32 on an incoming gradient of format g_fmt: 0 = fp32, 2 = plain bf16 (configs[3]'s bf16 mode: the
- * gradient of a bf16 tensor is a bf16 tensor - written so by trid_gemm_p16 with c_format 2) */
-int trid_bn_bwd_reduce_g_f32(const void* g, int g_fmt, const float* y, const float* act, const float* mean,
+ * gradient of a bf16 tensor is a bf16 tensor - written so by trid_gemm_p16 with c_format 2); y_fmt likewise for the conv
+ * output y (in that mode a bf16 tensor too, as under autocast) */
+int trid_bn_bwd_reduce_g_f32(const void* g, int g_fmt, const void* y, int y_fmt, const float* act, const float* mean,
                              const float* invstd, const float* scale, const float* shift, int mask_mode,
                              int pooled, int B, int H, int W, int C, float* dgamma, float* dbeta, float* ws,
                              void* stream);
 /* trid_bn_bwd_apply_f32 with dy written in format fmt (1: P16 scaled for bound[0]; 2: bf16); g - and dres, its masked
  * copy - in format g_fmt (0 / 2) */
-int trid_bn_bwd_apply_p16_f32(const void* g, int g_fmt, const float* y, const float* act, const float* mean, const float* invstd,
+int trid_bn_bwd_apply_p16_f32(const void* g, int g_fmt, const void* y, int y_fmt, const float* act, const float* mean, const float* invstd,
                               const float* scale, const float* shift, const float* dgamma, const float* dbeta,
                               int mask_mode, int pooled, int B, int H, int W, int C, void* dy, int fmt, void* dres,
                               const float* bound, void* stream);

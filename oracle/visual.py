@@ -21,7 +21,8 @@ BN_MOMENTUM = 0.1
 # FLOPs) takes its operands in bf16 - activations, filters and, in backward, the incoming gradient are rounded to bf16
 # (round-to-nearest-even) where the convolution reads them - and every block OUTPUT is a bf16 tensor (so the identity
 # residual of the next block reads the rounded value too); the gradient w.r.t. such a bf16 ACTIVATION tensor (a conv
-# input, a block output) is a bf16 tensor as well (as under autocast); products are exact, accumulation / BatchNorm /
+# input, a conv output, a block output) is a bf16 tensor as well (as under autocast), and so is the raw conv OUTPUT (the
+# BatchNorm statistics are those of the rounded tensor); products are exact, accumulation / BatchNorm arithmetic /
 # weight gradients / the 3-conv stem / the attention pool's own arithmetic / everything else stays fp32.  `with bf16_conv():` switches
 # the oracle to that arithmetic: the comparator of the HIP path's TRID_CONV_PRECISION=1 mode.
 BF16_CONV = False
@@ -65,21 +66,13 @@ class _RoundActivation(torch.autograd.Function):
         return _to_bf16(g)
 
 
-class _RoundIncomingGrad(torch.autograd.Function):
-    """identity whose backward rounds: the gradient arriving at a conv output is an operand of its two backward convs"""
-
-    @staticmethod
-    def forward(ctx, y):
-        return y.view_as(y)
-
-    @staticmethod
-    def backward(ctx, g):
-        return _to_bf16(g)
-
-
-def _conv(x, w, **kw):
+def _conv(x, w, round_input_grad=True, **kw):
     if BF16_CONV:
-        return _RoundIncomingGrad.apply(F.conv2d(_RoundActivation.apply(x), _RoundOperand.apply(w), **kw))
+        # the conv OUTPUT is a bf16 tensor too (BatchNorm sees the rounded values); the gradient arriving at it - an
+        # operand of the two backward convs - is rounded on its way in.  round_input_grad=False: the input is a block
+        # input, whose gradient (this conv's share + the shortcut's) is rounded ONCE where that tensor was produced
+        xin = _RoundActivation.apply(x) if round_input_grad else _RoundOperand.apply(x)
+        return _RoundActivation.apply(F.conv2d(xin, _RoundOperand.apply(w), **kw))
     return F.conv2d(x, w, **kw)
 
 
@@ -201,7 +194,7 @@ def _bn(st, p, x, training):
 
 def bottleneck(st, p, x, stride, has_down, training, taps=None):
     # m_resnet.py:54-67
-    out = _relu(_bn(st, p + ".bn1", _conv(x, st[p + ".conv1.weight"]), training), taps)
+    out = _relu(_bn(st, p + ".bn1", _conv(x, st[p + ".conv1.weight"], round_input_grad=False), training), taps)
     out = _relu(_bn(st, p + ".bn2", _conv(out, st[p + ".conv2.weight"], padding=1), training), taps)
     if stride > 1:
         out = F.avg_pool2d(out, stride)
@@ -248,6 +241,8 @@ def visual_forward(st, images, spec, training, taps=None):
     x = _relu(_bn(st, "bn2", F.conv2d(x, st["conv2.weight"], padding=1), training), taps)
     x = _relu(_bn(st, "bn3", F.conv2d(x, st["conv3.weight"], padding=1), training), taps)
     x = F.avg_pool2d(x, 2)
+    if BF16_CONV:
+        x = _RoundActivation.apply(x)  # the first block's input is a bf16 tensor like every other block's
     if taps is not None:
         taps["stem"] = x
     for p, inpl, planes, stride in block_plan(spec):

@@ -270,6 +270,28 @@ def test_bf16_gradient_tensors(ops):
         assert torch.equal(a[0].data, b[0].data) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
         if dres:
             assert b[3].dtype == torch.bfloat16 and torch.equal(b[3].float(), a[3])
+    # (2b) ... and on a bf16 conv output y (forward apply, pooled apply, backward): exact widenings again
+    y16 = _bf(yc)
+    yw = y16.float()
+    st16 = ops.bn_finalize(ops.conv1x1(yw, torch.eye(C, device="cuda"), stats=True)[1], B * H * W, gamma, beta, None, None)
+    res16 = _bf(dev(nhwc(R("bres", B, C, H, W))))
+    for kw in (dict(), dict(res=ops.P16(res16, None, 2)), dict(res=res16, res_st=bst)):
+        kw32 = dict(kw, res=kw["res"].float()) if "res_st" in kw else kw
+        a = ops.bn_apply_p16(yw, st16, None, relu=True, fmt=2, **kw32)
+        b = ops.bn_apply_p16(y16, st16, None, relu=True, fmt=2, **kw)
+        assert torch.equal(a.data, b.data)
+    assert torch.equal(ops.bn_apply_pool2_p16(yw, st16, None, fmt=2).data, ops.bn_apply_pool2_p16(y16, st16, None, fmt=2).data)
+    g = _bf(dev(nhwc(R("bgy", B, C, H, W))))
+    a, b = ops.bn_bwd_p16(g, yw, st16, 1, fmt=2), ops.bn_bwd_p16(g, y16, st16, 1, fmt=2)
+    assert torch.equal(a[0].data, b[0].data) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    # (2c) a conv writing a bf16 output: the BatchNorm partials are those of the ROUNDED tensor
+    xin = ops.p16_pack(dev(R("bxin", B * H * W, N)), None, 2)
+    yq = torch.empty(B * H * W, C, device="cuda", dtype=torch.bfloat16)
+    stq = ops.stats_buffer(B * H * W, C, yq)
+    ops.gemm_p16(xin, wt, yq, B * H * W, C, N, C, stats=stq)
+    fin = ops.bn_finalize(stq, B * H * W, gamma, beta, None, None)
+    ref = yq.float().double()
+    assert rel(fin.mean, ref.mean(0)) < 1e-5 and rel(fin.invstd, 1.0 / torch.sqrt(ref.var(0, unbiased=False) + 1e-5)) < 1e-5
     # (3) AvgPool backward, plain and accumulating
     g = _bf(dev(nhwc(R("bpg", B, C, H // 2, W // 2))))
     d32 = ops.avgpool2_bwd(g.float())

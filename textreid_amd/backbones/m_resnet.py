@@ -398,7 +398,7 @@ def block_forward_p16(blk, x, WP, dev, training, save, nbt, masks=None):
         out, rmask = out
         rec = (x, ya, sta, aa, yb, stb, ab, yc, stc, xd, yd, std, rmask)
     if masks is not None:
-        masks.extend([aa.unpack() > 0, (ops.bn_apply(yb, stb, relu=True) if stride > 1 else ab.unpack()) > 0, out.unpack() > 0])
+        masks.extend([aa.unpack() > 0, (ops.bn_apply(yb.float(), stb, relu=True) if stride > 1 else ab.unpack()) > 0, out.unpack() > 0])
     return out, rec
 
 

@@ -301,7 +301,7 @@ __global__ void bn_apply_kernel(const float4* __restrict__ y, const float4* __re
                                 float4* __restrict__ out, long long total4, int CQ, int relu,
                                 unsigned long long* __restrict__ mask, float* __restrict__ amax,
                                 const float* __restrict__ oa, const float* __restrict__ ob, float* __restrict__ osum,
-                                const float* __restrict__ res_amax) {
+                                const float* __restrict__ res_amax, int y_fmt) {
     unsigned am = 0;
     constexpr bool P16OUT = OFMT == 1;
     const float oscale = P16OUT ? p16_out_scale(oa, ob, osum) : 1.f;
@@ -309,7 +309,8 @@ __global__ void bn_apply_kernel(const float4* __restrict__ y, const float4* __re
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4;
          i += (long long)gridDim.x * blockDim.x) {
         const int cq = (int)(i % CQ);
-        float4 v = affine4(y[i], scale[cq], shift[cq]);
+        // y_fmt 2: the raw conv output itself is a bf16 tensor (bf16 mode)
+        float4 v = affine4(y_fmt == 2 ? bf16_load4(reinterpret_cast<const uint2*>(y), i) : y[i], scale[cq], shift[cq]);
         if (res != nullptr) {
             float4 r = RFMT == 1 ? p16_load4(reinterpret_cast<const uint2*>(res), i, CQ, rinv)
                      : RFMT == 2 ? bf16_load4(reinterpret_cast<const uint2*>(res), i) : res[i];
@@ -421,6 +422,7 @@ struct BnBwdArgs {
     const float4* shift;
     int mask_mode, pooled;
     int g_fmt;  // 0: g (and dres) fp32; 2: plain bf16 (configs[3]: gradients of bf16 tensors are bf16 tensors)
+    int y_fmt;  // 0: y fp32; 2: plain bf16 (configs[3]: the conv outputs themselves)
     int B, H, W, CQ;
     long long total4;  // B*H*W*CQ
     FastDiv fdW, fdH;
@@ -441,7 +443,7 @@ __device__ __forceinline__ void bn_bwd_elem(const BnBwdArgs& a, long long i, int
     } else {
         g = a.g_fmt == 2 ? bf16_load4(reinterpret_cast<const uint2*>(a.g), i) : a.g[i];
     }
-    const float4 yv = a.y[i];
+    const float4 yv = a.y_fmt == 2 ? bf16_load4(reinterpret_cast<const uint2*>(a.y), i) : a.y[i];
     const float4 mu = a.mean[cq], is = a.invstd[cq];
     xh = make_float4((yv.x - mu.x) * is.x, (yv.y - mu.y) * is.y, (yv.z - mu.z) * is.z, (yv.w - mu.w) * is.w);
     if (a.mask_mode == 1) {
@@ -698,11 +700,11 @@ extern "C" int trid_bn_apply_f32(const float* y, const float* scale, const float
                        (const float4*)y, (const float4*)scale, (const float4*)shift, (const float4*)res,
                        (const float4*)rscale, (const float4*)rshift, (float4*)out, total4, C / 4, relu,
                        (unsigned long long*)relu_mask, amax, (const float*)nullptr, (const float*)nullptr, (float*)nullptr,
-                       (const float*)nullptr);
+                       (const float*)nullptr, 0);
     return check_launch("trid_bn_apply_f32");
 }
 
-extern "C" int trid_bn_apply_p16_f32(const float* y, const float* scale, const float* shift, const void* res,
+extern "C" int trid_bn_apply_p16_f32(const void* y, int y_fmt, const float* scale, const float* shift, const void* res,
                                      const float* rscale, const float* rshift, int res_fmt, const float* res_amax, void* out,
                                      int fmt, long long M, int C, int relu, uint64_t* relu_mask, const float* bound_a,
                                      const float* bound_b, float* bound_sum, void* stream) {
@@ -710,7 +712,8 @@ extern "C" int trid_bn_apply_p16_f32(const float* y, const float* scale, const f
                  "trid_bn_apply_p16_f32: bad arguments (fmt 1 / 2, C%%32)");
     TRID_REQUIRE(res_fmt >= 0 && res_fmt <= 2 && (res_fmt != 1 || res_amax), "trid_bn_apply_p16_f32: bad residual format");
     TRID_REQUIRE((rscale == nullptr) == (rshift == nullptr), "trid_bn_apply_p16_f32: rscale/rshift both or none");
-    TRID_REQUIRE(!(res_fmt != 0 && rscale), "trid_bn_apply_p16_f32: a P16 / bf16 residual is an identity residual (no BatchNorm on it)");
+    TRID_REQUIRE(!(res_fmt == 1 && rscale), "trid_bn_apply_p16_f32: a P16 residual is an identity residual (no BatchNorm on it)");
+    TRID_REQUIRE(y_fmt == 0 || (y_fmt == 2 && fmt == 2), "trid_bn_apply_p16_f32: y_fmt is 0, or 2 in the bf16 mode (fmt 2)");
     TRID_REQUIRE(aligned16(y) && aligned16(out) && aligned16(scale) && aligned16(shift) && (!res || aligned16(res)), "trid_bn_apply_p16_f32: 16-byte alignment");
     const long long total4 = M * (C / 4);
     const dim3 grid(grid_for(total4, 256 * 4));
@@ -718,7 +721,7 @@ extern "C" int trid_bn_apply_p16_f32(const float* y, const float* scale, const f
     hipLaunchKernelGGL((bn_apply_kernel<OF, RF>), grid, dim3(256), 0, (hipStream_t)stream, (const float4*)y,              \
                        (const float4*)scale, (const float4*)shift, (const float4*)res, (const float4*)rscale,              \
                        (const float4*)rshift, (float4*)out, total4, C / 4, relu, (unsigned long long*)relu_mask,           \
-                       (float*)nullptr, bound_a, bound_b, bound_sum, res_amax)
+                       (float*)nullptr, bound_a, bound_b, bound_sum, res_amax, y_fmt)
     if (fmt == 1) {
         if (res_fmt == 1) TRID_BN_APPLY_P16(1, 1); else TRID_BN_APPLY_P16(1, 0);
     } else {
@@ -782,9 +785,9 @@ extern "C" long long trid_bn_bwd_ws_floats(int C) {
 
 static int bn_bwd_fill(BnBwdArgs& a, const float* g, const float* y, const float* act, const float* mean,
                        const float* invstd, const float* scale, const float* shift, int mask_mode, int pooled, int B,
-                       int H, int W, int C, int g_fmt = 0) {
+                       int H, int W, int C, int g_fmt = 0, int y_fmt = 0) {
     TRID_REQUIRE(g && y && mean && invstd && scale && shift, "bn_bwd: null pointer");
-    TRID_REQUIRE(g_fmt == 0 || g_fmt == 2, "bn_bwd: g_fmt must be 0 (fp32) or 2 (bf16)");
+    TRID_REQUIRE((g_fmt == 0 || g_fmt == 2) && (y_fmt == 0 || y_fmt == 2), "bn_bwd: g_fmt / y_fmt must be 0 (fp32) or 2 (bf16)");
     TRID_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "bn_bwd: bad shape");
     const int CQ = C / 4;
     TRID_REQUIRE(256 % CQ == 0 || CQ % 256 == 0, "bn_bwd: C/4 must divide 256 or be a multiple of 256 (C=%d)", C);
@@ -796,6 +799,7 @@ static int bn_bwd_fill(BnBwdArgs& a, const float* g, const float* y, const float
     a.scale = (const float4*)scale; a.shift = (const float4*)shift;
     a.mask_mode = mask_mode; a.pooled = pooled;
     a.g_fmt = g_fmt;
+    a.y_fmt = y_fmt;
     a.B = B; a.H = H; a.W = W; a.CQ = CQ;
     a.total4 = (long long)B * H * W * CQ;
     a.fdW = make_fastdiv((uint32_t)W);
@@ -807,15 +811,15 @@ extern "C" int trid_bn_bwd_reduce_f32(const float* g, const float* y, const floa
                                       const float* invstd, const float* scale, const float* shift, int mask_mode,
                                       int pooled, int B, int H, int W, int C, float* dgamma, float* dbeta, float* ws,
                                       void* stream) {
-    return trid_bn_bwd_reduce_g_f32(g, 0, y, act, mean, invstd, scale, shift, mask_mode, pooled, B, H, W, C, dgamma, dbeta, ws, stream);
+    return trid_bn_bwd_reduce_g_f32(g, 0, y, 0, act, mean, invstd, scale, shift, mask_mode, pooled, B, H, W, C, dgamma, dbeta, ws, stream);
 }
 
-extern "C" int trid_bn_bwd_reduce_g_f32(const void* g, int g_fmt, const float* y, const float* act, const float* mean,
+extern "C" int trid_bn_bwd_reduce_g_f32(const void* g, int g_fmt, const void* y, int y_fmt, const float* act, const float* mean,
                                         const float* invstd, const float* scale, const float* shift, int mask_mode,
                                         int pooled, int B, int H, int W, int C, float* dgamma, float* dbeta, float* ws,
                                         void* stream) {
     BnBwdArgs a;
-    int rc = bn_bwd_fill(a, (const float*)g, y, act, mean, invstd, scale, shift, mask_mode, pooled, B, H, W, C, g_fmt);
+    int rc = bn_bwd_fill(a, (const float*)g, (const float*)y, act, mean, invstd, scale, shift, mask_mode, pooled, B, H, W, C, g_fmt, y_fmt);
     if (rc) return rc;
     TRID_REQUIRE(dgamma && dbeta && ws, "trid_bn_bwd_reduce_f32: null output");
     const int grid = bn_bwd_grid(a.total4, a.CQ);
@@ -857,12 +861,12 @@ extern "C" int trid_bn_bwd_apply_f32(const float* g, const float* y, const float
     return check_launch("trid_bn_bwd_apply_f32");
 }
 
-extern "C" int trid_bn_bwd_apply_p16_f32(const void* g, int g_fmt, const float* y, const float* act, const float* mean,
+extern "C" int trid_bn_bwd_apply_p16_f32(const void* g, int g_fmt, const void* y, int y_fmt, const float* act, const float* mean,
                                          const float* invstd, const float* scale, const float* shift, const float* dgamma,
                                          const float* dbeta, int mask_mode, int pooled, int B, int H, int W, int C,
                                          void* dy, int fmt, void* dres, const float* bound, void* stream) {
     BnBwdArgs a;
-    int rc = bn_bwd_fill(a, (const float*)g, y, act, mean, invstd, scale, shift, mask_mode, pooled, B, H, W, C, g_fmt);
+    int rc = bn_bwd_fill(a, (const float*)g, (const float*)y, act, mean, invstd, scale, shift, mask_mode, pooled, B, H, W, C, g_fmt, y_fmt);
     if (rc) return rc;
     TRID_REQUIRE(dgamma && dbeta && dy && (fmt == 2 || bound) && (fmt == 1 || fmt == 2) && C % 32 == 0,
                  "trid_bn_bwd_apply_p16_f32: null pointer, fmt not 1 / 2 or C %% 32 != 0");

@@ -437,8 +437,10 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 && STAGES == 2) ? 2 : (W
                     for (int i = 0; i < TM; ++i)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
-                            const float v = p.alpha * unscale * acc[i][j][r] + bv;
-                            acc[i][j][r] = p.relu ? fmaxf(v, 0.f) : v;
+                            float v = p.alpha * unscale * acc[i][j][r] + bv;
+                            v = p.relu ? fmaxf(v, 0.f) : v;
+                            // a bf16 output: the partials are those of the tensor as stored
+                            acc[i][j][r] = p.c_fmt == 2 ? __builtin_bit_cast(float, cvt_pk_bf16(v, 0.f) << 16) : v;
                         }
                 }
                 emit_stats();  // (ends with a barrier: the partial buffers in LDS are free again)
@@ -520,7 +522,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 && STAGES == 2) ? 2 : (W
                     if (p.c_fmt == 2) Cb[at] = (unsigned short)(cvt_pk_bf16(v, 0.f) & 0xffffu);  // round to nearest even
                     else C[at] = v;
                 }
-                acc[i][j][r] = v;
+                acc[i][j][r] = p.c_fmt == 2 ? __builtin_bit_cast(float, cvt_pk_bf16(v, 0.f) << 16) : v;
             }
         }
     }
@@ -1039,8 +1041,8 @@ extern "C" int trid_gemm_p16(const trid_gemm_desc* d, int variant, void* stream_
     p.c_fmt = d->c_format;
     static const int wide_env = getenv("TRID_GEMM_WIDE_EPILOGUE") ? atoi(getenv("TRID_GEMM_WIDE_EPILOGUE")) : 1;  // (0: A/B runs)
     p.wide_epilogue = wide_env;
-    TRID_REQUIRE(p.c_fmt == 0 || (p.c_fmt == 2 && d->batch == 1 && d->splits == 1 && !d->stats),
-                 "trid_gemm_p16: c_format must be 0, or 2 with batch == splits == 1 and no stats");
+    TRID_REQUIRE(p.c_fmt == 0 || (p.c_fmt == 2 && d->batch == 1 && d->splits == 1),
+                 "trid_gemm_p16: c_format must be 0, or 2 with batch == splits == 1");
     if (d->a_mode == A_CONV) {
         TRID_REQUIRE(d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cin % bke == 0 && d->K == 9 * d->Cin && d->M % (d->H * d->W) == 0 && d->splits == 1,
                      "trid_gemm_p16: A_CONV needs Cin %% %d == 0, K == 9*Cin, M a multiple of H*W, splits == 1", bke);

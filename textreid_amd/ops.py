@@ -114,6 +114,9 @@ _finalize_ws_capture = {}
 # bf16 mode (conv precision 1): the residual blocks' DATA gradients (dL/d block output, dL/d conv input) are bf16 tensors,
 # as the gradients of bf16 tensors are under autocast; 0: fp32 gradient tensors, only the GEMM operands rounded (A/B runs)
 BF16_GRADS = os.environ.get("TRID_BF16_GRADS", "1") != "0"
+# ... and the raw conv outputs y of the residual blocks are bf16 tensors (BatchNorm statistics are those of the rounded
+# tensor, as under autocast); 0: y stays fp32 (A/B runs)
+BF16_Y = os.environ.get("TRID_BF16_Y", "1") != "0"
 _FINALIZE_SPLIT = os.environ.get("TRID_BN_FINALIZE_SPLIT", "1") != "0"  # (0: always one workgroup per channel, for A/B runs)
 
 
@@ -299,7 +302,7 @@ def conv_p16(x, w, conv3=False, stats=True):
     C = x.shape[-1]
     M = x.data.numel() // C
     N = w.shape[0]
-    y = empty(tuple(x.shape[:-1]) + (N,), x.data)
+    y = empty(tuple(x.shape[:-1]) + (N,), x.data, dtype=torch.bfloat16 if (x.fmt == 2 and BF16_Y) else torch.float32)
     mm = stats and x.fmt == 1  # bf16 operands need no scale, hence no extremes
     st = empty(((M + STATS_ROWS - 1) // STATS_ROWS, N, 4 if mm else 2), x.data) if stats else None
     if conv3:
@@ -323,16 +326,17 @@ def bn_finalize_minmax(partials, M, gamma, beta, running_mean, running_var, relu
 
 def bn_apply_p16(y, st, bound, relu=True, res=None, res_st=None, bound_res=None, want_mask=False, fmt=1):
     """act(bn(y) (+ res | bn(res))) written as a P16 tensor.  bound: device scalar >= max|bn(y)| (bn_finalize_minmax);
-    with a residual, bound_res bounds the residual term and the output's amax scalar is their sum.  res: fp32 raw
-    conv output (with res_st) or a P16 tensor (identity)."""
+    with a residual, bound_res bounds the residual term and the output's amax scalar is their sum.  res: raw conv
+    output (with res_st; fp32, or bf16 in the bf16 mode - like y) or a P16 tensor (identity)."""
     C = y.shape[-1]
     M = y.numel() // C
     out = p16_empty(y.shape, y, fmt)
     mask = torch.empty(((M * C // 4 + 63) // 64) * 4, dtype=torch.int64, device=y.device) if want_mask else None
     res_p16 = isinstance(res, P16)
     osum = amax_slot(y.device) if (res is not None and fmt == 1) else None
-    call("trid_bn_apply_p16_f32", _p(y), _p(st.scale), _p(st.shift), _p(res.data if res_p16 else res),
-         _p(res_st.scale) if res_st else None, _p(res_st.shift) if res_st else None, res.fmt if res_p16 else 0,
+    res_fmt = res.fmt if res_p16 else (2 if (res is not None and res.dtype == torch.bfloat16) else 0)
+    call("trid_bn_apply_p16_f32", _p(y), 2 if y.dtype == torch.bfloat16 else 0, _p(st.scale), _p(st.shift),
+         _p(res.data if res_p16 else res), _p(res_st.scale) if res_st else None, _p(res_st.shift) if res_st else None, res_fmt,
          _p(res.amax) if res_p16 else None, _p(out), fmt, M, C, 1 if relu else 0, _p(mask), _p(bound), _p(bound_res), _p(osum),
          stream())
     o = P16(out, (osum if res is not None else bound) if fmt == 1 else None, fmt)
@@ -346,7 +350,7 @@ def bn_apply_pool2_p16(y, st, bound, relu=True, fmt=1):
     Bi, H, W, C = src.shape
     out = p16_empty((Bi, H // 2, W // 2, C), src, fmt)
     call("trid_bn_apply_pool2_p16_f32", _p(src), _p(st.scale) if st else None, _p(st.shift) if st else None,
-         y.fmt if isinstance(y, P16) else 0, _p(y.amax) if isinstance(y, P16) else None, _p(out), fmt, Bi, H, W, C,
+         y.fmt if isinstance(y, P16) else (2 if y.dtype == torch.bfloat16 else 0), _p(y.amax) if isinstance(y, P16) else None, _p(out), fmt, Bi, H, W, C,
          1 if (relu and st is not None) else 0, _p(bound), stream())
     return P16(out, bound if fmt == 1 else None, fmt)
 
@@ -361,17 +365,18 @@ def bn_bwd_p16(g, y, st, mask_mode, act=None, pooled=False, want_dres=False, fmt
     ws = _bn_ws(C, y)
     bound = None
     g_fmt = 2 if g.dtype == torch.bfloat16 else 0
+    y_fmt = 2 if y.dtype == torch.bfloat16 else 0
     if fmt == 1:
-        assert g_fmt == 0
+        assert g_fmt == 0 and y_fmt == 0
         bound = amax_slot(y.device)
         call("trid_bn_bwd_reduce_bound_f32", _p(g), _p(y), _p(act), _p(st.mean), _p(st.invstd), _p(st.scale), _p(st.shift),
              mask_mode, 1 if pooled else 0, Bi, H, W, C, _p(dgamma), _p(dbeta), _p(ws), _p(bound), stream())
     else:
-        call("trid_bn_bwd_reduce_g_f32", _p(g), g_fmt, _p(y), _p(act), _p(st.mean), _p(st.invstd), _p(st.scale), _p(st.shift),
+        call("trid_bn_bwd_reduce_g_f32", _p(g), g_fmt, _p(y), y_fmt, _p(act), _p(st.mean), _p(st.invstd), _p(st.scale), _p(st.shift),
              mask_mode, 1 if pooled else 0, Bi, H, W, C, _p(dgamma), _p(dbeta), _p(ws), stream())
     dy = p16_empty(y.shape, y, fmt)
     dres = torch.empty(y.shape, dtype=g.dtype, device=y.device) if want_dres else None
-    call("trid_bn_bwd_apply_p16_f32", _p(g), g_fmt, _p(y), _p(act), _p(st.mean), _p(st.invstd), _p(st.scale), _p(st.shift),
+    call("trid_bn_bwd_apply_p16_f32", _p(g), g_fmt, _p(y), y_fmt, _p(act), _p(st.mean), _p(st.invstd), _p(st.scale), _p(st.shift),
          _p(dgamma), _p(dbeta), mask_mode, 1 if pooled else 0, Bi, H, W, C, _p(dy), fmt, _p(dres), _p(bound), stream())
     return P16(dy, bound, fmt), dgamma, dbeta, dres
 
