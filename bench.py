@@ -509,16 +509,16 @@ def main():
     # measurement of the committed build, not a counter read of this run: `traffic_source` names the file.
     traffic, traffic_note, traffic_src = None, None, None
     here = os.path.dirname(os.path.abspath(__file__))
-    for fn in ("r03i_pmc_hbm_traffic.txt", "r03_pmc_hbm_traffic.txt", "r02d_pmc_hbm_traffic.txt", "r02c_pmc_hbm_traffic.txt", "r02a_pmc_hbm_traffic.txt", "r01j_pmc_hbm_traffic.txt"):
+    for fn in ("r03k_pmc_hbm_traffic.txt", "r03_pmc_hbm_traffic.txt", "r02d_pmc_hbm_traffic.txt", "r02c_pmc_hbm_traffic.txt", "r02a_pmc_hbm_traffic.txt", "r01j_pmc_hbm_traffic.txt"):
         try:
             for line in open(os.path.join(here, "profiles", fn)):
                 f = line.split()
                 want = "0, 16, 128>(trid::GemmParams)" if cprec == 16 else "0, 3, 128>(trid::GemmParams)"
-                hit = ("gemm_p16_kernel<2, 128, 128, 2, 4, 2>" in line) if p16 else ("gemm_bf16s_kernel<2," in line and line.rstrip().endswith(want))
+                hit = ("gemm_p16_kernel<2, 128, 128, 2, 4, 2, 2" in line) if p16 else ("gemm_bf16s_kernel<2," in line and line.rstrip().endswith(want))
                 if prec == 6 and len(f) > 5 and hit:
                     traffic = (float(f[2]) + float(f[3])) * 1e6
                     traffic_src = "profiles/" + fn
-                    traffic_note = "read %s MB + write %s MB per launch (separate --pmc passes, stored; average over all launches of this kernel incl. layer1); algorithmic input + weights + output of the layer2-4 shapes ~ 58 + 9 + 58 MB" % (f[2], f[3])
+                    traffic_note = "read %s MB + write %s MB per launch (separate --pmc passes, stored; average over all launches of this kernel incl. layer1); algorithmic input + weights + output of the layer2-4 shapes ~ 58 + 9 + 58 MB; + the (mean, M2, min, max) BatchNorm partials" % (f[2], f[3])
                     break
         except OSError:
             pass
