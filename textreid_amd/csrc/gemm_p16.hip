@@ -20,6 +20,7 @@
 // Pipeline: STAGES LDS buffers, DMA issued STAGES-1 tiles ahead, ONE barrier per K tile, counted s_waitcnt vmcnt
 // (never 0 in steady state for STAGES >= 3), raw s_barrier so in-flight DMA survives the barrier.
 
+#include <algorithm>
 #include <mutex>
 
 #include "split_common.h"
@@ -877,10 +878,13 @@ static int launch_p16(GemmParams& p, hipStream_t stream) {
     p.mblocks = (p.M + BM - 1) / BM;
     p.nblocks = (p.N + BN - 1) / BN;
     dim3 grid((unsigned)(p.mblocks * p.nblocks), 1, (unsigned)(p.batch * p.splits));
-    constexpr size_t lds = (size_t)STAGES * (BM + BN) * 128;
+    // TRID_GEMM_LDS_PAD=<KB>: request at least that much LDS per workgroup - an occupancy knob for experiments (e.g. 96:
+    // one workgroup per CU, which leaves registers and wave slots to the HBM-bound kernels of the other streams)
+    static const size_t pad = getenv("TRID_GEMM_LDS_PAD") ? (size_t)atoi(getenv("TRID_GEMM_LDS_PAD")) * 1024 : 0;
+    const size_t lds = std::max((size_t)STAGES * (BM + BN) * 128, pad);
     static std::once_flag once;
     static hipError_t attr_err = hipSuccess;
-    std::call_once(once, [] {
+    std::call_once(once, [lds] {
         if (lds > 48 * 1024)
             attr_err = hipFuncSetAttribute((const void*)gemm_p16_kernel<AMODE, BM, BN, WM, WN, STAGES, PL, PP>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -950,10 +954,11 @@ static int launch_p16_wgrad(GemmParams& p, hipStream_t stream) {
     p.xcd_split = (xcd_env && p.splits >= 8) ? 1 : 0;
     dim3 grid((unsigned)(p.mblocks * p.nblocks), 1, (unsigned)p.splits);
     if (p.xcd_split) grid = dim3((unsigned)(p.mblocks * p.nblocks) * 8u * (unsigned)((p.splits + 7) / 8), 1, 1);
-    constexpr size_t lds = (size_t)STAGES * ((BM / 32) + 4) * 4096;  // (same bytes for both operand formats)
+    static const size_t pad = getenv("TRID_WGRAD_LDS_PAD") ? (size_t)atoi(getenv("TRID_WGRAD_LDS_PAD")) * 1024 : 0;  // (see launch_p16)
+    const size_t lds = std::max((size_t)STAGES * ((BM / 32) + 4) * 4096, pad);  // (same bytes for both operand formats)
     static std::once_flag once;
     static hipError_t attr_err = hipSuccess;
-    std::call_once(once, [] {
+    std::call_once(once, [lds] {
         if (lds > 48 * 1024)
             attr_err = hipFuncSetAttribute((const void*)gemm_p16_wgrad_kernel<BMODE, BM, STAGES, PL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     });
