@@ -350,3 +350,41 @@ def test_image_resize_restatement_is_pillow_bit_exact():
         b0, k0 = OT.resample_coeffs(n_in, n_out)
         b1, k1 = resample_tables(n_in, n_out)
         assert np.array_equal(b0, b1) and np.array_equal(k0, k1), (n_in, n_out)
+
+
+def test_wgrad_split_rule():
+    """ops._wgrad_splits: one >= 90 %-full round of resident workgroups when the tile count allows it, else two; counts
+    >= 8 are multiples of 8 (every XCD owns whole splits); at least 512 reduction rows per split."""
+    from textreid_amd.ops import _wgrad_splits
+
+    B = 128
+    cases = {  # (tiles, pixels, slots) -> splits, the RN50 layer shapes at B=128 (profiles/r03i_wgrad_split_sweep.txt)
+        (9, B * 48 * 16, 512): 56, (9, B * 96 * 32, 512): 56, (36, B * 24 * 8, 512): 24, (144, B * 12 * 4, 512): 7,
+        (5, B * 96 * 32, 768): 152, (16, B * 24 * 8, 512): 32, (64, B * 12 * 4, 512): 8, (2, B * 96 * 32, 512): 256,
+    }
+    for (tiles, K, slots), want in cases.items():
+        assert _wgrad_splits(tiles, K, slots=slots) == want, (tiles, K, slots)
+    for tiles in (1, 3, 7, 20, 100, 500):
+        for K in (300, 4096, 100000, 2000000):
+            s = _wgrad_splits(tiles, K)
+            assert s >= 1 and (s < 8 or s % 8 == 0) and s <= max(1, K // 512) and s * tiles <= 2 * 512 + tiles
+
+
+def test_oracle_bf16_mode_rounding_points():
+    """oracle.visual.bf16_conv (the definition of configs[3]'s bf16 mode): conv outputs, block outputs and the gradients
+    w.r.t. them are bf16-representable; filters' gradients are NOT rounded; outside the context nothing is rounded."""
+    import oracle.visual as OV
+
+    torch.manual_seed(0)
+    x = torch.randn(2, 8, 6, 4, requires_grad=True)
+    w = torch.randn(8, 8, 3, 3, requires_grad=True)
+    rep = lambda t: torch.equal(t.to(torch.bfloat16).to(t.dtype), t)
+    with OV.bf16_conv():
+        y = OV._conv(x, w, padding=1)
+        assert rep(y.detach())
+        (y * torch.randn_like(y)).sum().backward()
+    assert rep(x.grad) and not rep(w.grad)
+    x.grad = None
+    y = OV._conv(x, w, padding=1)
+    (y * torch.randn_like(y)).sum().backward()
+    assert not rep(y.detach()) and not rep(x.grad)
