@@ -911,6 +911,7 @@ static int pick_p16(GemmParams& p, int variant, int planes, hipStream_t stream) 
         case 3: return launch_p16<AMODE, 128, 128, 2, 4, 2>(p, stream);   // 8 waves of 64x32, 2 stages (64 KB): 2 WG / CU
         case 4: return launch_p16<AMODE, 256, 128, 4, 2, 2>(p, stream);   // 8 waves of 64x64, 2 stages (96 KB)
         case 5: return launch_p16<AMODE, 128, 128, 2, 4, 3>(p, stream);   // 8 waves of 64x32, 3 stages (96 KB)
+        case 8: return launch_p16<AMODE, 128, 64, 2, 2, 2>(p, stream);    // 4 waves of 64x32, 2 stages (48 KB): 3 WG / CU
         case 6: return launch_p16<AMODE, 128, 128, 2, 4, 2, 2, true>(p, stream);  // variant 3 with the ping-pong schedule
         case 7: return launch_p16<AMODE, 256, 128, 4, 2, 2, 2, true>(p, stream);  // variant 4 with the ping-pong schedule
         default: return launch_p16<AMODE, 128, 128, 2, 2, 2>(p, stream);  // 4 waves of 64x64, 2 stages (64 KB): 2 WG / CU
