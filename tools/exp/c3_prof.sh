@@ -1,7 +1,7 @@
+# rocprofv3 kernel stats of ten configs[3]-shape steps (RN101, K=65536, B=128) in the bf16 mode and the fp32-class default
 cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/c3prof; rm -rf $OUT; mkdir -p $OUT
-for g in 0 1; do
-export TRID_BF16_GRADS=$g
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ks$g -- python3 $GRAFT_REPO_ROOT/tools/exp/c3_prof.py 1 > $OUT/log$g 2>&1
-cp $(find $OUT/ks$g -name "*kernel_stats.csv" | head -1) $OUT/stats_bf16_g$g.csv; rm -rf $OUT/ks$g
+for prec in 1 16; do
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ks$prec -- python3 $GRAFT_REPO_ROOT/tools/exp/c3_prof.py $prec > $OUT/log$prec 2>&1
+cp $(find $OUT/ks$prec -name "*kernel_stats.csv" | head -1) $OUT/stats_prec$prec.csv; rm -rf $OUT/ks$prec
 done
