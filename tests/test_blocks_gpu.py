@@ -206,3 +206,69 @@ def test_stem_b128_unstructured_masks(gpu):
     assert flips <= FLIP_FRACTION * total and fmax <= FLIP_MAGNITUDE, (flips, total, fmax)
     bad = {k: v for k, v in errs.items() if not v <= TOL}
     assert not bad, bad
+
+
+BF16_BLOCKS = [RN50_BLOCKS[1], RN50_BLOCKS[2], RN50_BLOCKS[5]]  # identity / strided + downsample / deep identity
+
+
+@pytest.mark.parametrize("name,inpl,planes,stride,H,W", BF16_BLOCKS, ids=[b[0] for b in BF16_BLOCKS])
+def test_bottleneck_bf16_mode(gpu, name, inpl, planes, stride, H, W):
+    """configs[3]'s bf16 mode on one Bottleneck (B = 32, He-style weights, unstructured masks): bf16 operands written
+    by their producers, bf16 conv outputs, bf16 data gradients - against `oracle.visual.bf16_conv` (the definition of
+    the mode) in fp64 with the HIP path's ReLU decisions imposed.  Rounding to bf16 is a step function, so two correct
+    evaluations differ wherever an fp32-level difference straddles a rounding boundary; the bound is therefore the
+    oracle's own fp32-vs-fp64 spread in that arithmetic (3x, floor 1e-3), as in test_config3_rn101_k65536_bf16."""
+    from textreid_amd import ops
+    from textreid_amd.backbones import m_resnet as M
+
+    B, seed = 32, 13
+    blk = M.Bottleneck(inpl, planes, stride)
+    has_down = blk.downsample is not None
+    shapes = {k: tuple(v.shape) for k, v in blk.state_dict().items()}
+    st = {}
+    for k, shp in shapes.items():
+        st[name + "." + k] = torch.zeros((), dtype=torch.int64) if k.endswith("num_batches_tracked") else OF.fill(name + "." + k, shp, seed)
+    blk.load_state_dict({k: st[name + "." + k].clone() for k in shapes})
+    blk = blk.to(gpu).train()
+    for m in blk.modules():
+        if isinstance(m, torch.nn.Conv2d) and m.kernel_size == (3, 3):
+            m.weight.data = m.weight.data.contiguous(memory_format=torch.channels_last)
+    bf = lambda t: t.to(torch.bfloat16).to(t.dtype)
+    x = bf(F.relu(_randn((B, inpl, H, W), seed)))  # a block input IS a bf16 tensor in this mode
+    Ho, Wo = H // stride, W // stride
+    gout = _randn((B, planes * 4, Ho, Wo), seed + 1)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(gpu)
+    gd = gout.permute(0, 2, 3, 1).contiguous().to(gpu).to(torch.bfloat16)  # the gradient of a bf16 block output
+    WA = M.weight_amax(blk)
+    nbt, masks, G = [], [], {}
+    ws = M._WgradStream(gpu)
+    outp, rec = M.block_forward_p16(blk, ops.p16_pack(xd, None, 2), M.p16_weights(blk, WA, False, 2), gpu, True, True, nbt, masks)
+    assert rec[1].dtype == torch.bfloat16  # the conv outputs are stored as bf16 tensors
+    dx = M.block_backward_p16(blk, rec, gd, M.p16_weights(blk, WA, True, 2), ws, G)
+    assert dx.dtype == torch.bfloat16
+    ws.join()
+    torch.cuda.synchronize()
+    forced = [m_.permute(0, 3, 1, 2).cpu() for m_ in masks]
+
+    def run(dtype):
+        with OV.bf16_conv():
+            o, dxr, g, s, taps = _oracle_block(st, name, x, gout, stride, has_down, dtype, forced)
+        return o, bf(dxr), g, s, taps  # (a block input's gradient is rounded where that tensor was produced)
+
+    o64, dx64, g64, s64, taps = run(torch.float64)
+    o32, dx32, g32, s32, _ = run(torch.float32)
+    named = dict(blk.named_parameters())
+    sd = blk.state_dict()
+    hip, spread = {"out": relmax(outp.unpack().permute(0, 3, 1, 2), o64), "dx": relmax(dx.float().permute(0, 3, 1, 2), dx64)}, \
+                  {"out": relmax(o32, o64), "dx": relmax(dx32, dx64)}
+    for k, p in named.items():
+        hip["grad:" + k], spread["grad:" + k] = relmax(G[id(p)].reshape(p.shape), g64[name + "." + k]), relmax(g32[name + "." + k], g64[name + "." + k])
+    for k in sd:
+        if k.endswith(("running_mean", "running_var")):
+            hip["state:" + k], spread["state:" + k] = relmax(sd[k], s64[name + "." + k]), relmax(s32[name + "." + k], s64[name + "." + k])
+    ratio = {k: hip[k] / max(spread[k], TOL / 3) for k in hip}
+    worst = sorted(ratio, key=ratio.get)[-3:]
+    print("%s bf16 mode B=%d: %d ReLU decisions of %d differ from the fp64 oracle's; HIP error / oracle fp32-vs-fp64 spread: worst %s" % (
+        name, B, taps.get("flips", 0), taps["relu_elems"], [(k, "%.1e vs %.1e" % (hip[k], spread[k])) for k in worst]))
+    bad = {k: (hip[k], spread[k]) for k in hip if not hip[k] <= max(TOL, 3.0 * spread[k])}
+    assert not bad, bad
