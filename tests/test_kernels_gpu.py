@@ -234,6 +234,23 @@ def test_bn_eval_and_pool(ops):
     assert rel(dx.permute(0, 3, 1, 2), yr.grad) < 1e-6
 
 
+@pytest.mark.parametrize("M", [4096, 128 * 1100 + 37])
+def test_bn_finalize_large_mean_offset(ops, M):
+    """Channels whose mean is hundreds of standard deviations from zero: the merge of the per-tile (mean, M2) partials
+    must only ever subtract means (Chan) - an E[x^2] - mean^2 form amplifies the fp32 rounding of the partial means
+    by (mean / std)^2 = 1e5 here.  Both forms of the kernel: one launch (32 parts) and range sums + merge (1101 parts)."""
+    C = 64
+    g = torch.Generator().manual_seed(5)
+    y = torch.randn(M, C, generator=g) * torch.linspace(0.5, 2.0, C) + torch.linspace(-300.0, 300.0, C)
+    yd, st = ops.conv1x1(dev(y), torch.eye(C, device="cuda"), stats=True, prec=0)  # exact fp32 MFMA: yd == y
+    fin = ops.bn_finalize(st, M, torch.ones(C, device="cuda"), torch.zeros(C, device="cuda"), None, None)
+    ref = yd.double()
+    assert rel(fin.mean, ref.mean(0)) < 1e-6
+    var = ref.var(0, unbiased=False)
+    got = 1.0 / fin.invstd.double() ** 2 - 1e-5
+    assert float(((got - var).abs() / var).max()) < 1e-4
+
+
 def _bf(t):
     return t.to(torch.bfloat16)
 

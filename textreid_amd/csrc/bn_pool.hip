@@ -92,17 +92,17 @@ __global__ void stem_im2col_kernel(const float* __restrict__ img, float* __restr
 }
 
 // ---------------------------------------------------------------- BN finalize
-// The per-tile (mean_b, M2_b) partials (n_b rows each) of a channel combine exactly as
-//     mean = sum n_b mean_b / N,      M2 = sum (M2_b + n_b mean_b^2) - N mean^2,
-// evaluated in fp64 in ONE sweep (the subtraction loses log2(N mean^2 / M2) of fp64's 53 bits: nothing next to the
-// fp32 partials).  pw: floats per (part, channel): 2 = (mean, M2), 4 = (mean, M2, min, max).  With the extremes the
+// The per-tile (n_b, mean_b, M2_b) partials of a channel are merged pairwise with Chan's formula in fp64,
+//     n = na + nb,  d = mean_b - mean_a,  mean = mean_a + d nb / n,  M2 = M2_a + M2_b + d^2 na nb / n,
+// which only ever subtracts MEANS (an E[x^2] - mean^2 form would amplify the fp32 rounding of the partial means by
+// (mean / std)^2).  pw: floats per (part, channel): 2 = (mean, M2), 4 = (mean, M2, min, max).  With the extremes the
 // largest magnitude of act(y * scale + shift) over the channel is known exactly before the apply pass (an affine map
 // takes extremes to extremes): folded over the channels into amax_out (zeroed by the caller; integer atomicMax on the
 // bit pattern of a non-negative float: order-independent).
 //   * up to ~1000 parts: one workgroup per channel (CH = 1), one launch.
 //   * the layers with thousands of parts (stem, layer1: M = 4e5..1.6e6 rows): a workgroup owns a channel OCTET (CH = 8:
 //     with 2 / 4 floats per (part, channel) a contiguous 64 / 128 bytes of every part - whole lines) and one of S ranges
-//     of the parts; the range sums go to `scratch` and a second small launch merges them in range order.  (A single
+//     of the parts; the range results go to `scratch` and a second small launch merges them in range order.  (A single
 //     launch with a last-arriver ticket was measured SLOWER: its device-scope release / acquire fences write back and
 //     invalidate the whole L2 of an XCD under the GEMMs running beside it.)
 struct BnFinalizeOut {
@@ -119,12 +119,22 @@ struct BnFinalizeOut {
     float* amax_out;  // null: no bound
 };
 
-__device__ __forceinline__ void bn_finalize_channel(const BnFinalizeOut& f, int c, long long M, double s0, double s1, float lo,
-                                                    float hi) {
-    const double nt = (double)M;
-    const double mu = s0 / nt;
-    const double m2 = fmax(s1 - nt * mu * mu, 0.0);
-    const double var = m2 / nt;
+struct Moments {
+    double n, mean, m2;
+};
+__device__ __forceinline__ void chan_merge(Moments& a, double nb, double mb, double qb) {
+    const double nt = a.n + nb;
+    if (nt > 0.0) {
+        const double d = mb - a.mean;
+        a.mean += d * (nb / nt);
+        a.m2 += qb + d * d * (a.n * nb / nt);
+        a.n = nt;
+    }
+}
+
+__device__ __forceinline__ void bn_finalize_channel(const BnFinalizeOut& f, int c, const Moments& m, float lo, float hi) {
+    const double nt = m.n, mu = m.mean;
+    const double var = m.m2 / nt;
     const float invstd = (float)(1.0 / sqrt(var + (double)f.eps));
     const float sc = f.gamma[c] * invstd;
     const float shf = f.beta[c] - (float)mu * sc;
@@ -138,18 +148,19 @@ __device__ __forceinline__ void bn_finalize_channel(const BnFinalizeOut& f, int 
         atomicMax(reinterpret_cast<unsigned*>(f.amax_out), __builtin_bit_cast(unsigned, bound));
     }
     if (f.running_mean != nullptr) {
-        const double unb = nt > 1.0 ? m2 / (nt - 1.0) : var;
+        const double unb = nt > 1.0 ? m.m2 / (nt - 1.0) : var;
         f.running_mean[c] = (1.f - f.momentum) * f.running_mean[c] + f.momentum * (float)mu;
         f.running_var[c] = (1.f - f.momentum) * f.running_var[c] + f.momentum * (float)unb;
     }
 }
 
-// grid: ceil(C / CH) * S workgroups; S == 1: finalizes; S > 1: range sums to scratch [C groups][S][CH][4] doubles
+// grid: ceil(C / CH) * S workgroups; S == 1: finalizes; S > 1: range results to scratch [C groups][S][CH][4] doubles
+// (n, mean, M2, the (min, max) pair packed into the fourth)
 template <int CH>
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partials, int nparts, int rows_per_part,
                                                           long long M, int C, int pw, int S, double* __restrict__ scratch,
                                                           BnFinalizeOut f) {
-    __shared__ double sh0[4][CH], sh1[4][CH];
+    __shared__ double sn[4][CH], sm[4][CH], sq[4][CH];
     __shared__ float slo[4][CH], shi[4][CH];
     const int O = (C + CH - 1) / CH;
     const int o = blockIdx.x % O, r = blockIdx.x / O;
@@ -157,69 +168,68 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     const int c = o * CH + cl;
     const int per = (nparts + S - 1) / S;
     const int begin = r * per, end = min(nparts, begin + per);
-    double s0 = 0.0, s1 = 0.0;
+    Moments m{0.0, 0.0, 0.0};
     float lo = INFINITY, hi = -INFINITY;
     if (c < C) {
         for (int p = begin + sl; p < end; p += 256 / CH) {
             const long long rows_left = M - (long long)p * rows_per_part;
             const double nb = (double)(rows_left < rows_per_part ? rows_left : rows_per_part);
             const float* e = partials + ((long long)p * C + c) * pw;
-            double mb, m2b;
             if (pw == 4) {
                 const float4 v = *reinterpret_cast<const float4*>(e);
-                mb = (double)v.x; m2b = (double)v.y;
+                chan_merge(m, nb, (double)v.x, (double)v.y);
                 lo = fminf(lo, v.z);
                 hi = fmaxf(hi, v.w);
             } else {
                 const float2 v = *reinterpret_cast<const float2*>(e);
-                mb = (double)v.x; m2b = (double)v.y;
+                chan_merge(m, nb, (double)v.x, (double)v.y);
             }
-            s0 += nb * mb;
-            s1 += m2b + nb * mb * mb;
         }
     }
 #pragma unroll
     for (int x = CH; x < 64; x <<= 1) {  // the lanes of a wave that hold the same channel
-        s0 += __shfl_xor(s0, x, 64);
-        s1 += __shfl_xor(s1, x, 64);
+        chan_merge(m, __shfl_xor(m.n, x, 64), __shfl_xor(m.mean, x, 64), __shfl_xor(m.m2, x, 64));
         lo = fminf(lo, __shfl_xor(lo, x, 64));
         hi = fmaxf(hi, __shfl_xor(hi, x, 64));
     }
     if ((tid & 63) < CH) {
-        sh0[tid >> 6][cl] = s0; sh1[tid >> 6][cl] = s1;
+        sn[tid >> 6][cl] = m.n; sm[tid >> 6][cl] = m.mean; sq[tid >> 6][cl] = m.m2;
         slo[tid >> 6][cl] = lo; shi[tid >> 6][cl] = hi;
     }
     __syncthreads();
     if (tid < CH && c < C) {
-        s0 = (sh0[0][tid] + sh0[1][tid]) + (sh0[2][tid] + sh0[3][tid]);
-        s1 = (sh1[0][tid] + sh1[1][tid]) + (sh1[2][tid] + sh1[3][tid]);
-        lo = fminf(fminf(slo[0][tid], slo[1][tid]), fminf(slo[2][tid], slo[3][tid]));
-        hi = fmaxf(fmaxf(shi[0][tid], shi[1][tid]), fmaxf(shi[2][tid], shi[3][tid]));
+        m = Moments{sn[0][tid], sm[0][tid], sq[0][tid]};
+        lo = slo[0][tid]; hi = shi[0][tid];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            chan_merge(m, sn[w][tid], sm[w][tid], sq[w][tid]);
+            lo = fminf(lo, slo[w][tid]);
+            hi = fmaxf(hi, shi[w][tid]);
+        }
         if (S == 1) {
-            bn_finalize_channel(f, c, M, s0, s1, lo, hi);
+            bn_finalize_channel(f, c, m, lo, hi);
         } else {
             double* d = scratch + (((long long)o * S + r) * CH + tid) * 4;
-            d[0] = s0; d[1] = s1; d[2] = (double)lo; d[3] = (double)hi;
+            d[0] = m.n; d[1] = m.mean; d[2] = m.m2;
+            d[3] = __hiloint2double(__float_as_int(hi), __float_as_int(lo));
         }
     }
 }
 
 template <int CH>
-__global__ __launch_bounds__(64) void bn_finalize_merge_kernel(const double* __restrict__ scratch, int S, long long M, int C,
-                                                               BnFinalizeOut f) {
+__global__ __launch_bounds__(64) void bn_finalize_merge_kernel(const double* __restrict__ scratch, int S, int C, BnFinalizeOut f) {
     const int c = blockIdx.x * 64 + threadIdx.x;
     if (c >= C) return;
     const int o = c / CH, cl = c % CH;
-    double s0 = 0.0, s1 = 0.0;
+    Moments m{0.0, 0.0, 0.0};
     float lo = INFINITY, hi = -INFINITY;
     for (int r = 0; r < S; ++r) {
         const double* d = scratch + (((long long)o * S + r) * CH + cl) * 4;
-        s0 += d[0];
-        s1 += d[1];
-        lo = fminf(lo, (float)d[2]);
-        hi = fmaxf(hi, (float)d[3]);
+        chan_merge(m, d[0], d[1], d[2]);
+        lo = fminf(lo, __int_as_float(__double2loint(d[3])));
+        hi = fmaxf(hi, __int_as_float(__double2hiint(d[3])));
     }
-    bn_finalize_channel(f, c, M, s0, s1, lo, hi);
+    bn_finalize_channel(f, c, m, lo, hi);
 }
 
 constexpr int FIN_MAX_WG = 1024;  // octets x ranges of the two-launch form
@@ -235,7 +245,7 @@ static int bn_finalize_launch(const float* partials, int nparts, int rows_per_pa
         double* scratch = reinterpret_cast<double*>(ws);
         hipLaunchKernelGGL(bn_finalize_kernel<8>, dim3(O * S), dim3(256), 0, stream, partials, nparts, rows_per_part, M, C, pw, S,
                            scratch, f);
-        hipLaunchKernelGGL(bn_finalize_merge_kernel<8>, dim3((C + 63) / 64), dim3(64), 0, stream, (const double*)scratch, S, M, C, f);
+        hipLaunchKernelGGL(bn_finalize_merge_kernel<8>, dim3((C + 63) / 64), dim3(64), 0, stream, (const double*)scratch, S, C, f);
         return 0;
     }
     hipLaunchKernelGGL(bn_finalize_kernel<1>, dim3(C), dim3(256), 0, stream, partials, nparts, rows_per_part, M, C, pw, 1,
