@@ -388,3 +388,17 @@ def test_oracle_bf16_mode_rounding_points():
     y = OV._conv(x, w, padding=1)
     (y * torch.randn_like(y)).sum().backward()
     assert not rep(y.detach()) and not rep(x.grad)
+
+
+def test_bench_gpus_n_never_prints_a_smaller_jobs_line():
+    """`bench.py --gpus N` with fewer than N visible GPUs (here: none) refuses with a non-zero exit code and no JSON
+    line - never a silent N=1 measurement; likewise a launcher whose WORLD_SIZE contradicts --gpus."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "--gpus 2 requested" in r.stderr and "{" not in r.stdout
+    env.update(WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "{" not in r.stdout
