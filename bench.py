@@ -50,47 +50,64 @@ def synth_batch(B, step, device, seed, vocab=49408, Lpad=105, L=64):
 def cpu_baseline(sample_b=128, steps=3, warm_b=32):
     """Oracle (port of the reference train step incl. Adam) on the host cores: configs[1]'s own batch
     (B = 128), `steps` timed steps after one warm-up step at B = `warm_b` (thread pool,
-    allocator); the warm-up size is also timed for one more step and reported as a second point."""
-    import oracle.fill as OF
+    allocator); the warm-up size is also timed for one more step and reported as a second point.
+
+    The FIRST timed step doubles as the parity reference of the bench line: it starts from the `margin`-style state and
+    batch of tests/test_model_gpu.py::test_config1_b128_k8192_step_vs_oracle (oracle/cases.py), and its losses, all 183
+    gradients and the post-step state are returned under "_parity_ref" for `parity_vs_oracle()` below."""
     import oracle.head as OH
     import oracle.visual as OV
+    from oracle.cases import full_step_case, synth_batch as cpu_batch
 
     ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     ncpu = min(ncpu, int(os.environ.get("TRID_CPU_THREADS", "32")))  # more threads only adds sync overhead at this size
     torch.set_num_threads(ncpu)
     log("cpu_baseline: %d usable cores (os.cpu_count=%s)" % (ncpu, os.cpu_count()))
-    spec, K, C, NC = OV.RN50, 8192, 256, 11003
-    st = {}
-    for k, s in OH.state_shapes(spec, K, C, NC).items():
-        if k.endswith("num_batches_tracked"):
-            st[k] = torch.zeros((), dtype=torch.int64)
-        elif k in ("id_queue", "queue_ptr"):
-            st[k] = torch.zeros(s, dtype=torch.int64)
-        else:
-            st[k] = OF.fill(k, s, 0)
-    OH.init_queues(st, 0)
-    table = torch.randn(49408, 512) * 0.02
+    spec, K, vocab, seed = OV.RN50, 8192, 3000, PARITY_SEED
+    st, table, images0, tokens0, lengths0, ids0 = full_step_case(spec, sample_b, K, vocab, seed)
+    st0 = {k: v.clone() for k, v in st.items()}
     names = OH.trainable_names(st)
+
+    def fwd_bwd(state, bsz, s, first=False):
+        images, tokens, lengths, ids = (images0, tokens0, lengths0, ids0) if first else cpu_batch(bsz, s, 1234, vocab=vocab)
+        taps = {} if first else None
+        ld = OH.train_forward(state, spec, table, images, tokens, lengths, ids, m=0.999, epsilon=0.1, taps=taps)
+        for k in names:
+            state[k].grad = None
+        sum(ld.values()).backward()
+        return ld, taps
+
+    # warm-up (thread pool, allocator) on a throw-away copy of the state: the parity step must start from st0 itself
+    t0 = time.time()
+    sw = {k: v.clone() for k, v in st0.items()}
+    for k in names:
+        sw[k].requires_grad_(True)
+    fwd_bwd(sw, warm_b, 0)
+    del sw
+    log("cpu_baseline warm-up step B=%d: %.1fs" % (warm_b, time.time() - t0))
     groups = []
     for k in names:
         st[k].requires_grad_(True)
         groups.append({"params": [st[k]], "lr": 2e-4 if "bias" in k else 1e-4, "weight_decay": 0.0 if "bias" in k else 4e-5})
     opt = torch.optim.Adam(groups, lr=1e-4)
+    ref = None
 
-    def one(bsz, s):
-        images, tokens, lengths, ids = synth_batch(bsz, s, "cpu", 1234)
+    def one(bsz, s, first=False):
+        nonlocal ref
         t0 = time.time()
-        ld = OH.train_forward(st, spec, table, images, tokens, lengths, ids, m=0.999, epsilon=0.1)
-        opt.zero_grad()
-        sum(ld.values()).backward()
+        ld, taps = fwd_bwd(st, bsz, s, first)
+        t1 = time.time()
+        if first:  # (copies, not timed)
+            ref = ({k: v.detach().clone() for k, v in ld.items()}, {k: st[k].grad.clone() for k in names},
+                   {k: v.detach().clone() for k, v in st.items()}, float(taps["visual_q"]["relu_min"]))
+        t2 = time.time()
         opt.step()
-        dt = time.time() - t0
+        dt = (t1 - t0) + (time.time() - t2)
         log("cpu_baseline step B=%d: %.1fs" % (bsz, dt))
         return dt
 
-    one(warm_b, 0)  # warm-up
+    times = [one(sample_b, 2 + s, first=(s == 0)) for s in range(steps)]
     small = one(warm_b, 1)
-    times = [one(sample_b, 2 + s) for s in range(steps)]
     dt = sum(times) / len(times)
     return {
         "value": sample_b / dt,
@@ -99,7 +116,49 @@ def cpu_baseline(sample_b=128, steps=3, warm_b=32):
         "kind": "port",
         "sample": "%d timed train steps (fwd q+k, bwd, Adam) at B=%d (configs[1]'s batch), K=8192, fp32, after 1 warm-up step at B=%d; CPU oracle = port of the reference step" % (steps, sample_b, warm_b),
         "value_at_B%d" % warm_b: warm_b / small,
+        "_parity_ref": (st0, table, (images0, tokens0, lengths0, ids0), ref),
     }
+
+
+PARITY_SEED = 100  # tools/pick_fullstep_seed.py rn50 128 8192 100 (oracle/cases.py: RELU_MIN_BY_BATCH)
+
+
+def parity_vs_oracle(device, pref, tol=1e-3):
+    """ONE HIP train step (forward of the four encoders, three losses, backward - no optimizer) from the state and batch
+    of the CPU-baseline leg's first timed step, compared with that oracle step: the three losses, all 183 trainable
+    gradients in full, both queues after the push, every momentum-updated key parameter, every BatchNorm running
+    statistic.  The oracle is the checker here, never the thing timed."""
+    from oracle.cases import relu_floor, step_errors
+    from textreid_amd.caption import CaptionBatch
+    from textreid_amd.config import moco_cfg
+    from textreid_amd.model import build_model
+
+    st0, table, (images, tokens, lengths, ids), (rl, rg, rs, relu_min) = pref
+    B, K = images.shape[0], st0["v_queue"].shape[1]
+    model = build_model(moco_cfg("m_resnet50", K=K), vocab_dict=table)
+    head = model.embed_model
+    head.load_state_dict({k: v.clone() for k, v in st0.items()})
+    model.to(device).train()
+    ld = model(images.to(device), CaptionBatch(tokens.to(device), lengths.to(device), ids.to(device)))
+    sum(ld.values()).backward()
+    torch.cuda.synchronize()
+    named = dict(head.named_parameters())
+    errs = step_errors(ld, lambda k: named[k].grad, head.state_dict(), (rl, rg, rs))
+    worst = max(errs, key=errs.get)
+    out = {
+        "worst_rel_err": errs[worst],
+        "worst_quantity": worst,
+        "quantities": len(errs),
+        "gradients_compared": sum(k.startswith("grad:") for k in errs),
+        "loss_rel_err": {k[5:]: v for k, v in errs.items() if k.startswith("loss:")},
+        "tolerance": tol,
+        "within_tolerance": bool(errs[worst] <= tol),
+        "case": "configs[1] at its exact size: CLIP-RN50 + BiGRU, B=%d, K=%d, margin-style state (oracle.fill seed %d), ragged captions; smallest |ReLU input| of the oracle's query encoder %.1e (floor %.0e)" % (
+            B, K, PARITY_SEED, relu_min, relu_floor(B)),
+    }
+    del model, head, named, ld
+    torch.cuda.empty_cache()
+    return out
 
 
 def queue_similarity_bench(device, B=128, C=256, K=8192, reps=20, bf16=False):
@@ -261,14 +320,43 @@ def retrieval_bench(device, world, rank, G_total=1000000, Q=10000, k=10, shard_r
     }
 
 
+def visible_gpus():
+    """Number of GPUs this process could use, WITHOUT touching HIP: the KFD topology in sysfs (nodes with SIMDs), cut by
+    the usual visibility masks.  None when sysfs cannot be read (the ranks then check for themselves).
+    torch.cuda.device_count() is not used here: without amdsmi it falls through to hipGetDeviceCount, which brings the
+    HIP / HSA runtime up in the parent - harmless today (ranks are fresh child processes, never an exec of this one),
+    but an initialised parent must never be followed by a re-exec or launcher hop on this pool."""
+    import glob
+
+    n = 0
+    if not os.path.isdir("/sys/class/kfd"):
+        return 0  # no KFD driver: no AMD GPU on this machine
+    try:
+        for f in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+            for line in open(f):
+                k, _, v = line.partition(" ")
+                if k == "simd_count" and int(v) > 0:
+                    n += 1
+    except OSError:
+        return None
+    if n == 0:
+        return None
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        m = os.environ.get(var)
+        if m is not None:
+            n = min(n, len([x for x in m.split(",") if x.strip() != ""]))
+    return n
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher: start N rank processes (one per GPU, env:// rendezvous on
-    127.0.0.1) and return the worst exit code.  This parent never initialises the GPU (device_count() does not)."""
+    127.0.0.1) and return the worst exit code.  The parent only COUNTS devices (sysfs, no HIP call); the ranks are
+    always fresh child processes of it, never an exec of this process."""
     import socket
     import subprocess
 
-    have = torch.cuda.device_count()
-    if have < n:
+    have = visible_gpus()
+    if have is not None and have < n:
         print("bench.py: --gpus %d requested but only %d GPU(s) are visible; refusing to print a smaller job's line" % (n, have),
               file=sys.stderr)
         return 2
@@ -286,7 +374,7 @@ def spawn_ranks(n):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="ranks = GPUs (default: the launcher's WORLD_SIZE, else 1)")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=128, help="per-GPU batch (weak scaling)")
@@ -300,6 +388,8 @@ def main():
 
     import torch.distributed as dist
 
+    if args.gpus is None:  # `torchrun --nproc-per-node N bench.py` without --gpus: the launcher's world is the job
+        args.gpus = int(os.environ.get("WORLD_SIZE", "1"))
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(spawn_ranks(args.gpus))  # no launcher: become one (before anything touches the GPU)
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -548,7 +638,7 @@ def main():
     # second roofline object: the 1x1-conv / linear kernel <A_KC,B_KC> has the largest TOTAL time per step
     roofline_1x1 = {
         "bound": "mfma",
-        "kernel": kname.replace("A_CONV,B_KC", "A_KC,B_KC").split(" (")[0] + " (1x1 convs fwd, linears; K = 64..2048: the short-K layers are HBM/launch-bound)",
+        "kernel": (kname.split(" (")[0].replace("A_CONV", "A_KC")) + " (1x1 convs fwd + dgrad; K = 64..2048: the short-K layers are HBM-bound)",
         "achieved": flops2 / (ms2 * 1e-3) / 1e12 if ms2 > 0 else 0.0,
         "peak": peak,
         "unit": "TFLOP/s",
@@ -557,7 +647,7 @@ def main():
         "launches": nlaunch2,
         "avg_launch_ms": ms2 / max(nlaunch2, 1),
         "algorithmic_gflop_per_launch": flops2 / max(nlaunch2, 1) / 1e9,
-        "note": "live events around every launch of this kernel during the timed steps (all streams running)",
+        "note": "live events around every launch of this kernel " + ("in the %d eager re-runs of the step right after the timed region" % profiled_eager if profiled_eager else "during the timed steps") + " (all streams running)",
     }
     retr = None
     if not args.no_retrieval:
@@ -613,9 +703,15 @@ def main():
         out["queue_similarity"] = qsim
         out["configs3_1gpu"] = c3
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline()
+            cb = cpu_baseline()
+            pref = cb.pop("_parity_ref")
+            out["cpu_baseline"] = cb
+            out["parity_vs_oracle"] = parity_vs_oracle(device, pref)
+            log("parity vs oracle at B=128: worst %.1e (%s) over %d quantities" % (out["parity_vs_oracle"]["worst_rel_err"],
+                                                                                 out["parity_vs_oracle"]["worst_quantity"], out["parity_vs_oracle"]["quantities"]))
         else:
             out["cpu_baseline"] = None
+            out["parity_vs_oracle"] = None
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -234,6 +234,50 @@ def test_dp_stage_finish_layouts_and_id_lanes_gloo_world2(tmp_path):
         assert "rank %d ok" % r in o
 
 
+PRED_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from textreid_amd.engine.inference import _gather_predictions
+dist.init_process_group("gloo", init_method="env://")
+W, r = dist.get_world_size(), dist.get_rank()
+C = 6
+# uneven shards (rank 1 holds more samples), indices beyond 2^24 (an fp32 VALUE could not carry them)
+mine = {0: [3, 16777217, 40], 1: [1, 2 ** 33 + 5, 7, 9]}[r]
+g = lambda k, s: torch.arange(C, dtype=torch.float32) * (s + 1) + float(k %% 1000)
+pred = {k: [g(k, 0), g(k, 1)] for k in mine}
+out = _gather_predictions(pred)
+if r == 0:
+    want = [3, 16777217, 40, 1, 2 ** 33 + 5, 7, 9]
+    assert sorted(out) == sorted(want), sorted(out)
+    for k in want:
+        assert torch.equal(out[k][0], g(k, 0)) and torch.equal(out[k][1], g(k, 1)), k
+else:
+    assert out is None
+# a rank with no samples at all still takes part
+out = _gather_predictions(pred if r == 0 else {})
+if r == 0:
+    assert sorted(out) == sorted(mine)
+print("rank", r, "ok")
+dist.destroy_process_group()
+"""
+
+
+def test_inference_prediction_gather_gloo_world2(tmp_path):
+    """engine.inference._gather_predictions (the cross-rank accumulation of `lib/engine/inference.py:28-45`): uneven
+    shards, 64-bit dataset indices, an empty rank - two gloo ranks on CPU."""
+    script = tmp_path / "pred_worker.py"
+    script.write_text(PRED_WORKER % ROOT)
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="2")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o
+        assert "rank %d ok" % r in o
+
+
 def test_lr_schedule_values():
     from textreid_amd.solver import LRSchedulerWithWarmup
 

@@ -367,6 +367,76 @@ def test_gemm_arithmetic_modes(ops, prec, tol):
         ops.GEMM_PRECISION = old
 
 
+def _col_err(got, ref, dim=0):
+    """worst error of any column (dim 0) / row (dim 1), each relative to ITS OWN largest reference entry"""
+    got, ref = torch.as_tensor(got).detach().double().cpu(), torch.as_tensor(ref).detach().double().cpu()
+    return float(((got - ref).abs().amax(dim) / ref.abs().amax(dim).clamp_min(1e-300)).max())
+
+
+def test_fp16_split_dynamic_range_inside_one_tensor(ops):
+    """The two-plane fp16 split scales per TENSOR: an element far below the tensor's maximum keeps an
+    ABSOLUTE error (2^-38 of that maximum, the spacing of fp16 subnormals in the scaled domain), not a relative one.
+    `test_gemm_arithmetic_modes` varies the magnitude BETWEEN operands only; here ONE operand has channel groups that
+    span 2^20 (what one small-variance BatchNorm channel beside ordinary ones produces), and the outputs that depend
+    on the small channels only must still hold north_star's 1e-3 relative to THEIR OWN magnitude - for the on-the-fly
+    split (precision 16), for pre-split P16 operands (producer-side split + LDS-DMA GEMM) and for the weight-gradient
+    forms whose small ROWS depend on the small channels only.  Measured: <= 2e-6 down to 2^-20; the bound is reached
+    at 2^-29 of the maximum (absolute error 2^-25 in the scaled domain against a 2^-15 value)."""
+    M_, K, N = 2048, 256, 64
+    g = torch.Generator().manual_seed(3)
+    chan = 2.0 ** (-20.0 * (torch.arange(K) // 32).double() / 7.0)  # 8 groups of 32 channels: 2^0 ... 2^-20
+    x = (torch.randn(M_, K, generator=g).double() * chan).float()
+    grp = torch.arange(N) % 8
+    w = torch.randn(N, K, generator=g) * ((torch.arange(K)[None, :] // 32) == grp[:, None])  # output n reads group n % 8 only
+    ref = x.double() @ w.double().t()
+    assert float(ref[:, 7].abs().max() / ref[:, 0].abs().max()) < 2.0 ** -17  # the columns really span the range
+    xd, wd = dev(x), dev(w)
+    e_split = _col_err(ops.linear(xd, wd, prec=16, aa=ops.amax(xd), ba=ops.amax(wd)), ref)
+    A, Bm = ops.p16_pack(xd), ops.p16_pack(wd)
+    assert _col_err(A.unpack(), x) < 1e-5  # the packed tensor itself: every channel relative to its own magnitude
+    out = ops.empty((M_, N), xd)
+    ops.gemm_p16(A, Bm, out, M_, N, K, N)
+    e_p16 = _col_err(out, ref)
+    # weight-gradient forms: dW[k, n] = sum_m x[m, k] dy[m, n] - row k scales with channel k
+    dy = torch.randn(M_, 128, generator=g)
+    dyd = dev(dy)
+    refw = x.double().t() @ dy.double()
+    e_tn = _col_err(ops.matmul_tn(xd, dyd, prec=16, aa=ops.amax(xd), ba=ops.amax(dyd)), refw, dim=1)
+    e_wg = _col_err(ops.wgrad_p16(A, ops.p16_pack(dyd)), refw, dim=1)  # dW [256, 128] = x^T dy on the transposing P16 kernel
+    print("fp16 split, channels spanning 2^20 inside one operand: on-the-fly %.1e, P16 %.1e, wgrad %.1e / %.1e" % (e_split, e_p16, e_tn, e_wg))
+    assert max(e_split, e_p16, e_tn, e_wg) < 1e-3, (e_split, e_p16, e_tn, e_wg)
+
+
+@pytest.mark.parametrize("mask_mode", [0, 1])
+def test_bn_backward_bound_with_a_tiny_variance_channel(ops, mask_mode):
+    """BatchNorm backward writes dy as a P16 tensor scaled by a BOUND of max|dy| that is known before the pass runs:
+    |scale_c| (max|g_c| + (|dbeta_c| + max|xhat_c| |dgamma_c|) / M), maximised over channels.  One channel of variance
+    1e-8 has invstd = 316 (eps 1e-5) and sets that bound for all the others.  (1) the bound is tight: within 4x of the
+    true max|dy| (each factor 2 costs one bit of the low plane); (2) every OTHER channel, ~300x below the tensor's
+    maximum, still holds 1e-3 of its own largest entry after the split."""
+    B, H, W, C = 4, 16, 8, 64
+    g = torch.Generator().manual_seed(9)
+    y = torch.randn(B, C, H, W, generator=g) * 1.5 + 0.2
+    y[:, 5] = 0.01 + 1e-4 * torch.randn(B, H, W, generator=g)  # variance 1e-8
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3
+    gout = torch.randn(B, C, H, W, generator=g)
+    yr = y.double().requires_grad_(True)
+    z = F.batch_norm(yr, None, None, gamma.double(), beta.double(), True, 0.1, 1e-5)
+    (F.relu(z) if mask_mode == 1 else z).backward(gout.double())
+    yd = dev(nhwc(y))
+    y2, part = ops.conv1x1(yd, torch.eye(C, device="cuda"), stats=True, prec=0)  # exact fp32 MFMA: y2 == y
+    st = ops.bn_finalize(part, B * H * W, dev(gamma), dev(beta), None, None)
+    dy, dg, db, _ = ops.bn_bwd_p16(dev(nhwc(gout)), y2, st, mask_mode)
+    got = dy.unpack().permute(0, 3, 1, 2)
+    true = float(yr.grad.abs().max())
+    per_chan = lambda t: t.permute(1, 0, 2, 3).reshape(C, -1)
+    err = _col_err(per_chan(got).t(), per_chan(yr.grad).t())
+    print("BatchNorm backward, one channel of variance 1e-8: bound / true max|dy| = %.2f, worst channel error %.1e (its own scale)" % (float(dy.amax) / true, err))
+    assert true * (1 - 1e-6) <= float(dy.amax) <= 4.0 * true, (float(dy.amax), true)
+    assert float(yr.grad[:, 5].abs().max()) > 50 * float(yr.grad[:, 6].abs().max())  # the tiny-variance channel really dominates
+    assert err < 1e-3, err
+
+
 def test_abi_argument_errors_are_reported_not_fatal(ops):
     """C-ABI contract: bad arguments return a negative TRID_E_* code with a thread-local message
     (surfaced as RuntimeError by the binding) and leave the device usable - no abort, no sticky HIP error."""
@@ -392,7 +462,10 @@ def test_abi_argument_errors_are_reported_not_fatal(ops):
 
 
 @pytest.mark.parametrize("B,K,wgs,prec", [(128, 8192, 0, 6), (5, 64, 0, 6), (130, 96, 0, 6), (128, 2048, 3, 6), (33, 65536, 0, 6), (128, 8192, 0, 1), (300, 1024, 0, 6), (128, 8192, 0, 3),
-                                           (128, 32, 0, 6), (7, 2080, 1, 6), (600, 1024, 0, 6)])
+                                           (128, 32, 0, 6), (7, 2080, 1, 6), (600, 1024, 0, 6),
+                                           # the GLOBAL batches of configs[2] / configs[3] against their queues: 4 x 128 rows x 8192
+                                           # slots (the largest batch of the in-kernel id set) and 8 x 128 rows x 65536 slots (flag pre-pass)
+                                           (512, 8192, 0, 6), (1024, 65536, 0, 6)])
 def test_fused_queue_infonce(ops, B, K, wgs, prec):
     """queue_nce.hip - ONE pass over both [K,256] queues: similarity, batch-wide negative filter, InfoNCE and
     dL/dq - against the oracle's materialised form (head.py:148-170 + losses.py:206-217) evaluated in fp64.

@@ -439,6 +439,10 @@ def test_captured_train_step_equals_eager_bitwise(gpu):
         for i in range(steps):
             images, tokens, lengths, ids = batches[i]
             cb = CaptionBatch(tokens, lengths, ids % 11003, max_len=64)
+            if i == 3:  # a resume in mid-run: the optimizer's moment tensors AND its pointer tables are replaced - the
+                # recorded Adam launch has the old tables' addresses baked in, so the runner must notice, run one eager
+                # step (which rebuilds them) and record again (never replay against freed tables)
+                opt.load_state_dict(opt.state_dict())
             if i == 4:  # an LR scheduler step between two training steps
                 for grp in opt.param_groups:
                     grp["lr"] *= 0.5
@@ -451,7 +455,7 @@ def test_captured_train_step_equals_eager_bitwise(gpu):
             losses.append(torch.stack([v.detach().clone() for v in ld.values()]))
         torch.cuda.synchronize()
         if mode == "graph":
-            assert runner.graph is not None
+            assert runner.graph is not None and runner.recaptures == 1 and runner.plan is opt._plan
         runs[mode] = (torch.stack(losses), {k: v.detach().clone() for k, v in model.state_dict().items()},
                       [opt.state[p]["exp_avg_sq"].clone() for g_ in opt.param_groups for p in g_["params"]],
                       [int(opt.state[p]["step"]) for g_ in opt.param_groups for p in g_["params"]])
@@ -462,6 +466,111 @@ def test_captured_train_step_equals_eager_bitwise(gpu):
     for a, b in zip(runs["eager"][2], runs["graph"][2]):
         assert torch.equal(a, b)
     assert runs["eager"][3] == runs["graph"][3] and set(runs["graph"][3]) == {steps + 1}
+
+
+def test_failed_capture_falls_back_to_eager(gpu):
+    """A capture that fails (a non-capturable call, a recording invalidated by another thread) must not end the run:
+    the runner restores the gradients, disables further attempts and keeps training eagerly."""
+    import bench
+    from textreid_amd.caption import CaptionBatch
+    from textreid_amd.config import moco_cfg
+    from textreid_amd.engine.graph import CapturedTrainStep
+    from textreid_amd.model import build_model
+    from textreid_amd.solver import make_optimizer
+
+    cfg = moco_cfg("m_resnet50", K=64)
+    torch.manual_seed(0)
+    model = build_model(cfg, vocab_dict=torch.randn(1000, 512) * 0.02).to(gpu).train()
+    opt = make_optimizer(cfg, model)
+    runner = CapturedTrainStep(model, opt, warmup=1, caption_bound=64)
+
+    def boom(images, cb):
+        with torch.cuda.graph(torch.cuda.CUDAGraph(), capture_error_mode="thread_local"):
+            torch.zeros(4, device=gpu).sum().item()  # a host read inside a capture: the runtime refuses it
+
+    runner._capture = boom
+    out = []
+    for s in range(3):
+        images, tokens, lengths, ids = bench.synth_batch(4, s, gpu, 3, vocab=1000)
+        ld = runner(images, CaptionBatch(tokens, lengths, ids, max_len=64))
+        out.append(float(sum(ld.values())))
+    torch.cuda.synchronize()
+    assert runner.disabled and runner.graph is None and all(np.isfinite(out))
+    assert {int(opt.state[p]["step"]) for g_ in opt.param_groups for p in g_["params"]} == {3}  # three real optimizer steps
+
+
+def test_do_train_captured_matches_eager(gpu):
+    """engine.trainer.do_train with its DEFAULT capture=True against capture=False on the same data: seven
+    steps - two eager warm-ups, the recording, replays, a RAGGED last batch (other shape: eager fall-back) - with
+    captions of at most 40 tokens inside 105-wide token tensors, i.e. the recorded text encoder loops over a bound
+    (105) far above every batch's true maximum and reads that maximum from the device.  Losses of every step agree to
+    1e-4 (the two paths differ only in summation order: the text encoder's weight-gradient GEMMs split their (t, b) rows
+    differently for 105 and for <= 40 steps); queue ids / pointer bit-exact; parameters within Adam's own
+    sign-amplified rounding (a gradient entry at rounding level moves its weight by lr whatever its size)."""
+    import bench
+    from textreid_amd.caption import CaptionBatch
+    from textreid_amd.config import moco_cfg
+    from textreid_amd.engine.trainer import do_train
+    from textreid_amd.model import build_model
+    from textreid_amd.solver import make_lr_scheduler, make_optimizer
+
+    B, K, full = 16, 64, 6
+    cfg = moco_cfg("m_resnet50", K=K)
+    table = torch.randn(3000, 512, generator=torch.Generator().manual_seed(1)) * 0.02
+    gen = torch.Generator().manual_seed(4)
+    batches = []
+    for s in range(full + 1):
+        b = B if s < full else B // 2
+        im, tk, ln, ids = bench.synth_batch(b, s, "cpu", 6, vocab=3000)
+        ln = torch.randint(3, 41, (b,), generator=gen)
+        for i, n in enumerate(ln.tolist()):
+            tk[i, n:] = 0
+        batches.append((im, tk, ln, ids % 11003))
+    assert batches[0][1].shape[1] == 105 and max(int(b_[2].max()) for b_ in batches) <= 40
+
+    class Loader:
+        def __len__(self):
+            return len(batches)
+
+        def __iter__(self):
+            for im, tk, ln, ids in batches:
+                yield im, CaptionBatch(tk, ln, ids), None  # (no host-side max_len: as the reference's collate hands captions over)
+
+    runs = {}
+    for capture in (False, True):
+        torch.manual_seed(0)
+        model = build_model(cfg, vocab_dict=table).to(gpu)
+        opt = make_optimizer(cfg, model)
+        sched = make_lr_scheduler(cfg, opt)
+        seen = []
+
+        class Meters:
+            def update(self, **kw):
+                seen.append(kw)
+
+            def __str__(self):
+                return ""
+
+        args = {"max_epoch": 1, "epoch": 0, "iteration": 0}
+        do_train(model, Loader(), None, opt, sched, None, Meters(), gpu, checkpoint_period=10, evaluate_period=10, arguments=args,
+                 log_period=3, capture=capture)
+        torch.cuda.synchronize()
+        assert args["iteration"] == full + 1
+        runs[capture] = ([kw for kw in seen if "loss" in kw], {k: v.detach().clone() for k, v in model.state_dict().items()}, opt.param_groups[0]["lr"])
+        del model, opt
+    (le, se, lr), (lg, sg, _) = runs[False], runs[True]
+    assert len(le) == len(lg) == full + 1
+    for a, b in zip(le, lg):
+        for k in a:
+            assert abs(a[k] - b[k]) <= 1e-4 * abs(a[k]) + 1e-6, (k, a[k], b[k])
+    head = "embed_model."
+    assert torch.equal(se[head + "id_queue"], sg[head + "id_queue"]) and torch.equal(se[head + "queue_ptr"], sg[head + "queue_ptr"])
+    worst = 0.0
+    for k, v in se.items():
+        if v.dtype.is_floating_point and "queue" not in k and "running" not in k:
+            worst = max(worst, float((v - sg[k]).abs().max()))
+    print("do_train captured vs eager: %d steps, largest parameter difference %.2e (lr %.1e)" % (full + 1, worst, lr))
+    assert worst <= 2.5 * (full + 1) * 2e-4  # every step may move an entry by its lr (bias lr = 2 x base) in either path
 
 
 def test_k_reciprocal_rerank_matches_reference_golden(gpu, golden_dir):

@@ -345,29 +345,7 @@ def test_moco_head_three_steps(gpu, golden_dir, fname):
     assert_within(errs, TOL)
 
 
-def full_step_case(spec, B, K, vocab, seed, style="margin"):
-    """CPU-only construction of a full-size one-step case: (`margin`-style head state, embedding table,
-    images, tokens, lengths, ids).  Shared with tools/pick_fullstep_seed.py, which chose the seeds used
-    below so that the query encoder's smallest |ReLU input| is >= oracle.fill.RELU_MIN."""
-    import bench
-
-    torch.manual_seed(0)
-    table = torch.randn(vocab, 512) * 0.02
-    shapes = OH.state_shapes(spec, K)
-    st = {}
-    for k, s_ in shapes.items():
-        if k.endswith("num_batches_tracked"):
-            st[k] = torch.zeros((), dtype=torch.int64)
-        elif k in ("id_queue", "queue_ptr"):
-            st[k] = torch.zeros(s_, dtype=torch.int64)
-        else:
-            st[k] = OF.fill("full." + k, s_, seed, style=style)
-    OH.init_queues(st, seed)
-    images, tokens, lengths, ids = bench.synth_batch(B, 0, "cpu", 5, vocab=vocab)
-    lengths = torch.tensor(([64, 40, 64, 9, 33, 64, 12, 64, 50, 64, 21, 64, 64, 7, 64, 30] * ((B + 15) // 16))[:B])
-    for i, n in enumerate(lengths.tolist()):
-        tokens[i, n:] = 0
-    return st, table, images, tokens, lengths, ids
+from oracle.cases import full_step_case, oracle_step as _oracle_full_step_impl, relu_floor, step_errors as _step_errors  # noqa: E402,F401
 
 
 def _full_step_vs_oracle(gpu, arch, spec, B, K, vocab, seed, captured=False):
@@ -408,7 +386,8 @@ def _full_step_vs_oracle(gpu, arch, spec, B, K, vocab, seed, captured=False):
     key0 = st["v_encoder_k.layer3.2.conv2.weight"].clone()
     taps = {}
     old = OH.train_forward(st, spec, table, images, tokens, lengths, ids, m=0.999, epsilon=0.1, taps=taps)
-    assert taps["visual_q"]["relu_min"] >= 0.5 * OF.RELU_MIN, "case is not well-conditioned (ReLU margin %g): pick another seed" % taps["visual_q"]["relu_min"]
+    floor = relu_floor(B) if relu_floor(B) != OF.RELU_MIN else 0.5 * OF.RELU_MIN
+    assert taps["visual_q"]["relu_min"] >= floor, "case is not well-conditioned (ReLU margin %g): pick another seed" % taps["visual_q"]["relu_min"]
     sum(old.values()).backward()
     errs = {"loss:" + k: rel(ld[k], old[k]) for k in old}
     named = dict(head.named_parameters())
@@ -435,6 +414,22 @@ def test_full_size_step_vs_oracle(gpu):
     errs = _full_step_vs_oracle(gpu, "m_resnet50", OV.RN50, B=16, K=64, vocab=3000, seed=30)  # seed: tools/pick_fullstep_seed.py
     worst = sorted(errs.items(), key=lambda kv: -kv[1])[:5]
     print(len(errs), "quantities; worst:", [(k, "%.1e" % v) for k, v in worst])
+    assert sum(k.startswith("grad:") for k in errs) == 183
+    assert_within(errs, TOL)
+
+
+def test_config1_b128_k8192_step_vs_oracle(gpu):
+    """BASELINE configs[1] at its EXACT size - CLIP-RN50 + BiGRU, B = 128, 384x128 images, ragged captions padded to
+    105, MoCo queue 8192 - one whole train step against the fp32 CPU oracle (~25 s on the box's host cores): the three
+    losses over 128 rows, all 183 trainable gradients in full (the split-count rules, tile shapes and BatchNorm partial
+    counts that depend on M are the benchmarked ones), both queues after the push, every momentum-updated key
+    parameter, every BatchNorm running statistic.  Flat 1e-3.  (`bench.py` prints the same comparison as
+    `parity_vs_oracle` from the first step of its CPU-baseline leg.)"""
+    from fixture_check import assert_within
+
+    errs = _full_step_vs_oracle(gpu, "m_resnet50", OV.RN50, B=128, K=8192, vocab=3000, seed=100)  # seed: tools/pick_fullstep_seed.py rn50 128 8192 100
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+    print("configs[1] B=128 K=8192:", len(errs), "quantities; worst:", [(k, "%.1e" % v) for k, v in worst])
     assert sum(k.startswith("grad:") for k in errs) == 183
     assert_within(errs, TOL)
 
@@ -509,28 +504,7 @@ def test_full_size_step_he_style_unstructured_masks(gpu):
 
 
 def _oracle_full_step(spec, st0, table, images, tokens, lengths, ids, dtype):
-    """One oracle train step from state st0 in `dtype`: (losses, {name: gradient}, state after the step)."""
-    st = {k: (v.to(dtype).clone() if v.dtype.is_floating_point else v.clone()) for k, v in st0.items()}
-    tr = OH.trainable_names(st)
-    for k in tr:
-        st[k].requires_grad_(True)
-    ld = OH.train_forward(st, spec, table.to(dtype), images.to(dtype), tokens, lengths, ids, m=0.999, epsilon=0.1)
-    sum(ld.values()).backward()
-    return {k: v.detach() for k, v in ld.items()}, {k: st[k].grad for k in tr}, {k: v.detach() for k, v in st.items()}
-
-
-def _step_errors(losses, grad_of, state, ref):
-    """{name: relative error} of (losses, gradients, post-step state) against the reference triple `ref`."""
-    rl, rg, rs = ref
-    errs = {"loss:" + k: rel(losses[k], rl[k]) for k in rl}
-    gfl = 1e-3 * max(float(g.abs().max()) for g in rg.values())
-    for k, g in rg.items():
-        fl = gfl * (100.0 if k.endswith("attnpool.k_proj.bias") else 1.0)
-        errs["grad:" + k] = float((grad_of(k).detach().cpu().double() - g.double()).abs().max() / max(float(g.abs().max()), fl))
-    for k, v in rs.items():
-        if k.startswith(("v_encoder_k.", "t_encoder_k.")) and v.dtype.is_floating_point or k.endswith(("running_mean", "running_var")) or k in ("v_queue", "t_queue"):
-            errs["state:" + k] = rel(state[k], v)
-    return errs
+    return _oracle_full_step_impl(spec, st0, table, images, tokens, lengths, ids, dtype)
 
 
 def test_config3_rn101_k65536_bf16(gpu):

@@ -37,6 +37,9 @@ class CapturedTrainStep:
         self.static = None
         self.out = None
         self.signature = None
+        self.plan = None         # the optimizer's pointer tables the recorded Adam launch reads (kept alive with the graph)
+        self.disabled = False    # a failed capture: stay eager for the rest of the run
+        self.recaptures = 0
         self.log = logging.getLogger("PersonSearch.trainer")
         if dp_active():
             raise RuntimeError("CapturedTrainStep covers the single-process step; under data parallelism the step runs eagerly "
@@ -85,7 +88,10 @@ class CapturedTrainStep:
         ops.begin_capture()
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        # thread_local: every launch of the step is issued from this thread (the backward runs on the autograd engine's
+        # thread for this device, which torch's capture tracks); a HIP call from an UNRELATED thread - a DataLoader's
+        # pin_memory thread allocating or polling events - must not invalidate the ~1100-launch recording
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
             loss_dict = self.model(self.static["images"], scb)
             losses = sum(loss_dict.values())
             losses.backward()
@@ -95,15 +101,55 @@ class CapturedTrainStep:
         del loss_dict, losses
         self.grads = [(p, p.grad) for p in self.model.parameters() if p.grad is not None]  # live in the graph's pool
         self.signature = self._sig(images, cb)
+        # the recorded Adam launch has the ADDRESSES of this plan's tables baked in: hold it (so the allocator cannot
+        # recycle them under the graph) and replay only while the optimizer still uses this very object
+        self.plan = getattr(self.optimizer, "_plan", None)
         self.log.info("train step captured: one graph launch per step from here on")
+
+    def _drop_graph(self, why):
+        self.log.warning("train step: %s - dropping the recorded graph", why)
+        self.graph = self.static = self.out = self.signature = None
+        self.grads = []
+
+    def _try_capture(self, images, cb):
+        """Record the step; on ANY failure (a non-capturable call, an invalidated capture) keep training eagerly - eager
+        is the documented fall-back for everything else, a failed recording must not end the run at step 3."""
+        saved = [(p, p.grad) for p in self.model.parameters()]
+        try:
+            self._capture(images, cb)
+            return True
+        except Exception as e:  # noqa: BLE001 - whatever the runtime raised mid-capture
+            self.log.warning("train step: hipGraph capture failed (%s: %s) - the step stays eager for the rest of the run",
+                             type(e).__name__, str(e).splitlines()[0] if str(e) else "")
+            try:
+                torch.cuda.synchronize()
+            except Exception:  # noqa: BLE001
+                pass
+            for p, g in saved:
+                p.grad = g
+            self.graph = self.static = self.out = self.signature = None
+            self.grads = []
+            self.disabled = True
+            return False
 
     def __call__(self, images, captions):
         cb = CaptionBatch.from_list(captions)
         self.calls += 1
+        if self.disabled:
+            return self._eager(images, cb)
+        if self.graph is not None and self.optimizer is not None and getattr(self.optimizer, "_plan", None) is not self.plan:
+            # load_state_dict / __setstate__ / a moved parameter replaced the optimizer's pointer tables: the recorded
+            # launch would read the old ones.  One eager step rebuilds them, the next call records again.
+            self._drop_graph("the optimizer's pointer tables were rebuilt (state loaded or a tensor moved)")
+            self.recaptures += 1
+            return self._eager(images, cb)
         if self.graph is None:
             if self.calls <= self.warmup:
                 return self._eager(images, cb)
-            self._capture(images, cb)
+            if self.optimizer is not None and getattr(self.optimizer, "_plan", None) is None:
+                return self._eager(images, cb)  # (tables dropped since the warm-up: this eager step rebuilds them)
+            if not self._try_capture(images, cb):
+                return self._eager(images, cb)
         if self._sig(images, cb) != self.signature or cb.max_len > self.bound:
             self.log.warning("train step: batch signature %s (longest caption %d) does not fit the captured one %s (bound %d) - running this step eagerly",
                              self._sig(images, cb), cb.max_len, self.signature, self.bound)

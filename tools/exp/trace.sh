@@ -1,7 +1,10 @@
+set -euo pipefail
+: "${GRAFT_REPO_ROOT:?run on the GPU box through gpurun (GRAFT_REPO_ROOT is the repo copy there)}"
 cd /tmp && export TMPDIR=/tmp
-OUT=$GRAFT_REPO_ROOT/gpurun_out/trace_tmp; rm -rf $OUT; mkdir -p $OUT
+OUT="$GRAFT_REPO_ROOT/gpurun_out/trace_tmp"; rm -rf "$OUT"; mkdir -p "$OUT"
 rocprofv3 --kernel-trace --output-format csv -d $OUT/kt -- python3 $GRAFT_REPO_ROOT/bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-retrieval --no-configs3 > $OUT/line.json 2> $OUT/err
-F=$(find $OUT/kt -name "*kernel_trace.csv" | head -1)
+F=$(find "$OUT/kt" -name "*kernel_trace.csv" | head -1)
+if [ -z "$F" ]; then echo "no kernel trace was written: see $OUT/err" >&2; exit 1; fi
 cd $GRAFT_REPO_ROOT
 python tools/trace_gaps.py $F 6 9 > $OUT/gaps.txt 2>&1
 python tools/trace_streams.py $F adam 6 9 > $OUT/streams.txt 2>&1

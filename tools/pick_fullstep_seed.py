@@ -15,7 +15,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle.fill as OF  # noqa: E402
 import oracle.head as OH  # noqa: E402
 import oracle.visual as OV  # noqa: E402
-from test_model_gpu import full_step_case  # noqa: E402
+from oracle.cases import full_step_case, relu_floor  # noqa: E402
 
 spec = {"rn50": OV.RN50, "rn101": OV.RN101}[sys.argv[1]]
 B, K, start = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
@@ -25,5 +25,5 @@ for seed in range(start, start + 100):
     with torch.no_grad():
         OV.visual_forward(OH._Sub(st, "v_encoder_q"), images, spec, True, taps)
     print("seed %d: smallest |ReLU input| %.2e" % (seed, taps["relu_min"]), flush=True)
-    if taps["relu_min"] >= OF.RELU_MIN:
+    if taps["relu_min"] >= relu_floor(B):
         break
