@@ -499,6 +499,55 @@ def test_failed_capture_falls_back_to_eager(gpu):
     assert {int(opt.state[p]["step"]) for g_ in opt.param_groups for p in g_["params"]} == {3}  # three real optimizer steps
 
 
+def test_captured_step_with_a_loose_caption_bound(gpu):
+    """The recorded step as engine.trainer.do_train builds it (caption_bound=None: the text encoder's recorded loop runs
+    the token tensor's full width, 105 steps, and reads the batch's true maximum from the device - the reference's
+    zero-pad-enters-the-max quirk, gru.py:63, depends on it) against the eager step that knows the maximum on the host:
+    same parameters (no optimizer), captions of at most 40 tokens with a different maximum per batch.  Losses to fp32
+    rounding, every gradient to 1e-4 of its maximum (the text encoder's weight-gradient GEMMs split their (t, b) rows
+    differently for 105 and for <= 40 steps: summation order only)."""
+    import bench
+    from textreid_amd.caption import CaptionBatch
+    from textreid_amd.config import moco_cfg
+    from textreid_amd.engine.graph import CapturedTrainStep
+    from textreid_amd.model import build_model
+
+    B, K = 8, 64
+    cfg = moco_cfg("m_resnet50", K=K)
+    torch.manual_seed(0)
+    model = build_model(cfg, vocab_dict=torch.randn(3000, 512) * 0.02).to(gpu).train()
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+    gen = torch.Generator().manual_seed(8)
+
+    def batch(s, top):
+        im, tk, ln, ids = bench.synth_batch(B, s, gpu, 7, vocab=3000)
+        ln = torch.randint(2, top + 1, (B,), generator=gen)
+        ln[s % B] = top
+        tk = tk.cpu()
+        for i, n in enumerate(ln.tolist()):
+            tk[i, n:] = 0
+        return im, tk.to(gpu), ln.to(gpu), ids
+
+    batches = [batch(0, 33), batch(1, 40), batch(2, 17)]
+    runner = CapturedTrainStep(model, None, warmup=1)  # caption_bound=None, as do_train
+    got = []
+    for im, tk, ln, ids in batches:
+        model.load_state_dict(state)  # same parameters, queues and BatchNorm buffers for every batch and both paths
+        ld = runner(im, CaptionBatch(tk, ln, ids))
+        torch.cuda.synchronize()
+        got.append(({k: float(v) for k, v in ld.items()}, {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}))
+    assert runner.graph is not None and runner.bound == 105 and runner.calls == 3
+    for (im, tk, ln, ids), (gl, gg) in zip(batches, got):
+        model.load_state_dict(state)
+        ld = runner._eager(im, CaptionBatch(tk, ln, ids))  # host-side maximum: the loop runs max(ln) steps
+        torch.cuda.synchronize()
+        for k, v in ld.items():
+            assert abs(float(v) - gl[k]) <= 1e-5 * abs(float(v)), (k, float(v), gl[k])
+        worst = max(float((gg[n] - p.grad).abs().max() / (p.grad.abs().max() + 1e-30)) for n, p in model.named_parameters() if p.grad is not None)
+        assert worst <= 1e-4, worst
+    assert len(got[0][1]) == 183
+
+
 def test_do_train_captured_matches_eager(gpu):
     """engine.trainer.do_train with its DEFAULT capture=True against capture=False on the same data: seven
     steps - two eager warm-ups, the recording, replays, a RAGGED last batch (other shape: eager fall-back) - with
@@ -560,9 +609,15 @@ def test_do_train_captured_matches_eager(gpu):
         del model, opt
     (le, se, lr), (lg, sg, _) = runs[False], runs[True]
     assert len(le) == len(lg) == full + 1
-    for a, b in zip(le, lg):
+    print("do_train captured vs eager, total loss per step:", [("%.6f" % a["loss"], "%.6f" % b["loss"]) for a, b in zip(le, lg)])
+    for i, (a, b) in enumerate(zip(le, lg)):
+        # steps 1-2 are eager in both runs: identical bits.  Step 3 is the first REPLAY: it starts from identical parameters,
+        # so its losses (the forward of the recorded step, text encoder looping 105 steps over <= 40-token captions) must
+        # agree to fp32 rounding.  From step 4 on the two runs differ by what Adam makes of rounding-level gradient
+        # differences (an update of lr whatever the gradient's size): a few 1e-4 of the loss on this random-init model.
+        tol = 0.0 if i < 2 else (1e-5 if i == 2 else 5e-3)
         for k in a:
-            assert abs(a[k] - b[k]) <= 1e-4 * abs(a[k]) + 1e-6, (k, a[k], b[k])
+            assert abs(a[k] - b[k]) <= tol * abs(a[k]), (i, k, a[k], b[k])
     head = "embed_model."
     assert torch.equal(se[head + "id_queue"], sg[head + "id_queue"]) and torch.equal(se[head + "queue_ptr"], sg[head + "queue_ptr"])
     worst = 0.0

@@ -1,0 +1,477 @@
+// The stem's convolutions (m_resnet.py:161-170, 199-207) as bandwidth-shaped kernels.
+//
+// The stem works on the largest images of the network (B x 192 x 64 pixels at 384 x 128 input) with the fewest channels
+// (3 -> 32 -> 32 -> 64): every convolution is HBM-bound by construction (conv2: 201 MB in, 201 MB out, 29 GFLOP), so a
+// GEMM-shaped kernel that stages one K tile per tap re-reads every activation nine times through the texture path and
+// never gets near the memory rate.  Here each input pixel crosses the load path ONCE:
+//
+//   * conv3x3_halo_p16_kernel (conv2, conv3, and their data gradients): the input is a P16 NHWC tensor (gemm_p16.hip: a
+//     pixel's 32 channels are one 128-byte line = [hi x 32 | lo x 32] fp16).  A persistent workgroup walks down a band of
+//     image rows with a RING of image rows in LDS: each step brings TH new rows in by LDS-DMA (zero columns left and
+//     right, zero rows above / below the image: the padding of the convolution is data in LDS, not masks in the loop),
+//     computes TH output rows from the TH + 2 rows it has, and stores them.  The nine taps are nine shifted ds_read_b128
+//     fragment reads of the SAME LDS image (16-byte units XOR-swizzled by the pixel index: conflict-free for any shift).
+//     The filters never touch LDS: a wave owns one (32 output channels x 32 input channels) slice, whose 9 x 2 x 2
+//     MFMA B fragments live in 144 VGPRs for the whole launch.  Same arithmetic as gemm_p16_kernel<A_CONV> (products
+//     hi*lo + lo*hi + hi*hi on v_mfma_f32_32x32x16_f16, same order: bit-identical for 32 input channels).
+//     Epilogue: BatchNorm partials (mean, M2, min, max) per step tile, Chan-merged over the waves of a tile.
+//   * stem_conv1_kernel: the 3x3 / stride 2 convolution of the 3-channel image, straight from the NCHW input (no im2col
+//     tensor: 176 MB written and read back per pass before) on the exact fp32 MFMA (v_mfma_f32_32x32x2_f32, K = 27).
+
+#include <algorithm>
+#include <mutex>
+
+#include "split_common.h"
+
+namespace trid {
+
+namespace {
+
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ void dma16(const __amdgpu_buffer_rsrc_t& rs, void* lds_base, unsigned voffset) {
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)lds_base, 16, voffset, 0, 0, 0);
+}
+
+struct HaloParams {
+    const char* x;        // P16 NHWC [B][H][W][CIN]
+    const char* w;        // P16 [COUT][9 * CIN] (k = tap * CIN + c)
+    float* y;             // fp32 [B][H][W][COUT]
+    float* stats;         // [B * H / TH][COUT][4] = (mean, M2, min, max) per step tile of TH * W pixels, or null
+    const float* x_amax;
+    const float* w_amax;
+    int B, H, W;
+    int TH;               // image rows per step
+    int R;                // ring rows = 2 * TH + 2
+    int rowb;             // ring row pitch in bytes (a multiple of 1024 >= (W + 2) * pixel bytes)
+    int rg_per_chunk;     // steps per chunk; a chunk = a band of rows of ONE image
+    int chunks_per_image;
+    int nchunks;
+    FastDiv fdW;
+};
+
+// 16-byte unit u of pixel slot q is stored at unit u ^ swz(q) of that pixel's LDS line(s): the 16-lane groups of a
+// ds_read_b128 fragment read (lanes = consecutive pixels, one unit) then cover all 64 banks for ANY pixel offset
+template <int PIXB>
+__device__ __forceinline__ int swz(int q) {
+    return PIXB == 128 ? ((q >> 1) & 7) : (q & 15);
+}
+
+}  // namespace
+
+// CIN, COUT in {32, 64} (not both 64).  8 waves = PB pixel blocks x (COUT / 32) column blocks x (CIN / 32) channel groups;
+// a wave multiplies its 32 pixels x 32 input channels x 9 taps into 32 output channels.
+template <int CIN, int COUT>
+__global__ __launch_bounds__(512, 2) void conv3x3_halo_p16_kernel(HaloParams p) {
+    constexpr int NW = 8, CB = COUT / 32, KG = CIN / 32, PB = NW / (CB * KG);
+    constexpr int PIXB = CIN * 4;           // bytes of one pixel in LDS / HBM
+    constexpr int UPP = PIXB / 16;          // 16-byte units (= loader lanes) per pixel
+    constexpr int PPC = 64 / UPP;           // pixels per 1-KB DMA chunk
+    extern __shared__ __attribute__((aligned(16))) uint4 smem[];
+    char* const ring = reinterpret_cast<char*>(smem);
+    float4* const sstat = reinterpret_cast<float4*>(ring + (size_t)p.R * p.rowb);  // [2][NW][32]
+    float* const ksum = reinterpret_cast<float*>(sstat + 2 * NW * 32);              // KG == 2: [PB][16][64]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pb = wave / (CB * KG), cb = (wave / KG) % CB, kg = wave % KG;
+    const int khalf = lane >> 5;
+    const int W = p.W, H = p.H, TH = p.TH, R = p.R, rowb = p.rowb;
+    const int cpr = rowb >> 10;  // DMA chunks per ring row
+
+    const float unscale = 1.f / (f16_scale_of(*p.x_amax) * f16_scale_of(*p.w_amax));
+
+    // ---- this wave's filter slice: B fragments [tap][k step][plane], 144 VGPRs, loaded once
+    f16x8 bf[9][2][2];
+    {
+        const char* wr = p.w + (size_t)(cb * 32 + (lane & 31)) * (9 * CIN * 4);
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl)
+                    bf[t][ks][pl] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(wr + (t * KG + kg) * 128 + (4 * pl + 2 * ks + khalf) * 16));
+    }
+
+    // ---- this lane's pixel of the step tile (row-major over TH x W) and its three shifted LDS columns
+    const int pp = pb * 32 + (lane & 31);
+    const int ty = (int)fdiv((uint32_t)pp, p.fdW);
+    const int tx = pp - ty * W;
+    int qoff[3], qsw[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const int q = tx + d;  // pixel slot of (x + d - 1): slot 0 is the zero column left of the image
+        qoff[d] = q * PIXB;
+        qsw[d] = swz<PIXB>(q);
+    }
+
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (unsigned)((size_t)p.B * H * W * PIXB), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, (unsigned)((size_t)p.B * H * W * COUT * 4), 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+
+    // rows [y_first, y_first + nrows) of image b -> ring slots slot_first ... (mod R); rows outside the image and the
+    // pixel slots outside [1, W] become zeros (an out-of-range DMA lane writes zeros)
+    auto issue_rows = [&](int b, int y_first, int nrows, int slot_first) {
+        const int total = nrows * cpr;
+        for (int i = wave; i < total; i += NW) {
+            const int rr = i / cpr, c = i - rr * cpr;
+            const int y = y_first + rr;
+            int slot = slot_first + rr;
+            slot = slot >= R ? slot - R : slot;
+            const int q = c * PPC + lane / UPP;  // pixel slot
+            const int j = lane % UPP;            // stored unit position
+            const int u = j ^ swz<PIXB>(q);      // source unit
+            const int x = q - 1;
+            const bool ok = (y >= 0) && (y < H) && (x >= 0) && (x < W);
+            const unsigned vo = ok ? (unsigned)((((size_t)b * H + y) * W + x) * PIXB + u * 16) : OOB;
+            dma16(rsX, ring + (size_t)slot * rowb + c * 1024, vo);
+        }
+    };
+
+    for (int chunk = blockIdx.x; chunk < p.nchunks; chunk += gridDim.x) {
+        const int b = chunk / p.chunks_per_image;
+        const int rg0 = (chunk - b * p.chunks_per_image) * p.rg_per_chunk;
+        int y0 = rg0 * TH;
+        int slot0 = 0;  // ring slot of image row y0 - 1
+        issue_rows(b, y0 - 1, TH + 2, 0);
+        for (int s = 0; s < p.rg_per_chunk; ++s) {
+            // rows y0-1 .. y0+TH were issued before this wave's stores of the previous step (vmcnt retires in order)
+            if (s == 0) wait_vm<0>();
+            else if (KG == 1 || kg == 0) wait_vm<16>();
+            else wait_vm<0>();
+            lds_barrier();
+            // previous step's BatchNorm partials: merged by the first lanes of wave 0 (one column each)
+            if (p.stats != nullptr && s > 0 && wave == 0 && lane < COUT) {
+                const float4* src = sstat + ((s - 1) & 1) * NW * 32;
+                const int c2 = lane >> 5, n = lane & 31;
+                float cnt = 0.f, mean = 0.f, m2 = 0.f, lo = INFINITY, hi = -INFINITY;
+#pragma unroll
+                for (int k = 0; k < PB; ++k) {
+                    const float4 v = src[((k * CB + c2) * KG) * 32 + n];
+                    const float nt = cnt + 32.f, d = v.x - mean;
+                    mean += d * (32.f / nt);
+                    m2 += v.y + d * d * (cnt * 32.f / nt);
+                    cnt = nt;
+                    lo = fminf(lo, v.z);
+                    hi = fmaxf(hi, v.w);
+                }
+                const long long part = ((long long)b * H + (y0 - TH)) / TH;
+                reinterpret_cast<float4*>(p.stats)[part * COUT + lane] = make_float4(mean, m2, lo, hi);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (keeps the counted wait below exact: nothing of wave 0's is left in flight but the DMA that follows)
+            }
+            if (s + 1 < p.rg_per_chunk) {
+                int sl = slot0 + TH + 2;
+                sl = sl >= R ? sl - R : sl;
+                issue_rows(b, y0 + TH + 1, TH, sl);
+            }
+
+            // ---- 9 taps x 2 k steps x 3 products on the TH + 2 ring rows
+            v16f acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                int rs = slot0 + ty + dy;
+                rs = rs >= R ? rs - R : rs;
+                rs = rs >= R ? rs - R : rs;
+                const char* rowp = ring + (size_t)rs * rowb;
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const char* px = rowp + qoff[dx];
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        const int u0 = (KG == 2 ? kg * 8 : 0) + 2 * ks + khalf;
+                        const f16x8 a0 = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(px + (((u0) ^ qsw[dx]) << 4)));
+                        const f16x8 a1 = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(px + (((u0 + 4) ^ qsw[dx]) << 4)));
+                        const int t = dy * 3 + dx;
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, bf[t][ks][1], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, bf[t][ks][0], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, bf[t][ks][0], acc, 0, 0, 0);
+                    }
+                }
+            }
+
+            // ---- epilogue
+            if constexpr (KG == 2) {  // the two channel-group halves of a pixel block meet in LDS
+                float* dst = ksum + pb * (16 * 64);
+                if (kg == 1) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) dst[r * 64 + lane] = acc[r];
+                }
+                lds_barrier();
+                if (kg == 0) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[r] += dst[r * 64 + lane];
+                }
+            }
+            if (KG == 1 || kg == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] *= unscale;
+                if (p.stats != nullptr) {
+                    float sum = 0.f, lo = INFINITY, hi = -INFINITY;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        sum += acc[r];
+                        lo = fminf(lo, acc[r]);
+                        hi = fmaxf(hi, acc[r]);
+                    }
+                    sum += __shfl_xor(sum, 32, 64);
+                    const float mean = sum * (1.f / 32.f);
+                    float m2 = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float d = acc[r] - mean;
+                        m2 += d * d;
+                    }
+                    m2 += __shfl_xor(m2, 32, 64);
+                    lo = fminf(lo, __shfl_xor(lo, 32, 64));
+                    hi = fmaxf(hi, __shfl_xor(hi, 32, 64));
+                    if (khalf == 0) sstat[(s & 1) * NW * 32 + wave * 32 + (lane & 31)] = make_float4(mean, m2, lo, hi);
+                }
+                const size_t m0 = ((size_t)b * H + y0) * W + pb * 32 + 4 * khalf;
+                const unsigned col = (unsigned)(cb * 32 + (lane & 31)) * 4u;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const unsigned off = (unsigned)((m0 + (r & 3) + 8 * (r >> 2)) * (COUT * 4)) + col;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[r]), rsY, off, 0, 0);
+                }
+            }
+            y0 += TH;
+            slot0 += TH;
+            slot0 = slot0 >= R ? slot0 - R : slot0;
+        }
+        // chunk end: the last step's partials, and every wave is done with the ring before the next chunk primes it
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        lds_barrier();
+        if (p.stats != nullptr && wave == 0 && lane < COUT) {
+            const int s = p.rg_per_chunk;
+            const float4* src = sstat + ((s - 1) & 1) * NW * 32;
+            const int c2 = lane >> 5, n = lane & 31;
+            float cnt = 0.f, mean = 0.f, m2 = 0.f, lo = INFINITY, hi = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < PB; ++k) {
+                const float4 v = src[((k * CB + c2) * KG) * 32 + n];
+                const float nt = cnt + 32.f, d = v.x - mean;
+                mean += d * (32.f / nt);
+                m2 += v.y + d * d * (cnt * 32.f / nt);
+                cnt = nt;
+                lo = fminf(lo, v.z);
+                hi = fmaxf(hi, v.w);
+            }
+            const long long part = ((long long)b * H + (y0 - TH)) / TH;
+            reinterpret_cast<float4*>(p.stats)[part * COUT + lane] = make_float4(mean, m2, lo, hi);
+        }
+        lds_barrier();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------- conv1
+// y[b, yo, xo, n] = sum_{c, ky, kx} img[b, c, 2 yo - 1 + ky, 2 xo - 1 + kx] * w[n, c, ky, kx]   (3x3, stride 2, pad 1)
+// on v_mfma_f32_32x32x2_f32 (exact fp32): a wave = 32 consecutive output pixels x all 32 output channels, K = 27 (+1 zero)
+// in 14 steps; A[i = pixel][k] gathered straight from the NCHW image (out-of-range taps read as zero through the buffer
+// descriptor), B[k][n] = the filter, 14 VGPRs for the whole launch.  A workgroup = 4 waves = one 128-row BatchNorm slab:
+// (mean, M2, min, max) per channel, Chan-merged over its four 32-row wave partials.
+struct Conv1Params {
+    const float* img;   // [B][3][Hi][Wi]
+    const float* w;     // [32][27]
+    float* y;           // [B][Ho][Wo][32]
+    float* stats;       // [ceil(M / 128)][32][4] or null
+    int B, Hi, Wi, Ho, Wo;
+    long long M;        // B * Ho * Wo
+    int nslabs;
+    FastDiv fdWo, fdHo;
+};
+
+__global__ __launch_bounds__(256) void stem_conv1_kernel(Conv1Params p) {
+    __shared__ float4 sstat[2][4][32];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kh = lane >> 5, n = lane & 31;
+    float bw[14];
+#pragma unroll
+    for (int kk = 0; kk < 14; ++kk) {
+        const int j = 2 * kk + kh;
+        bw[kk] = j < 27 ? p.w[n * 27 + j] : 0.f;
+    }
+    const size_t img_bytes = (size_t)p.B * 3 * p.Hi * p.Wi * 4;
+    const __amdgpu_buffer_rsrc_t rsI = __builtin_amdgcn_make_buffer_rsrc((void*)p.img, 0, (unsigned)img_bytes, 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+    int it = 0;
+    for (int slab = blockIdx.x; slab < p.nslabs; slab += gridDim.x, ++it) {
+        const long long m = (long long)slab * 128 + wave * 32 + (lane & 31);
+        const bool live = m < p.M;
+        const uint32_t mm = live ? (uint32_t)m : 0u;
+        const uint32_t q = fdiv(mm, p.fdWo);
+        const int xo = (int)(mm - q * p.Wo);
+        const uint32_t b = fdiv(q, p.fdHo);
+        const int yo = (int)(q - b * p.Ho);
+        float a[14];
+#pragma unroll
+        for (int kk = 0; kk < 14; ++kk) {
+            const int j = 2 * kk + kh;  // (compile-time per half: both halves evaluated, selected by kh)
+            const int j0 = 2 * kk, j1 = 2 * kk + 1;
+            const int c = kh ? j1 / 9 : j0 / 9, r9 = kh ? j1 % 9 : j0 % 9;
+            const int ky = r9 / 3, kx = r9 - ky * 3;
+            const int yy = 2 * yo - 1 + ky, xx = 2 * xo - 1 + kx;
+            const bool ok = live && j < 27 && yy >= 0 && yy < p.Hi && xx >= 0 && xx < p.Wi;
+            const unsigned off = ok ? (unsigned)(((((size_t)b * 3 + c) * p.Hi + yy) * p.Wi + xx) * 4) : OOB;
+            a[kk] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsI, off, 0, 0));
+        }
+        v16f acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 14; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk], bw[kk], acc, 0, 0, 0);
+        // rows of this wave that exist
+        const long long row0 = (long long)slab * 128 + wave * 32;
+        const int cnt_w = (int)(p.M - row0 < 32 ? (p.M - row0 > 0 ? p.M - row0 : 0) : 32);
+        if (p.stats != nullptr) {
+            float sum = 0.f, lo = INFINITY, hi = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * kh;
+                if (row < cnt_w) {
+                    sum += acc[r];
+                    lo = fminf(lo, acc[r]);
+                    hi = fmaxf(hi, acc[r]);
+                }
+            }
+            sum += __shfl_xor(sum, 32, 64);
+            const float mean = cnt_w > 0 ? sum / (float)cnt_w : 0.f;
+            float m2 = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * kh;
+                const float d = acc[r] - mean;
+                if (row < cnt_w) m2 += d * d;
+            }
+            m2 += __shfl_xor(m2, 32, 64);
+            lo = fminf(lo, __shfl_xor(lo, 32, 64));
+            hi = fmaxf(hi, __shfl_xor(hi, 32, 64));
+            if (kh == 0) sstat[it & 1][wave][n] = make_float4(mean, m2, lo, hi);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * kh;
+            if (row < cnt_w) p.y[(row0 + row) * 32 + n] = acc[r];
+        }
+        if (p.stats != nullptr) {
+            __syncthreads();  // (double-buffered: the next slab's partials go to the other half)
+            if (wave == 0 && lane < 32) {
+                float cnt = 0.f, mean = 0.f, m2 = 0.f, lo = INFINITY, hi = -INFINITY;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const long long r0 = (long long)slab * 128 + k * 32;
+                    const float nb = (float)(p.M - r0 < 32 ? (p.M - r0 > 0 ? p.M - r0 : 0) : 32);
+                    if (nb > 0.f) {
+                        const float4 v = sstat[it & 1][k][lane];
+                        const float nt = cnt + nb, d = v.x - mean;
+                        mean += d * (nb / nt);
+                        m2 += v.y + d * d * (cnt * nb / nt);
+                        cnt = nt;
+                        lo = fminf(lo, v.z);
+                        hi = fmaxf(hi, v.w);
+                    }
+                }
+                reinterpret_cast<float4*>(p.stats)[(long long)slab * 32 + lane] = make_float4(mean, m2, lo, hi);
+            }
+        }
+    }
+}
+
+template <int CIN, int COUT>
+static int launch_halo(HaloParams& p, hipStream_t stream) {
+    constexpr int NW = 8, CB = COUT / 32, KG = CIN / 32, PB = NW / (CB * KG);
+    const size_t lds = (size_t)p.R * p.rowb + 2 * NW * 32 * sizeof(float4) + (KG == 2 ? (size_t)PB * 16 * 64 * 4 : 0);
+    static std::once_flag once;
+    static hipError_t attr_err = hipSuccess;
+    std::call_once(once, [] {
+        attr_err = hipFuncSetAttribute((const void*)conv3x3_halo_p16_kernel<CIN, COUT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    });
+    if (attr_err != hipSuccess) {
+        set_error("trid_conv3x3_halo_p16: cannot reserve LDS: %s", hipGetErrorString(attr_err));
+        return (int)attr_err;
+    }
+    const int grid = std::min(p.nchunks, 256);
+    hipLaunchKernelGGL((conv3x3_halo_p16_kernel<CIN, COUT>), dim3(grid), dim3(512), lds, stream, p);
+    return check_launch("trid_conv3x3_halo_p16");
+}
+
+}  // namespace trid
+
+using namespace trid;
+
+// rows per step of the halo kernel for this geometry, or 0 when it does not apply (the caller then uses trid_gemm_p16)
+static int halo_rows_per_step(int H, int W, int Cin, int Cout) {
+    if (!((Cin == 32 || Cin == 64) && (Cout == 32 || Cout == 64)) || (Cin == 64 && Cout == 64)) return 0;
+    const int pb = 8 / ((Cin / 32) * (Cout / 32));
+    const int pix = pb * 32;
+    if (W <= 0 || pix % W != 0) return 0;
+    const int th = pix / W;
+    if (H % th != 0) return 0;
+    const int rowb = ((W + 2) * Cin * 4 + 1023) / 1024 * 1024;
+    const size_t lds = (size_t)(2 * th + 2) * rowb + 2 * 8 * 32 * 16 + (Cin == 64 ? (size_t)pb * 16 * 64 * 4 : 0);
+    if (lds > 160 * 1024) return 0;
+    return th;
+}
+
+extern "C" int trid_conv3x3_halo_rows(int H, int W, int Cin, int Cout) { return halo_rows_per_step(H, W, Cin, Cout); }
+
+extern "C" int trid_conv3x3_halo_p16(const void* x, const float* x_amax, const void* w, const float* w_amax, float* y, float* stats,
+                                     int B, int H, int W, int Cin, int Cout, void* stream) {
+    TRID_REQUIRE(x && w && y && x_amax && w_amax && B > 0 && H > 0 && W > 0, "trid_conv3x3_halo_p16: bad arguments");
+    TRID_REQUIRE(aligned16(x) && aligned16(w) && aligned16(y) && (!stats || aligned16(stats)), "trid_conv3x3_halo_p16: operands must be 16-byte aligned");
+    const int th = halo_rows_per_step(H, W, Cin, Cout);
+    TRID_REQUIRE(th > 0, "trid_conv3x3_halo_p16: geometry H=%d W=%d Cin=%d Cout=%d is not covered (trid_conv3x3_halo_rows() == 0)", H, W, Cin, Cout);
+    TRID_REQUIRE((long long)B * H * W * std::max(Cin, Cout) * 4 < (1ll << 31), "trid_conv3x3_halo_p16: tensors must stay below 2 GB (31-bit buffer offsets)");
+    HaloParams p;
+    memset(&p, 0, sizeof(p));
+    p.x = (const char*)x; p.w = (const char*)w; p.y = y; p.stats = stats;
+    p.x_amax = x_amax; p.w_amax = w_amax;
+    p.B = B; p.H = H; p.W = W;
+    p.TH = th;
+    p.R = 2 * th + 2;
+    p.rowb = ((W + 2) * Cin * 4 + 1023) / 1024 * 1024;
+    const int rg = H / th;
+    int cpi = rg;  // chunks per image: the smallest divisor of the step count that gives the chip >= 256 chunks
+    for (int d = 1; d <= rg; ++d)
+        if (rg % d == 0 && (long long)B * d >= 256) {
+            cpi = d;
+            break;
+        }
+    p.chunks_per_image = cpi;
+    p.rg_per_chunk = rg / cpi;
+    p.nchunks = B * cpi;
+    p.fdW = make_fastdiv((uint32_t)W);
+    hipStream_t s = (hipStream_t)stream;
+    if (Cin == 32 && Cout == 32) return launch_halo<32, 32>(p, s);
+    if (Cin == 32 && Cout == 64) return launch_halo<32, 64>(p, s);
+    return launch_halo<64, 32>(p, s);
+}
+
+extern "C" int trid_stem_conv1_f32(const float* img, const float* w, float* y, float* stats, int B, int Hi, int Wi, void* stream) {
+    TRID_REQUIRE(img && w && y && B > 0 && Hi > 0 && Wi > 0, "trid_stem_conv1_f32: bad arguments");
+    TRID_REQUIRE((long long)B * 3 * Hi * Wi * 4 < (1ll << 31), "trid_stem_conv1_f32: the image batch must stay below 2 GB");
+    Conv1Params p;
+    memset(&p, 0, sizeof(p));
+    p.img = img; p.w = w; p.y = y; p.stats = stats;
+    p.B = B; p.Hi = Hi; p.Wi = Wi;
+    p.Ho = (Hi + 1) / 2; p.Wo = (Wi + 1) / 2;
+    p.M = (long long)B * p.Ho * p.Wo;
+    TRID_REQUIRE(p.M < (1ll << 31), "trid_stem_conv1_f32: too many output pixels");
+    p.nslabs = (int)((p.M + 127) / 128);
+    p.fdWo = make_fastdiv((uint32_t)p.Wo);
+    p.fdHo = make_fastdiv((uint32_t)p.Ho);
+    const int grid = std::min(p.nslabs, 256 * 8);
+    hipLaunchKernelGGL(stem_conv1_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+    return check_launch("trid_stem_conv1_f32");
+}
