@@ -134,6 +134,25 @@ int trid_weight_transpose_f32(const float* w, float* wt, int N, int T, int C, in
 int trid_stem_im2col_f32(const float* img, float* col, int B, int Cin, int H, int W, int Ho, int Wo,
                          int ldcol, void* stream);
 
+/* ---- the stem as bandwidth-shaped kernels (csrc/stem_conv.hip): every input pixel crosses the load path once.
+ * Stem conv1 (nn.Conv2d(3, 32, 3, stride=2, padding=1, bias=False), m_resnet.py:161,205) straight from the NCHW image
+ * batch [B][3][Hi][Wi] on the exact fp32 MFMA: y [B][Ho][Wo][32] (Ho = ceil(Hi/2), Wo = ceil(Wi/2)), w [32][27] as
+ * stored; stats (may be NULL): [ceil(M/128)][32][4] = per-128-row (mean, M2, min, max) BatchNorm partials
+ * (trid_bn_finalize_minmax_f32 with rows_per_part 128). */
+int trid_stem_conv1_f32(const float* img, const float* w, float* y, float* stats, int B, int Hi, int Wi, void* stream);
+/* 3x3 / stride 1 / pad 1 convolution (nn.Conv2d(C, N, 3, padding=1, bias=False): stem conv2 / conv3,
+ * m_resnet.py:165-170,206-207, and - with the transposed, 180-degree rotated filters of trid_p16_pack_multi_f32 - their
+ * data gradients) for 32 / 64 channels on P16 operands: x = P16 NHWC [B][H][W][Cin] (scale from x_amax), w = P16
+ * [Cout][9*Cin] (k = tap*Cin + c; w_amax), y fp32 [B][H][W][Cout].  A ring of image rows in LDS (LDS-DMA, zero padding
+ * as data) feeds all nine taps; the filter slice of a wave lives in registers.  stats (may be NULL):
+ * [B*H/rows][Cout][4] = (mean, M2, min, max) per step tile of rows*W pixels, rows = trid_conv3x3_halo_rows(H, W, Cin,
+ * Cout) (= rows_per_part / W of trid_bn_finalize_minmax_f32); 0 there: the geometry is not covered, use trid_gemm_p16.
+ * chunks_per_image: bands of rows an image is cut into (each band is walked by one persistent workgroup and re-reads
+ * two halo rows); 0 = chosen so that the launch has >= 256 bands. */
+int trid_conv3x3_halo_rows(int H, int W, int Cin, int Cout);
+int trid_conv3x3_halo_p16(const void* x, const float* x_amax, const void* w, const float* w_amax, float* y, float* stats,
+                          int B, int H, int W, int Cin, int Cout, int chunks_per_image, void* stream);
+
 /* ------------------------------------------------------------------------- *
  * BatchNorm2d (train: batch statistics + running update; eval: running stats),
  * ReLU, residual add, AvgPool2d(2).  m_resnet.py:19-29,38-49,57-66,164-171.

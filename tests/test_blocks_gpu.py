@@ -154,10 +154,13 @@ def test_bottleneck_b128_unstructured_masks(gpu, name, inpl, planes, stride, H, 
     assert (true * (1 - 1e-6) <= a <= 2.0 * true) if path == "p16" else amax_err <= 1e-4, (a, true)
 
 
-def test_stem_b128_unstructured_masks(gpu):
-    """The stem at the benchmarked size: 3x3/s2 conv through im2col + GEMM, the two 32-channel 3x3 convolutions on the
-    256x32 / 128x64 fp16-split tiles, BatchNorm + ReLU with random masks, 2x2 average pool - forward, all nine
-    gradients, running statistics against the oracle (m_resnet.py:198-207)."""
+@pytest.mark.parametrize("path", ["p16", "split"])
+def test_stem_b128_unstructured_masks(gpu, path):
+    """The stem at the benchmarked size, BatchNorm + ReLU with random masks, 2x2 average pool - forward, all nine
+    gradients, running statistics against the oracle (m_resnet.py:198-207).  path "p16": the production path
+    (csrc/stem_conv.hip: conv1 straight from the NCHW image on the exact fp32 MFMA, conv2 / conv3 and their data
+    gradients on the ring-of-rows kernel over P16 tensors written by the BatchNorm passes, weight gradients on the
+    transposing P16 kernel); "split": the general path (im2col + GEMM, on-the-fly fp16 split on 256x32 / 128x64 tiles)."""
     from textreid_amd import ops
     from textreid_amd.backbones import m_resnet as M
 
@@ -172,10 +175,19 @@ def test_stem_b128_unstructured_masks(gpu):
     gout = _randn((B, spec.width, spec.height // 4, spec.in_width // 4), seed + 1)
     ar = M.ConvArith(gpu, M.weight_amax(m))
     nbt, masks = [], []
-    x, ax, rec = M.stem_forward(m, images.to(gpu), ar, True, nbt, masks)
     ws = M._WgradStream(gpu)
     G = {}
-    M.stem_backward(m, rec, gout.permute(0, 2, 3, 1).contiguous().to(gpu), ar, ws, G)
+    gd = gout.permute(0, 2, 3, 1).contiguous().to(gpu)
+    if path == "p16":
+        imd = images.to(gpu)
+        assert M.stem_p16_ok(m, imd)
+        xp, rec = M.stem_forward_p16(m, imd, M.p16_weights(m, ar.WA, False), gpu, nbt, masks)
+        x = xp.unpack()
+        assert float(xp.amax) >= float(x.abs().max()) * (1 - 1e-6)  # the bound the residual blocks scale by
+        M.stem_backward_p16(m, rec, gd, M.p16_weights(m, ar.WA, True), ws, G)
+    else:
+        x, ax, rec = M.stem_forward(m, images.to(gpu), ar, True, nbt, masks)
+        M.stem_backward(m, rec, gd, ar, ws, G)
     ws.join()
     torch.cuda.synchronize()
 
@@ -202,7 +214,7 @@ def test_stem_b128_unstructured_masks(gpu):
         elif k.endswith(("running_mean", "running_var")):
             errs["state:" + k] = relmax(m.state_dict()[k], s64[k])
     flips, total, fmax = taps.get("flips", 0), taps["relu_elems"], taps.get("flip_max_rel", 0.0)
-    print("stem B=%d: %d of %d ReLU decisions differ (|pre-activation| <= %.1e of max);" % (B, flips, total, fmax), {k: "%.1e" % v for k, v in errs.items()})
+    print("stem (%s) B=%d: %d of %d ReLU decisions differ (|pre-activation| <= %.1e of max);" % (path, B, flips, total, fmax), {k: "%.1e" % v for k, v in errs.items()})
     assert flips <= FLIP_FRACTION * total and fmax <= FLIP_MAGNITUDE, (flips, total, fmax)
     bad = {k: v for k, v in errs.items() if not v <= TOL}
     assert not bad, bad

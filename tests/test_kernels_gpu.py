@@ -151,6 +151,64 @@ def test_conv1x1_all(ops, B, C, H, W, N, prec):
     assert rel(ops.conv1x1_wgrad(gd, xd, **_prec_kw(ops, prec, gd, xd)), wr.grad.reshape(N, C)) < TOL
 
 
+# (B, Cin, H, W, Cout, chunks per image): the stem's three channel pairs at its own 192x64 geometry (4 / 2 rows per step,
+# steady-state ring rotation over 12 / 24 steps per band) and at the tiny test encoders' 48x16 (16 / 8 rows per step)
+HALO_SHAPES = [(2, 32, 192, 64, 32, 4), (2, 32, 192, 64, 64, 4), (2, 64, 192, 64, 32, 4), (3, 32, 48, 16, 32, 1), (3, 32, 48, 16, 64, 3),
+               (3, 64, 48, 16, 32, 0), (1, 32, 192, 64, 32, 0)]
+
+
+@pytest.mark.parametrize("B,C,H,W,N,cpi", HALO_SHAPES)
+def test_conv3x3_halo_p16(ops, B, C, H, W, N, cpi):
+    """csrc/stem_conv.hip: the 3x3 convolution of the stem (ring of image rows in LDS, filters in registers) against
+    F.conv2d - forward with BatchNorm partials, and the data-gradient form with rotated / transposed filters - and, for
+    32 input channels, BIT for bit against the implicit-GEMM kernel it replaces (same products, same order)."""
+    x, w, gy = R("hx", B, C, H, W), R("hw", N, C, 3, 3, scale=0.1), R("hg", B, N, H, W)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    y_ref = F.conv2d(xr, wr, padding=1)
+    y_ref.backward(gy)
+    assert ops.conv3x3_halo_rows(H, W, C, N) > 0
+    xp, wp = ops.p16_pack(dev(nhwc(x))), ops.p16_pack(dev(ohwi(w)))
+    y, st, rpp = ops.conv3x3_halo_p16(xp, wp, chunks_per_image=cpi)
+    assert rel(y.permute(0, 3, 1, 2), y_ref) < TOL
+    y2, _ = ops.conv_p16(xp, wp, conv3=True)
+    if C == 32:
+        assert torch.equal(y, y2)
+    else:
+        assert rel(y, y2) < 1e-6  # (two 32-channel halves summed once instead of one 64-deep chain)
+    # the (mean, M2, min, max) partials -> batch statistics and the exact bound of max|relu(bn(y))|
+    gamma, beta = R("hgm", N).abs() + 0.5, R("hbt", N)
+    bound = ops.amax_slot(y.device)
+    fin = ops.bn_finalize_minmax(st, B * H * W, dev(gamma), dev(beta), None, None, True, bound, rows_per_part=rpp)
+    yr = y_ref.detach()
+    mean, var = yr.mean((0, 2, 3)), yr.var((0, 2, 3), unbiased=False)
+    assert rel(fin.mean, mean) < 1e-5 and rel(fin.invstd, 1 / torch.sqrt(var + 1e-5)) < 1e-5
+    act = F.relu(F.batch_norm(yr, None, None, gamma, beta, True, 0.1, 1e-5))
+    assert abs(float(bound) - float(act.max())) <= 1e-4 * float(act.max())
+    # data gradient: the same kernel on dL/dy with the filters transposed and rotated by 180 degrees
+    gp = ops.p16_pack(dev(nhwc(gy)))
+    wt = ops.p16_pack_wt(dev(ohwi(w)), N, 9, C, True, ops.amax(dev(ohwi(w))))
+    if ops.conv3x3_halo_rows(H, W, N, C) > 0:
+        dx = ops.conv3x3_halo_p16(gp, wt, stats=False, chunks_per_image=cpi)
+        assert rel(dx.permute(0, 3, 1, 2), xr.grad) < TOL
+
+
+@pytest.mark.parametrize("B,H,W", [(3, 24, 16), (2, 384, 128), (5, 96, 32), (1, 22, 10)])
+def test_stem_conv1_direct(ops, B, H, W):
+    """csrc/stem_conv.hip: the 3 -> 32 channel, stride-2 convolution straight from the NCHW image (exact fp32 MFMA, no
+    im2col tensor) against F.conv2d, with its per-128-row BatchNorm partials (ragged last slab included)."""
+    x, w = R("c1x", B, 3, H, W), R("c1w", 32, 3, 3, 3, scale=0.3)
+    y_ref = F.conv2d(x, w, stride=2, padding=1)
+    y, st = ops.stem_conv1(dev(x), dev(w))
+    assert tuple(y.shape) == (B, (H + 1) // 2, (W + 1) // 2, 32)
+    assert rel(y.permute(0, 3, 1, 2), y_ref) < 2e-6
+    M = y.numel() // 32
+    bound = ops.amax_slot(y.device)
+    fin = ops.bn_finalize_minmax(st, M, torch.ones(32, device="cuda"), torch.zeros(32, device="cuda"), None, None, False, bound)
+    assert rel(fin.mean, y_ref.mean((0, 2, 3))) < 1e-5 and rel(fin.invstd, 1 / torch.sqrt(y_ref.var((0, 2, 3), unbiased=False) + 1e-5)) < 1e-5
+    z = (y_ref - y_ref.mean((0, 2, 3), keepdim=True)) / torch.sqrt(y_ref.var((0, 2, 3), unbiased=False, keepdim=True) + 1e-5)
+    assert abs(float(bound) - float(z.abs().max())) <= 1e-4 * float(z.abs().max())
+
+
 def test_stem_im2col_conv(ops):
     x, w = R("sx", 3, 3, 24, 16), R("sw", 8, 3, 3, 3)
     col, Ho, Wo = ops.stem_im2col(dev(x))

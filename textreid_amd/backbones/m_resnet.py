@@ -192,6 +192,8 @@ def p16_weights(mod, WA, transposed, fmt=1):
     index = {id(w): i for i, w in enumerate(convs)}
     blocks = mod.blocks() if hasattr(mod, "blocks") else [mod]  # (a single Bottleneck: per-block parity tests)
     mine = [m.weight for blk in blocks for m in blk.modules() if isinstance(m, nn.Conv2d)]
+    if fmt == 1 and hasattr(mod, "blocks") and stem_p16_channels(mod):
+        mine = [mod.conv2.weight, mod.conv3.weight] + mine  # the stem's 3x3 convolutions run on P16 operands too (stem_forward_p16)
     key = tuple(w.data_ptr() for w in mine)
     plans = mod.__dict__.setdefault("_p16_plans", {})
     plan = plans.get((transposed, fmt))
@@ -269,6 +271,69 @@ def stem_backward(mod, rec, g, ar, ws, G):
     G[id(mod.conv2.weight)] = _g3x3(ws.run(ops.conv3x3_wgrad, dy2, a1), c2o, c2i)
     dy1, dg, db, _ = ops.bn_bwd(da1, y1, st1, None, 1)
     G[id(mod.bn1.weight)], G[id(mod.bn1.bias)] = dg, db
+    dw1 = ws.run(ops.conv1x1_wgrad, dy1, col)  # [32, 28]
+    c1 = mod.conv1.weight
+    G[id(c1)] = dw1[:, : c1[0].numel()].reshape(c1.shape)
+
+
+def stem_p16_channels(mod):
+    """The P16 stem flow covers the CLIP stem's channel counts: 3 -> 32 -> 32 -> 64."""
+    return (mod.conv1.in_channels, mod.conv1.out_channels, mod.conv2.out_channels, mod.conv3.out_channels) == (3, 32, 32, 64)
+
+
+def stem_p16_ok(mod, images):
+    """... and the map sizes the ring-of-rows convolution kernel tiles (csrc/stem_conv.hip): 192x64 at 384x128 input."""
+    Ho, Wo = (images.shape[2] + 1) // 2, (images.shape[3] + 1) // 2
+    return (stem_p16_channels(mod) and Ho % 2 == 0 and Wo % 2 == 0 and images.is_contiguous()
+            and all(ops.conv3x3_halo_rows(Ho, Wo, ci, co) > 0 for ci, co in ((32, 32), (32, 64), (64, 32))))
+
+
+def stem_forward_p16(mod, images, WP, dev, nbt, masks=None):
+    """The stem (m_resnet.py:199-207) as bandwidth-shaped kernels on pre-split operands: conv1 straight from the NCHW
+    image (exact fp32 MFMA, no im2col tensor), conv2 / conv3 on the ring-of-rows kernel with their inputs written as
+    P16 tensors by the BatchNorm passes (bounds from the conv epilogues' column extremes), and the pooled output handed
+    to the residual blocks as the P16 tensor they consume (no fp32 copy + pack pass).  Returns (x P16, record)."""
+    y1, p1 = ops.stem_conv1(images, mod.conv1.weight)
+    M = y1.numel() // y1.shape[-1]
+    b1 = ops.amax_slot(dev)
+    st1 = _finalize_minmax(mod.bn1, p1, M, True, b1, nbt)
+    a1 = ops.bn_apply_p16(y1, st1, b1, relu=True)
+    y2, p2, rpp2 = ops.conv3x3_halo_p16(a1, WP[id(mod.conv2.weight)])
+    b2 = ops.amax_slot(dev)
+    st2 = _finalize_minmax(mod.bn2, p2, M, True, b2, nbt, rpp2)
+    a2 = ops.bn_apply_p16(y2, st2, b2, relu=True)
+    y3, p3, rpp3 = ops.conv3x3_halo_p16(a2, WP[id(mod.conv3.weight)])
+    b3 = ops.amax_slot(dev)
+    st3 = _finalize_minmax(mod.bn3, p3, M, True, b3, nbt, rpp3)
+    x = ops.bn_apply_pool2_p16(y3, st3, b3, relu=True)  # (an average never exceeds the maximum: b3 bounds the pooled tensor)
+    if masks is not None:
+        masks.extend([a1.unpack() > 0, a2.unpack() > 0, _pre_mask(y3, st3)])
+    return x, (images, y1, st1, a1, y2, st2, a2, y3, st3)
+
+
+def stem_backward_p16(mod, rec, g, WPT, ws, G):
+    """Backward of stem_forward_p16.  g: dL/d(pooled stem output) fp32.  BatchNorm-backward outputs are P16 tensors, the
+    data gradients of conv3 / conv2 run on the ring-of-rows kernel with the rotated / transposed filters, the weight
+    gradients on the transposing P16 kernel (side stream); conv1's weight gradient gathers the image once more (im2col,
+    backward only)."""
+    images, y1, st1, a1, y2, st2, a2, y3, st3 = rec
+    Bi, H, W, _ = y3.shape
+
+    def wgrad(dy, act, C):
+        return ws.run(lambda d_, x_: ops.wgrad_p16(ops.P16(d_, dy.amax), ops.P16(x_, act.amax), conv=(H, W, C)), dy.data, act.data,
+                      keep=(dy.amax, act.amax))
+
+    dy3, dg, db, _ = ops.bn_bwd_p16(g, y3, st3, 1, pooled=True)
+    G[id(mod.bn3.weight)], G[id(mod.bn3.bias)] = dg, db
+    da2 = ops.conv3x3_halo_p16(dy3, WPT[id(mod.conv3.weight)], stats=False)
+    G[id(mod.conv3.weight)] = _g3x3(wgrad(dy3, a2, 32), 64, 32)
+    dy2, dg, db, _ = ops.bn_bwd_p16(da2, y2, st2, 1)
+    G[id(mod.bn2.weight)], G[id(mod.bn2.bias)] = dg, db
+    da1 = ops.conv3x3_halo_p16(dy2, WPT[id(mod.conv2.weight)], stats=False)
+    G[id(mod.conv2.weight)] = _g3x3(wgrad(dy2, a1, 32), 32, 32)
+    dy1, dg, db, _ = ops.bn_bwd(da1, y1, st1, None, 1)
+    G[id(mod.bn1.weight)], G[id(mod.bn1.bias)] = dg, db
+    col, _, _ = ops.stem_im2col(images)
     dw1 = ws.run(ops.conv1x1_wgrad, dy1, col)  # [32, 28]
     c1 = mod.conv1.weight
     G[id(c1)] = dw1[:, : c1[0].numel()].reshape(c1.shape)
@@ -402,8 +467,8 @@ def block_forward_p16(blk, x, WP, dev, training, save, nbt, masks=None):
     return out, rec
 
 
-def _finalize_minmax(bn, partials, M, relu, bound, counters):
-    st = ops.bn_finalize_minmax(partials, M, bn.weight, bn.bias, bn.running_mean, bn.running_var, relu, bound)
+def _finalize_minmax(bn, partials, M, relu, bound, counters, rows_per_part=ops.STATS_ROWS):
+    st = ops.bn_finalize_minmax(partials, M, bn.weight, bn.bias, bn.running_mean, bn.running_var, relu, bound, rows_per_part=rows_per_part)
     counters.append(bn.num_batches_tracked)
     return st
 
@@ -613,9 +678,17 @@ class ModifiedResNet(nn.Module):
         nbt = []  # num_batches_tracked buffers, incremented together at the end of the pass
         # ---- stem (m_resnet.py:199-207)
         masks = getattr(self, "_debug_masks", None)  # parity tests: every ReLU decision of the pass, in execution order
-        x, ax, srec = stem_forward(self, images, ar, training, nbt, masks)
+        p16 = ops.USE_P16 and training and ar.PB in (16, 1) and p16_eligible(self, 32 if ar.PB == 16 else 64)
+        fmt = (1 if ar.PB == 16 else 2) if p16 else 0
+        WP = p16_weights(self, ar.WA, False, fmt) if p16 else None  # every filter the pass multiplies with, ONE launch
+        stem16 = fmt == 1 and ops.USE_P16_STEM and stem_p16_ok(self, images)
+        if stem16:
+            x, srec = stem_forward_p16(self, images, WP, images.device, nbt, masks)
+        else:
+            x, ax, srec = stem_forward(self, images, ar, training, nbt, masks)
         if save:
             S["stem"] = srec
+            S["stem_p16"] = stem16
             S["wamax"] = ar.WA
             S["prec"] = ar.PB
         # ---- residual layers (m_resnet.py:54-67)
@@ -623,17 +696,16 @@ class ModifiedResNet(nn.Module):
             S["blocks"] = []
         taps = getattr(self, "_debug_taps", None)  # parity tests: per-stage activations (NHWC), keyed like the oracle's taps
         if taps is not None:
-            taps["stem"] = x
+            taps["stem"] = x.unpack() if stem16 else x
             names = {id(blk): "layer%d.%d" % (li + 1, bi) for li, layer in enumerate((self.layer1, self.layer2, self.layer3, self.layer4))
                      for bi, blk in enumerate(layer)}
-        p16 = ops.USE_P16 and training and ar.PB in (16, 1) and p16_eligible(self, 32 if ar.PB == 16 else 64)
         if p16:
             # residual blocks on pre-split operands: filters packed once per pass, activations written split by the
-            # BatchNorm passes; the stem stays on the fp32 path (32-channel tiles) and hands over one packed tensor.
-            # PB == 1 (configs[3]): the same data flow on plain bf16 tensors
-            fmt = 1 if ar.PB == 16 else 2
-            WP = p16_weights(self, ar.WA, False, fmt)
-            x = ops.p16_pack(x, ax, fmt)
+            # BatchNorm passes.  The stem hands over a P16 tensor (stem_forward_p16) or, on geometries / modes its
+            # kernels do not cover, an fp32 tensor that is packed here.  PB == 1 (configs[3]): the same data flow on
+            # plain bf16 tensors
+            if not stem16:
+                x = ops.p16_pack(x, ax, fmt)
             for blk in self.blocks():
                 x, rec = block_forward_p16(blk, x, WP, images.device, training, save, nbt, masks)
                 if save:
@@ -783,8 +855,11 @@ class ModifiedResNet(nn.Module):
             if id(blk) in first_of_layer:  # a whole residual layer (and, the first time, the attention pool) is done
                 stage_ready()
         S["blocks"] = None
-        g = g.float()  # the stem runs on fp32 tensors in every mode
-        stem_backward(self, S["stem"], g, ar, ws, G)
+        g = g.float()  # the stem's BatchNorm passes take fp32 gradients in every mode
+        if S.get("stem_p16"):
+            stem_backward_p16(self, S["stem"], g, WPT, ws, G)
+        else:
+            stem_backward(self, S["stem"], g, ar, ws, G)
         ws.join()
         if sync is not None:
             stage_ready()  # the stem

@@ -41,6 +41,19 @@ __device__ __forceinline__ void dma16(const __amdgpu_buffer_rsrc_t& rs, void* ld
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)lds_base, 16, voffset, 0, 0, 0);
 }
 
+// LDS stores the compiler does not see: beside an LDS-DMA in flight hipcc orders every ds_write behind `s_waitcnt vmcnt(0)`
+// (the DMA is a pending LDS write on the VM counter and it cannot prove the two do not alias), which would serialise the
+// epilogue behind the prefetch of the next rows.  The scratch regions written here are disjoint from the ring.
+__device__ __forceinline__ unsigned lds_off(const void* p) { return (unsigned)(uintptr_t)p; }
+typedef float v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void lds_store4(const void* p, float4 v) {
+    const v4f r = {v.x, v.y, v.z, v.w};  // (a 128-bit register tuple: the HIP float4 struct is not an asm operand)
+    asm volatile("ds_write_b128 %0, %1" ::"v"(lds_off(p)), "v"(r) : "memory");
+}
+__device__ __forceinline__ void lds_store1(const void* p, float v) {
+    asm volatile("ds_write_b32 %0, %1" ::"v"(lds_off(p)), "v"(v) : "memory");
+}
+
 struct HaloParams {
     const char* x;        // P16 NHWC [B][H][W][CIN]
     const char* w;        // P16 [COUT][9 * CIN] (k = tap * CIN + c)
@@ -174,30 +187,35 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_p16_kernel(HaloParams p) 
                 issue_rows(b, y0 + TH + 1, TH, sl);
             }
 
-            // ---- 9 taps x 2 k steps x 3 products on the TH + 2 ring rows
+            // ---- 9 taps x 2 k steps x 3 products on the TH + 2 ring rows; the fragments of group g + 1 are fetched
+            // before the MFMAs of group g issue (two register sets, statically indexed)
             v16f acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            const char* rowp[3];
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy) {
                 int rs = slot0 + ty + dy;
                 rs = rs >= R ? rs - R : rs;
                 rs = rs >= R ? rs - R : rs;
-                const char* rowp = ring + (size_t)rs * rowb;
+                rowp[dy] = ring + (size_t)rs * rowb;
+            }
+            f16x8 af[2][2];
+            auto fetch = [&](int g, f16x8(&dst)[2]) {  // g = tap * 2 + ks
+                const int t = g >> 1, ks = g & 1, dy = t / 3, dx = t - 3 * dy;
+                const char* px = rowp[dy] + qoff[dx];
+                const int u0 = (KG == 2 ? kg * 8 : 0) + 2 * ks + khalf;
+                dst[0] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(px + (((u0) ^ qsw[dx]) << 4)));
+                dst[1] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(px + (((u0 + 4) ^ qsw[dx]) << 4)));
+            };
+            fetch(0, af[0]);
 #pragma unroll
-                for (int dx = 0; dx < 3; ++dx) {
-                    const char* px = rowp + qoff[dx];
-#pragma unroll
-                    for (int ks = 0; ks < 2; ++ks) {
-                        const int u0 = (KG == 2 ? kg * 8 : 0) + 2 * ks + khalf;
-                        const f16x8 a0 = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(px + (((u0) ^ qsw[dx]) << 4)));
-                        const f16x8 a1 = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(px + (((u0 + 4) ^ qsw[dx]) << 4)));
-                        const int t = dy * 3 + dx;
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, bf[t][ks][1], acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, bf[t][ks][0], acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, bf[t][ks][0], acc, 0, 0, 0);
-                    }
-                }
+            for (int g = 0; g < 18; ++g) {
+                if (g + 1 < 18) fetch(g + 1, af[(g + 1) & 1]);
+                const int t = g >> 1, ks = g & 1;
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[g & 1][0], bf[t][ks][1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[g & 1][1], bf[t][ks][0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[g & 1][0], bf[t][ks][0], acc, 0, 0, 0);
             }
 
             // ---- epilogue
@@ -205,7 +223,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_p16_kernel(HaloParams p) 
                 float* dst = ksum + pb * (16 * 64);
                 if (kg == 1) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) dst[r * 64 + lane] = acc[r];
+                    for (int r = 0; r < 16; ++r) {
+                        const float v = acc[r];
+                        lds_store1(dst + r * 64 + lane, v);
+                    }
                 }
                 lds_barrier();
                 if (kg == 0) {
@@ -235,14 +256,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_p16_kernel(HaloParams p) 
                     m2 += __shfl_xor(m2, 32, 64);
                     lo = fminf(lo, __shfl_xor(lo, 32, 64));
                     hi = fmaxf(hi, __shfl_xor(hi, 32, 64));
-                    if (khalf == 0) sstat[(s & 1) * NW * 32 + wave * 32 + (lane & 31)] = make_float4(mean, m2, lo, hi);
+                    if (khalf == 0) lds_store4(sstat + (s & 1) * NW * 32 + wave * 32 + (lane & 31), make_float4(mean, m2, lo, hi));
                 }
                 const size_t m0 = ((size_t)b * H + y0) * W + pb * 32 + 4 * khalf;
                 const unsigned col = (unsigned)(cb * 32 + (lane & 31)) * 4u;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const unsigned off = (unsigned)((m0 + (r & 3) + 8 * (r >> 2)) * (COUT * 4)) + col;
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[r]), rsY, off, 0, 0);
+                    const float v = acc[r];  // (a bit_cast of the vector ELEMENT itself stores element 0 sixteen times)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsY, off, 0, 0);
                 }
             }
             y0 += TH;
@@ -304,6 +326,7 @@ __global__ __launch_bounds__(256) void stem_conv1_kernel(Conv1Params p) {
     }
     const size_t img_bytes = (size_t)p.B * 3 * p.Hi * p.Wi * 4;
     const __amdgpu_buffer_rsrc_t rsI = __builtin_amdgcn_make_buffer_rsrc((void*)p.img, 0, (unsigned)img_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, (unsigned)(p.M * 128), 0x00020000);
     constexpr unsigned OOB = 0x80000000u;
     int it = 0;
     for (int slab = blockIdx.x; slab < p.nslabs; slab += gridDim.x, ++it) {
@@ -314,17 +337,19 @@ __global__ __launch_bounds__(256) void stem_conv1_kernel(Conv1Params p) {
         const int xo = (int)(mm - q * p.Wo);
         const uint32_t b = fdiv(q, p.fdHo);
         const int yo = (int)(q - b * p.Ho);
+        // branch-free gather: the byte offset of every tap is formed in 32-bit arithmetic whether or not the tap exists,
+        // a tap outside the image (or k = 27, or a pixel beyond M) gets the out-of-range offset and reads as zero
+        const unsigned img0 = (unsigned)b * 3u * (unsigned)(p.Hi * p.Wi);
         float a[14];
 #pragma unroll
         for (int kk = 0; kk < 14; ++kk) {
-            const int j = 2 * kk + kh;  // (compile-time per half: both halves evaluated, selected by kh)
-            const int j0 = 2 * kk, j1 = 2 * kk + 1;
+            const int j0 = 2 * kk, j1 = 2 * kk + 1;  // this lane's k index is j0 (lower half-wave) or j1 (upper)
             const int c = kh ? j1 / 9 : j0 / 9, r9 = kh ? j1 % 9 : j0 % 9;
-            const int ky = r9 / 3, kx = r9 - ky * 3;
+            const int ky = kh ? (j1 % 9) / 3 : (j0 % 9) / 3, kx = r9 - ky * 3;
             const int yy = 2 * yo - 1 + ky, xx = 2 * xo - 1 + kx;
-            const bool ok = live && j < 27 && yy >= 0 && yy < p.Hi && xx >= 0 && xx < p.Wi;
-            const unsigned off = ok ? (unsigned)(((((size_t)b * 3 + c) * p.Hi + yy) * p.Wi + xx) * 4) : OOB;
-            a[kk] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsI, off, 0, 0));
+            const bool ok = live & ((2 * kk + kh) < 27) & (yy >= 0) & (yy < p.Hi) & (xx >= 0) & (xx < p.Wi);
+            const unsigned off = (img0 + (unsigned)((c * p.Hi + yy) * p.Wi + xx)) * 4u;
+            a[kk] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsI, ok ? off : OOB, 0, 0));
         }
         v16f acc;
 #pragma unroll
@@ -360,9 +385,10 @@ __global__ __launch_bounds__(256) void stem_conv1_kernel(Conv1Params p) {
             if (kh == 0) sstat[it & 1][wave][n] = make_float4(mean, m2, lo, hi);
         }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * kh;
-            if (row < cnt_w) p.y[(row0 + row) * 32 + n] = acc[r];
+        for (int r = 0; r < 16; ++r) {  // (rows beyond M lie beyond the descriptor's range: the store is dropped)
+            const unsigned off = (unsigned)((row0 + (r & 3) + 8 * (r >> 2) + 4 * kh) * 128 + n * 4);
+            const float v = acc[r];
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsY, off, 0, 0);
         }
         if (p.stats != nullptr) {
             __syncthreads();  // (double-buffered: the next slab's partials go to the other half)
@@ -427,7 +453,7 @@ static int halo_rows_per_step(int H, int W, int Cin, int Cout) {
 extern "C" int trid_conv3x3_halo_rows(int H, int W, int Cin, int Cout) { return halo_rows_per_step(H, W, Cin, Cout); }
 
 extern "C" int trid_conv3x3_halo_p16(const void* x, const float* x_amax, const void* w, const float* w_amax, float* y, float* stats,
-                                     int B, int H, int W, int Cin, int Cout, void* stream) {
+                                     int B, int H, int W, int Cin, int Cout, int chunks_per_image, void* stream) {
     TRID_REQUIRE(x && w && y && x_amax && w_amax && B > 0 && H > 0 && W > 0, "trid_conv3x3_halo_p16: bad arguments");
     TRID_REQUIRE(aligned16(x) && aligned16(w) && aligned16(y) && (!stats || aligned16(stats)), "trid_conv3x3_halo_p16: operands must be 16-byte aligned");
     const int th = halo_rows_per_step(H, W, Cin, Cout);
@@ -448,6 +474,10 @@ extern "C" int trid_conv3x3_halo_p16(const void* x, const float* x_amax, const v
             cpi = d;
             break;
         }
+    if (chunks_per_image > 0) {
+        TRID_REQUIRE(rg % chunks_per_image == 0, "trid_conv3x3_halo_p16: chunks_per_image must divide the %d steps of an image", rg);
+        cpi = chunks_per_image;
+    }
     p.chunks_per_image = cpi;
     p.rg_per_chunk = rg / cpi;
     p.nchunks = B * cpi;
@@ -467,7 +497,7 @@ extern "C" int trid_stem_conv1_f32(const float* img, const float* w, float* y, f
     p.B = B; p.Hi = Hi; p.Wi = Wi;
     p.Ho = (Hi + 1) / 2; p.Wo = (Wi + 1) / 2;
     p.M = (long long)B * p.Ho * p.Wo;
-    TRID_REQUIRE(p.M < (1ll << 31), "trid_stem_conv1_f32: too many output pixels");
+    TRID_REQUIRE(p.M * 128 < (1ll << 31), "trid_stem_conv1_f32: the output must stay below 2 GB (31-bit buffer offsets)");
     p.nslabs = (int)((p.M + 127) / 128);
     p.fdWo = make_fastdiv((uint32_t)p.Wo);
     p.fdHo = make_fastdiv((uint32_t)p.Ho);

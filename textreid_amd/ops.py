@@ -295,6 +295,7 @@ def gemm_p16(A, B, C, M, N, K, ldc, conv=None, alpha=1.0, accumulate=False, bias
 
 
 USE_P16 = __import__("os").environ.get("TRID_P16", "1") != "0"  # residual blocks on pre-split operands (csrc/gemm_p16.hip)
+USE_P16_STEM = __import__("os").environ.get("TRID_P16_STEM", "1") != "0"  # ... and the stem on csrc/stem_conv.hip (0: A/B runs)
 
 
 def conv_p16(x, w, conv3=False, stats=True):
@@ -312,11 +313,46 @@ def conv_p16(x, w, conv3=False, stats=True):
     return (y, st) if stats else y
 
 
-def bn_finalize_minmax(partials, M, gamma, beta, running_mean, running_var, relu, bound, momentum=BN_MOMENTUM, eps=BN_EPS):
+def conv3x3_halo_rows(H, W, Cin, Cout):
+    """Image rows per step of the stem's ring-of-rows convolution kernel for this geometry (csrc/stem_conv.hip), 0 when
+    the kernel does not cover it (channel counts other than 32 / 64, a width that does not tile 128 / 256 pixels)."""
+    return int(L.load().trid_conv3x3_halo_rows(int(H), int(W), int(Cin), int(Cout)))
+
+
+def conv3x3_halo_p16(x, w, stats=True, chunks_per_image=0):
+    """3x3 / stride 1 / pad 1 convolution of a P16 NHWC image x [B,H,W,Cin] with P16 filters w [Cout, 9*Cin] (Cin, Cout in
+    {32, 64}: the stem) -> raw output y fp32 [B,H,W,Cout]; with stats also the (mean, M2, min, max) BatchNorm partials
+    [steps][Cout][4] and the rows each of them covers (the `rows_per_part` of bn_finalize_minmax)."""
+    Bi, H, W, C = x.shape
+    N = w.shape[0]
+    th = conv3x3_halo_rows(H, W, C, N)
+    if th == 0 or x.fmt != 1 or w.fmt != 1:
+        raise RuntimeError("conv3x3_halo_p16: geometry H=%d W=%d Cin=%d Cout=%d (or a non-P16 operand) is not covered" % (H, W, C, N))
+    y = empty((Bi, H, W, N), x.data)
+    st = empty((Bi * H // th, N, 4), x.data) if stats else None
+    call("trid_conv3x3_halo_p16", _p(x.data), _p(x.amax), _p(w.data), _p(w.amax), _p(y), _p(st), Bi, H, W, C, N, int(chunks_per_image), stream())
+    return (y, st, th * W) if stats else y
+
+
+def stem_conv1(images, w, stats=True):
+    """The stem's first convolution (3 -> 32 channels, 3x3, stride 2, pad 1) straight from the NCHW image batch: y fp32
+    [B,Ho,Wo,32] (+ per-128-row (mean, M2, min, max) partials)."""
+    Bi, Cin, Hi, Wi = images.shape
+    if Cin != 3 or w.shape[0] != 32 or not w.is_contiguous() or not images.is_contiguous():
+        raise RuntimeError("stem_conv1: a contiguous [B,3,H,W] image batch and contiguous [32,3,3,3] filters are needed")
+    Ho, Wo = (Hi + 1) // 2, (Wi + 1) // 2
+    y = empty((Bi, Ho, Wo, 32), images)
+    M = Bi * Ho * Wo
+    st = empty(((M + STATS_ROWS - 1) // STATS_ROWS, 32, 4), images) if stats else None
+    call("trid_stem_conv1_f32", _p(images), _p(w), _p(y), _p(st), Bi, Hi, Wi, stream())
+    return (y, st) if stats else y
+
+
+def bn_finalize_minmax(partials, M, gamma, beta, running_mean, running_var, relu, bound, momentum=BN_MOMENTUM, eps=BN_EPS, rows_per_part=STATS_ROWS):
     """bn_finalize on (mean, M2, min, max) partials; `bound` (a zeroed amax_slot) receives max|act(BatchNorm(y))|."""
     C = gamma.numel()
     st = BNState(C, gamma)
-    call("trid_bn_finalize_minmax_f32", _p(partials), partials.shape[0], STATS_ROWS, M, C, _p(gamma), _p(beta),
+    call("trid_bn_finalize_minmax_f32", _p(partials), partials.shape[0], rows_per_part, M, C, _p(gamma), _p(beta),
          _p(running_mean), _p(running_var), momentum, eps, _p(st.mean), _p(st.invstd), _p(st.scale), _p(st.shift),
          1 if relu else 0, _p(bound), _p(bn_finalize_ws(partials.device)), stream())
     if running_mean is not None:
