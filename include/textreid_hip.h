@@ -114,6 +114,15 @@ int trid_p16_pack_multi_f32(const long long* table, const float* amax, int n_ten
  * partials) with A ([M][K], or an NHWC image for a_mode TRID_A_CONV) and B ([N][K]) in P16; lda / ldb = row pitch
  * in elements; a_amax / b_amax = the scalars the operands were packed with.  variant: tile shape (0 = default). */
 int trid_gemm_p16(const trid_gemm_desc* d, int variant, void* stream);
+/* The same product for SHORT reductions (K = 64 / 128 / 256: the expand 1x1 convolutions conv3 / downsample of layer1-3,
+ * m_resnet.py:26,41-47, and the data gradients of conv1) as a streaming kernel (csrc/gemm_stream.hip): persistent
+ * workgroups, the [32][K] filter panel of a wave in registers, activation tiles by LDS-DMA, stores straight from the
+ * accumulators; bit-identical to trid_gemm_p16.  A P16 [M][K], B P16 [N][K] (N % 32 == 0), C fp32 [M][ldc]; accumulate:
+ * C += A . B^T; stats (may be NULL, not with accumulate): [ceil(M / rows)][N][4] = (mean, M2, min, max) per `rows` rows,
+ * rows = trid_gemm_p16_stream_rows(M, N, K, accumulate) (0 there: shape not covered, use trid_gemm_p16). */
+int trid_gemm_p16_stream_rows(int M, int N, int K, int accumulate);
+int trid_gemm_p16_stream(const void* A, const float* a_amax, const void* B, const float* b_amax, float* C, long long ldc,
+                         float* stats, int M, int N, int K, int accumulate, void* stream);
 /* Weight gradients on P16 operands: C[M][N] = alpha * sum_k A[k][m] * B[k][n] with A = dL/dy [K pixels][M] and
  * B = the layer input [K pixels][N] (b_mode TRID_B_NC) or its 3x3 gather (TRID_B_CONV: N = 9*Cin, the NHWC image
  * [K pixels][Cin]); the K-major operands are transposed by the LDS read (ds_read_b64_tr_b16).  splits > 1 writes

@@ -209,6 +209,53 @@ def test_stem_conv1_direct(ops, B, H, W):
     assert abs(float(bound) - float(z.abs().max())) <= 1e-4 * float(z.abs().max())
 
 
+# (M, N, K): every RN50 short-K 1x1 shape family (column waves 8 / 4 / 2, 128- and 64-row steps), ragged row counts, N that
+# does not fill the last column panel, several column panels
+STREAM_SHAPES = [(3072 * 2, 256, 64), (768 * 3, 512, 128), (192 * 5, 1024, 256), (3072, 64, 64), (3072, 128, 128), (1000, 256, 64),
+                 (77, 160, 128), (4097, 128, 64), (333, 64, 128), (130, 512, 256), (64 * 9 + 5, 192, 256)]
+
+
+@pytest.mark.parametrize("M_,N,K", STREAM_SHAPES)
+def test_gemm_p16_stream(ops, M_, N, K):
+    """csrc/gemm_stream.hip: the streaming short-K kernel (filter panel in registers, activation tiles by LDS-DMA, BatchNorm
+    partials in registers) BIT for bit against the tile kernel it replaces - plain, accumulate and with (mean, M2, min,
+    max) partials - and its partials against the batch statistics."""
+    import torch as T
+
+    x, w = R("sx%d" % K, M_, K), R("sw%d" % N, N, K, scale=0.2)
+    xp, wp = ops.p16_pack(dev(x)), ops.p16_pack(dev(w))
+    rows = ops.gemm_p16_stream_rows(M_, N, K)
+    assert rows in (64, 128)
+    old = ops.USE_STREAM
+    try:
+        ops.USE_STREAM = False
+        ref = ops.empty((M_, N), xp.data)
+        ops.gemm_p16(xp, wp, ref, M_, N, K, N)
+        ops.USE_STREAM = True
+        y, st = ops.conv_p16(xp, wp)
+        assert T.equal(y, ref) and st.shape == ((M_ + rows - 1) // rows, N, 4) and st.rows_per_part == rows
+        assert rel(y, x.double() @ w.double().t()) < 2e-6
+        out = ops.empty((M_, N), xp.data)
+        ops.gemm_p16(xp, wp, out, M_, N, K, N)  # (no partials: the data-gradient form)
+        assert T.equal(out, ref)
+        if ops.gemm_p16_stream_rows(M_, N, K, True):
+            c0 = dev(R("sc", M_, N))
+            a, b = c0.clone(), c0.clone()
+            ops.gemm_p16(xp, wp, a, M_, N, K, N, accumulate=True)
+            ops.USE_STREAM = False
+            ops.gemm_p16(xp, wp, b, M_, N, K, N, accumulate=True)
+            assert T.equal(a, b)
+    finally:
+        ops.USE_STREAM = old
+    bound = ops.amax_slot(y.device)
+    gamma, beta = R("sg", N).abs() + 0.5, R("sb", N)
+    fin = ops.bn_finalize_minmax(st, M_, dev(gamma), dev(beta), None, None, False, bound)
+    yr = ref.double().cpu()
+    assert rel(fin.mean, yr.mean(0)) < 1e-5 and rel(fin.invstd, 1 / T.sqrt(yr.var(0, unbiased=False) + 1e-5)) < 1e-5
+    z = (yr - yr.mean(0)) / T.sqrt(yr.var(0, unbiased=False) + 1e-5) * gamma.double() + beta.double()
+    assert abs(float(bound) - float(z.abs().max())) <= 1e-4 * float(z.abs().max())
+
+
 def test_stem_im2col_conv(ops):
     x, w = R("sx", 3, 3, 24, 16), R("sw", 8, 3, 3, 3)
     col, Ho, Wo = ops.stem_im2col(dev(x))

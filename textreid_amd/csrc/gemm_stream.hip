@@ -1,0 +1,403 @@
+// Short-K 1x1 convolutions (K = 64 / 128 / 256 input channels) as a STREAMING kernel.
+//
+// C[M][N] = A[M][K] . B[N][K]^T with both operands P16 (gemm_p16.hip).  In the residual blocks these are the expand
+// convolutions conv3 / downsample of layer1-3 (m_resnet.py:26,41-47: K = planes, N = 4 planes) and the data gradients
+// of conv1 (K = planes): 4 K bytes read and 4 N bytes written per row against 6 K N flops - HBM-bound by construction
+// (layer1 conv3: 100 MB in, 403 MB out, 12.9 GFLOP).  A tile kernel whose K loop is two tiles long spends its time in
+// prologue, BatchNorm-partial barriers and an epilogue that nothing overlaps; here
+//   * the FILTER never touches LDS: a wave owns 32 output columns and keeps their whole [32][K] panel as MFMA B
+//     fragments in K/2 VGPRs for the lifetime of the (persistent) workgroup;
+//   * the workgroup walks down the rows: each step brings the next RB x K activation tile in by LDS-DMA (two stages, one
+//     barrier per step, 16-byte units XOR-swizzled by the row: conflict-free fragment reads) while the MFMAs of the
+//     current tile run and its output drains;
+//   * with 8 column waves (N >= 256) a wave sees ALL rows of a step for its columns: the BatchNorm (mean, M2, min, max)
+//     partials are taken in registers and stored by the wave itself - no barrier, no LDS;
+//   * stores go out as whole 128-byte segments of C rows straight from the accumulator layout.
+// Arithmetic and product order are those of gemm_p16_kernel<A_KC> (hi*lo + lo*hi + hi*hi per 16-deep k step, k ascending):
+// results are bit-identical.
+
+#include <algorithm>
+#include <mutex>
+
+#include "split_common.h"
+
+namespace trid {
+
+namespace {
+
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ void dma16(const __amdgpu_buffer_rsrc_t& rs, void* lds_base, unsigned voffset) {
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)lds_base, 16, voffset, 0, 0, 0);
+}
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+// (an LDS store the compiler does not see: beside an LDS-DMA in flight it would be ordered behind s_waitcnt vmcnt(0))
+__device__ __forceinline__ void lds_store4(const void* p, float4 v) {
+    const v4f r = {v.x, v.y, v.z, v.w};
+    asm volatile("ds_write_b128 %0, %1" ::"v"((unsigned)(uintptr_t)p), "v"(r) : "memory");
+}
+
+struct StreamParams {
+    const char* A;   // P16 [M][K]
+    const char* B;   // P16 [N][K]
+    float* C;        // fp32 [M][ldc]
+    float* stats;    // [ceil(M / RB)][N][4] = (mean, M2, min, max) per step tile, or null
+    const float* a_amax;
+    const float* b_amax;
+    int M, N;
+    long long ldc;
+    int accumulate;
+    int panels;      // column panels of CW * 32 columns
+    int workers;     // persistent workgroups per panel
+    int tiles;       // ceil(M / RB)
+};
+
+}  // namespace
+
+// K: reduction length; CW: column waves (each 32 columns); TM: 32-row blocks per wave and step.  8 waves = CW x RW.
+template <int K, int CW, int TM, bool ACC>
+__global__ __launch_bounds__(512, 2) void gemm_p16_stream_kernel(StreamParams p) {
+    constexpr int NW = 8, RW = NW / CW;
+    constexpr int RB = RW * TM * 32;          // rows per step
+    constexpr int ROWB = K * 4;               // bytes of one A row
+    constexpr int UPR = ROWB / 16;            // 16-byte units per row (16 / 32 / 64)
+    constexpr int RPC = 1024 / ROWB;          // rows per 1-KB DMA chunk (4 / 2 / 1)
+    constexpr int STAGE = RB * ROWB;          // bytes of one stage
+    constexpr int NCH = STAGE / 1024;         // DMA chunks per stage
+    constexpr int DPW = NCH / NW;             // DMA instructions per wave and step
+    constexpr int KG = K / 32;
+    static_assert(NCH % NW == 0, "stage must split evenly over the waves");
+    extern __shared__ __attribute__((aligned(16))) uint4 smem[];
+    char* const ring = reinterpret_cast<char*>(smem);
+    float4* const sstat = reinterpret_cast<float4*>(ring + 2 * STAGE);  // RW > 1: [2][NW][32]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cw = wave % CW, rw = wave / CW;
+    const int khalf = lane >> 5;
+
+    // workgroup -> (panel, worker): the panels of one worker index share an XCD (block b runs on XCD b % 8) and walk the same
+    // row tiles, so an activation tile is fetched from HBM once and found in that L2 by the other panels
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int panel = idx % p.panels;
+    const int worker = xcd + 8 * (idx / p.panels);
+    if (worker >= p.workers) return;
+    const int n0 = panel * (CW * 32) + cw * 32;
+    const bool col_live = n0 < p.N;  // (N % 32 == 0: a wave's 32 columns exist or do not)
+
+    const float unscale = 1.f / (f16_scale_of(*p.a_amax) * f16_scale_of(*p.b_amax));
+
+    // ---- this wave's filter panel: [k group][k step][plane] fragments, K/2 VGPRs
+    f16x8 bf[KG][2][2];
+    {
+        const char* br = p.B + (size_t)((col_live ? n0 : 0) + (lane & 31)) * ROWB;
+#pragma unroll
+        for (int g = 0; g < KG; ++g)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl)
+                    bf[g][ks][pl] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(br + g * 128 + (4 * pl + 2 * ks + khalf) * 16));
+    }
+
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (unsigned)((size_t)p.M * ROWB), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc((void*)p.C, 0, (unsigned)((size_t)p.M * p.ldc * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc((void*)(p.stats != nullptr ? p.stats : p.C), 0, (unsigned)((size_t)p.tiles * p.N * 16), 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+
+    // loader: chunk c (1 KB = RPC rows) of a stage; lane -> (row, stored unit j); source unit = j ^ (row & 15).  The per-chunk
+    // offsets are re-derived from the lane index in every step (`zero` is opaque to the compiler): kept across the loop
+    // they would cost DPW x 2 VGPRs of a budget that the filter panel (K/2) and the accumulators already fill
+    auto issue = [&](int tile, int stage, int zero) {
+        const size_t base = (size_t)tile * RB * ROWB;
+        char* dst = ring + stage * STAGE;
+        const int ln = lane + zero;
+        const int lr = ln / UPR, j = ln % UPR;
+#pragma unroll
+        for (int d = 0; d < DPW; ++d) {
+            const int r = (d * NW + wave) * RPC + lr;
+            const bool ok = (long long)tile * RB + r < p.M;
+            dma16(rsA, dst + (d * NW + wave) * 1024, ok ? (unsigned)(base + r * ROWB + ((j ^ (r & 15)) << 4)) : OOB);
+        }
+    };
+
+    // fragment reads: row block i of this wave = rows (rw * TM + i) * 32 + (lane & 31) of the step tile
+    int a_off[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) a_off[i] = ((rw * TM + i) * 32 + (lane & 31)) * ROWB;
+    const int rsw = lane & 15;  // (row & 15) of this lane's rows: the tile's row blocks start at multiples of 32
+
+    int t = worker;
+    if (t < p.tiles) issue(t, 0, 0);
+    int stage = 0;
+    bool first = true;
+    for (; t < p.tiles; t += p.workers, stage ^= 1) {
+        // the DMA of this tile was issued before this wave's stores of the previous step: vmcnt retires in order
+        // (the counter has 6 bits: with 64 stores per step the oldest two are waited for as well)
+        constexpr int NST = TM * 16 + 1 > 63 ? 63 : TM * 16 + 1, NSC = TM * 16 > 63 ? 63 : TM * 16;
+        if (first) wait_vm<0>();
+        else if (p.stats != nullptr && RW == 1) wait_vm<NST>();
+        else wait_vm<NSC>();
+        lds_barrier();
+        const int tn = t + p.workers;
+        // RW > 1: the previous step's BatchNorm partials, merged by the first lanes of the workgroup (one column each)
+        if (RW > 1 && p.stats != nullptr && !first && tid < CW * 32) {
+            const float4* src = sstat + (stage ^ 1) * NW * 32;
+            const int c2 = tid >> 5, n = tid & 31;
+            const long long row0 = (long long)(t - p.workers) * RB;
+            float cnt = 0.f, mean = 0.f, m2 = 0.f, lo = INFINITY, hi = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < RW; ++k) {
+                const long long left = p.M - (row0 + (long long)k * TM * 32);
+                const float nb = (float)(left < TM * 32 ? (left > 0 ? left : 0) : TM * 32);
+                if (nb > 0.f) {
+                    const float4 v = src[(k * CW + c2) * 32 + n];
+                    const float nt = cnt + nb, d = v.x - mean;
+                    mean += d * (nb / nt);
+                    m2 += v.y + d * d * (cnt * nb / nt);
+                    cnt = nt;
+                    lo = fminf(lo, v.z);
+                    hi = fmaxf(hi, v.w);
+                }
+            }
+            const int col = panel * (CW * 32) + tid;
+            if (col < p.N) reinterpret_cast<float4*>(p.stats)[(long long)(t - p.workers) * p.N + col] = make_float4(mean, m2, lo, hi);
+        }
+        if (RW > 1 && p.stats != nullptr && !first && wave < (CW * 32 + 63) / 64) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // accumulate: the old C values of this step, fetched under the MFMAs (issued BEFORE the DMA so that a counted
+        // wait retires them without waiting for the next tile)
+        float oldc[ACC ? TM : 1][16];
+        if constexpr (ACC) {
+            const unsigned ldcb = (unsigned)p.ldc * 4u;
+            const unsigned base = col_live ? ((unsigned)t * RB + rw * TM * 32 + 4u * khalf) * ldcb + (unsigned)(n0 + (lane & 31)) * 4u : OOB;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    oldc[i][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsC, base + (unsigned)(i * 32 + (r & 3) + 8 * (r >> 2)) * ldcb, 0, 0));
+        }
+        int zero = 0;
+        asm volatile("" : "+v"(zero));
+        if (tn < p.tiles) issue(tn, stage ^ 1, zero);
+
+        // ---- MFMAs of this tile: per 16-deep k step 2 fragment reads per row block, 3 products
+        v16f acc[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        const char* sA = ring + stage * STAGE;
+        f16x8 af[2][TM][2];
+        auto fetch = [&](int q, f16x8(&dst)[TM][2]) {  // q = k group * 2 + k step
+            const int g = q >> 1, ks = q & 1;
+            const int u0 = g * 8 + 2 * ks + khalf;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                dst[i][0] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(sA + a_off[i] + (((u0) ^ rsw) << 4)));
+                dst[i][1] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(sA + a_off[i] + (((u0 + 4) ^ rsw) << 4)));
+            }
+        };
+        fetch(0, af[0]);
+#pragma unroll
+        for (int q = 0; q < 2 * KG; ++q) {
+            if (q + 1 < 2 * KG) fetch(q + 1, af[(q + 1) & 1]);
+            const int g = q >> 1, ks = q & 1;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[q & 1][i][0], bf[g][ks][1], acc[i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[q & 1][i][1], bf[g][ks][0], acc[i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[q & 1][i][0], bf[g][ks][0], acc[i], 0, 0, 0);
+        }
+
+        // ---- epilogue
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] *= unscale;
+        if constexpr (ACC) {
+            wait_vm<DPW>();  // the old C values (older than this step's DMA)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][r] += oldc[i][r];
+        }
+        const long long row0 = (long long)t * RB + rw * TM * 32;  // first row of this wave's blocks
+        if (p.stats != nullptr) {
+            const long long left = p.M - row0;
+            const int cnt_w = __builtin_amdgcn_readfirstlane((int)(left < TM * 32 ? (left > 0 ? left : 0) : TM * 32));
+            float sum = 0.f, lo = INFINITY, hi = -INFINITY, m2 = 0.f, mean = 0.f;
+            if (cnt_w == TM * 32) {  // (wave-uniform: every tile but a ragged last one)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        sum += acc[i][r];
+                        lo = fminf(lo, acc[i][r]);
+                        hi = fmaxf(hi, acc[i][r]);
+                    }
+                sum += __shfl_xor(sum, 32, 64);
+                mean = sum * (1.f / (TM * 32));
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float d = acc[i][r] - mean;
+                        m2 += d * d;
+                    }
+            } else {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const bool in = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf < cnt_w;
+                        sum += in ? acc[i][r] : 0.f;
+                        lo = fminf(lo, in ? acc[i][r] : INFINITY);
+                        hi = fmaxf(hi, in ? acc[i][r] : -INFINITY);
+                    }
+                sum += __shfl_xor(sum, 32, 64);
+                mean = cnt_w > 0 ? sum / (float)cnt_w : 0.f;
+                int cnt2 = cnt_w;  // (opaque copy: the 64 row predicates are re-derived, not kept alive in SGPR pairs across the loops)
+                asm volatile("" : "+s"(cnt2));
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const bool in = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf < cnt2;
+                        const float d = acc[i][r] - mean;
+                        m2 += in ? d * d : 0.f;
+                    }
+            }
+            m2 += __shfl_xor(m2, 32, 64);
+            lo = fminf(lo, __shfl_xor(lo, 32, 64));
+            hi = fmaxf(hi, __shfl_xor(hi, 32, 64));
+            if constexpr (RW == 1) {
+                // (every wave, one instruction: the counted wait at the top of the next step relies on it)
+                const unsigned off = (col_live && khalf == 0 && cnt_w > 0) ? (unsigned)(((unsigned)t * (unsigned)p.N + n0 + (lane & 31)) * 16u) : OOB;
+                const v4f sv = {mean, m2, lo, hi};
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, sv), rsS, off, 0, 0);
+            } else {
+                if (khalf == 0) lds_store4(sstat + stage * NW * 32 + wave * 32 + (lane & 31), make_float4(mean, m2, lo, hi));
+            }
+        }
+        {
+            // 32-bit byte offsets (the tensor stays below 2 GB); rows >= M lie beyond the descriptor's range: dropped.  A wave
+            // whose columns do not exist stores everything out of range
+            const unsigned ldcb = (unsigned)p.ldc * 4u;
+            const unsigned base = col_live ? (unsigned)row0 * ldcb + 4u * khalf * ldcb + (unsigned)(n0 + (lane & 31)) * 4u : OOB;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float v = acc[i][r];
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsC, base + (unsigned)(i * 32 + (r & 3) + 8 * (r >> 2)) * ldcb, 0, 0);
+                }
+        }
+        first = false;
+    }
+    if (RW > 1 && p.stats != nullptr && !first) {  // the last step's partials
+        lds_barrier();
+        if (tid < CW * 32) {
+            const int tl = t - p.workers;
+            const float4* src = sstat + (stage ^ 1) * NW * 32;
+            const int c2 = tid >> 5, n = tid & 31;
+            const long long row0 = (long long)tl * RB;
+            float cnt = 0.f, mean = 0.f, m2 = 0.f, lo = INFINITY, hi = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < RW; ++k) {
+                const long long left = p.M - (row0 + (long long)k * TM * 32);
+                const float nb = (float)(left < TM * 32 ? (left > 0 ? left : 0) : TM * 32);
+                if (nb > 0.f) {
+                    const float4 v = src[(k * CW + c2) * 32 + n];
+                    const float nt = cnt + nb, d = v.x - mean;
+                    mean += d * (nb / nt);
+                    m2 += v.y + d * d * (cnt * nb / nt);
+                    cnt = nt;
+                    lo = fminf(lo, v.z);
+                    hi = fmaxf(hi, v.w);
+                }
+            }
+            const int col = panel * (CW * 32) + tid;
+            if (col < p.N) reinterpret_cast<float4*>(p.stats)[(long long)tl * p.N + col] = make_float4(mean, m2, lo, hi);
+        }
+    }
+}
+
+template <int K, int CW, int TM, bool ACC>
+static int launch_stream(StreamParams& p, hipStream_t stream) {
+    constexpr int RW = 8 / CW, RB = RW * TM * 32;
+    const size_t lds = (size_t)2 * RB * K * 4 + (RW > 1 ? 2 * 8 * 32 * sizeof(float4) : 0);
+    static std::once_flag once;
+    static hipError_t attr_err = hipSuccess;
+    std::call_once(once, [] {
+        attr_err = hipFuncSetAttribute((const void*)gemm_p16_stream_kernel<K, CW, TM, ACC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    });
+    if (attr_err != hipSuccess) {
+        set_error("trid_gemm_p16_stream: cannot reserve LDS: %s", hipGetErrorString(attr_err));
+        return (int)attr_err;
+    }
+    p.panels = (p.N + CW * 32 - 1) / (CW * 32);
+    p.tiles = (p.M + RB - 1) / RB;
+    int per = 256 / p.panels;          // persistent workgroups per panel: one per CU in all
+    per = per / 8 * 8;                 // whole XCD rounds
+    if (per < 8) per = 8;
+    int need = (p.tiles + 7) / 8 * 8;  // no more workers than tiles
+    p.workers = std::min(per, need);
+    const int grid = p.workers * p.panels;
+    hipLaunchKernelGGL((gemm_p16_stream_kernel<K, CW, TM, ACC>), dim3(grid), dim3(512), lds, stream, p);
+    return check_launch("trid_gemm_p16_stream");
+}
+
+// shapes -> (column waves, row blocks per wave): two stages of RB x K x 4 bytes must fit the LDS, so K = 256 steps 64 rows
+template <int K>
+static int pick_stream(StreamParams& p, hipStream_t stream) {
+    const bool acc = p.accumulate != 0;
+    if constexpr (K == 256) {  // (the 128-VGPR filter panel leaves no room for the old C values: no accumulate form)
+        if (acc || p.N <= 128) return TRID_E_UNSUPPORTED;
+        return launch_stream<K, 8, 2, false>(p, stream);
+    } else {
+        if (p.N > 128) return acc ? launch_stream<K, 8, 2, true>(p, stream) : launch_stream<K, 8, 4, false>(p, stream);
+        if (p.N > 64) return acc ? launch_stream<K, 4, 2, true>(p, stream) : launch_stream<K, 4, 2, false>(p, stream);
+        return acc ? launch_stream<K, 2, 1, true>(p, stream) : launch_stream<K, 2, 1, false>(p, stream);
+    }
+}
+
+}  // namespace trid
+
+using namespace trid;
+
+// rows per BatchNorm partial (= rows per step) of the streaming kernel for this shape, 0 when it does not apply
+extern "C" int trid_gemm_p16_stream_rows(int M, int N, int K, int accumulate) {
+    if (!(K == 64 || K == 128 || K == 256) || N <= 0 || N % 32 != 0 || M <= 0) return 0;
+    if (K == 256 && (accumulate || N <= 128)) return 0;  // (256 -> 128 measured no faster than the tile kernel: 146 vs 142 us)
+    if (N > 128) return (accumulate || K == 256) ? 64 : 128;
+    if (N > 64) return K == 256 ? 64 : 128;
+    return 128;
+}
+
+extern "C" int trid_gemm_p16_stream(const void* A, const float* a_amax, const void* B, const float* b_amax, float* C, long long ldc,
+                                    float* stats, int M, int N, int K, int accumulate, void* stream) {
+    TRID_REQUIRE(A && B && C && a_amax && b_amax, "trid_gemm_p16_stream: null operand");
+    TRID_REQUIRE(trid_gemm_p16_stream_rows(M, N, K, accumulate) > 0, "trid_gemm_p16_stream: needs K in {64, 128, 256} and N %% 32 == 0 (M=%d N=%d K=%d)", M, N, K);
+    TRID_REQUIRE(aligned16(A) && aligned16(B) && aligned16(C) && (!stats || aligned16(stats)), "trid_gemm_p16_stream: operands must be 16-byte aligned");
+    TRID_REQUIRE(ldc >= N && !(stats && accumulate), "trid_gemm_p16_stream: ldc >= N; BatchNorm partials only without accumulate");
+    TRID_REQUIRE((long long)M * K * 4 < (1ll << 31) && (long long)M * ldc * 4 < (1ll << 31), "trid_gemm_p16_stream: operands must stay below 2 GB (31-bit buffer offsets)");
+    StreamParams p;
+    memset(&p, 0, sizeof(p));
+    p.A = (const char*)A; p.B = (const char*)B; p.C = C; p.stats = stats;
+    p.a_amax = a_amax; p.b_amax = b_amax;
+    p.M = M; p.N = N; p.ldc = ldc; p.accumulate = accumulate;
+    hipStream_t s = (hipStream_t)stream;
+    if (K == 64) return pick_stream<64>(p, s);
+    if (K == 128) return pick_stream<128>(p, s);
+    return pick_stream<256>(p, s);
+}

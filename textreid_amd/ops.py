@@ -259,6 +259,9 @@ def gemm_p16(A, B, C, M, N, K, ldc, conv=None, alpha=1.0, accumulate=False, bias
              relu=False, splits=1, strideSplit=0, variant=None, minmax=False):
     """C[M,N] = alpha * A . B^T with both operands P16: A [M][K] (or an NHWC image [B,H,W,Cin] with conv=(H,W,Cin),
     K = 9*Cin), B [N][K].  minmax: the BatchNorm partials `stats` are [tiles][N][4] = (mean, M2, min, max)."""
+    if (USE_STREAM and conv is None and A.fmt == 1 and B.fmt == 1 and C.dtype == torch.float32 and stats is None and alpha == 1.0
+            and bias is None and residual is None and not relu and splits == 1 and gemm_p16_stream_rows(M, N, K, accumulate)):
+        return gemm_p16_stream(A, B, C, M, N, K, ldc, accumulate=accumulate)  # short-K data gradients (conv1 of a block)
     d = GemmDesc()
     d.A, d.B, d.C = _p(A.data), _p(B.data), _p(C)
     d.M, d.N, d.K = M, N, K
@@ -294,6 +297,19 @@ def gemm_p16(A, B, C, M, N, K, ldc, conv=None, alpha=1.0, accumulate=False, bias
     call("trid_gemm_p16", ctypes.addressof(d), v, stream())
 
 
+USE_STREAM = __import__("os").environ.get("TRID_STREAM_1X1", "1") != "0"  # short-K 1x1 convolutions on csrc/gemm_stream.hip (0: A/B runs)
+
+
+def gemm_p16_stream_rows(M, N, K, accumulate=False):
+    """Rows per step (= per BatchNorm partial) of the streaming short-K kernel for this shape; 0: not covered."""
+    return int(L.load().trid_gemm_p16_stream_rows(int(M), int(N), int(K), 1 if accumulate else 0))
+
+
+def gemm_p16_stream(A, B, C, M, N, K, ldc, accumulate=False, stats=None):
+    """C[M,N] (+)= A . B^T on the streaming kernel (A P16 [M][K], B P16 [N][K], K in {64, 128, 256})."""
+    call("trid_gemm_p16_stream", _p(A.data), _p(A.amax), _p(B.data), _p(B.amax), _p(C), ldc, _p(stats), M, N, K, 1 if accumulate else 0, stream())
+
+
 USE_P16 = __import__("os").environ.get("TRID_P16", "1") != "0"  # residual blocks on pre-split operands (csrc/gemm_p16.hip)
 USE_P16_STEM = __import__("os").environ.get("TRID_P16_STEM", "1") != "0"  # ... and the stem on csrc/stem_conv.hip (0: A/B runs)
 
@@ -305,6 +321,14 @@ def conv_p16(x, w, conv3=False, stats=True):
     N = w.shape[0]
     y = empty(tuple(x.shape[:-1]) + (N,), x.data, dtype=torch.bfloat16 if (x.fmt == 2 and BF16_Y) else torch.float32)
     mm = stats and x.fmt == 1  # bf16 operands need no scale, hence no extremes
+    if not conv3 and x.fmt == 1 and USE_STREAM:
+        rows = gemm_p16_stream_rows(M, N, C)  # short reductions (K = 64 / 128 / 256): the streaming kernel
+        if rows:
+            st = empty(((M + rows - 1) // rows, N, 4), x.data) if stats else None
+            gemm_p16_stream(x, w, y, M, N, C, N, stats=st)
+            if stats:
+                st.rows_per_part = rows  # (bn_finalize_minmax reads it: 64-row partials for K = 256)
+            return (y, st) if stats else y
     st = empty(((M + STATS_ROWS - 1) // STATS_ROWS, N, 4 if mm else 2), x.data) if stats else None
     if conv3:
         gemm_p16(x, w, y, M, N, 9 * C, N, conv=(x.shape[1], x.shape[2], C), stats=st, minmax=mm)
@@ -352,6 +376,7 @@ def bn_finalize_minmax(partials, M, gamma, beta, running_mean, running_var, relu
     """bn_finalize on (mean, M2, min, max) partials; `bound` (a zeroed amax_slot) receives max|act(BatchNorm(y))|."""
     C = gamma.numel()
     st = BNState(C, gamma)
+    rows_per_part = getattr(partials, "rows_per_part", rows_per_part)  # (conv_p16 on the streaming kernel: its own step size)
     call("trid_bn_finalize_minmax_f32", _p(partials), partials.shape[0], rows_per_part, M, C, _p(gamma), _p(beta),
          _p(running_mean), _p(running_var), momentum, eps, _p(st.mean), _p(st.invstd), _p(st.scale), _p(st.shift),
          1 if relu else 0, _p(bound), _p(bn_finalize_ws(partials.device)), stream())
