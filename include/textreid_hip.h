@@ -361,12 +361,16 @@ int trid_infonce_queue_rows_f32(float* S, const float* q, const float* key, cons
  * scales, 6 MFMA products per query x row x channel), 3 = fp32-class on three bf16 planes (11 products), 1 = bf16 operands.  nwg_hint: workgroups per modality (0 = default).  Built for C = 256 and
  * K % 32 == 0, otherwise TRID_E_UNSUPPORTED (the caller then takes trid_gemm_f32 + trid_infonce_queue_rows_f32).
  * ws floats >= trid_queue_nce_ws_floats(B, K, C, nwg_hint) (0 = unsupported shape).  Bit-reproducible: partial
- * sums are folded in a fixed order, no atomics. */
+ * sums are folded in a fixed order, no floating-point atomics.
+ * ticket / loss (both or NULL): with a device word that holds ZERO on entry (one fresh word per call; it is left at
+ * 2 B) the finish launch also writes loss[0] = loss_scale * sum(loss_rows) - the mean over the batch of losses.py:216-217
+ * with loss_scale = 1 / B - folded in index order by whichever workgroup finishes last: two launches for the block. */
 long long trid_queue_nce_ws_floats(int B, int K, int C, int nwg_hint);
 int trid_queue_nce_f32(const float* v_q, const float* t_q, const float* v_key, const float* t_key,
                        const float* t_queue, const float* v_queue, const int64_t* id_queue, const int64_t* ids,
                        float* loss_rows, float* dq, int B, int K, int C, float invT, float logit_bound, float gscale,
-                       int precision, int nwg_hint, float* ws, void* stream);
+                       int precision, int nwg_hint, float* ws, unsigned int* ticket, float* loss, float loss_scale,
+                       void* stream);
 /* Largest magnitudes as device scalars (operand scales of trid_gemm_desc.precision == 16; no reference
  * counterpart: PyTorch's fp32 convolutions need no range management).
  * trid_amax_f32: out[0] = max(out[0], max|x|) - `out` must hold 0 (or an earlier partial maximum) on entry.

@@ -613,6 +613,16 @@ def test_fused_queue_infonce(ops, B, K, wgs, prec):
     assert e[0] < tol_l and e[1] < tol_g and e[2] < tol_g, e
     assert torch.equal(out, out2)  # bit-reproducible (fixed-order fold of the partials, no atomics)
     assert rel(out3, ref) < tol_l
+    # the two-launch form (loss rows folded by the last workgroup of the finish launch; opt-in, measured slower): same value
+    old_sum = L.FUSED_QUEUE_SUM
+    try:
+        L.FUSED_QUEUE_SUM = True
+        ops.GEMM_PRECISION = prec
+        out4 = L.queue_infonce_loss(dev(vq), dev(tq), dev(vk), dev(tk), dev(ids), dev(tqueue), dev(vqueue), dev(idq), T)
+        out5 = L.queue_infonce_loss(dev(vq), dev(tq), dev(vk), dev(tk), dev(ids), dev(tqueue), dev(vqueue), dev(idq), T)
+    finally:
+        L.FUSED_QUEUE_SUM, ops.GEMM_PRECISION = old_sum, old[0]
+    assert rel(out4, ref) < tol_l and torch.equal(out4, out5)
 
 
 @pytest.mark.parametrize("B,H,L", [(5, 64, 7), (130, 512, 12), (128, 512, 64), (16, 96, 3), (1, 32, 1), (33, 768, 5)])

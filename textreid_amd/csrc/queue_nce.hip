@@ -513,10 +513,17 @@ __global__ __launch_bounds__(256, 1) void queue_nce_f16_kernel(QnceParams p) {
 // One workgroup per (query row, modality): positive logit, fold of the partials, loss row and dL/dq.
 // Thread (grp = tid >> 6, c4 = tid & 63): group grp folds the partials w = grp, grp + 4, ... of columns
 // 4*c4 .. 4*c4+3 (float4 loads, independent accumulators), then the four groups are added in a fixed order.
+// ticket / loss (both or none): the workgroup that finishes LAST (a device-scope counter that starts at zero: the caller
+// hands over a fresh word of a zero-filled pool, nothing is reset) also folds the 2 B loss rows - in index order, so the
+// result does not depend on which workgroup that was - into loss[0] = loss_scale * sum: the block's third launch
+// (trid_sum_f32) is gone.  Hand-off: rows are published with an agent-scope release before the ticket is drawn, the last
+// arriver acquires once (cdna guide G16, counter form).
 __global__ __launch_bounds__(256) void queue_nce_finish_kernel(QnceParams p, const float* __restrict__ key0,
                                                                const float* __restrict__ key1, float* __restrict__ loss_rows,
-                                                               float* __restrict__ dq, float invT, float shift, float gs) {
+                                                               float* __restrict__ dq, float invT, float shift, float gs,
+                                                               unsigned* __restrict__ ticket, float* __restrict__ loss, float loss_scale) {
     __shared__ float red[8];
+    __shared__ unsigned last;
     __shared__ float4 osum[4][64];
     const int b = blockIdx.x, mod = blockIdx.y, c = threadIdx.x;  // blockDim.x == QC
     const int grp = c >> 6, c4 = c & 63;
@@ -552,6 +559,22 @@ __global__ __launch_bounds__(256) void queue_nce_finish_kernel(QnceParams p, con
     dq[((long long)mod * p.B + b) * QC + c] = gs * (o * inv + (x0 * inv - 1.f) * kr[c]);
     // lse - pos/T = log(ltot / x0) = log1p(lneg / x0): no cancellation between the shift and log(ltot)
     if (c == 0) loss_rows[(long long)mod * p.B + b] = log1pf(lneg / x0);
+    if (ticket == nullptr) return;
+    if (c == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(2 * p.B - 1) ? 1u : 0u;
+    }
+    __syncthreads();
+    if (last == 0u) return;
+    if (c == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __syncthreads();
+    float acc = 0.f;
+    for (int i = c; i < 2 * p.B; i += QC) acc += __hip_atomic_load(loss_rows + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (L2-served)
+    acc = wave_sum(acc);
+    if ((c & 63) == 0) red[c >> 6] = acc;
+    __syncthreads();
+    if (c == 0) loss[0] = loss_scale * ((red[0] + red[1]) + (red[2] + red[3]));
 }
 
 static int plan(int B, int K, int nwg_hint, int* nbb, int* nwg, int* tpw) {
@@ -611,7 +634,8 @@ extern "C" long long trid_queue_nce_ws_floats(int B, int K, int C, int nwg_hint)
 extern "C" int trid_queue_nce_f32(const float* v_q, const float* t_q, const float* v_key, const float* t_key,
                                   const float* t_queue, const float* v_queue, const int64_t* id_queue, const int64_t* ids,
                                   float* loss_rows, float* dq, int B, int K, int C, float invT, float logit_bound,
-                                  float gscale, int precision, int nwg_hint, float* ws, void* stream) {
+                                  float gscale, int precision, int nwg_hint, float* ws, unsigned int* ticket, float* loss,
+                                  float loss_scale, void* stream) {
     TRID_REQUIRE(v_q && t_q && v_key && t_key && t_queue && v_queue && id_queue && ids && loss_rows && dq && ws,
                  "trid_queue_nce_f32: null pointer");
     TRID_REQUIRE(B > 0 && K > 0 && invT > 0.f && logit_bound > 0.f, "trid_queue_nce_f32: bad sizes / scalars");
@@ -648,7 +672,8 @@ extern "C" int trid_queue_nce_f32(const float* v_q, const float* t_q, const floa
     const hipStream_t st = (hipStream_t)stream;
     const int rc = (precision == 1) ? launch_qnce<1>(p, nbb, st) : (precision == 3) ? launch_qnce<3>(p, nbb, st) : hashed ? launch_qnce_f16<true>(p, nbb, st) : launch_qnce_f16<false>(p, nbb, st);
     if (rc != TRID_OK) return rc;
+    TRID_REQUIRE((ticket == nullptr) == (loss == nullptr), "trid_queue_nce_f32: ticket and loss both or none");
     hipLaunchKernelGGL(queue_nce_finish_kernel, dim3(B, 2), dim3(QC), 0, st, p, t_key, v_key, loss_rows, dq, invT, shift,
-                       gscale * invT / (float)B);
+                       gscale * invT / (float)B, ticket, loss, loss_scale);
     return check_launch("trid_queue_nce_f32(finish)");
 }

@@ -154,6 +154,10 @@ def infonce_loss(v_pos, v_neg, t_pos, t_neg, T=0.07):
 
 FUSED_QUEUE_NCE = os.environ.get("TRID_FUSED_QNCE", "1") != "0"  # A/B switch: 0 = GEMM + row kernels
 QUEUE_NCE_WGS = int(os.environ.get("TRID_QNCE_WGS", "0"))            # workgroups per modality (0 = library default)
+# loss rows folded by the finish launch's last workgroup (a ticket word + one agent-scope release per workgroup) instead of a
+# third launch: MEASURED SLOWER on the MI355X - 38.0 vs 35.7 us at K = 8192, 74.6 vs 72.0 us at K = 65536
+# (profiles/r04f_qsim_tune.txt): 256 release fences cost more than the 4.5 us trid_sum_f32 launch they replace.  Off.
+FUSED_QUEUE_SUM = os.environ.get("TRID_QNCE_FUSED_SUM", "0") != "0"
 
 
 class _QueueInfoNCEFn(torch.autograd.Function):
@@ -172,10 +176,15 @@ class _QueueInfoNCEFn(torch.autograd.Function):
             dq = ops.empty((2, B, C), v_q)
             ws = ops.empty((nws,), v_q)
             vq_, tq_, vk_, tk_ = (x.detach().contiguous() for x in (v_q, t_q, v_k, t_k))  # alive until the call returns
+            # (the ticket word: a fresh zero from the amax-slot pool - zero-filled once per 4096 calls, re-recorded with a
+            # captured step - so the finish launch folds the loss rows itself: two launches for the whole block)
+            ticket = ops.amax_slot(v_q.device) if FUSED_QUEUE_SUM else None
             call("trid_queue_nce_f32", _p(vq_), _p(tq_), _p(vk_),
                  _p(tk_), _p(t_queue), _p(v_queue), _p(id_queue), _p(ids), _p(rows), _p(dq), B, K, C, 1.0 / T,
-                 1.0, 1.0, {1: 1, 3: 3}.get(ops.GEMM_PRECISION, 6), QUEUE_NCE_WGS, _p(ws), stream())
-            ops.sum_to(rows.view(-1), loss, 1.0 / B)
+                 1.0, 1.0, {1: 1, 3: 3}.get(ops.GEMM_PRECISION, 6), QUEUE_NCE_WGS, _p(ws), _p(ticket), _p(loss) if ticket is not None else None,
+                 1.0 / B, stream())
+            if ticket is None:
+                ops.sum_to(rows.view(-1), loss, 1.0 / B)
             ctx.saved = [dq[0], dq[1]]
             return loss[0]
         hit = torch.empty(K, dtype=torch.uint8, device=v_q.device)

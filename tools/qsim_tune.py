@@ -37,3 +37,7 @@ for K in (8192, 65536):
         ms = timeit(fn)
         print("K=%6d fused wgs/mod %4d %.3f ms  %.0f GB/s  (%.1f TFLOP/s fp32-equivalent)" % (K, wgs, ms, nbytes / ms / 1e6, 8.0 * B * C * K / ms / 1e9))
     L.QUEUE_NCE_WGS = 0
+    for fused_sum in (False, True):
+        L.FUSED_QUEUE_SUM = fused_sum
+        ms = timeit(fn, reps=200)
+        print("K=%6d default workgroups, loss rows folded by %s: %.4f ms  %.0f GB/s" % (K, "the finish launch" if fused_sum else "trid_sum_f32", ms, nbytes / ms / 1e6))
