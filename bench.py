@@ -440,10 +440,12 @@ def main():
     # single process: the whole step (four streams, ~1100 launches) is recorded once as a hipGraph and replayed
     # (engine/graph.py); data parallel: eager (RCCL collectives are issued from inside backward)
     runner = None
-    if world == 1 and os.environ.get("TRID_CAPTURE", "1") != "0":
+    dp_capture = world > 1 and os.environ.get("TRID_DP_CAPTURE", "0") == "1" and backend == "nccl"  # (opt-in: see engine/trainer.py)
+    if (world == 1 or dp_capture) and os.environ.get("TRID_CAPTURE", "1") != "0":
         from textreid_amd.engine.graph import CapturedTrainStep
 
-        runner = CapturedTrainStep(model, opt, warmup=2, caption_bound=64)  # 64-token captions (padded to 105)
+        runner = CapturedTrainStep(model, opt, warmup=2, caption_bound=64,  # 64-token captions (padded to 105)
+                                   reducer=reducer if world > 1 else None, pre_gather=pre_gather)
 
     def batch(i):
         images, tokens, lengths, ids = batches[i % len(batches)]

@@ -115,6 +115,41 @@ def main():
     if r == 0:
         print("DP_REPLICAS_IDENTICAL")
         print("DP_TRANSPORT backend=%s world=%d staged_bytes=%d post_bytes=%d" % (dist.get_backend(), W, red.bytes_staged, red.bytes_post))
+    # ---- the data-parallel step RECORDED as one hipGraph (engine.graph.CapturedTrainStep with the run's GradReducer): the packed
+    # all-gather of the forward, the all-reduces staged from inside backward, the bucketed ones after it and the fused Adam
+    # step, replayed - bit for bit the eager data-parallel step (RCCL only: a host-staged transport cannot be recorded)
+    if os.environ.get("TRID_DP_CAPTURED", "0") == "1":
+        from textreid_amd.engine.graph import CapturedTrainStep
+        from textreid_amd.solver import FusedAdam
+
+        runs = {}
+        ld = None  # (the first step's autograd graph must be gone: a stale AccumulateGrad node drags ITS stream into the recording)
+        torch.cuda.synchronize()
+        for mode in ("eager", "graph"):
+            head.load_state_dict(filled)
+            for p_ in head.parameters():
+                p_.grad = None
+            red2 = GradReducer(bucket_mb=1)
+            head.v_encoder_q.grad_sync = red2
+            opt = FusedAdam([{"params": [p_], "lr": 2e-3 if n.endswith("bias") else 1e-3} for n, p_ in head.named_parameters() if p_.requires_grad], lr=1e-3)
+            runner = CapturedTrainStep(head, opt, warmup=2, reducer=red2, pre_gather=pre)
+            losses = []
+            for i in range(5):
+                xi = x[sl].roll(i, 0).to(dev)
+                cb = CaptionBatch(tok[sl].roll(i, 0).to(dev), ln[sl].roll(i, 0).to(dev), ((ids[sl] + i) % NC).to(dev))
+                out = runner._eager(xi, cb) if mode == "eager" else runner(xi, cb)
+                losses.append(torch.stack([v.detach().clone() for v in out.values()]))
+            torch.cuda.synchronize()
+            if mode == "graph":
+                assert runner.graph is not None and not runner.disabled, "the data-parallel step was not recorded"
+                assert red2.bytes_staged > 0 and red2.bytes_post > 0
+            runs[mode] = (torch.stack(losses), {k: v.detach().clone() for k, v in head.state_dict().items()})
+            del runner, opt
+        assert torch.equal(runs["eager"][0], runs["graph"][0]), (runs["eager"][0] - runs["graph"][0]).abs().max()
+        for k, v in runs["eager"][1].items():
+            assert torch.equal(v, runs["graph"][1][k]), k
+        if r == 0:
+            print("DP_CAPTURED_OK backend=%s world=%d" % (dist.get_backend(), W))
     # ---- sharded retrieval: every rank scores its own (unevenly sized) gallery shard, lists are merged
     from textreid_amd.evaluation import similarity_topk
 

@@ -62,6 +62,23 @@ def test_dp_collectives_execute_on_rccl():
     assert staged > 0 and post > 0, line  # both reducer entry points really ran their collectives
 
 
+def test_dp_step_recorded_with_its_rccl_collectives():
+    """the data-parallel step as ONE hipGraph - the `nccl` one-rank group with TRID_DP_FORCE=1 drives the
+    packed all-gather, the in-backward staged all-reduces and the bucketed ones inside the recording; five steps (two
+    eager warm-ups, the recording, replays) equal the eager data-parallel steps bit for bit: losses, every parameter,
+    queue, BatchNorm buffer."""
+    out = _run_ranks(1, need=("DP_OK", "DP_REPLICAS_IDENTICAL", "DP_RETRIEVAL_OK", "DP_CAPTURED_OK"), TRID_DIST_BACKEND="nccl",
+                     TRID_DP_FORCE="1", TRID_DP_CAPTURED="1")
+    assert "DP_CAPTURED_OK backend=nccl" in out
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL with more than one rank needs two GPUs (none on the one-GPU build pool)")
+def test_dp_step_recorded_two_ranks_on_rccl():
+    """... and with one rank per GPU when the box has two."""
+    out = _run_ranks(2, need=("DP_OK", "DP_REPLICAS_IDENTICAL", "DP_RETRIEVAL_OK", "DP_CAPTURED_OK"), TRID_DIST_BACKEND="nccl", TRID_DP_CAPTURED="1")
+    assert "DP_CAPTURED_OK backend=nccl world=2" in out
+
+
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL with more than one rank needs two GPUs (none on the one-GPU build pool)")
 @pytest.mark.parametrize("fc", ["0", "1"], ids=["FC=False", "FC=True"])
 def test_dp_two_ranks_on_rccl(fc):

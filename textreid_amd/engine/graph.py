@@ -24,12 +24,18 @@ from ..parallel import dp_active
 
 
 class CapturedTrainStep:
-    def __init__(self, model, optimizer, warmup=2, caption_bound=None):
+    def __init__(self, model, optimizer, warmup=2, caption_bound=None, reducer=None, pre_gather=None):
         """warmup: eager steps before the capture (they build every cached pointer table / workspace / side stream the
         step uses; they are REAL training steps).  optimizer=None: forward + backward only (parity tests).
         caption_bound: number of recurrence steps the recorded text encoder runs (None: the token tensor's width, i.e.
-        any caption fits); batches whose longest caption exceeds it run eagerly."""
+        any caption fits); batches whose longest caption exceeds it run eagerly.
+        reducer / pre_gather (data parallel, `nccl` backend): the parallel.GradReducer of the run and the parameters it
+        SUM-reduces after backward; the packed embedding all-gather of the forward, the all-reduces staged from inside
+        backward and the bucketed ones after it are RCCL launches on RCCL's stream - stream-ordered, hence recordable
+        (probed: tools/exp/rccl_capture_probe.py).  Every rank records the same sequence; a transport that stages
+        through the host (gloo) fails the recording and the step stays eager."""
         self.model, self.optimizer = model, optimizer
+        self.reducer, self.pre_gather = reducer, pre_gather
         self.caption_bound = caption_bound
         self.warmup = max(int(warmup), 1)
         self.calls = 0
@@ -41,9 +47,14 @@ class CapturedTrainStep:
         self.disabled = False    # a failed capture: stay eager for the rest of the run
         self.recaptures = 0
         self.log = logging.getLogger("PersonSearch.trainer")
-        if dp_active():
-            raise RuntimeError("CapturedTrainStep covers the single-process step; under data parallelism the step runs eagerly "
-                               "(its RCCL collectives are issued from inside backward)")
+        if dp_active() and reducer is None:
+            raise RuntimeError("CapturedTrainStep under data parallelism needs the run's GradReducer (reducer=, pre_gather=): "
+                               "the gradient all-reduce is part of the recorded step")
+
+    def _sync_grads(self):
+        if self.reducer is not None and dp_active():
+            self.reducer.reduce(self.pre_gather)
+            self.reducer.wait()
 
     # ------------------------------------------------------------------ eager form (also the fall-back)
     def _eager(self, images, cb):
@@ -55,6 +66,7 @@ class CapturedTrainStep:
             for p in self.model.parameters():
                 p.grad = None
         losses.backward()
+        self._sync_grads()
         if self.optimizer is not None:
             self.optimizer.step()
         # detached: a caller that keeps the returned losses must not keep the autograd graph (and its AccumulateGrad
@@ -95,6 +107,7 @@ class CapturedTrainStep:
             loss_dict = self.model(self.static["images"], scb)
             losses = sum(loss_dict.values())
             losses.backward()
+            self._sync_grads()
             if self.optimizer is not None:
                 self.optimizer.step()
         self.graph, self.out = g, {k: v.detach() for k, v in loss_dict.items()}

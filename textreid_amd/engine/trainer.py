@@ -8,11 +8,13 @@ DDP path crashes), and logging keeps the per-step losses ON DEVICE a
 step's value, in order, as ``trainer.py:92-93`` feeds them."""
 
 import logging
+import os
 import time
 
 import torch
 
 from ..parallel import GradReducer, dp_active, world_size
+from ..parallel import _backend as parallel_backend
 from .inference import inference
 
 
@@ -37,15 +39,19 @@ def do_train(model, data_loader, data_loader_val, optimizer, scheduler, checkpoi
     max_epoch, epoch, iteration = arguments["max_epoch"], arguments["epoch"], arguments["iteration"]
     reducer = GradReducer()
     runner = None
-    if capture and not dp_active() and torch.device(device).type == "cuda":
+    pre_gather = [p for n, p in model.named_parameters() if p.requires_grad and "loss_evaluator" not in n][::-1]
+    if dp_active() and hasattr(getattr(model, "embed_model", None), "v_encoder_q"):
+        model.embed_model.v_encoder_q.grad_sync = reducer  # conv gradients all-reduced from inside backward
+    # data parallel: the step is recorded with its RCCL collectives only on request (TRID_DP_CAPTURE=1) - a recorded step is
+    # no faster than the eager one while the step is GPU-bound, and the multi-rank recording cannot be exercised on a one-GPU
+    # build box (one rank: tests/test_dp_gpu.py)
+    dp_capture = os.environ.get("TRID_DP_CAPTURE", "0") == "1" and parallel_backend() == "nccl"
+    if capture and (not dp_active() or dp_capture) and torch.device(device).type == "cuda":
         from ..solver import FusedAdam
         from .graph import CapturedTrainStep
 
         if isinstance(optimizer, FusedAdam):
-            runner = CapturedTrainStep(model, optimizer, warmup=2)
-    pre_gather = [p for n, p in model.named_parameters() if p.requires_grad and "loss_evaluator" not in n][::-1]
-    if dp_active() and hasattr(getattr(model, "embed_model", None), "v_encoder_q"):
-        model.embed_model.v_encoder_q.grad_sync = reducer  # conv gradients all-reduced from inside backward
+            runner = CapturedTrainStep(model, optimizer, warmup=2, reducer=reducer if dp_active() else None, pre_gather=pre_gather)
     best_top1 = 0.0
     pending, keys = [], None  # per-step loss vectors still on the device
 

@@ -188,7 +188,7 @@ class GradReducer:
             return
         self.steps += 1
         self._t0 = None
-        if params and params[0].is_cuda:
+        if params and params[0].is_cuda and not torch.cuda.is_current_stream_capturing():  # (timing events cannot be recorded into a graph)
             self._t0 = torch.cuda.Event(enable_timing=True)
             self._t0.record()  # backward is done on this stream
         bucket, n = [], 0
@@ -220,7 +220,7 @@ class GradReducer:
                 off += n
         self._pending = []
         self._staged = set()
-        if getattr(self, "_t0", None) is not None:
+        if getattr(self, "_t0", None) is not None and not torch.cuda.is_current_stream_capturing():
             t1 = torch.cuda.Event(enable_timing=True)
             t1.record()
             self._exposed.append((self._t0, t1))
