@@ -91,6 +91,13 @@ typedef struct trid_gemm_desc {
 
 int trid_gemm_f32(const trid_gemm_desc* d, void* stream);
 
+/* C[M][ldc] (+)= alpha * A[M][lda] . B + bias[N] for M <= 128 rows (M = the batch): nn.Linear / F.linear of the attention
+ * pool's q / c projections (m_resnet.py:114-133) and the embedding layers (head.py:50-51,126-129) and their data
+ * gradients.  b_mode TRID_B_KC: B[N][ldb] (weights as stored); TRID_B_NC: B[K][ldb].  Exact fp32 MFMA; a workgroup owns
+ * 32 columns, its 8 waves split the reduction, partial tiles folded in LDS in a fixed order (csrc/skinny_gemm.hip). */
+int trid_skinny_gemm_f32(const float* A, long long lda, const float* B, long long ldb, int b_mode, float* C, long long ldc,
+                         const float* bias, int M, int N, int K, float alpha, int accumulate, void* stream);
+
 /* ------------------------------------------------------------------------- *
  * P16: pre-split GEMM operands (no reference counterpart: PyTorch's fp32 convolutions need no operand format).
  * A [R rows][K] tensor (K % 32 == 0) in P16 holds x * 2^s (s from the tensor's amax, as precision 16 above) as TWO
@@ -260,6 +267,10 @@ int trid_bn_bwd_apply_p16_f32(const void* g, int g_fmt, const void* y, int y_fmt
  * rows T+1..ldt-1 are zero padding (ldt multiple of 4 keeps the token axis float4-addressable) */
 int trid_attnpool_tokens_f32(const float* x, const float* pos, float* tok, int B, int T, int C, int ldt,
                              void* stream);
+/* the same with x in the format the last residual block wrote it (x_fmt 0: fp32, 1: P16 with its amax scalar, 2: plain
+ * bf16) - no unpack pass - and the token loop spread over the workgroup */
+int trid_attnpool_tokens_fmt_f32(const void* x, int x_fmt, const float* x_amax, const float* pos, float* tok, int B, int T,
+                                 int C, int ldt, void* stream);
 /* dx[b,t,:] = dtok[b,1+t,:] + dtok[b,0,:]/T ; dpos[t,:] = sum_b dtok[b,t,:] */
 int trid_attnpool_tokens_bwd_f32(const float* dtok, float* dx, float* dpos, int B, int T, int C, int ldt,
                                  void* stream);

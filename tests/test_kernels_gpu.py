@@ -256,6 +256,34 @@ def test_gemm_p16_stream(ops, M_, N, K):
     assert abs(float(bound) - float(z.abs().max())) <= 1e-4 * float(z.abs().max())
 
 
+@pytest.mark.parametrize("M_,N,K", [(128, 2048, 2048), (128, 1024, 2048), (128, 256, 1024), (16, 256, 1024), (100, 96, 520), (33, 2048, 260), (1, 32, 256), (128, 512, 11008)])
+def test_skinny_gemm(ops, M_, N, K):
+    """csrc/skinny_gemm.hip: batch-sized GEMMs (M <= 128) with the reduction split over the waves of a workgroup - both weight
+    layouts, bias, alpha, accumulate, strided rows on both sides, ragged M / N / K slices - against fp64; exact fp32 MFMA
+    products (errors at fp32 summation level)."""
+    x, w, b = R("kx", M_, K), R("kw", N, K, scale=0.3), R("kb", N)
+    ref = x.double() @ w.double().t()
+    assert ops._skinny_ok(M_, N, K, K, K, None)
+    assert rel(ops.linear(dev(x), dev(w), dev(b)), ref + b.double()) < 2e-6
+    assert rel(ops.linear(dev(x), dev(w), alpha=0.5), 0.5 * ref) < 2e-6
+    wt = w.t().contiguous()  # [K, N]: the N-contiguous (data-gradient) form
+    c0 = R("kc", M_, N)
+    out = dev(c0).clone()
+    ops.matmul_nn(dev(x), dev(wt), out=out, accumulate=True)
+    assert rel(out, ref + c0.double()) < 2e-6
+    # strided rows: A rows at a pitch of 3 K (token 0 of [M, 3, K]), C rows at a pitch of 2 N
+    xs = R("kxs", M_, 3, K)
+    big = torch.zeros(M_, 2, N, device="cuda")
+    ops.matmul_nn(dev(xs)[:, 0], dev(wt), out=big[:, 1])
+    assert rel(big[:, 1], xs[:, 0].double() @ w.double().t()) < 2e-6 and float(big[:, 0].abs().max()) == 0.0
+    old = ops.USE_SKINNY
+    try:
+        ops.USE_SKINNY = False
+        assert rel(ops.linear(dev(x), dev(w), dev(b)), ref + b.double()) < 2e-5  # (the tiled path it replaces)
+    finally:
+        ops.USE_SKINNY = old
+
+
 def test_stem_im2col_conv(ops):
     x, w = R("sx", 3, 3, 24, 16), R("sw", 8, 3, 3, 3)
     col, Ho, Wo = ops.stem_im2col(dev(x))

@@ -712,9 +712,8 @@ class ModifiedResNet(nn.Module):
                     S["blocks"].append(rec)
                 if taps is not None:
                     taps[names[id(blk)]] = x.unpack()
-            x = x.unpack()
             if save:
-                S["p16"] = fmt
+                S["p16"] = fmt  # (x stays in its P16 / bf16 form: the attention pool's token kernel decodes it)
         else:
             for blk in self.blocks():
                 x, ax, rec = block_forward(blk, x, ax, ar, training, save, nbt, masks)
@@ -739,9 +738,12 @@ class ModifiedResNet(nn.Module):
         heads = ap.num_heads
         hd = C // heads
         scale = float(hd) ** -0.5
-        tok = ops.empty((B, T1p, C), x)
-        ops.call("trid_attnpool_tokens_f32", ops._p(x), ops._p(ap.positional_embedding), ops._p(tok), B, T, C, T1p,
-                 ops.stream())
+        xd = x.data if isinstance(x, ops.P16) else x
+        x_fmt = x.fmt if isinstance(x, ops.P16) else 0
+        tok = ops.empty((B, T1p, C), xd)
+        ops.call("trid_attnpool_tokens_fmt_f32", ops._p(xd), x_fmt, ops._p(x.amax) if x_fmt == 1 else None, ops._p(ap.positional_embedding),
+                 ops._p(tok), B, T, C, T1p, ops.stream())
+        x = tok  # (shape / device carrier for what follows)
         q = ops.linear(tok[:, 0], ap.q_proj.weight, ap.q_proj.bias)  # [B,C]
         # U[b,h,:] = scale * q[b,h,:] @ Wk[h]  (k bias is softmax-invariant and dropped)
         U = ops.empty((B, heads, C), x)
@@ -760,7 +762,7 @@ class ModifiedResNet(nn.Module):
         ops.gemm(Z, ap.v_proj.weight, o, B, hd, C, heads * C, C, C, batch=heads, strideA=C, strideB=hd * C, strideC=hd,
                  bias=ap.v_proj.bias, strideBias=hd)
         out = ops.linear(o, ap.c_proj.weight, ap.c_proj.bias)
-        return out, ((x.shape, tok, q, U, P, Z, o) if save else None)
+        return out, (((B, H, W, C), tok, q, U, P, Z, o) if save else None)
 
     # ------------------------------------------------------------------ backward
     def _attnpool_backward(self, asave, gout, G):
@@ -813,7 +815,7 @@ class ModifiedResNet(nn.Module):
         G[id(Wk)] = dWk
         G[id(ap.k_proj.bias)] = torch.zeros_like(ap.k_proj.bias)  # softmax is shift-invariant: exactly zero
         # q projection (token 0)
-        ops.gemm(dq, Wq, dtok, B, C, C, C, C, T1p * C, b_mode=ops.B_NC, accumulate=True)
+        ops.matmul_nn(dq, Wq, out=dtok[:, 0], accumulate=True)  # (rows of dtok at pitch T1p * C: token 0 of every image)
         G[id(Wq)] = ops.matmul_tn(dq, tok[:, 0])
         G[id(ap.q_proj.bias)] = ops.colsum(dq)
         dx = ops.empty((B, H, W, C), tok)

@@ -3,7 +3,7 @@
 // BiGRU cell forward/backward with the max-over-time fused in.
 // The dense parts (projections, recurrent h @ W_hh^T) run on trid_gemm_f32.
 
-#include "common.h"
+#include "split_common.h"
 
 namespace trid {
 
@@ -27,6 +27,43 @@ __global__ void attnpool_tokens_kernel(const float4* __restrict__ x, const float
     const float inv = 1.f / (float)T;
     const float4 p0 = pos[cq];
     tb[0] = make_float4(s.x * inv + p0.x, s.y * inv + p0.y, s.z * inv + p0.z, s.w * inv + p0.w);
+}
+
+// The same with the token loop spread over the workgroup (the kernel above walks a thread through all T tokens: 65 536
+// threads, each a chain of T dependent iterations - 150-190 us for 200 MB) and the input read in the format the last
+// residual block wrote it (IFMT 1: P16, 2: plain bf16; 0: fp32) - no unpack pass in front.  Block = 64 channel quads x 4
+// token lanes; grid (C / 256, B).
+template <int IFMT>
+__global__ __launch_bounds__(256) void attnpool_tokens_wide_kernel(const float4* __restrict__ x, const float* __restrict__ x_amax,
+                                                                   const float4* __restrict__ pos, float4* __restrict__ tok,
+                                                                   int T, int CQ, int ldt) {
+    __shared__ float4 red[4][64];
+    const int cl = threadIdx.x & 63, tl = threadIdx.x >> 6;
+    const int cq = blockIdx.x * 64 + cl, b = blockIdx.y;
+    const bool live = cq < CQ;
+    const float inv_scale = IFMT == 1 ? 1.f / f16_scale_of(*x_amax) : 1.f;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live) {
+        float4* tb = tok + (long long)b * ldt * CQ + cq;
+        for (int t = tl; t < T; t += 4) {
+            const long long i = ((long long)b * T + t) * CQ + cq;
+            const float4 v = IFMT == 1 ? p16_load4(reinterpret_cast<const uint2*>(x), i, CQ, inv_scale)
+                           : IFMT == 2 ? bf16_load4(reinterpret_cast<const uint2*>(x), i) : x[i];
+            const float4 p = pos[(long long)(t + 1) * CQ + cq];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            tb[(long long)(t + 1) * CQ] = make_float4(v.x + p.x, v.y + p.y, v.z + p.z, v.w + p.w);
+        }
+        for (int t = T + 1 + tl; t < ldt; t += 4) tb[(long long)t * CQ] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    red[tl][cl] = s;
+    __syncthreads();
+    if (tl == 0 && live) {
+        const float4 a = red[0][cl], c = red[1][cl], d = red[2][cl], e = red[3][cl];
+        const float inv = 1.f / (float)T;
+        const float4 p0 = pos[cq];
+        tok[(long long)b * ldt * CQ + cq] = make_float4(((a.x + c.x) + (d.x + e.x)) * inv + p0.x, ((a.y + c.y) + (d.y + e.y)) * inv + p0.y,
+                                                         ((a.z + c.z) + (d.z + e.z)) * inv + p0.z, ((a.w + c.w) + (d.w + e.w)) * inv + p0.w);
+    }
 }
 
 __global__ void attnpool_tokens_bwd_dx_kernel(const float4* __restrict__ dtok, float4* __restrict__ dx, int B, int T,
@@ -214,6 +251,19 @@ extern "C" int trid_attnpool_tokens_f32(const float* x, const float* pos, float*
     hipLaunchKernelGGL(attnpool_tokens_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        (const float4*)x, (const float4*)pos, (float4*)tok, B, T, C / 4, ldt);
     return check_launch("trid_attnpool_tokens_f32");
+}
+
+extern "C" int trid_attnpool_tokens_fmt_f32(const void* x, int x_fmt, const float* x_amax, const float* pos, float* tok, int B, int T,
+                                            int C, int ldt, void* stream) {
+    TRID_REQUIRE(x && pos && tok && B > 0 && T > 0 && C > 0 && ldt >= T + 1 && x_fmt >= 0 && x_fmt <= 2, "trid_attnpool_tokens_fmt_f32: bad arguments");
+    TRID_REQUIRE(C % (x_fmt == 0 ? 4 : 32) == 0 && (x_fmt != 1 || x_amax), "trid_attnpool_tokens_fmt_f32: C %% 4 (fp32) / C %% 32 (P16, bf16); P16 needs its amax scalar");
+    const int CQ = C / 4;
+    const dim3 grid((unsigned)((CQ + 63) / 64), (unsigned)B);
+    hipStream_t s = (hipStream_t)stream;
+    if (x_fmt == 1) hipLaunchKernelGGL(attnpool_tokens_wide_kernel<1>, grid, dim3(256), 0, s, (const float4*)x, x_amax, (const float4*)pos, (float4*)tok, T, CQ, ldt);
+    else if (x_fmt == 2) hipLaunchKernelGGL(attnpool_tokens_wide_kernel<2>, grid, dim3(256), 0, s, (const float4*)x, x_amax, (const float4*)pos, (float4*)tok, T, CQ, ldt);
+    else hipLaunchKernelGGL(attnpool_tokens_wide_kernel<0>, grid, dim3(256), 0, s, (const float4*)x, x_amax, (const float4*)pos, (float4*)tok, T, CQ, ldt);
+    return check_launch("trid_attnpool_tokens_fmt_f32");
 }
 
 extern "C" int trid_attnpool_tokens_bwd_f32(const float* dtok, float* dx, float* dpos, int B, int T, int C, int ldt,

@@ -8,41 +8,7 @@
 
 namespace trid {
 
-// ---------------------------------------------------------------- P16 (pre-split GEMM operand) element access
-// A [rows][C] tensor in P16 (gemm_p16.hip): per row and 32-channel group 128 bytes = [hi x 32 | lo x 32] fp16 of
-// x * 2^s.  These kernels work on channel QUADS (float4): quad cq of a row lives at 8-byte unit
-// row * (C/2) + (cq / 8) * 16 + (cq % 8) (high parts) and 8 units further (low parts): a wave writes whole
-// 64-byte plane halves, fully coalesced.
-__device__ __forceinline__ void p16_store4(uint2* __restrict__ base, long long i, int CQ, float4 v, float scale) {
-    const long long row = i / CQ;
-    const int cq = (int)(i - row * CQ);
-    unsigned h0, l0, h1, l1;
-    f16_split2(v.x * scale, v.y * scale, h0, l0);
-    f16_split2(v.z * scale, v.w * scale, h1, l1);
-    uint2* dst = base + row * (2 * CQ) + (cq >> 3) * 16 + (cq & 7);
-    dst[0] = make_uint2(h0, h1);
-    dst[8] = make_uint2(l0, l1);
-}
-__device__ __forceinline__ float4 p16_load4(const uint2* __restrict__ base, long long i, int CQ, float inv) {
-    const long long row = i / CQ;
-    const int cq = (int)(i - row * CQ);
-    const uint2* src = base + row * (2 * CQ) + (cq >> 3) * 16 + (cq & 7);
-    const uint2 h = src[0], l = src[8];
-    const f16x2 h0 = __builtin_bit_cast(f16x2, h.x), h1 = __builtin_bit_cast(f16x2, h.y);
-    const f16x2 l0 = __builtin_bit_cast(f16x2, l.x), l1 = __builtin_bit_cast(f16x2, l.y);
-    return make_float4(((float)h0.x + (float)l0.x) * inv, ((float)h0.y + (float)l0.y) * inv,
-                       ((float)h1.x + (float)l1.x) * inv, ((float)h1.y + (float)l1.y) * inv);
-}
-// the same tensors as plain bf16 (configs[3]'s arithmetic: the convolutions read bf16 operands; round-to-nearest-even
-// here = the rounding the GEMM loader would apply): quad i = 8 bytes at 8 * i, no scale
-__device__ __forceinline__ void bf16_store4(uint2* __restrict__ base, long long i, float4 v) {
-    base[i] = make_uint2(cvt_pk_bf16(v.x, v.y), cvt_pk_bf16(v.z, v.w));
-}
-__device__ __forceinline__ float4 bf16_load4(const uint2* __restrict__ base, long long i) {
-    const uint2 u = base[i];
-    return make_float4(__builtin_bit_cast(float, u.x << 16), __builtin_bit_cast(float, u.x & 0xffff0000u),
-                       __builtin_bit_cast(float, u.y << 16), __builtin_bit_cast(float, u.y & 0xffff0000u));
-}
+// (P16 / bf16 element access: p16_store4, p16_load4, bf16_store4, bf16_load4 - split_common.h)
 // scale of a P16 tensor whose largest magnitude is bounded by *a (+ *b): the bound is also published for the consumers
 __device__ __forceinline__ float p16_out_scale(const float* a, const float* b, float* sum_out) {
     const float bound = (a != nullptr ? *a : 0.f) + (b != nullptr ? *b : 0.f);

@@ -474,6 +474,21 @@ def wgrad_p16(dy, x, conv=None, alpha=1.0):
     return out
 
 
+USE_SKINNY = os.environ.get("TRID_SKINNY_GEMM", "1") != "0"  # M <= 128 linears on csrc/skinny_gemm.hip (0: A/B runs)
+
+
+def _skinny_ok(M, N, K, lda, ldb_k_contig, prec):
+    """The batch-sized GEMMs (attention-pool projections, embedding layers, their data gradients): one row of output tiles
+    on a tiled kernel - they run on the reduction-split, weight-streaming kernel instead (exact fp32)."""
+    return (USE_SKINNY and prec is None and M <= 128 and K >= 256 and K % 4 == 0 and N >= 32 and N <= 8192 and lda % 4 == 0
+            and (ldb_k_contig is None or ldb_k_contig % 4 == 0))
+
+
+def skinny_gemm(a, lda, b, ldb, b_mode, out, ldc, M, N, K, bias=None, alpha=1.0, accumulate=False, a_off=0, c_off=0):
+    call("trid_skinny_gemm_f32", _p(a) + 4 * a_off, lda, _p(b), ldb, b_mode, _p(out) + 4 * c_off, ldc, _p(bias), M, N, K, alpha,
+         1 if accumulate else 0, stream())
+
+
 def linear(x, w, bias=None, out=None, alpha=1.0, accumulate=False, prec=None, aa=None, ba=None, relu=False):
     """y[M,N] = alpha * x[M,K] @ w[N,K]^T + bias.  x may be a strided row view.
     prec / aa / ba (here and below): GEMM arithmetic override and the two operands' amax device scalars."""
@@ -481,6 +496,9 @@ def linear(x, w, bias=None, out=None, alpha=1.0, accumulate=False, prec=None, aa
     N = w.shape[0]
     if out is None:
         out = empty((M, N), x)
+    if not relu and x.stride(1) == 1 and w.stride(1) == 1 and _skinny_ok(M, N, K, x.stride(0), w.stride(0), prec) and x.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0:
+        skinny_gemm(x, x.stride(0), w, w.stride(0), B_KC, out, out.stride(0), M, N, K, bias=bias, alpha=alpha, accumulate=accumulate)
+        return out
     gemm(x, w, out, M, N, K, x.stride(0), w.stride(0), out.stride(0), alpha=alpha, accumulate=accumulate, bias=bias,
          precision=prec, a_amax=aa, b_amax=ba, relu=relu)
     return out
@@ -494,6 +512,9 @@ def matmul_nn(a, b, out=None, alpha=1.0, accumulate=False, prec=None, aa=None, b
     N = b.shape[1]
     if out is None:
         out = empty((M, N), a)
+    if a.stride(1) == 1 and b.stride(1) == 1 and _skinny_ok(M, N, K, a.stride(0), None, prec) and a.data_ptr() % 16 == 0:
+        skinny_gemm(a, a.stride(0), b, b.stride(0), B_NC, out, out.stride(0), M, N, K, alpha=alpha, accumulate=accumulate)
+        return out
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
     splits = min(K // 128, (256 + tiles - 1) // tiles) if (tiles < 64 and K >= 1024 and out.stride(0) == N) else 1
     if splits <= 1:
