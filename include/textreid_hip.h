@@ -94,9 +94,12 @@ int trid_gemm_f32(const trid_gemm_desc* d, void* stream);
 /* C[M][ldc] (+)= alpha * A[M][lda] . B + bias[N] for M <= 128 rows (M = the batch): nn.Linear / F.linear of the attention
  * pool's q / c projections (m_resnet.py:114-133) and the embedding layers (head.py:50-51,126-129) and their data
  * gradients.  b_mode TRID_B_KC: B[N][ldb] (weights as stored); TRID_B_NC: B[K][ldb].  Exact fp32 MFMA; a workgroup owns
- * 32 columns, its 8 waves split the reduction, partial tiles folded in LDS in a fixed order (csrc/skinny_gemm.hip). */
+ * 32 columns, its 8 waves split the reduction, partial tiles folded in LDS in a fixed order (csrc/skinny_gemm.hip).
+ * batch > 1: `batch` independent products at element strides strideA / strideB / strideC (/ strideBias) - the attention
+ * pool's per-image and per-head products (32 heads x 193 tokens x 2048 channels per image). */
 int trid_skinny_gemm_f32(const float* A, long long lda, const float* B, long long ldb, int b_mode, float* C, long long ldc,
-                         const float* bias, int M, int N, int K, float alpha, int accumulate, void* stream);
+                         const float* bias, int M, int N, int K, float alpha, int accumulate, int batch, long long strideA,
+                         long long strideB, long long strideC, long long strideBias, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * P16: pre-split GEMM operands (no reference counterpart: PyTorch's fp32 convolutions need no operand format).

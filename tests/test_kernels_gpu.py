@@ -284,6 +284,31 @@ def test_skinny_gemm(ops, M_, N, K):
         ops.USE_SKINNY = old
 
 
+def test_skinny_gemm_batched_attention_pool_shapes(ops):
+    """The attention pool's per-image / per-head products through the raw descriptor call (m_resnet.py:103-135 evaluated for
+    the token-0 query): interleaved batches (head h of image b at element stride hd inside a row), K = 196 padded tokens,
+    per-batch bias - each against fp64."""
+    Bn, heads, C, T1p = 6, 8, 512, 196
+    hd = C // heads
+    old_thr = (ops.SKINNY_MIN_K_BATCHED, ops.SKINNY_MIN_M_BATCHED)
+    ops.SKINNY_MIN_K_BATCHED, ops.SKINNY_MIN_M_BATCHED = 192, 1  # (every batched form through the kernel, not only the ones dispatched to it)
+    U, tok = R("bu", Bn, heads, C), R("bt", Bn, T1p, C)
+    P = ops.empty((Bn, heads, T1p), dev(U))
+    ops.gemm(dev(U), dev(tok), P, heads, T1p, C, C, C, T1p, batch=Bn, strideA=heads * C, strideB=T1p * C, strideC=heads * T1p)
+    assert rel(P, torch.einsum("bhc,btc->bht", U.double(), tok.double())) < 2e-6
+    Pm = R("bp", Bn, heads, T1p)
+    Z = ops.empty((Bn, heads, C), dev(U))
+    ops.gemm(dev(Pm), dev(tok), Z, heads, C, T1p, T1p, C, C, b_mode=ops.B_NC, batch=Bn, strideA=heads * T1p, strideB=T1p * C, strideC=heads * C)
+    assert rel(Z, torch.einsum("bht,btc->bhc", Pm.double(), tok.double())) < 2e-6
+    Wv, bv = R("bw", C, C, scale=0.2), R("bb", C)
+    Zs = R("bz", Bn, heads, C)
+    o = ops.empty((Bn, C), dev(U))
+    ops.gemm(dev(Zs), dev(Wv), o, Bn, hd, C, heads * C, C, C, batch=heads, strideA=C, strideB=hd * C, strideC=hd, bias=dev(bv), strideBias=hd)
+    want = torch.einsum("bhc,hdc->bhd", Zs.double(), Wv.double().view(heads, hd, C)).reshape(Bn, C) + bv.double()
+    ops.SKINNY_MIN_K_BATCHED, ops.SKINNY_MIN_M_BATCHED = old_thr
+    assert rel(o, want) < 2e-6
+
+
 def test_stem_im2col_conv(ops):
     x, w = R("sx", 3, 3, 24, 16), R("sw", 8, 3, 3, 3)
     col, Ho, Wo = ops.stem_im2col(dev(x))

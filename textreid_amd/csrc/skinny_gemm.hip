@@ -27,6 +27,7 @@ struct SkinnyParams {
     float alpha;
     int accumulate;
     int kslice;       // k range of one wave (multiple of 8)
+    long long sA, sB, sC, sBias;  // batch strides (elements); blockIdx.z = batch index
 };
 
 template <int BMODE>
@@ -38,9 +39,14 @@ __global__ __launch_bounds__(512) void skinny_gemm_f32_kernel(SkinnyParams p) {
     const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 64;
     const int nrb = (p.M - m0 > 32) ? 2 : 1;  // row blocks of this workgroup that hold rows
 
-    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (unsigned)((size_t)p.M * p.lda * 4), 0x00020000);
-    const size_t b_rows = BMODE == 0 ? (size_t)p.N : (size_t)p.K;
-    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (unsigned)(b_rows * p.ldb * 4), 0x00020000);
+    const long long z = blockIdx.z;
+    const float* Ab = p.A + z * p.sA;
+    const float* Bb = p.B + z * p.sB;
+    float* Cb = p.C + z * p.sC;
+    // (descriptor ranges: the last row ends after its K / N elements, not after a full pitch - batched operands interleave)
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)Ab, 0, (unsigned)(((size_t)(p.M - 1) * p.lda + p.K) * 4), 0x00020000);
+    const size_t b_bytes = BMODE == 0 ? ((size_t)(p.N - 1) * p.ldb + p.K) * 4 : ((size_t)(p.K - 1) * p.ldb + p.N) * 4;
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)Bb, 0, (unsigned)b_bytes, 0x00020000);
     constexpr unsigned OOB = 0x80000000u;
 
     const int k_begin = wave * p.kslice;
@@ -84,7 +90,7 @@ __global__ __launch_bounds__(512) void skinny_gemm_f32_kernel(SkinnyParams p) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[0][t], f.b[t], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[1][t], f.b[t], acc[1], 0, 0, 0);
+            if (nrb == 2) acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[1][t], f.b[t], acc[1], 0, 0, 0);  // (workgroup-uniform)
         }
     };
     // four 8-deep groups in flight: the loads of groups j+4 .. j+7 are issued before the MFMAs of groups j .. j+3
@@ -115,14 +121,14 @@ __global__ __launch_bounds__(512) void skinny_gemm_f32_kernel(SkinnyParams p) {
         for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[rb][r] += part[w][rb][r][lane];
-    const float bv = (p.bias != nullptr && n < p.N) ? p.bias[n] : 0.f;
+    const float bv = (p.bias != nullptr && n < p.N) ? p.bias[z * p.sBias + n] : 0.f;
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
             if (m < p.M && n < p.N) {
-                float* dst = p.C + (size_t)m * p.ldc + n;
+                float* dst = Cb + (size_t)m * p.ldc + n;
                 float v = p.alpha * acc[rb][r] + bv;
                 if (p.accumulate) v += *dst;
                 *dst = v;
@@ -135,8 +141,10 @@ __global__ __launch_bounds__(512) void skinny_gemm_f32_kernel(SkinnyParams p) {
 using namespace trid;
 
 extern "C" int trid_skinny_gemm_f32(const float* A, long long lda, const float* B, long long ldb, int b_mode, float* C, long long ldc,
-                                    const float* bias, int M, int N, int K, float alpha, int accumulate, void* stream) {
-    TRID_REQUIRE(A && B && C && M > 0 && M <= 128 && N > 0 && K > 0, "trid_skinny_gemm_f32: needs 0 < M <= 128 (M=%d N=%d K=%d)", M, N, K);
+                                    const float* bias, int M, int N, int K, float alpha, int accumulate, int batch, long long strideA,
+                                    long long strideB, long long strideC, long long strideBias, void* stream) {
+    TRID_REQUIRE(A && B && C && M > 0 && M <= 128 && N > 0 && K > 0 && batch >= 1 && batch <= 65535, "trid_skinny_gemm_f32: needs 0 < M <= 128, 1 <= batch <= 65535 (M=%d N=%d K=%d)", M, N, K);
+    TRID_REQUIRE(strideA % 4 == 0 && (b_mode == B_NC || strideB % 4 == 0), "trid_skinny_gemm_f32: batch strides of k-contiguous operands must be multiples of 4");
     TRID_REQUIRE(b_mode == B_KC || b_mode == B_NC, "trid_skinny_gemm_f32: b_mode is TRID_B_KC or TRID_B_NC");
     TRID_REQUIRE(K % 4 == 0 && lda % 4 == 0 && aligned16(A) && (b_mode == B_NC || (ldb % 4 == 0 && aligned16(B))),
                  "trid_skinny_gemm_f32: K, the k-contiguous row pitches must be multiples of 4 and the operands 16-byte aligned");
@@ -148,7 +156,8 @@ extern "C" int trid_skinny_gemm_f32(const float* A, long long lda, const float* 
     p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.alpha = alpha; p.accumulate = accumulate;
     p.kslice = ((K + 7) / 8 + 63) / 64 * 64;  // (whole 64-deep loop trips; the tail reads zeros)
-    const dim3 grid((unsigned)((N + 31) / 32), (unsigned)((M + 63) / 64));
+    p.sA = strideA; p.sB = strideB; p.sC = strideC; p.sBias = strideBias;
+    const dim3 grid((unsigned)((N + 31) / 32), (unsigned)((M + 63) / 64), (unsigned)batch);
     if (b_mode == B_KC) hipLaunchKernelGGL(skinny_gemm_f32_kernel<0>, grid, dim3(512), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(skinny_gemm_f32_kernel<1>, grid, dim3(512), 0, (hipStream_t)stream, p);
     return check_launch("trid_skinny_gemm_f32");

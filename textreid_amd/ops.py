@@ -162,6 +162,13 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, a_mode=A_KC, b_mode=B_KC, alpha=1.0, a
     """Raw descriptor call.  a_off/b_off/c_off are element offsets into A/B/C.  precision=16 (fp16-split
     arithmetic) takes the operands' largest magnitudes as device scalars; a missing one is computed here over the
     WHOLE tensor object passed (a superset of the operand is a valid, merely looser, scale)."""
+    if (a_mode == A_KC and b_mode in (B_KC, B_NC) and stats is None and splits == 1 and residual is None and not relu and conv is None
+            and a_off == 0 and b_off == 0 and c_off == 0 and bias_off == 0 and batch <= 65535
+            and _skinny_ok(M, N, K, lda, ldb if b_mode == B_KC else None, precision, SKINNY_MIN_K_BATCHED) and A.data_ptr() % 16 == 0
+            and (b_mode == B_NC or B.data_ptr() % 16 == 0) and strideA % 4 == 0 and (b_mode == B_NC or strideB % 4 == 0)
+            and (batch == 1 or M >= SKINNY_MIN_M_BATCHED)):
+        return skinny_gemm(A, lda, B, ldb, b_mode, C, ldc, M, N, K, bias=bias, alpha=alpha, accumulate=accumulate, batch=batch,
+                           strideA=strideA, strideB=strideB, strideC=strideC, strideBias=strideBias)
     prec = GEMM_PRECISION if precision is None else precision
     if prec == 16 and _uses_split(M, N, K, a_mode, conv, 16):
         if a_amax is None:
@@ -477,16 +484,24 @@ def wgrad_p16(dy, x, conv=None, alpha=1.0):
 USE_SKINNY = os.environ.get("TRID_SKINNY_GEMM", "1") != "0"  # M <= 128 linears on csrc/skinny_gemm.hip (0: A/B runs)
 
 
-def _skinny_ok(M, N, K, lda, ldb_k_contig, prec):
+# raw gemm() calls (the attention pool's batched products): only the per-HEAD ones with all 128 batch rows and a long reduction
+# (o = Z Wv^T, dq = dU Wk^T: 59 -> 34 us).  The per-IMAGE ones (32 heads x 196 tokens: M = 32, or K = 196) measured SLOWER on
+# this kernel (S 68 -> 86 us, Z 60 -> 186 us, tools/exp/attn_bench.py): thousands of workgroups with half their waves idle
+SKINNY_MIN_K_BATCHED = 512
+SKINNY_MIN_M_BATCHED = 65
+
+
+def _skinny_ok(M, N, K, lda, ldb_k_contig, prec, min_k=256):
     """The batch-sized GEMMs (attention-pool projections, embedding layers, their data gradients): one row of output tiles
     on a tiled kernel - they run on the reduction-split, weight-streaming kernel instead (exact fp32)."""
-    return (USE_SKINNY and prec is None and M <= 128 and K >= 256 and K % 4 == 0 and N >= 32 and N <= 8192 and lda % 4 == 0
+    return (USE_SKINNY and prec is None and M <= 128 and K >= min_k and K % 4 == 0 and N >= 32 and N <= 8192 and lda % 4 == 0
             and (ldb_k_contig is None or ldb_k_contig % 4 == 0))
 
 
-def skinny_gemm(a, lda, b, ldb, b_mode, out, ldc, M, N, K, bias=None, alpha=1.0, accumulate=False, a_off=0, c_off=0):
-    call("trid_skinny_gemm_f32", _p(a) + 4 * a_off, lda, _p(b), ldb, b_mode, _p(out) + 4 * c_off, ldc, _p(bias), M, N, K, alpha,
-         1 if accumulate else 0, stream())
+def skinny_gemm(a, lda, b, ldb, b_mode, out, ldc, M, N, K, bias=None, alpha=1.0, accumulate=False, batch=1, strideA=0, strideB=0, strideC=0,
+                strideBias=0):
+    call("trid_skinny_gemm_f32", _p(a), lda, _p(b), ldb, b_mode, _p(out), ldc, _p(bias), M, N, K, alpha,
+         1 if accumulate else 0, batch, strideA, strideB, strideC, strideBias, stream())
 
 
 def linear(x, w, bias=None, out=None, alpha=1.0, accumulate=False, prec=None, aa=None, ba=None, relu=False):
