@@ -135,10 +135,13 @@ def main():
                 vkf.append(head.v_encoder_k(x))
                 tkf.append(head.t_encoder_k(cb))
         vw, vb, tw, tb = head.v_embed_layer.weight, head.v_embed_layer.bias, head.t_embed_layer.weight, head.t_embed_layer.bias
-        ve, te = L.linear(torch.cat(vf), vw, vb), L.linear(torch.cat(tf), tw, tb)
+        # (the embedding layers per shard, as every rank applies them BEFORE the gather: the same launch shapes - a 128-row
+        # product runs on another kernel than a 1024-row one, and in the bf16 mode a last-bit difference in dL/d(feature)
+        # flips bf16 roundings further down)
+        ve, te = torch.cat([L.linear(f_, vw, vb) for f_ in vf]), torch.cat([L.linear(f_, tw, tb) for f_ in tf])
         with torch.no_grad():
-            vk = L.l2_normalize(L.linear(torch.cat(vkf), vw, vb))
-            tk = L.l2_normalize(L.linear(torch.cat(tkf), tw, tb))
+            vk = L.l2_normalize(torch.cat([L.linear(f_, vw, vb) for f_ in vkf]))
+            tk = L.l2_normalize(torch.cat([L.linear(f_, tw, tb) for f_ in tkf]))
         one = head.loss_evaluator.forward_fused(ve, te, L.l2_normalize(ve), L.l2_normalize(te), vk, tk, ids.to(dev),
                                                 head._queue_kc("t_queue"), head._queue_kc("v_queue"), head.id_queue)
         sum(one.values()).backward()

@@ -132,7 +132,9 @@ def main():
             red2 = GradReducer(bucket_mb=1)
             head.v_encoder_q.grad_sync = red2
             opt = FusedAdam([{"params": [p_], "lr": 2e-3 if n.endswith("bias") else 1e-3} for n, p_ in head.named_parameters() if p_.requires_grad], lr=1e-3)
-            runner = CapturedTrainStep(head, opt, warmup=2, reducer=red2, pre_gather=pre)
+            # (caption_bound = the batches' own maximum: the recorded text encoder then runs the SAME launch shapes as the eager
+            # one - with the token tensor's width as bound its [t x b, E] products change size, hence kernel and rounding)
+            runner = CapturedTrainStep(head, opt, warmup=2, caption_bound=int(ln[sl].max()), reducer=red2, pre_gather=pre)
             losses = []
             for i in range(5):
                 xi = x[sl].roll(i, 0).to(dev)
