@@ -123,9 +123,6 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 && STAGES == 2) ? 2 : (W
     const int cgroups = (AMODE == A_CONV) ? p.Cin / BKE : 1;
 
     auto issue = [&](int kt, int stage) {
-#ifdef P16_EXP_NODMA
-        return;
-#endif
         uint4* sA = smem + stage * STAGE_SLOTS;
         uint4* sB = sA + BM * 8;
         unsigned soA, soB;
@@ -192,28 +189,11 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 && STAGES == 2) ? 2 : (W
 #pragma unroll
                 for (int pl = 0; pl < 2; ++pl) {
                     const int s = (4 * pl + 2 * ks + khalf) ^ xs;
-#ifdef P16_EXP_NOLDS
-#pragma unroll
-                    for (int i = 0; i < TM; ++i) a[pl][i] = __builtin_bit_cast(f16x8, uint4{(unsigned)lane, (unsigned)s, (unsigned)i, 1u});
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) b[pl][j] = __builtin_bit_cast(f16x8, uint4{(unsigned)lane, (unsigned)s, (unsigned)j, 2u});
-#else
 #pragma unroll
                     for (int i = 0; i < TM; ++i) a[pl][i] = __builtin_bit_cast(f16x8, sA[(a_row + 32 * i) * 8 + s]);
 #pragma unroll
                     for (int j = 0; j < TN; ++j) b[pl][j] = __builtin_bit_cast(f16x8, sB[(b_row + 32 * j) * 8 + s]);
-#endif
                 }
-#ifdef P16_EXP_NOMFMA
-#pragma unroll
-                for (int pl = 0; pl < 2; ++pl) {
-#pragma unroll
-                    for (int i = 0; i < TM; ++i) asm volatile("" ::"v"(a[pl][i]));
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(b[pl][j]));
-                }
-                continue;
-#endif
                 // small terms first; consecutive MFMAs hit different accumulators
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
