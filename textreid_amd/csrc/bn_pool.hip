@@ -277,7 +277,7 @@ __global__ void bn_apply_kernel(const float4* __restrict__ y, const float4* __re
                                 float4* __restrict__ out, long long total4, int CQ, int relu,
                                 unsigned long long* __restrict__ mask, float* __restrict__ amax,
                                 const float* __restrict__ oa, const float* __restrict__ ob, float* __restrict__ osum,
-                                const float* __restrict__ res_amax, int y_fmt) {
+                                const float* __restrict__ res_amax, int y_fmt, int nt) {
     unsigned am = 0;
     constexpr bool P16OUT = OFMT == 1;
     const float oscale = P16OUT ? p16_out_scale(oa, ob, osum) : 1.f;
@@ -286,10 +286,10 @@ __global__ void bn_apply_kernel(const float4* __restrict__ y, const float4* __re
          i += (long long)gridDim.x * blockDim.x) {
         const int cq = (int)(i % CQ);
         // y_fmt 2: the raw conv output itself is a bf16 tensor (bf16 mode)
-        float4 v = affine4(y_fmt == 2 ? bf16_load4(reinterpret_cast<const uint2*>(y), i) : y[i], scale[cq], shift[cq]);
+        float4 v = affine4(y_fmt == 2 ? bf16_load4(reinterpret_cast<const uint2*>(y), i) : ld_stream4(y + i, nt), scale[cq], shift[cq]);
         if (res != nullptr) {
             float4 r = RFMT == 1 ? p16_load4(reinterpret_cast<const uint2*>(res), i, CQ, rinv)
-                     : RFMT == 2 ? bf16_load4(reinterpret_cast<const uint2*>(res), i) : res[i];
+                     : RFMT == 2 ? bf16_load4(reinterpret_cast<const uint2*>(res), i) : ld_stream4(res + i, nt);
             if (rscale != nullptr) r = affine4(r, rscale[cq], rshift[cq]);
             v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
         }
@@ -305,11 +305,11 @@ __global__ void bn_apply_kernel(const float4* __restrict__ y, const float4* __re
         }
         if (relu) v = relu4(v);
         if (OFMT == 1) {
-            p16_store4(reinterpret_cast<uint2*>(out), i, CQ, v, oscale);
+            p16_store4(reinterpret_cast<uint2*>(out), i, CQ, v, oscale, nt);
         } else if (OFMT == 2) {
             bf16_store4(reinterpret_cast<uint2*>(out), i, v);
         } else {
-            out[i] = v;
+            st_stream4(out + i, v, nt);
             am = amax4(am, v);
         }
     }
@@ -402,6 +402,7 @@ struct BnBwdArgs {
     int B, H, W, CQ;
     long long total4;  // B*H*W*CQ
     FastDiv fdW, fdH;
+    int nt;            // non-temporal streaming accesses (tensors beyond the Infinity Cache: split_common.h)
 };
 
 // masked effective gradient and xhat for element i (channel quad cq)
@@ -417,9 +418,9 @@ __device__ __forceinline__ void bn_bwd_elem(const BnBwdArgs& a, long long i, int
         g = a.g_fmt == 2 ? bf16_load4(reinterpret_cast<const uint2*>(a.g), src) : a.g[src];
         g.x *= 0.25f; g.y *= 0.25f; g.z *= 0.25f; g.w *= 0.25f;
     } else {
-        g = a.g_fmt == 2 ? bf16_load4(reinterpret_cast<const uint2*>(a.g), i) : a.g[i];
+        g = a.g_fmt == 2 ? bf16_load4(reinterpret_cast<const uint2*>(a.g), i) : ld_stream4(a.g + i, a.nt);
     }
-    const float4 yv = a.y_fmt == 2 ? bf16_load4(reinterpret_cast<const uint2*>(a.y), i) : a.y[i];
+    const float4 yv = a.y_fmt == 2 ? bf16_load4(reinterpret_cast<const uint2*>(a.y), i) : ld_stream4(a.y + i, a.nt);
     const float4 mu = a.mean[cq], is = a.invstd[cq];
     xh = make_float4((yv.x - mu.x) * is.x, (yv.y - mu.y) * is.y, (yv.z - mu.z) * is.z, (yv.w - mu.w) * is.w);
     if (a.mask_mode == 1) {
@@ -577,19 +578,25 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a, const fl
         o.z = sc.z * (gm.z - db.z * invM - xh.z * dg.z * invM);
         o.w = sc.w * (gm.w - db.w * invM - xh.w * dg.w * invM);
         if (OFMT == 1) {
-            p16_store4(reinterpret_cast<uint2*>(dy), i, a.CQ, o, oscale);
+            p16_store4(reinterpret_cast<uint2*>(dy), i, a.CQ, o, oscale, a.nt);
         } else if (OFMT == 2) {
             bf16_store4(reinterpret_cast<uint2*>(dy), i, o);
         } else {
-            dy[i] = o;
+            st_stream4(dy + i, o, a.nt);
             am = amax4(am, o);
         }
         if (dres != nullptr) {
             if (a.g_fmt == 2) bf16_store4(reinterpret_cast<uint2*>(dres), i, gm);  // (a masked bf16 value: exact)
-            else dres[i] = gm;
+            else st_stream4(dres + i, gm, a.nt);
         }
     }
     if (OFMT == 0 && amax != nullptr) amax_commit(am, amax);
+}
+
+// non-temporal accesses for this launch?  (bytes of ONE fp32-sized tensor of the pass; TRID_BN_NT=0 / 1 forces it off / on)
+static int stream_nt(long long tensor_bytes) {
+    static const int env = getenv("TRID_BN_NT") ? atoi(getenv("TRID_BN_NT")) : -1;
+    return env >= 0 ? (env != 0) : (tensor_bytes >= STREAM_NT_MIN_BYTES);
 }
 
 static int bn_bwd_grid(long long total4, int CQ) {
@@ -676,7 +683,7 @@ extern "C" int trid_bn_apply_f32(const float* y, const float* scale, const float
                        (const float4*)y, (const float4*)scale, (const float4*)shift, (const float4*)res,
                        (const float4*)rscale, (const float4*)rshift, (float4*)out, total4, C / 4, relu,
                        (unsigned long long*)relu_mask, amax, (const float*)nullptr, (const float*)nullptr, (float*)nullptr,
-                       (const float*)nullptr, 0);
+                       (const float*)nullptr, 0, stream_nt(total4 * 16));
     return check_launch("trid_bn_apply_f32");
 }
 
@@ -697,7 +704,7 @@ extern "C" int trid_bn_apply_p16_f32(const void* y, int y_fmt, const float* scal
     hipLaunchKernelGGL((bn_apply_kernel<OF, RF>), grid, dim3(256), 0, (hipStream_t)stream, (const float4*)y,              \
                        (const float4*)scale, (const float4*)shift, (const float4*)res, (const float4*)rscale,              \
                        (const float4*)rshift, (float4*)out, total4, C / 4, relu, (unsigned long long*)relu_mask,           \
-                       (float*)nullptr, bound_a, bound_b, bound_sum, res_amax, y_fmt)
+                       (float*)nullptr, bound_a, bound_b, bound_sum, res_amax, y_fmt, stream_nt(total4 * 16))
     if (fmt == 1) {
         if (res_fmt == 1) TRID_BN_APPLY_P16(1, 1); else TRID_BN_APPLY_P16(1, 0);
     } else {
@@ -780,6 +787,7 @@ static int bn_bwd_fill(BnBwdArgs& a, const float* g, const float* y, const float
     a.total4 = (long long)B * H * W * CQ;
     a.fdW = make_fastdiv((uint32_t)W);
     a.fdH = make_fastdiv((uint32_t)H);
+    a.nt = stream_nt(a.total4 * 16);
     return TRID_OK;
 }
 

@@ -34,9 +34,16 @@ __device__ __forceinline__ void lds_barrier() {
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 }
-__device__ __forceinline__ void dma16(const __amdgpu_buffer_rsrc_t& rs, void* lds_base, unsigned voffset) {
+// (nt: the activation tile is read once by one workgroup and the output written once - non-temporal for tensors far beyond
+// the Infinity Cache, split_common.h STREAM_NT_MIN_BYTES)
+__device__ __forceinline__ void dma16(const __amdgpu_buffer_rsrc_t& rs, void* lds_base, unsigned voffset, bool nt) {
     typedef __attribute__((address_space(3))) void* lds_ptr;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)lds_base, 16, voffset, 0, 0, 0);
+    if (nt) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)lds_base, 16, voffset, 0, 0, 2);
+    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)lds_base, 16, voffset, 0, 0, 0);
+}
+__device__ __forceinline__ void store_c(unsigned v, const __amdgpu_buffer_rsrc_t& rs, unsigned off, bool nt) {
+    if (nt) __builtin_amdgcn_raw_buffer_store_b32(v, rs, off, 0, 2);
+    else __builtin_amdgcn_raw_buffer_store_b32(v, rs, off, 0, 0);
 }
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
@@ -59,6 +66,7 @@ struct StreamParams {
     int panels;      // column panels of CW * 32 columns
     int workers;     // persistent workgroups per panel
     int tiles;       // ceil(M / RB)
+    int nt_a, nt_c;  // non-temporal activation loads / output stores
 };
 
 }  // namespace
@@ -126,7 +134,7 @@ __global__ __launch_bounds__(512, 2) void gemm_p16_stream_kernel(StreamParams p)
         for (int d = 0; d < DPW; ++d) {
             const int r = (d * NW + wave) * RPC + lr;
             const bool ok = (long long)tile * RB + r < p.M;
-            dma16(rsA, dst + (d * NW + wave) * 1024, ok ? (unsigned)(base + r * ROWB + ((j ^ (r & 15)) << 4)) : OOB);
+            dma16(rsA, dst + (d * NW + wave) * 1024, ok ? (unsigned)(base + r * ROWB + ((j ^ (r & 15)) << 4)) : OOB, p.nt_a != 0);
         }
     };
 
@@ -299,7 +307,7 @@ __global__ __launch_bounds__(512, 2) void gemm_p16_stream_kernel(StreamParams p)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float v = acc[i][r];
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsC, base + (unsigned)(i * 32 + (r & 3) + 8 * (r >> 2)) * ldcb, 0, 0);
+                    store_c(__float_as_uint(v), rsC, base + (unsigned)(i * 32 + (r & 3) + 8 * (r >> 2)) * ldcb, p.nt_c != 0);
                 }
         }
         first = false;
@@ -396,6 +404,12 @@ extern "C" int trid_gemm_p16_stream(const void* A, const float* a_amax, const vo
     p.A = (const char*)A; p.B = (const char*)B; p.C = C; p.stats = stats;
     p.a_amax = a_amax; p.b_amax = b_amax;
     p.M = M; p.N = N; p.ldc = ldc; p.accumulate = accumulate;
+    static const int nt_env = getenv("TRID_STREAM_NT") ? atoi(getenv("TRID_STREAM_NT")) : -1;
+    // measured per shape (tools/exp/nt_ab2.sh, profiles/r04i_stream_nontemporal.txt): non-temporal OUTPUT stores pay for outputs
+    // beyond the Infinity Cache (layer1 conv3: 103.6 -> 81.9 us = 6.1 TB/s); non-temporal activation loads only beside the
+    // read-modify-write of a large C (the accumulate forms: 181 -> 171 us), elsewhere they cost 5-15 %
+    p.nt_a = nt_env >= 0 ? (nt_env & 1) : (accumulate && (long long)M * N * 4 >= 2 * STREAM_NT_MIN_BYTES);
+    p.nt_c = nt_env >= 0 ? ((nt_env >> 1) & 1) : ((long long)M * N * 4 >= STREAM_NT_MIN_BYTES && !accumulate);
     hipStream_t s = (hipStream_t)stream;
     if (K == 64) return pick_stream<64>(p, s);
     if (K == 128) return pick_stream<128>(p, s);

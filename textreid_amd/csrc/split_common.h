@@ -151,15 +151,41 @@ __device__ __forceinline__ void split_store_wide_f16(const float4 (&w)[4], float
 // x * 2^s.  These kernels work on channel QUADS (float4): quad cq of a row lives at 8-byte unit
 // row * (C/2) + (cq / 8) * 16 + (cq % 8) (high parts) and 8 units further (low parts): a wave writes whole
 // 64-byte plane halves, fully coalesced.
-__device__ __forceinline__ void p16_store4(uint2* __restrict__ base, long long i, int CQ, float4 v, float scale) {
+// Streaming accesses of the HBM-bound passes: `nt` (uniform per launch) selects non-temporal loads / stores.  Measured on
+// the BatchNorm passes (tools/exp/nt_ab.sh, profiles/r04i_bn_nontemporal.txt): tensors of >= 200 MB - read once and written
+// once per pass, far beyond what the 256 MB Infinity Cache can hand to the next kernel - gain 8-14 % (5.2-5.4 -> 5.9-6.6
+// TB/s); tensors of <= 100 MB LOSE 5-12 % (their consumer finds part of them on chip).  The launchers set it by size.
+typedef float nt_v4f __attribute__((ext_vector_type(4)));
+constexpr long long STREAM_NT_MIN_BYTES = 128ll << 20;
+__device__ __forceinline__ float4 ld_stream4(const float4* p, bool nt) {
+    if (nt) {
+        const nt_v4f v = __builtin_nontemporal_load(reinterpret_cast<const nt_v4f*>(p));
+        return make_float4(v.x, v.y, v.z, v.w);
+    }
+    return *p;
+}
+__device__ __forceinline__ void st_stream4(float4* p, float4 v, bool nt) {
+    if (nt) {
+        const nt_v4f r = {v.x, v.y, v.z, v.w};
+        __builtin_nontemporal_store(r, reinterpret_cast<nt_v4f*>(p));
+    } else {
+        *p = v;
+    }
+}
+__device__ __forceinline__ void st_stream2(uint2* p, uint2 v, bool nt) {
+    if (nt) __builtin_nontemporal_store(((unsigned long long)v.y << 32) | v.x, reinterpret_cast<unsigned long long*>(p));
+    else *p = v;
+}
+
+__device__ __forceinline__ void p16_store4(uint2* __restrict__ base, long long i, int CQ, float4 v, float scale, bool nt = false) {
     const long long row = i / CQ;
     const int cq = (int)(i - row * CQ);
     unsigned h0, l0, h1, l1;
     f16_split2(v.x * scale, v.y * scale, h0, l0);
     f16_split2(v.z * scale, v.w * scale, h1, l1);
     uint2* dst = base + row * (2 * CQ) + (cq >> 3) * 16 + (cq & 7);
-    dst[0] = make_uint2(h0, h1);
-    dst[8] = make_uint2(l0, l1);
+    st_stream2(dst, make_uint2(h0, h1), nt);
+    st_stream2(dst + 8, make_uint2(l0, l1), nt);
 }
 __device__ __forceinline__ float4 p16_load4(const uint2* __restrict__ base, long long i, int CQ, float inv) {
     const long long row = i / CQ;

@@ -36,9 +36,10 @@ __device__ __forceinline__ void lds_barrier() {
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 }
-__device__ __forceinline__ void dma16(const __amdgpu_buffer_rsrc_t& rs, void* lds_base, unsigned voffset) {
+__device__ __forceinline__ void dma16(const __amdgpu_buffer_rsrc_t& rs, void* lds_base, unsigned voffset, bool nt) {
     typedef __attribute__((address_space(3))) void* lds_ptr;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)lds_base, 16, voffset, 0, 0, 0);
+    if (nt) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)lds_base, 16, voffset, 0, 0, 2);
+    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)lds_base, 16, voffset, 0, 0, 0);
 }
 
 // LDS stores the compiler does not see: beside an LDS-DMA in flight hipcc orders every ds_write behind `s_waitcnt vmcnt(0)`
@@ -69,6 +70,7 @@ struct HaloParams {
     int chunks_per_image;
     int nchunks;
     FastDiv fdW;
+    int nt;               // non-temporal image loads / output stores (tensors far beyond the Infinity Cache)
 };
 
 // 16-byte unit u of pixel slot q is stored at unit u ^ swz(q) of that pixel's LDS line(s): the 16-lane groups of a
@@ -146,7 +148,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_p16_kernel(HaloParams p) 
             const int x = q - 1;
             const bool ok = (y >= 0) && (y < H) && (x >= 0) && (x < W);
             const unsigned vo = ok ? (unsigned)((((size_t)b * H + y) * W + x) * PIXB + u * 16) : OOB;
-            dma16(rsX, ring + (size_t)slot * rowb + c * 1024, vo);
+            dma16(rsX, ring + (size_t)slot * rowb + c * 1024, vo, p.nt != 0);
         }
     };
 
@@ -264,7 +266,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_p16_kernel(HaloParams p) 
                 for (int r = 0; r < 16; ++r) {
                     const unsigned off = (unsigned)((m0 + (r & 3) + 8 * (r >> 2)) * (COUT * 4)) + col;
                     const float v = acc[r];  // (a bit_cast of the vector ELEMENT itself stores element 0 sixteen times)
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsY, off, 0, 0);
+                    if (p.nt) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsY, off, 0, 2);
+                    else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsY, off, 0, 0);
                 }
             }
             y0 += TH;
@@ -482,6 +485,8 @@ extern "C" int trid_conv3x3_halo_p16(const void* x, const float* x_amax, const v
     p.rg_per_chunk = rg / cpi;
     p.nchunks = B * cpi;
     p.fdW = make_fastdiv((uint32_t)W);
+    static const int nt_env = getenv("TRID_STREAM_NT") ? atoi(getenv("TRID_STREAM_NT")) : -1;
+    p.nt = nt_env >= 0 ? (nt_env != 0) : ((long long)B * H * W * std::min(Cin, Cout) * 4 >= STREAM_NT_MIN_BYTES);
     hipStream_t s = (hipStream_t)stream;
     if (Cin == 32 && Cout == 32) return launch_halo<32, 32>(p, s);
     if (Cin == 32 && Cout == 64) return launch_halo<32, 64>(p, s);
