@@ -483,7 +483,7 @@ def main():
     split = ops.GEMM_PRECISION in (1, 3, 6)
     dom = (ops.A_CONV, ops.B_KC, 128, 128, split)
     dom2 = (ops.A_KC, ops.B_KC, 128, 128, split)  # 1x1 convs / linears: the largest TOTAL time of any kernel
-    labels = {dom: "conv3x3", dom2: "gemm1x1"}
+    labels = {dom: "conv3x3", dom2: "gemm1x1", "stream1x1": "stream1x1"}  # (the streaming short-K kernel: HBM-bound, events carry bytes)
     if runner is None:  # eager steps: events bracket every launch of the two kernels inside the timed region
         ops.PROFILE = {"match": labels.get, "events": []}
     reducer.reset_stats()
@@ -530,6 +530,7 @@ def main():
     flops, ms, nlaunch = live("conv3x3")
     achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
     flops2, ms2, nlaunch2 = live("gemm1x1")
+    bytes3, ms3, nlaunch3 = live("stream1x1")
     dp_stats = reducer.stats() if world > 1 else None
 
     # the same kernel alone on the GPU (no side-stream work sharing the CUs): the 3x3 layers of layer2-4
@@ -640,7 +641,7 @@ def main():
     # second roofline object: the 1x1-conv / linear kernel <A_KC,B_KC> has the largest TOTAL time per step
     roofline_1x1 = {
         "bound": "mfma",
-        "kernel": (kname.split(" (")[0].replace("A_CONV", "A_KC")) + " (1x1 convs fwd + dgrad; K = 64..2048: the short-K layers are HBM-bound)",
+        "kernel": (kname.split(" (")[0].replace("A_CONV", "A_KC")) + " (1x1 convs fwd + dgrad with K >= 512 - layer3 / layer4 - and the 256 -> 64 / 128 ones; the short-K layers run on the streaming kernel, roofline_stream)",
         "achieved": flops2 / (ms2 * 1e-3) / 1e12 if ms2 > 0 else 0.0,
         "peak": peak,
         "unit": "TFLOP/s",
@@ -650,6 +651,26 @@ def main():
         "avg_launch_ms": ms2 / max(nlaunch2, 1),
         "algorithmic_gflop_per_launch": flops2 / max(nlaunch2, 1) / 1e9,
         "note": "live events around every launch of this kernel " + ("in the %d eager re-runs of the step right after the timed region" % profiled_eager if profiled_eager else "during the timed steps") + " (all streams running)",
+    }
+    # the two MFMA-bound tile kernels as equals, the one with the larger total per step first; and the HBM-bound streaming kernel
+    nrun = max(profiled_eager, 1) if runner is not None else args.steps
+    roofline["total_ms_per_step"] = ms / nrun
+    roofline_1x1["total_ms_per_step"] = ms2 / nrun
+    if roofline_1x1["total_ms_per_step"] > roofline["total_ms_per_step"]:
+        roofline, roofline_1x1 = roofline_1x1, roofline
+    roofline_stream = {
+        "bound": "hbm",
+        "kernel": "trid::gemm_p16_stream_kernel<K,CW,TM,ACC> (short-K 1x1 convolutions of layer1-3 and the data gradients of conv1, K = 64 / 128 / 256: filter panel in registers, activation tiles by LDS-DMA, BatchNorm partials in registers, persistent workgroups)",
+        "achieved": (bytes3 / (ms3 * 1e-3) / 1e9) if ms3 > 0 else 0.0,
+        "peak": 8000.0,
+        "unit": "GB/s",
+        "frac": (bytes3 / (ms3 * 1e-3) / 1e9 / 8000.0) if ms3 > 0 else 0.0,
+        "traffic": None,
+        "launches": nlaunch3,
+        "avg_launch_ms": ms3 / max(nlaunch3, 1),
+        "algorithmic_MB_per_launch": bytes3 / max(nlaunch3, 1) / 1e6,
+        "total_ms_per_step": ms3 / nrun,
+        "note": "algorithmic bytes = activations once + output once (read and written when accumulating) + filter, over live event time, all streams running; HBM peak 8 TB/s (a float4 copy reaches 6.29: MI355X_MICROARCH.md)",
     }
     retr = None
     if not args.no_retrieval:
@@ -694,7 +715,8 @@ def main():
                 "final_loss": loss_val,
             },
             "roofline": roofline,
-            "roofline_1x1": roofline_1x1,
+            "roofline_second": roofline_1x1,
+            "roofline_stream": roofline_stream,
         }
         if world > 1:
             # data-parallel accounting of the timed steps: one RCCL rank per GPU, gradient bytes all-reduced per step,

@@ -314,6 +314,15 @@ def gemm_p16_stream_rows(M, N, K, accumulate=False):
 
 def gemm_p16_stream(A, B, C, M, N, K, ldc, accumulate=False, stats=None):
     """C[M,N] (+)= A . B^T on the streaming kernel (A P16 [M][K], B P16 [N][K], K in {64, 128, 256})."""
+    prof = PROFILE
+    if prof is not None and prof["match"]("stream1x1"):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        call("trid_gemm_p16_stream", _p(A.data), _p(A.amax), _p(B.data), _p(B.amax), _p(C), ldc, _p(stats), M, N, K, 1 if accumulate else 0, stream())
+        e1.record()
+        # (events carry ALGORITHMIC BYTES for this HBM-bound kernel: A once, C once - twice when accumulating -, the filter)
+        prof["events"].append(("stream1x1", 4.0 * (M * K + M * N * (2 if accumulate else 1) + N * K), e0, e1))
+        return
     call("trid_gemm_p16_stream", _p(A.data), _p(A.amax), _p(B.data), _p(B.amax), _p(C), ldc, _p(stats), M, N, K, 1 if accumulate else 0, stream())
 
 

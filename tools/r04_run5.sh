@@ -15,6 +15,6 @@ python - <<'PY'
 import json
 for f in ("bench1_stream1","bench1_stream0","bench2_stream1","bench2_stream0"):
     try:
-        d=json.load(open("gpurun_out/r04e/%s.json"%f)); print(f, "ms_per_step %.2f"%d["ms_per_step"], "1x1 frac %.3f"%d["roofline_1x1"]["frac"], "avg1x1 ms %.4f"%d["roofline_1x1"]["avg_launch_ms"])
+        d=json.load(open("gpurun_out/r04e/%s.json"%f)); print(f, "ms_per_step %.2f"%d["ms_per_step"], "1x1 frac %.3f"%d["roofline_second"]["frac"], "avg1x1 ms %.4f"%d["roofline_second"]["avg_launch_ms"])
     except Exception as e: print(f, "failed", e)
 PY
