@@ -99,7 +99,7 @@ def _bn_coeffs(bn, partials, M, training, counters=None):
 
 
 import os as _os
-_SERIAL_WGRAD = _os.environ.get("TRID_SERIAL_WGRAD", "0") == "1"  # experiment: weight gradients on the main stream
+_SERIAL_WGRAD = "1" in (_os.environ.get("TRID_SERIAL_WGRAD", "0"), _os.environ.get("TRID_SERIAL", "0"))  # experiment: weight gradients on the main stream
 
 
 class _WgradStream:

@@ -58,19 +58,22 @@ __global__ void stem_im2col_kernel(const float* __restrict__ img, float* __restr
 }
 
 // ---------------------------------------------------------------- BN finalize
-// The per-tile (n_b, mean_b, M2_b) partials of a channel are merged pairwise with Chan's formula in fp64,
-//     n = na + nb,  d = mean_b - mean_a,  mean = mean_a + d nb / n,  M2 = M2_a + M2_b + d^2 na nb / n,
-// which only ever subtracts MEANS (an E[x^2] - mean^2 form would amplify the fp32 rounding of the partial means by
-// (mean / std)^2).  pw: floats per (part, channel): 2 = (mean, M2), 4 = (mean, M2, min, max).  With the extremes the
-// largest magnitude of act(y * scale + shift) over the channel is known exactly before the apply pass (an affine map
+// The per-tile (n_b, mean_b, M2_b) partials of a channel (n_b = rows_per_part, the last part ragged) are combined as
+//     mean = K + S1 / n,   M2 = sum_b M2_b + S2 - S1^2 / n,   S1 = sum_b n_b (mean_b - K),  S2 = sum_b n_b (mean_b - K)^2
+// in fp64 with the shift K = the channel's mean over part 0: only MEANS are ever subtracted and the shifted sums are of the
+// size of the spread of the partial means (an unshifted E[x^2] - mean^2 form would amplify the fp32 rounding of the
+// partial means by (mean / std)^2: test_bn_finalize_large_mean_offset) - and the sums are plain additions: no division
+// per part, any grouping.  pw: floats per (part, channel): 2 = (mean, M2), 4 = (mean, M2, min, max).  With the extremes
+// the largest magnitude of act(y * scale + shift) over the channel is known exactly before the apply pass (an affine map
 // takes extremes to extremes): folded over the channels into amax_out (zeroed by the caller; integer atomicMax on the
 // bit pattern of a non-negative float: order-independent).
-//   * up to ~1000 parts: one workgroup per channel (CH = 1), one launch.
-//   * the layers with thousands of parts (stem, layer1: M = 4e5..1.6e6 rows): a workgroup owns a channel OCTET (CH = 8:
-//     with 2 / 4 floats per (part, channel) a contiguous 64 / 128 bytes of every part - whole lines) and one of S ranges
-//     of the parts; the range results go to `scratch` and a second small launch merges them in range order.  (A single
-//     launch with a last-arriver ticket was measured SLOWER: its device-scope release / acquire fences write back and
-//     invalidate the whole L2 of an XCD under the GEMMs running beside it.)
+// A workgroup owns FIN_CH = 16 adjacent channels (a contiguous 128 / 256 bytes of every part) and one of S ranges of the
+// parts; its 256 threads are 16 channels x 16 part slots, each with a handful of independent loads in flight.
+//   * up to FIN_ONE_LAUNCH parts: S = 1, the workgroup finalizes its channels itself.
+//   * the layers with thousands of parts (stem, layer1: M = 4e5..1.6e6 rows): the range sums go to `scratch` and a second
+//     small launch (same thread layout over the S ranges) adds them in range order.  (A single launch with a
+//     last-arriver ticket was measured SLOWER: its device-scope release / acquire fences write back and invalidate the
+//     whole L2 of an XCD under the GEMMs running beside it.)
 struct BnFinalizeOut {
     const float* gamma;
     const float* beta;
@@ -85,22 +88,18 @@ struct BnFinalizeOut {
     float* amax_out;  // null: no bound
 };
 
-struct Moments {
-    double n, mean, m2;
+struct FinSums {  // shifted sums of a channel over some of its parts
+    double s1, s2, q;
+    float lo, hi;
 };
-__device__ __forceinline__ void chan_merge(Moments& a, double nb, double mb, double qb) {
-    const double nt = a.n + nb;
-    if (nt > 0.0) {
-        const double d = mb - a.mean;
-        a.mean += d * (nb / nt);
-        a.m2 += qb + d * d * (a.n * nb / nt);
-        a.n = nt;
-    }
-}
 
-__device__ __forceinline__ void bn_finalize_channel(const BnFinalizeOut& f, int c, const Moments& m, float lo, float hi) {
-    const double nt = m.n, mu = m.mean;
-    const double var = m.m2 / nt;
+constexpr int FIN_CH = 16, FIN_SLOTS = 256 / FIN_CH;
+
+__device__ __forceinline__ void bn_finalize_channel(const BnFinalizeOut& f, int c, double nt, double K, const FinSums& t) {
+    const double mu = K + t.s1 / nt;
+    double m2 = t.q + t.s2 - t.s1 * t.s1 / nt;
+    if (m2 < 0.0) m2 = 0.0;
+    const double var = m2 / nt;
     const float invstd = (float)(1.0 / sqrt(var + (double)f.eps));
     const float sc = f.gamma[c] * invstd;
     const float shf = f.beta[c] - (float)mu * sc;
@@ -109,113 +108,135 @@ __device__ __forceinline__ void bn_finalize_channel(const BnFinalizeOut& f, int 
     f.scale[c] = sc;
     f.shift[c] = shf;
     if (f.amax_out != nullptr) {
-        const float zl = fmaf(lo, sc, shf), zh = fmaf(hi, sc, shf);  // the apply pass's own arithmetic
+        const float zl = fmaf(t.lo, sc, shf), zh = fmaf(t.hi, sc, shf);  // the apply pass's own arithmetic
         const float bound = f.relu ? fmaxf(fmaxf(zl, zh), 0.f) : fmaxf(fabsf(zl), fabsf(zh));
         atomicMax(reinterpret_cast<unsigned*>(f.amax_out), __builtin_bit_cast(unsigned, bound));
     }
     if (f.running_mean != nullptr) {
-        const double unb = nt > 1.0 ? m.m2 / (nt - 1.0) : var;
+        const double unb = nt > 1.0 ? m2 / (nt - 1.0) : var;
         f.running_mean[c] = (1.f - f.momentum) * f.running_mean[c] + f.momentum * (float)mu;
         f.running_var[c] = (1.f - f.momentum) * f.running_var[c] + f.momentum * (float)unb;
     }
 }
 
-// grid: ceil(C / CH) * S workgroups; S == 1: finalizes; S > 1: range results to scratch [C groups][S][CH][4] doubles
-// (n, mean, M2, the (min, max) pair packed into the fourth)
-template <int CH>
+// the 16 slots of a channel -> thread (slot 0, channel): fixed order, so the result does not depend on the schedule
+__device__ __forceinline__ FinSums fin_fold_slots(FinSums t, double (*sd)[256], float (*sf)[256]) {
+    const int tid = threadIdx.x;
+    sd[0][tid] = t.s1; sd[1][tid] = t.s2; sd[2][tid] = t.q;
+    sf[0][tid] = t.lo; sf[1][tid] = t.hi;
+    __syncthreads();
+    if (tid < FIN_CH) {
+#pragma unroll
+        for (int k = 1; k < FIN_SLOTS; ++k) {
+            const int j = tid + k * FIN_CH;
+            t.s1 += sd[0][j]; t.s2 += sd[1][j]; t.q += sd[2][j];
+            t.lo = fminf(t.lo, sf[0][j]); t.hi = fmaxf(t.hi, sf[1][j]);
+        }
+    }
+    return t;
+}
+
+// grid: ceil(C / 16) * S workgroups; S == 1: finalizes; S > 1: range sums to scratch [C groups][S][16]
+template <int PW>
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partials, int nparts, int rows_per_part,
-                                                          long long M, int C, int pw, int S, double* __restrict__ scratch,
+                                                          long long M, int C, int S, FinSums* __restrict__ scratch,
                                                           BnFinalizeOut f) {
-    __shared__ double sn[4][CH], sm[4][CH], sq[4][CH];
-    __shared__ float slo[4][CH], shi[4][CH];
-    const int O = (C + CH - 1) / CH;
-    const int o = blockIdx.x % O, r = blockIdx.x / O;
-    const int tid = threadIdx.x, cl = tid % CH, sl = tid / CH;
-    const int c = o * CH + cl;
+    __shared__ double sd[3][256];
+    __shared__ float sf[2][256];
+    const int G = (C + FIN_CH - 1) / FIN_CH;
+    const int o = blockIdx.x % G, r = blockIdx.x / G;
+    const int tid = threadIdx.x, cl = tid % FIN_CH, slot = tid / FIN_CH;
+    const int c = o * FIN_CH + cl;
     const int per = (nparts + S - 1) / S;
     const int begin = r * per, end = min(nparts, begin + per);
-    Moments m{0.0, 0.0, 0.0};
-    float lo = INFINITY, hi = -INFINITY;
+    FinSums t{0.0, 0.0, 0.0, INFINITY, -INFINITY};
+    double K = 0.0;
     if (c < C) {
-        for (int p = begin + sl; p < end; p += 256 / CH) {
-            const long long rows_left = M - (long long)p * rows_per_part;
-            const double nb = (double)(rows_left < rows_per_part ? rows_left : rows_per_part);
-            const float* e = partials + ((long long)p * C + c) * pw;
-            if (pw == 4) {
-                const float4 v = *reinterpret_cast<const float4*>(e);
-                chan_merge(m, nb, (double)v.x, (double)v.y);
-                lo = fminf(lo, v.z);
-                hi = fmaxf(hi, v.w);
-            } else {
-                const float2 v = *reinterpret_cast<const float2*>(e);
-                chan_merge(m, nb, (double)v.x, (double)v.y);
+        K = (double)partials[(long long)c * PW];
+        const double n_full = (double)rows_per_part, n_last = (double)(M - (long long)(nparts - 1) * rows_per_part);
+        constexpr int U = 4;  // independent loads in flight per thread
+        for (int p0 = begin + slot; p0 < end; p0 += U * FIN_SLOTS) {
+            float4 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int p = p0 + u * FIN_SLOTS;
+                if (p < end) {
+                    const float* e = partials + ((long long)p * C + c) * PW;
+                    if (PW == 4) {
+                        v[u] = *reinterpret_cast<const float4*>(e);
+                    } else {
+                        const float2 w = *reinterpret_cast<const float2*>(e);
+                        v[u] = make_float4(w.x, w.y, 0.f, 0.f);
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int p = p0 + u * FIN_SLOTS;
+                if (p < end) {
+                    const double nb = p == nparts - 1 ? n_last : n_full;
+                    const double d = (double)v[u].x - K;
+                    const double nd = nb * d;
+                    t.s1 += nd;
+                    t.s2 = fma(nd, d, t.s2);
+                    t.q += (double)v[u].y;
+                    if (PW == 4) {
+                        t.lo = fminf(t.lo, v[u].z);
+                        t.hi = fmaxf(t.hi, v[u].w);
+                    }
+                }
             }
         }
     }
-#pragma unroll
-    for (int x = CH; x < 64; x <<= 1) {  // the lanes of a wave that hold the same channel
-        chan_merge(m, __shfl_xor(m.n, x, 64), __shfl_xor(m.mean, x, 64), __shfl_xor(m.m2, x, 64));
-        lo = fminf(lo, __shfl_xor(lo, x, 64));
-        hi = fmaxf(hi, __shfl_xor(hi, x, 64));
-    }
-    if ((tid & 63) < CH) {
-        sn[tid >> 6][cl] = m.n; sm[tid >> 6][cl] = m.mean; sq[tid >> 6][cl] = m.m2;
-        slo[tid >> 6][cl] = lo; shi[tid >> 6][cl] = hi;
-    }
-    __syncthreads();
-    if (tid < CH && c < C) {
-        m = Moments{sn[0][tid], sm[0][tid], sq[0][tid]};
-        lo = slo[0][tid]; hi = shi[0][tid];
-#pragma unroll
-        for (int w = 1; w < 4; ++w) {
-            chan_merge(m, sn[w][tid], sm[w][tid], sq[w][tid]);
-            lo = fminf(lo, slo[w][tid]);
-            hi = fmaxf(hi, shi[w][tid]);
-        }
-        if (S == 1) {
-            bn_finalize_channel(f, c, m, lo, hi);
-        } else {
-            double* d = scratch + (((long long)o * S + r) * CH + tid) * 4;
-            d[0] = m.n; d[1] = m.mean; d[2] = m.m2;
-            d[3] = __hiloint2double(__float_as_int(hi), __float_as_int(lo));
-        }
+    t = fin_fold_slots(t, sd, sf);
+    if (tid < FIN_CH && c < C) {
+        if (S == 1) bn_finalize_channel(f, c, (double)M, K, t);
+        else scratch[((long long)o * S + r) * FIN_CH + tid] = t;
     }
 }
 
-template <int CH>
-__global__ __launch_bounds__(64) void bn_finalize_merge_kernel(const double* __restrict__ scratch, int S, int C, BnFinalizeOut f) {
-    const int c = blockIdx.x * 64 + threadIdx.x;
-    if (c >= C) return;
-    const int o = c / CH, cl = c % CH;
-    Moments m{0.0, 0.0, 0.0};
-    float lo = INFINITY, hi = -INFINITY;
-    for (int r = 0; r < S; ++r) {
-        const double* d = scratch + (((long long)o * S + r) * CH + cl) * 4;
-        chan_merge(m, d[0], d[1], d[2]);
-        lo = fminf(lo, __int_as_float(__double2loint(d[3])));
-        hi = fmaxf(hi, __int_as_float(__double2hiint(d[3])));
+// grid: ceil(C / 16) workgroups: the S range sums of its 16 channels, added in range order
+template <int PW>
+__global__ __launch_bounds__(256) void bn_finalize_merge_kernel(const float* __restrict__ partials, long long M, int C, int S,
+                                                                const FinSums* __restrict__ scratch, BnFinalizeOut f) {
+    __shared__ double sd[3][256];
+    __shared__ float sf[2][256];
+    const int o = blockIdx.x, tid = threadIdx.x, cl = tid % FIN_CH, slot = tid / FIN_CH;
+    const int c = o * FIN_CH + cl;
+    FinSums t{0.0, 0.0, 0.0, INFINITY, -INFINITY};
+    if (c < C) {
+        for (int r = slot; r < S; r += FIN_SLOTS) {
+            const FinSums e = scratch[((long long)o * S + r) * FIN_CH + cl];
+            t.s1 += e.s1; t.s2 += e.s2; t.q += e.q;
+            t.lo = fminf(t.lo, e.lo); t.hi = fmaxf(t.hi, e.hi);
+        }
     }
-    bn_finalize_channel(f, c, m, lo, hi);
+    t = fin_fold_slots(t, sd, sf);
+    if (tid < FIN_CH && c < C) bn_finalize_channel(f, c, (double)M, (double)partials[(long long)c * PW], t);
 }
 
-constexpr int FIN_MAX_WG = 1024;  // octets x ranges of the two-launch form
-constexpr size_t FIN_WS_BYTES = (size_t)FIN_MAX_WG * 8 * 4 * sizeof(double);
+constexpr int FIN_ONE_LAUNCH = 768;  // parts up to which one workgroup per 16 channels sweeps them all (<= 48 per thread)
+constexpr int FIN_MAX_RANGES = 64;
+constexpr int FIN_MAX_WG = 2048;  // channel groups x ranges of the two-launch form
+constexpr size_t FIN_WS_BYTES = (size_t)FIN_MAX_WG * FIN_CH * sizeof(FinSums);
 
-static int bn_finalize_launch(const float* partials, int nparts, int rows_per_part, long long M, int C, int pw, void* ws,
+template <int PW>
+static int bn_finalize_launch(const float* partials, int nparts, int rows_per_part, long long M, int C, void* ws,
                               const BnFinalizeOut& f, hipStream_t stream) {
-    const int O = (C + 7) / 8;
-    if (ws != nullptr && nparts >= 1024 && O <= FIN_MAX_WG / 2) {
-        int S = nparts / 64;  // >= 2 sweep steps of 32 parts per workgroup
-        if (S > 32) S = 32;
-        if (S > FIN_MAX_WG / O) S = FIN_MAX_WG / O;
-        double* scratch = reinterpret_cast<double*>(ws);
-        hipLaunchKernelGGL(bn_finalize_kernel<8>, dim3(O * S), dim3(256), 0, stream, partials, nparts, rows_per_part, M, C, pw, S,
+    const int G = (C + FIN_CH - 1) / FIN_CH;
+    if (ws != nullptr && nparts > FIN_ONE_LAUNCH && 2 * G <= FIN_MAX_WG) {
+        int S = (nparts + 12 * FIN_SLOTS - 1) / (12 * FIN_SLOTS);  // ~12 parts per thread
+        if (S > FIN_MAX_RANGES) S = FIN_MAX_RANGES;
+        if (S > FIN_MAX_WG / G) S = FIN_MAX_WG / G;
+        FinSums* scratch = reinterpret_cast<FinSums*>(ws);
+        hipLaunchKernelGGL(bn_finalize_kernel<PW>, dim3(G * S), dim3(256), 0, stream, partials, nparts, rows_per_part, M, C, S,
                            scratch, f);
-        hipLaunchKernelGGL(bn_finalize_merge_kernel<8>, dim3((C + 63) / 64), dim3(64), 0, stream, (const double*)scratch, S, C, f);
+        hipLaunchKernelGGL(bn_finalize_merge_kernel<PW>, dim3(G), dim3(256), 0, stream, partials, M, C, S,
+                           (const FinSums*)scratch, f);
         return 0;
     }
-    hipLaunchKernelGGL(bn_finalize_kernel<1>, dim3(C), dim3(256), 0, stream, partials, nparts, rows_per_part, M, C, pw, 1,
-                       (double*)nullptr, f);
+    hipLaunchKernelGGL(bn_finalize_kernel<PW>, dim3(G), dim3(256), 0, stream, partials, nparts, rows_per_part, M, C, 1,
+                       (FinSums*)nullptr, f);
     return 0;
 }
 
@@ -644,7 +665,7 @@ extern "C" int trid_bn_finalize_f32(const float* partials, int nparts, int rows_
                  "trid_bn_finalize_f32: nparts=%d rows_per_part=%d inconsistent with M=%lld", nparts, rows_per_part, M);
     TRID_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "trid_bn_finalize_f32: running stats both or none");
     const BnFinalizeOut f{gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift, 0, nullptr};
-    bn_finalize_launch(partials, nparts, rows_per_part, M, C, 2, ws, f, (hipStream_t)stream);
+    bn_finalize_launch<2>(partials, nparts, rows_per_part, M, C, ws, f, (hipStream_t)stream);
     return check_launch("trid_bn_finalize_f32");
 }
 
@@ -659,7 +680,7 @@ extern "C" int trid_bn_finalize_minmax_f32(const float* partials, int nparts, in
                  "trid_bn_finalize_minmax_f32: nparts=%d rows_per_part=%d inconsistent with M=%lld", nparts, rows_per_part, M);
     TRID_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "trid_bn_finalize_minmax_f32: running stats both or none");
     const BnFinalizeOut f{gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift, relu, amax_out};
-    bn_finalize_launch(partials, nparts, rows_per_part, M, C, 4, ws, f, (hipStream_t)stream);
+    bn_finalize_launch<4>(partials, nparts, rows_per_part, M, C, ws, f, (hipStream_t)stream);
     return check_launch("trid_bn_finalize_minmax_f32");
 }
 

@@ -124,8 +124,28 @@ def last_error():
     return load().trid_last_error_string().decode("utf-8", "replace")
 
 
+# Optional call log (tools/step_calls.py): a list -> every entry-point call appends (name, scalar arguments, start event, end
+# event) on torch's current stream.  None in the product path.
+TRACE = None
+
+
+def _traced(name, args):
+    import torch
+
+    scal = tuple(a for a in args if isinstance(a, (int, float)) and not isinstance(a, bool) and abs(a) < (1 << 32))
+    if name in ("trid_gemm_f32", "trid_gemm_p16", "trid_gemm_p16_wgrad"):
+        d = GemmDesc.from_address(args[0])
+        scal = tuple("%s=%s" % (f, getattr(d, f)) for f in ("a_mode", "b_mode", "M", "N", "K", "batch", "splits", "accumulate", "precision", "H", "W", "Cin") if hasattr(d, f))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    rc = getattr(load(), name)(*args)
+    e1.record()
+    TRACE.append((name, scal, e0, e1))
+    return rc
+
+
 def call(name, *args):
     """Invoke a status-returning entry point; raise RuntimeError on failure."""
-    rc = getattr(load(), name)(*args)
+    rc = getattr(load(), name)(*args) if TRACE is None else _traced(name, args)
     if rc != 0:
         raise RuntimeError("%s failed (rc=%d): %s" % (name, rc, last_error()))
