@@ -87,6 +87,10 @@ typedef struct trid_gemm_desc {
     int32_t c_format;      /* trid_gemm_p16 only: 0 = C is fp32; 2 = C is a plain bf16 tensor (ldc in elements; read as such
                             * with accumulate; BatchNorm partials are those of the ROUNDED values) - conv outputs and data
                             * gradients of the bf16 mode; needs batch == splits == 1 */
+    const uint64_t* c_mask; /* trid_gemm_p16 only, with accumulate, batch == splits == 1, ldc == N, N % 4 == 0: NULL, or a bit per
+                            * element of C in the layout of trid_bn_apply_*'s relu_mask; C = A . B^T + (bit ? C : 0).  The data
+                            * gradient of a residual block's conv1 lands on dL/d(block output) masked by that output's ReLU
+                            * (m_resnet.py:49-66 backward: out = relu(bn3(..) + identity)) without a masked copy of it */
 } trid_gemm_desc;
 
 int trid_gemm_f32(const trid_gemm_desc* d, void* stream);
@@ -129,10 +133,11 @@ int trid_gemm_p16(const trid_gemm_desc* d, int variant, void* stream);
  * workgroups, the [32][K] filter panel of a wave in registers, activation tiles by LDS-DMA, stores straight from the
  * accumulators; bit-identical to trid_gemm_p16.  A P16 [M][K], B P16 [N][K] (N % 32 == 0), C fp32 [M][ldc]; accumulate:
  * C += A . B^T; stats (may be NULL, not with accumulate): [ceil(M / rows)][N][4] = (mean, M2, min, max) per `rows` rows,
- * rows = trid_gemm_p16_stream_rows(M, N, K, accumulate) (0 there: shape not covered, use trid_gemm_p16). */
+ * rows = trid_gemm_p16_stream_rows(M, N, K, accumulate) (0 there: shape not covered, use trid_gemm_p16).  c_mask (NULL, or
+ * with accumulate, ldc == N and N % 256 == 0): as trid_gemm_desc.c_mask, C = A . B^T + (bit ? C : 0). */
 int trid_gemm_p16_stream_rows(int M, int N, int K, int accumulate);
 int trid_gemm_p16_stream(const void* A, const float* a_amax, const void* B, const float* b_amax, float* C, long long ldc,
-                         float* stats, int M, int N, int K, int accumulate, void* stream);
+                         float* stats, int M, int N, int K, int accumulate, const uint64_t* c_mask, void* stream);
 /* Weight gradients on P16 operands: C[M][N] = alpha * sum_k A[k][m] * B[k][n] with A = dL/dy [K pixels][M] and
  * B = the layer input [K pixels][N] (b_mode TRID_B_NC) or its 3x3 gather (TRID_B_CONV: N = 9*Cin, the NHWC image
  * [K pixels][Cin]); the K-major operands are transposed by the LDS read (ds_read_b64_tr_b16).  splits > 1 writes

@@ -256,6 +256,48 @@ def test_gemm_p16_stream(ops, M_, N, K):
     assert abs(float(bound) - float(z.abs().max())) <= 1e-4 * float(z.abs().max())
 
 
+def _relu_mask_words(keep):
+    """bool [M, N] -> the relu_mask words of bn_apply (quad q = element / 4: four 64-bit words per 64 quads, one per component
+    element % 4, bit q % 64)."""
+    import torch as T
+
+    flat = keep.reshape(-1)
+    flat = T.cat([flat, T.zeros((-flat.numel()) % 256, dtype=T.bool)])  # (the last group of 64 quads may be ragged)
+    bits = flat.reshape(-1, 64, 4).permute(0, 2, 1).to(T.int64)
+    w = T.ones(64, dtype=T.int64) << T.arange(64)
+    return (bits * w).sum(-1).contiguous()
+
+
+# (M, N, K): streaming kernel (K = 64 / 128, N % 256 == 0), tile kernel wide epilogue (K = 256 / 512), tile kernel with N % 256 != 0
+@pytest.mark.parametrize("M_,N,K", [(3072, 256, 64), (768 * 2 + 64, 512, 128), (192 * 3, 1024, 256), (192 * 2 + 64, 2048, 512), (640, 128, 64), (130, 64, 512)])
+@pytest.mark.parametrize("bf16", [False, True])
+def test_gemm_p16_masked_accumulate(ops, M_, N, K, bf16):
+    """gemm_p16(accumulate, cmask): C = A . B^T + (bit ? C : 0) - the data gradient of an identity block's conv1 landing on
+    dL/d(block output) under that output's ReLU mask - against accumulate onto a masked COPY (bit for bit: same kernel,
+    same order), for the streaming and the tile kernel, fp32 and bf16 C."""
+    import torch as T
+
+    if bf16 and K < 256:
+        pytest.skip("bf16 C: tile kernel shapes only")
+    x, w = R("mx%d" % K, M_, K), R("mw%d" % N, N, K, scale=0.2)
+    g = R("mg%d" % N, M_, N)
+    keep = T.rand(M_, N, generator=T.Generator().manual_seed(M_ + N)) < 0.6
+    mask = _relu_mask_words(keep).cuda()
+    if bf16:
+        xp, wp = ops.p16_pack(dev(x), fmt=2), ops.p16_pack(dev(w), fmt=2)
+        c_ref = (dev(g) * keep.cuda()).to(T.bfloat16)
+        c = dev(g).to(T.bfloat16)
+    else:
+        xp, wp = ops.p16_pack(dev(x)), ops.p16_pack(dev(w))
+        c_ref = dev(g) * keep.cuda()
+        c = dev(g).clone()
+    ops.gemm_p16(xp, wp, c_ref, M_, N, K, N, accumulate=True)
+    ops.gemm_p16(xp, wp, c, M_, N, K, N, accumulate=True, cmask=mask)
+    assert T.equal(c, c_ref)
+    want = x.double() @ w.double().t() + g.double() * keep
+    assert rel(c.float(), want) < (1e-2 if bf16 else 2e-6)
+
+
 @pytest.mark.parametrize("M_,N,K", [(128, 2048, 2048), (128, 1024, 2048), (128, 256, 1024), (16, 256, 1024), (100, 96, 520), (33, 2048, 260), (1, 32, 256), (128, 512, 11008)])
 def test_skinny_gemm(ops, M_, N, K):
     """csrc/skinny_gemm.hip: batch-sized GEMMs (M <= 128) with the reduction split over the waves of a workgroup - both weight

@@ -473,6 +473,9 @@ def _finalize_minmax(bn, partials, M, relu, bound, counters, rows_per_part=ops.S
     return st
 
 
+_MASKED_ACC = _os.environ.get("TRID_MASKED_ACC", "1") != "0"
+
+
 def block_backward_p16(blk, rec, g, WPT, ws, G):
     """Backward of block_forward_p16.  g: dL/d(out) fp32.  The BatchNorm-backward passes write their outputs as P16
     tensors (bound of max|dy| from the reduce pass); data gradients on gemm_p16, weight gradients on the transposing
@@ -487,7 +490,11 @@ def block_backward_p16(blk, rec, g, WPT, ws, G):
         return ws.run(lambda d_, x_: ops.wgrad_p16(ops.P16(d_, dy.amax, fmt), ops.P16(x_, act.amax, fmt), conv=conv), dy.data, act.data,
                       keep=(dy.amax, act.amax))
 
-    dyc, dg, db, dres = ops.bn_bwd_p16(g, yc, stc, 3, act=rmask, want_dres=not has_down, fmt=fmt)
+    # identity blocks: dL/dx = relu_mask * g + conv1's data gradient.  The masked copy of g is never written: conv1's data
+    # gradient lands on g itself with the mask applied to the old values in its epilogue (gemm_p16 cmask) - g is dead after
+    # bn3's backward passes.  (TRID_MASKED_ACC=0: bn_bwd writes the masked copy, for A/B runs)
+    masked_acc = _MASKED_ACC and not has_down and g.is_contiguous()
+    dyc, dg, db, dres = ops.bn_bwd_p16(g, yc, stc, 3, act=rmask, want_dres=not has_down and not masked_acc, fmt=fmt)
     G[id(blk.bn3.weight)], G[id(blk.bn3.bias)] = dg, db
     if has_down:
         dyd, dg, db, _ = ops.bn_bwd_p16(g, yd, std, 3, act=rmask, fmt=fmt)
@@ -513,8 +520,8 @@ def block_backward_p16(blk, rec, g, WPT, ws, G):
         G[id(blk.downsample[1].weight)] = wgrad(dyd, xd).view_as(blk.downsample[1].weight)
         dx = ops.avgpool2_bwd(dxd) if stride > 1 else dxd
     else:
-        dx = dres
-    ops.gemm_p16(dya, WPT[id(blk.conv1.weight)], dx, Ma, cin, planes, cin, accumulate=True)
+        dx = g if masked_acc else dres
+    ops.gemm_p16(dya, WPT[id(blk.conv1.weight)], dx, Ma, cin, planes, cin, accumulate=True, cmask=rmask if masked_acc else None)
     G[id(blk.conv1.weight)] = wgrad(dya, x).view_as(blk.conv1.weight)
     return dx
 
@@ -852,7 +859,7 @@ class ModifiedResNet(nn.Module):
             g = g.to(torch.bfloat16)  # bf16 mode: the gradient of a bf16 tensor (the block outputs) is a bf16 tensor
         for blk, rec in zip(reversed(blocks), reversed(S["blocks"])):
             if dbg is not None:
-                dbg.append(g.float())
+                dbg.append(g.float().clone())  # (a copy: identity blocks overwrite g with dL/dx)
             g = block_backward_p16(blk, rec, g, WPT, ws, G) if p16 else block_backward(blk, rec, g, ar, ws, G)
             if id(blk) in first_of_layer:  # a whole residual layer (and, the first time, the attention pool) is done
                 stage_ready()

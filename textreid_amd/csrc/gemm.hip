@@ -465,6 +465,7 @@ int trid_gemm_launch(const trid_gemm_desc* d, const GemmFilter* filt, const int*
     TRID_REQUIRE(aligned16(d->A) && aligned16(d->B) && aligned16(d->C), "trid_gemm_f32: operands must be 16-byte aligned");
     TRID_REQUIRE(d->a_mode >= 0 && d->a_mode <= 2 && d->b_mode >= 0 && d->b_mode <= 2, "trid_gemm_f32: bad loader mode");
     TRID_REQUIRE(d->batch >= 1 && d->splits >= 1, "trid_gemm_f32: batch/splits must be >= 1");
+    TRID_REQUIRE(d->c_mask == nullptr, "trid_gemm_f32: c_mask is a trid_gemm_p16 epilogue");
     GemmParams p;
     memset(&p, 0, sizeof(p));
     p.A = d->A; p.B = d->B; p.C = d->C;

@@ -51,6 +51,7 @@ struct GemmParams {
     int c_fmt;            // gemm_p16.hip: 0 = C fp32, 2 = C plain bf16
     int wide_epilogue;    // gemm_p16.hip: stores (and accumulate / res reads) as whole rows through LDS
     int xcd_split;        // weight gradients (gemm_p16.hip): 1-D grid, every XCD owns whole K splits
+    const unsigned long long* cmask;  // gemm_p16.hip, accumulate: bit per element of C (relu_mask layout) gating the OLD values
 };
 
 constexpr int BK = 32;

@@ -452,14 +452,23 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 && STAGES == 2) ? 2 : (W
                 if (!pre) {
                     v.x += bv4.x; v.y += bv4.y; v.z += bv4.z; v.w += bv4.w;
                     if (p.accumulate) {
+                        float4 u;
                         if (p.c_fmt == 2) {
-                            const uint2 u = *reinterpret_cast<const uint2*>(Cb + at);
-                            v.x += __builtin_bit_cast(float, u.x << 16); v.y += __builtin_bit_cast(float, u.x & 0xffff0000u);
-                            v.z += __builtin_bit_cast(float, u.y << 16); v.w += __builtin_bit_cast(float, u.y & 0xffff0000u);
+                            const uint2 ub = *reinterpret_cast<const uint2*>(Cb + at);
+                            u = make_float4(__builtin_bit_cast(float, ub.x << 16), __builtin_bit_cast(float, ub.x & 0xffff0000u),
+                                            __builtin_bit_cast(float, ub.y << 16), __builtin_bit_cast(float, ub.y & 0xffff0000u));
                         } else {
-                            const float4 u = *reinterpret_cast<const float4*>(C + at);
-                            v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+                            u = *reinterpret_cast<const float4*>(C + at);
                         }
+                        if (p.cmask != nullptr) {  // quad at / 4: four words per 64 quads (one per component), bit = quad % 64
+                            const long long qi = at >> 2;
+                            const ulonglong2* mq = reinterpret_cast<const ulonglong2*>(p.cmask + (qi >> 6) * 4);
+                            const ulonglong2 m01 = mq[0], m23 = mq[1];
+                            const int bit = (int)(qi & 63);
+                            u.x = ((m01.x >> bit) & 1ull) ? u.x : 0.f; u.y = ((m01.y >> bit) & 1ull) ? u.y : 0.f;
+                            u.z = ((m23.x >> bit) & 1ull) ? u.z : 0.f; u.w = ((m23.y >> bit) & 1ull) ? u.w : 0.f;
+                        }
+                        v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
                     }
                     if (p.res != nullptr) {
                         const float4 rr = *reinterpret_cast<const float4*>(p.res + (long long)row * p.ldres + col);
@@ -485,10 +494,12 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 && STAGES == 2) ? 2 : (W
                 for (int r = 0; r < 16; ++r) {
                     const int row = row_base + i * 32 + (r & 3) + 8 * (r >> 2);
                     const long long at = (long long)row * p.ldc + col;
-                    if (row < p.M && col < p.N)
+                    if (row < p.M && col < p.N) {
                         oldv[r] = p.c_fmt == 2 ? __builtin_bit_cast(float, (unsigned)Cb[at] << 16) : C[at];
-                    else
+                        if (p.cmask != nullptr && !((p.cmask[((at >> 2) >> 6) * 4 + (at & 3)] >> ((at >> 2) & 63)) & 1ull)) oldv[r] = 0.f;
+                    } else {
                         oldv[r] = 0.f;
+                    }
                 }
             }
 #pragma unroll
@@ -1025,6 +1036,9 @@ extern "C" int trid_gemm_p16(const trid_gemm_desc* d, int variant, void* stream_
     p.a_amax = d->a_amax; p.b_amax = d->b_amax;
     p.stats_w = d->stats_minmax ? 4 : 2;
     p.c_fmt = d->c_format;
+    p.cmask = reinterpret_cast<const unsigned long long*>(d->c_mask);
+    TRID_REQUIRE(p.cmask == nullptr || (d->accumulate && d->batch == 1 && d->splits == 1 && d->ldc == d->N && d->N % 4 == 0 && !d->stats),
+                 "trid_gemm_p16: c_mask needs accumulate, batch == splits == 1, ldc == N, N %% 4 == 0");
     static const int wide_env = getenv("TRID_GEMM_WIDE_EPILOGUE") ? atoi(getenv("TRID_GEMM_WIDE_EPILOGUE")) : 1;  // (0: A/B runs)
     p.wide_epilogue = wide_env;
     TRID_REQUIRE(p.c_fmt == 0 || (p.c_fmt == 2 && d->batch == 1 && d->splits == 1),

@@ -67,6 +67,7 @@ struct StreamParams {
     int workers;     // persistent workgroups per panel
     int tiles;       // ceil(M / RB)
     int nt_a, nt_c;  // non-temporal activation loads / output stores
+    const unsigned* cmask;  // accumulate only, ldc == N, N % 256 == 0: bit mask over C (bn_apply's relu_mask layout) gating the OLD values
 };
 
 }  // namespace
@@ -120,6 +121,7 @@ __global__ __launch_bounds__(512, 2) void gemm_p16_stream_kernel(StreamParams p)
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (unsigned)((size_t)p.M * ROWB), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc((void*)p.C, 0, (unsigned)((size_t)p.M * p.ldc * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc((void*)(p.stats != nullptr ? p.stats : p.C), 0, (unsigned)((size_t)p.tiles * p.N * 16), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsM = __builtin_amdgcn_make_buffer_rsrc((void*)(p.cmask != nullptr ? (const void*)p.cmask : (const void*)p.C), 0, (unsigned)((size_t)p.M * p.N / 8), 0x00020000);
     constexpr unsigned OOB = 0x80000000u;
 
     // loader: chunk c (1 KB = RPC rows) of a stage; lane -> (row, stored unit j); source unit = j ^ (row & 15).  The per-chunk
@@ -193,6 +195,22 @@ __global__ __launch_bounds__(512, 2) void gemm_p16_stream_kernel(StreamParams p)
                 for (int r = 0; r < 16; ++r)
                     oldc[i][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsC, base + (unsigned)(i * 32 + (r & 3) + 8 * (r >> 2)) * ldcb, 0, 0));
         }
+        // ... gated by a bit mask over C (C = acc + (bit ? C : 0): the ReLU mask of the block output on the way back).  Element
+        // (row, col) of an [M][N] tensor with N % 256 == 0: quad q = col / 4 of 256-column group col / 256 of the row, four
+        // 64-bit words per group (one per component col % 4), bit q % 64; read as the 32-bit half that holds the bit
+        unsigned mw[ACC ? TM : 1][16];
+        if constexpr (ACC) {
+            if (p.cmask != nullptr) {
+                const unsigned col = (unsigned)(n0 + (lane & 31));
+                const unsigned rowb = (unsigned)p.N >> 3;  // mask bytes per row
+                const unsigned mbase = col_live ? ((unsigned)t * RB + rw * TM * 32 + 4u * khalf) * rowb + (col >> 8) * 32u + (col & 3u) * 8u + ((col >> 5) & 4u) : OOB;
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        mw[i][r] = __builtin_amdgcn_raw_buffer_load_b32(rsM, mbase + (unsigned)(i * 32 + (r & 3) + 8 * (r >> 2)) * rowb, 0, 0);
+            }
+        }
         int zero = 0;
         asm volatile("" : "+v"(zero));
         if (tn < p.tiles) issue(tn, stage ^ 1, zero);
@@ -234,10 +252,18 @@ __global__ __launch_bounds__(512, 2) void gemm_p16_stream_kernel(StreamParams p)
             for (int r = 0; r < 16; ++r) acc[i][r] *= unscale;
         if constexpr (ACC) {
             wait_vm<DPW>();  // the old C values (older than this step's DMA)
+            if (p.cmask != nullptr) {
+                const unsigned bit = ((unsigned)(n0 + (lane & 31)) >> 2) & 31u;
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][r] += oldc[i][r];
+                    for (int r = 0; r < 16; ++r) acc[i][r] += ((mw[i][r] >> bit) & 1u) ? oldc[i][r] : 0.f;
+            } else {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][r] += oldc[i][r];
+            }
         }
         const long long row0 = (long long)t * RB + rw * TM * 32;  // first row of this wave's blocks
         if (p.stats != nullptr) {
@@ -393,7 +419,7 @@ extern "C" int trid_gemm_p16_stream_rows(int M, int N, int K, int accumulate) {
 }
 
 extern "C" int trid_gemm_p16_stream(const void* A, const float* a_amax, const void* B, const float* b_amax, float* C, long long ldc,
-                                    float* stats, int M, int N, int K, int accumulate, void* stream) {
+                                    float* stats, int M, int N, int K, int accumulate, const uint64_t* c_mask, void* stream) {
     TRID_REQUIRE(A && B && C && a_amax && b_amax, "trid_gemm_p16_stream: null operand");
     TRID_REQUIRE(trid_gemm_p16_stream_rows(M, N, K, accumulate) > 0, "trid_gemm_p16_stream: needs K in {64, 128, 256} and N %% 32 == 0 (M=%d N=%d K=%d)", M, N, K);
     TRID_REQUIRE(aligned16(A) && aligned16(B) && aligned16(C) && (!stats || aligned16(stats)), "trid_gemm_p16_stream: operands must be 16-byte aligned");
@@ -404,6 +430,8 @@ extern "C" int trid_gemm_p16_stream(const void* A, const float* a_amax, const vo
     p.A = (const char*)A; p.B = (const char*)B; p.C = C; p.stats = stats;
     p.a_amax = a_amax; p.b_amax = b_amax;
     p.M = M; p.N = N; p.ldc = ldc; p.accumulate = accumulate;
+    TRID_REQUIRE(c_mask == nullptr || (accumulate && ldc == N && N % 256 == 0), "trid_gemm_p16_stream: c_mask needs accumulate, ldc == N and N %% 256 == 0 (N=%d)", N);
+    p.cmask = reinterpret_cast<const unsigned*>(c_mask);
     static const int nt_env = getenv("TRID_STREAM_NT") ? atoi(getenv("TRID_STREAM_NT")) : -1;
     // measured per shape (tools/exp/nt_ab2.sh, profiles/r04i_stream_nontemporal.txt): non-temporal OUTPUT stores pay for outputs
     // beyond the Infinity Cache (layer1 conv3: 103.6 -> 81.9 us = 6.1 TB/s); non-temporal activation loads only beside the

@@ -51,6 +51,7 @@ class GemmDesc(ctypes.Structure):
         ("b_amax", ctypes.c_void_p),
         ("stats_minmax", ctypes.c_int32),
         ("c_format", ctypes.c_int32),
+        ("c_mask", ctypes.c_void_p),
     ]
 
 

@@ -263,12 +263,14 @@ def p16_pack_wt(w, N, T, C, flip, amax_):
 
 
 def gemm_p16(A, B, C, M, N, K, ldc, conv=None, alpha=1.0, accumulate=False, bias=None, stats=None, residual=None, ldres=0,
-             relu=False, splits=1, strideSplit=0, variant=None, minmax=False):
+             relu=False, splits=1, strideSplit=0, variant=None, minmax=False, cmask=None):
     """C[M,N] = alpha * A . B^T with both operands P16: A [M][K] (or an NHWC image [B,H,W,Cin] with conv=(H,W,Cin),
-    K = 9*Cin), B [N][K].  minmax: the BatchNorm partials `stats` are [tiles][N][4] = (mean, M2, min, max)."""
+    K = 9*Cin), B [N][K].  minmax: the BatchNorm partials `stats` are [tiles][N][4] = (mean, M2, min, max).
+    cmask (with accumulate, ldc == N): a relu_mask of bn_apply_p16 over C; C = A . B^T + (bit ? C : 0)."""
     if (USE_STREAM and conv is None and A.fmt == 1 and B.fmt == 1 and C.dtype == torch.float32 and stats is None and alpha == 1.0
-            and bias is None and residual is None and not relu and splits == 1 and gemm_p16_stream_rows(M, N, K, accumulate)):
-        return gemm_p16_stream(A, B, C, M, N, K, ldc, accumulate=accumulate)  # short-K data gradients (conv1 of a block)
+            and bias is None and residual is None and not relu and splits == 1 and gemm_p16_stream_rows(M, N, K, accumulate)
+            and (cmask is None or N % 256 == 0)):
+        return gemm_p16_stream(A, B, C, M, N, K, ldc, accumulate=accumulate, cmask=cmask)  # short-K data gradients (conv1 of a block)
     d = GemmDesc()
     d.A, d.B, d.C = _p(A.data), _p(B.data), _p(C)
     d.M, d.N, d.K = M, N, K
@@ -288,6 +290,7 @@ def gemm_p16(A, B, C, M, N, K, ldc, conv=None, alpha=1.0, accumulate=False, bias
     d.residual = _p(residual)
     d.ldres = ldres
     d.relu = 1 if relu else 0
+    d.c_mask = _p(cmask)
     d.stats_minmax = 1 if minmax else 0
     d.c_format = 2 if C.dtype == torch.bfloat16 else 0  # (data gradients of the bf16 mode are bf16 tensors)
     v = P16_VARIANT if variant is None else variant
@@ -312,18 +315,18 @@ def gemm_p16_stream_rows(M, N, K, accumulate=False):
     return int(L.load().trid_gemm_p16_stream_rows(int(M), int(N), int(K), 1 if accumulate else 0))
 
 
-def gemm_p16_stream(A, B, C, M, N, K, ldc, accumulate=False, stats=None):
-    """C[M,N] (+)= A . B^T on the streaming kernel (A P16 [M][K], B P16 [N][K], K in {64, 128, 256})."""
+def gemm_p16_stream(A, B, C, M, N, K, ldc, accumulate=False, stats=None, cmask=None):
+    """C[M,N] (+)= A . B^T on the streaming kernel (A P16 [M][K], B P16 [N][K], K in {64, 128, 256}); cmask: see gemm_p16."""
     prof = PROFILE
     if prof is not None and prof["match"]("stream1x1"):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        call("trid_gemm_p16_stream", _p(A.data), _p(A.amax), _p(B.data), _p(B.amax), _p(C), ldc, _p(stats), M, N, K, 1 if accumulate else 0, stream())
+        call("trid_gemm_p16_stream", _p(A.data), _p(A.amax), _p(B.data), _p(B.amax), _p(C), ldc, _p(stats), M, N, K, 1 if accumulate else 0, _p(cmask), stream())
         e1.record()
         # (events carry ALGORITHMIC BYTES for this HBM-bound kernel: A once, C once - twice when accumulating -, the filter)
         prof["events"].append(("stream1x1", 4.0 * (M * K + M * N * (2 if accumulate else 1) + N * K), e0, e1))
         return
-    call("trid_gemm_p16_stream", _p(A.data), _p(A.amax), _p(B.data), _p(B.amax), _p(C), ldc, _p(stats), M, N, K, 1 if accumulate else 0, stream())
+    call("trid_gemm_p16_stream", _p(A.data), _p(A.amax), _p(B.data), _p(B.amax), _p(C), ldc, _p(stats), M, N, K, 1 if accumulate else 0, _p(cmask), stream())
 
 
 USE_P16 = __import__("os").environ.get("TRID_P16", "1") != "0"  # residual blocks on pre-split operands (csrc/gemm_p16.hip)
