@@ -154,7 +154,7 @@ def test_conv1x1_all(ops, B, C, H, W, N, prec):
 # (B, Cin, H, W, Cout, chunks per image): the stem's three channel pairs at its own 192x64 geometry (4 / 2 rows per step,
 # steady-state ring rotation over 12 / 24 steps per band) and at the tiny test encoders' 48x16 (16 / 8 rows per step)
 HALO_SHAPES = [(2, 32, 192, 64, 32, 4), (2, 32, 192, 64, 64, 4), (2, 64, 192, 64, 32, 4), (3, 32, 48, 16, 32, 1), (3, 32, 48, 16, 64, 3),
-               (3, 64, 48, 16, 32, 0), (1, 32, 192, 64, 32, 0)]
+               (3, 64, 48, 16, 32, 0), (1, 32, 192, 64, 32, 0), (2, 64, 96, 32, 64, 0), (3, 64, 48, 16, 64, 3), (2, 64, 192, 64, 64, 4)]
 
 
 @pytest.mark.parametrize("B,C,H,W,N,cpi", HALO_SHAPES)
@@ -170,7 +170,12 @@ def test_conv3x3_halo_p16(ops, B, C, H, W, N, cpi):
     xp, wp = ops.p16_pack(dev(nhwc(x))), ops.p16_pack(dev(ohwi(w)))
     y, st, rpp = ops.conv3x3_halo_p16(xp, wp, chunks_per_image=cpi)
     assert rel(y.permute(0, 3, 1, 2), y_ref) < TOL
-    y2, _ = ops.conv_p16(xp, wp, conv3=True)
+    old = ops.USE_HALO_BLOCKS
+    try:
+        ops.USE_HALO_BLOCKS = False  # (the implicit-GEMM tile kernel)
+        y2, _ = ops.conv_p16(xp, wp, conv3=True)
+    finally:
+        ops.USE_HALO_BLOCKS = old
     if C == 32:
         assert torch.equal(y, y2)
     else:

@@ -508,8 +508,11 @@ def block_backward_p16(blk, rec, g, WPT, ws, G):
     G[id(blk.bn2.weight)], G[id(blk.bn2.bias)] = dg, db
     Bi, H, W, _ = yb.shape
     Ma = Bi * H * W
-    daa = ops.empty(tuple(aa.shape), g, dtype=g.dtype)
-    ops.gemm_p16(dyb, WPT[id(blk.conv2.weight)], daa, Ma, planes, 9 * planes, planes, conv=(H, W, planes))
+    if fmt == 1 and ops.USE_HALO_BLOCKS and ops.conv3x3_halo_rows(H, W, planes, planes):
+        daa = ops.conv3x3_halo_p16(dyb, WPT[id(blk.conv2.weight)], stats=False)  # (layer1: 64 channels, the stem's ring-of-rows kernel)
+    else:
+        daa = ops.empty(tuple(aa.shape), g, dtype=g.dtype)
+        ops.gemm_p16(dyb, WPT[id(blk.conv2.weight)], daa, Ma, planes, 9 * planes, planes, conv=(H, W, planes))
     G[id(blk.conv2.weight)] = _g3x3(wgrad(dyb, aa, conv=(H, W, planes)), planes, planes)
     dya, dg, db, _ = ops.bn_bwd_p16(daa, ya, sta, 1, fmt=fmt)
     G[id(blk.bn1.weight)], G[id(blk.bn1.bias)] = dg, db

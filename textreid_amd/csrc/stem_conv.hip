@@ -82,7 +82,7 @@ __device__ __forceinline__ int swz(int q) {
 
 }  // namespace
 
-// CIN, COUT in {32, 64} (not both 64).  8 waves = PB pixel blocks x (COUT / 32) column blocks x (CIN / 32) channel groups;
+// CIN, COUT in {32, 64}.  8 waves = PB pixel blocks x (COUT / 32) column blocks x (CIN / 32) channel groups;
 // a wave multiplies its 32 pixels x 32 input channels x 9 taps into 32 output channels.
 template <int CIN, int COUT>
 __global__ __launch_bounds__(512, 2) void conv3x3_halo_p16_kernel(HaloParams p) {
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_p16_kernel(HaloParams p) 
     extern __shared__ __attribute__((aligned(16))) uint4 smem[];
     char* const ring = reinterpret_cast<char*>(smem);
     float4* const sstat = reinterpret_cast<float4*>(ring + (size_t)p.R * p.rowb);  // [2][NW][32]
-    float* const ksum = reinterpret_cast<float*>(sstat + 2 * NW * 32);              // KG == 2: [PB][16][64]
+    float* const ksum = reinterpret_cast<float*>(sstat + 2 * NW * 32);              // KG == 2: [PB * CB][16][64]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -220,9 +220,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_p16_kernel(HaloParams p) 
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[g & 1][0], bf[t][ks][0], acc, 0, 0, 0);
             }
 
-            // ---- epilogue
+            // ---- epilogue.  The scale (a power of two: exact) comes off first, in every wave: the accumulators then reach
+            // the inline-asm LDS stores below through a VALU instruction - straight from the last MFMA the compiler does
+            // not know the asm is an LDS read of the MFMA's destination and leaves out the wait states that hazard needs
+            // (element 0 of the <64, 64> form was stored before its final value had landed)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] *= unscale;
             if constexpr (KG == 2) {  // the two channel-group halves of a pixel block meet in LDS
-                float* dst = ksum + pb * (16 * 64);
+                float* dst = ksum + (pb * CB + cb) * (16 * 64);
                 if (kg == 1) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
@@ -237,8 +242,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_p16_kernel(HaloParams p) 
                 }
             }
             if (KG == 1 || kg == 0) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] *= unscale;
                 if (p.stats != nullptr) {
                     float sum = 0.f, lo = INFINITY, hi = -INFINITY;
 #pragma unroll
@@ -420,7 +423,7 @@ __global__ __launch_bounds__(256) void stem_conv1_kernel(Conv1Params p) {
 template <int CIN, int COUT>
 static int launch_halo(HaloParams& p, hipStream_t stream) {
     constexpr int NW = 8, CB = COUT / 32, KG = CIN / 32, PB = NW / (CB * KG);
-    const size_t lds = (size_t)p.R * p.rowb + 2 * NW * 32 * sizeof(float4) + (KG == 2 ? (size_t)PB * 16 * 64 * 4 : 0);
+    const size_t lds = (size_t)p.R * p.rowb + 2 * NW * 32 * sizeof(float4) + (KG == 2 ? (size_t)PB * CB * 16 * 64 * 4 : 0);
     static std::once_flag once;
     static hipError_t attr_err = hipSuccess;
     std::call_once(once, [] {
@@ -441,14 +444,14 @@ using namespace trid;
 
 // rows per step of the halo kernel for this geometry, or 0 when it does not apply (the caller then uses trid_gemm_p16)
 static int halo_rows_per_step(int H, int W, int Cin, int Cout) {
-    if (!((Cin == 32 || Cin == 64) && (Cout == 32 || Cout == 64)) || (Cin == 64 && Cout == 64)) return 0;
+    if (!((Cin == 32 || Cin == 64) && (Cout == 32 || Cout == 64))) return 0;
     const int pb = 8 / ((Cin / 32) * (Cout / 32));
     const int pix = pb * 32;
     if (W <= 0 || pix % W != 0) return 0;
     const int th = pix / W;
     if (H % th != 0) return 0;
     const int rowb = ((W + 2) * Cin * 4 + 1023) / 1024 * 1024;
-    const size_t lds = (size_t)(2 * th + 2) * rowb + 2 * 8 * 32 * 16 + (Cin == 64 ? (size_t)pb * 16 * 64 * 4 : 0);
+    const size_t lds = (size_t)(2 * th + 2) * rowb + 2 * 8 * 32 * 16 + (Cin == 64 ? (size_t)pb * (Cout / 32) * 16 * 64 * 4 : 0);
     if (lds > 160 * 1024) return 0;
     return th;
 }
@@ -490,6 +493,7 @@ extern "C" int trid_conv3x3_halo_p16(const void* x, const float* x_amax, const v
     hipStream_t s = (hipStream_t)stream;
     if (Cin == 32 && Cout == 32) return launch_halo<32, 32>(p, s);
     if (Cin == 32 && Cout == 64) return launch_halo<32, 64>(p, s);
+    if (Cin == 64 && Cout == 64) return launch_halo<64, 64>(p, s);  // (layer1's conv2, m_resnet.py:22)
     return launch_halo<64, 32>(p, s);
 }
 

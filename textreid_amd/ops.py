@@ -333,6 +333,9 @@ USE_P16 = __import__("os").environ.get("TRID_P16", "1") != "0"  # residual block
 USE_P16_STEM = __import__("os").environ.get("TRID_P16_STEM", "1") != "0"  # ... and the stem on csrc/stem_conv.hip (0: A/B runs)
 
 
+USE_HALO_BLOCKS = __import__("os").environ.get("TRID_HALO_BLOCKS", "1") != "0"  # layer1's 3x3 convolutions on csrc/stem_conv.hip (0: A/B runs)
+
+
 def conv_p16(x, w, conv3=False, stats=True):
     """x: P16 [B,H,W,C] (or [M,C]); w: P16 [N, K] -> raw conv output y fp32 [.., N] (+ (mean, M2, min, max) partials)."""
     C = x.shape[-1]
@@ -348,6 +351,12 @@ def conv_p16(x, w, conv3=False, stats=True):
             if stats:
                 st.rows_per_part = rows  # (bn_finalize_minmax reads it: 64-row partials for K = 256)
             return (y, st) if stats else y
+    if conv3 and x.fmt == 1 and USE_HALO_BLOCKS and y.dtype == torch.float32 and conv3x3_halo_rows(x.shape[1], x.shape[2], C, N):
+        if not stats:  # 64-channel 3x3 convolutions at large maps (layer1's conv2): the stem's ring-of-rows kernel
+            return conv3x3_halo_p16(x, w, stats=False)
+        y, st, rows = conv3x3_halo_p16(x, w)
+        st.rows_per_part = rows
+        return y, st
     st = empty(((M + STATS_ROWS - 1) // STATS_ROWS, N, 4 if mm else 2), x.data) if stats else None
     if conv3:
         gemm_p16(x, w, y, M, N, 9 * C, N, conv=(x.shape[1], x.shape[2], C), stats=st, minmax=mm)
