@@ -164,6 +164,11 @@ int trid_stem_im2col_f32(const float* img, float* col, int B, int Cin, int H, in
  * stored; stats (may be NULL): [ceil(M/128)][32][4] = per-128-row (mean, M2, min, max) BatchNorm partials
  * (trid_bn_finalize_minmax_f32 with rows_per_part 128). */
 int trid_stem_conv1_f32(const float* img, const float* w, float* y, float* stats, int B, int Hi, int Wi, void* stream);
+/* ... and its weight gradient (autograd of that nn.Conv2d): dw [32][27] = sum over output pixels of dy [B][Ho][Wo][32] (fp32)
+ * times the image values under the 27 taps, gathered from the NCHW image (no im2col tensor), exact fp32 MFMA; slabs: scratch
+ * of trid_stem_conv1_wgrad_slabs() * 864 floats (per-workgroup partial gradients, folded in a fixed order). */
+int trid_stem_conv1_wgrad_slabs(void);
+int trid_stem_conv1_wgrad_f32(const float* img, const float* dy, float* dw, float* slabs, int B, int Hi, int Wi, void* stream);
 /* 3x3 / stride 1 / pad 1 convolution (nn.Conv2d(C, N, 3, padding=1, bias=False): stem conv2 / conv3,
  * m_resnet.py:165-170,206-207, and - with the transposed, 180-degree rotated filters of trid_p16_pack_multi_f32 - their
  * data gradients) for 32 / 64 channels on P16 operands: x = P16 NHWC [B][H][W][Cin] (scale from x_amax), w = P16

@@ -197,6 +197,21 @@ def test_conv3x3_halo_p16(ops, B, C, H, W, N, cpi):
         assert rel(dx.permute(0, 3, 1, 2), xr.grad) < TOL
 
 
+@pytest.mark.parametrize("B,H,W", [(3, 24, 16), (2, 384, 128), (5, 96, 32), (1, 22, 10), (2, 23, 11)])
+def test_stem_conv1_wgrad_direct(ops, B, H, W):
+    """csrc/stem_conv.hip: the weight gradient of the 3 -> 32 channel, stride-2 convolution straight from the NCHW image
+    (exact fp32 MFMA over pixel pairs, per-workgroup slabs folded in a fixed order) against autograd; odd sizes, ragged
+    pixel runs; two runs give the same bits."""
+    x, w = R("w1x", B, 3, H, W), R("w1w", 32, 3, 3, 3, scale=0.3)
+    wr = w.clone().requires_grad_(True)
+    y = F.conv2d(x, wr, stride=2, padding=1)
+    gy = R("w1g", *y.shape)
+    y.backward(gy)
+    dw = ops.stem_conv1_wgrad(dev(x), dev(nhwc(gy)))
+    assert dw.shape == (32, 3, 3, 3) and rel(dw, wr.grad) < 2e-6
+    assert torch.equal(dw, ops.stem_conv1_wgrad(dev(x), dev(nhwc(gy))))
+
+
 @pytest.mark.parametrize("B,H,W", [(3, 24, 16), (2, 384, 128), (5, 96, 32), (1, 22, 10)])
 def test_stem_conv1_direct(ops, B, H, W):
     """csrc/stem_conv.hip: the 3 -> 32 channel, stride-2 convolution straight from the NCHW image (exact fp32 MFMA, no

@@ -314,8 +314,8 @@ def stem_forward_p16(mod, images, WP, dev, nbt, masks=None):
 def stem_backward_p16(mod, rec, g, WPT, ws, G):
     """Backward of stem_forward_p16.  g: dL/d(pooled stem output) fp32.  BatchNorm-backward outputs are P16 tensors, the
     data gradients of conv3 / conv2 run on the ring-of-rows kernel with the rotated / transposed filters, the weight
-    gradients on the transposing P16 kernel (side stream); conv1's weight gradient gathers the image once more (im2col,
-    backward only)."""
+    gradients on the transposing P16 kernel (side stream); conv1's weight gradient gathers the image once more, inside its
+    kernel (exact fp32 MFMA, no im2col tensor)."""
     images, y1, st1, a1, y2, st2, a2, y3, st3 = rec
     Bi, H, W, _ = y3.shape
 
@@ -333,10 +333,7 @@ def stem_backward_p16(mod, rec, g, WPT, ws, G):
     G[id(mod.conv2.weight)] = _g3x3(wgrad(dy2, a1, 32), 32, 32)
     dy1, dg, db, _ = ops.bn_bwd(da1, y1, st1, None, 1)
     G[id(mod.bn1.weight)], G[id(mod.bn1.bias)] = dg, db
-    col, _, _ = ops.stem_im2col(images)
-    dw1 = ws.run(ops.conv1x1_wgrad, dy1, col)  # [32, 28]
-    c1 = mod.conv1.weight
-    G[id(c1)] = dw1[:, : c1[0].numel()].reshape(c1.shape)
+    G[id(mod.conv1.weight)] = ws.run(lambda d_, i_: ops.stem_conv1_wgrad(i_, d_), dy1, images)
 
 
 def block_forward(blk, x, ax, ar, training, save, nbt, masks=None):

@@ -420,6 +420,73 @@ __global__ __launch_bounds__(256) void stem_conv1_kernel(Conv1Params p) {
     }
 }
 
+// conv1's weight gradient, dW[n][j] = sum over output pixels m of dy[m][n] * patch[m][j] (j = c * 9 + ky * 3 + kx, the image
+// value under tap j of pixel m), again straight from the NCHW image: on v_mfma_f32_32x32x2_f32 the OUTPUT is the [32][27 (+5)]
+// gradient itself and the reduction runs over pixels, two per MFMA - lane (col, k) feeds A with dy[pixel k][channel col]
+// (a coalesced 128-byte row per half-wave) and B with the image value under ITS tap col of pixel k (out-of-range taps, the
+// five unused columns and pixels beyond M read as zero through the buffer descriptor).  Every wave owns a contiguous run of
+// pixels (16 loads in flight per lane), the four waves of a workgroup meet in LDS, the workgroups' [32][27] slabs are folded
+// by trid_slab_reduce_f32: a fixed assignment and order, so the result is reproducible.
+struct Conv1WgradParams {
+    const float* img;   // [B][3][Hi][Wi]
+    const float* dy;    // [B][Ho][Wo][32]
+    float* slabs;       // [gridDim.x][32 * 27]
+    int B, Hi, Wi, Ho, Wo;
+    long long M;        // B * Ho * Wo
+    int per_wave;       // pixels per wave (a multiple of 16)
+    FastDiv fdWo, fdHo;
+};
+
+constexpr int C1W_SLABS = 512;  // workgroups (= slabs) of the weight-gradient launch
+
+__global__ __launch_bounds__(256) void stem_conv1_wgrad_kernel(Conv1WgradParams p) {
+    __shared__ float red[4][32][33];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kh = lane >> 5, j = lane & 31;
+    const int c = j / 9, ky = (j % 9) / 3, kx = j % 3;
+    const bool tap_live = j < 27;
+    const int tap_off = (c * p.Hi + ky - 1) * p.Wi + (kx - 1);  // relative to pixel (2 yo, 2 xo) of plane 0
+    const __amdgpu_buffer_rsrc_t rsI = __builtin_amdgcn_make_buffer_rsrc((void*)p.img, 0, (unsigned)((size_t)p.B * 3 * p.Hi * p.Wi * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, (unsigned)(p.M * 128), 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+    constexpr int U = 8;
+    const long long first = ((long long)blockIdx.x * 4 + wave) * p.per_wave;
+    long long last = first + p.per_wave;
+    last = last < p.M ? last : p.M;
+    v16f acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (long long t = first; t < last; t += 2 * U) {
+        float a[U], b[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long long m = t + 2 * u + kh;
+            const bool live = m < last;
+            const uint32_t mm = live ? (uint32_t)m : 0u;
+            a[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsD, live ? mm * 128u + (unsigned)j * 4u : OOB, 0, 0));
+            const uint32_t q = fdiv(mm, p.fdWo);
+            const int xo = (int)(mm - q * p.Wo);
+            const uint32_t bi = fdiv(q, p.fdHo);
+            const int yo = (int)(q - bi * p.Ho);
+            const int yy = 2 * yo - 1 + ky, xx = 2 * xo - 1 + kx;
+            const bool ok = live & tap_live & (yy >= 0) & (yy < p.Hi) & (xx >= 0) & (xx < p.Wi);
+            const unsigned off = (bi * 3u * (unsigned)(p.Hi * p.Wi) + (unsigned)(2 * yo * p.Wi + 2 * xo + tap_off)) * 4u;
+            b[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsI, ok ? off : OOB, 0, 0));
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave][(r & 3) + 8 * (r >> 2) + 4 * kh][j] = acc[r];
+    __syncthreads();
+    float* out = p.slabs + (size_t)blockIdx.x * (32 * 27);
+    for (int e = tid; e < 32 * 27; e += 256) {
+        const int n = e / 27, jj = e - n * 27;
+        out[e] = (red[0][n][jj] + red[1][n][jj]) + (red[2][n][jj] + red[3][n][jj]);
+    }
+}
+
 template <int CIN, int COUT>
 static int launch_halo(HaloParams& p, hipStream_t stream) {
     constexpr int NW = 8, CB = COUT / 32, KG = CIN / 32, PB = NW / (CB * KG);
@@ -495,6 +562,29 @@ extern "C" int trid_conv3x3_halo_p16(const void* x, const float* x_amax, const v
     if (Cin == 32 && Cout == 64) return launch_halo<32, 64>(p, s);
     if (Cin == 64 && Cout == 64) return launch_halo<64, 64>(p, s);  // (layer1's conv2, m_resnet.py:22)
     return launch_halo<64, 32>(p, s);
+}
+
+extern "C" int trid_stem_conv1_wgrad_slabs(void) { return C1W_SLABS; }
+
+extern "C" int trid_stem_conv1_wgrad_f32(const float* img, const float* dy, float* dw, float* slabs, int B, int Hi, int Wi, void* stream) {
+    TRID_REQUIRE(img && dy && dw && slabs && B > 0 && Hi > 0 && Wi > 0, "trid_stem_conv1_wgrad_f32: bad arguments");
+    TRID_REQUIRE(aligned16(dw) && aligned16(slabs), "trid_stem_conv1_wgrad_f32: dw / slabs must be 16-byte aligned");
+    TRID_REQUIRE((long long)B * 3 * Hi * Wi * 4 < (1ll << 31), "trid_stem_conv1_wgrad_f32: the image batch must stay below 2 GB");
+    Conv1WgradParams p;
+    memset(&p, 0, sizeof(p));
+    p.img = img; p.dy = dy; p.slabs = slabs;
+    p.B = B; p.Hi = Hi; p.Wi = Wi;
+    p.Ho = (Hi + 1) / 2; p.Wo = (Wi + 1) / 2;
+    p.M = (long long)B * p.Ho * p.Wo;
+    TRID_REQUIRE(p.M * 128 < (1ll << 31), "trid_stem_conv1_wgrad_f32: dy must stay below 2 GB (31-bit buffer offsets)");
+    const long long waves = (long long)C1W_SLABS * 4;
+    p.per_wave = (int)(((p.M + waves - 1) / waves + 15) / 16 * 16);
+    p.fdWo = make_fastdiv((uint32_t)p.Wo);
+    p.fdHo = make_fastdiv((uint32_t)p.Ho);
+    hipLaunchKernelGGL(stem_conv1_wgrad_kernel, dim3(C1W_SLABS), dim3(256), 0, (hipStream_t)stream, p);
+    int rc = check_launch("trid_stem_conv1_wgrad_f32");
+    if (rc) return rc;
+    return trid_slab_reduce_f32(slabs, dw, 32 * 27, C1W_SLABS, 32 * 27, 0, stream);
 }
 
 extern "C" int trid_stem_conv1_f32(const float* img, const float* w, float* y, float* stats, int B, int Hi, int Wi, void* stream) {

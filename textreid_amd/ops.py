@@ -400,6 +400,18 @@ def stem_conv1(images, w, stats=True):
     return (y, st) if stats else y
 
 
+def stem_conv1_wgrad(images, dy):
+    """Weight gradient of the stem's first convolution: dw [32, 3, 3, 3] from the NCHW image batch and dy fp32 [B,Ho,Wo,32]
+    (exact fp32 MFMA, no im2col tensor)."""
+    Bi, Cin, Hi, Wi = images.shape
+    if Cin != 3 or dy.shape[-1] != 32 or dy.dtype != torch.float32 or not dy.is_contiguous() or not images.is_contiguous():
+        raise RuntimeError("stem_conv1_wgrad: a contiguous [B,3,H,W] image batch and a contiguous fp32 [B,Ho,Wo,32] gradient are needed")
+    dw = empty((32, 3, 3, 3), images)
+    slabs = empty((int(L.load().trid_stem_conv1_wgrad_slabs()), 32 * 27), images)
+    call("trid_stem_conv1_wgrad_f32", _p(images), _p(dy), _p(dw), _p(slabs), Bi, Hi, Wi, stream())
+    return dw
+
+
 def bn_finalize_minmax(partials, M, gamma, beta, running_mean, running_var, relu, bound, momentum=BN_MOMENTUM, eps=BN_EPS, rows_per_part=STATS_ROWS):
     """bn_finalize on (mean, M2, min, max) partials; `bound` (a zeroed amax_slot) receives max|act(BatchNorm(y))|."""
     C = gamma.numel()

@@ -47,6 +47,11 @@ by1 = img.numel() * 4 + M * 32 * 4
 line("conv1 3->32 s2: im2col + GEMM (old)", t(old_conv1), by1)
 line("conv1 3->32 s2: direct fp32-MFMA kernel", t(lambda: ops.stem_conv1(img, w1)), by1)
 
+dy1 = torch.randn(B, H, W, 32, generator=g).to(dev)
+line("wgrad conv1: im2col + split GEMM [32, 28] (old)", t(lambda: ops.conv1x1_wgrad(dy1, ops.stem_im2col(img)[0]), reps=5), by1)
+line("wgrad conv1: direct fp32-MFMA kernel + slab fold", t(lambda: ops.stem_conv1_wgrad(img, dy1), reps=5), by1)
+del dy1
+
 # ---- 3x3 convs
 for (C, N, tag) in ((32, 32, "conv2 / dgrad conv2"), (32, 64, "conv3"), (64, 32, "dgrad conv3")):
     x = torch.relu(torch.randn(B, H, W, C, generator=g)).to(dev)
