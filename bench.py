@@ -504,11 +504,22 @@ def main():
     if runner is not None:
         # events cannot bracket individual nodes of a replayed graph: the per-launch timing of the dominant kernels comes
         # from eager re-runs of the SAME step (all four streams active) right after the timed region
+        # ... on ONE stream (TRID_SERIAL): with the four streams of the product step an event pair also counts the time a
+        # kernel WAITS for the CUs another stream's kernel holds (measured: 194 us per launch against 136 us in the rocprofv3
+        # trace of the replayed step) - on one stream the pair brackets the kernel's own duration (113-130 us)
+        import textreid_amd.backbones.m_resnet as _mr
+
         ops.PROFILE = {"match": labels.get, "events": []}
         profiled_eager = 3
-        for i in range(profiled_eager):
-            runner._eager(*batch(n_prep + args.warmup + args.steps + i))
-        torch.cuda.synchronize()
+        os.environ["TRID_SERIAL"] = "1"
+        serial_was, _mr._SERIAL_WGRAD = _mr._SERIAL_WGRAD, True
+        try:
+            for i in range(profiled_eager):
+                runner._eager(*batch(n_prep + args.warmup + args.steps + i))
+            torch.cuda.synchronize()
+        finally:
+            os.environ.pop("TRID_SERIAL", None)
+            _mr._SERIAL_WGRAD = serial_was
     prof, ops.PROFILE = ops.PROFILE, None
     tmax = torch.tensor([dt], device=device)
     if world > 1:
@@ -602,7 +613,40 @@ def main():
     # measurement of the committed build, not a counter read of this run: `traffic_source` names the file.
     traffic, traffic_note, traffic_src = None, None, None
     here = os.path.dirname(os.path.abspath(__file__))
-    for fn in ("r03k_pmc_hbm_traffic.txt", "r03_pmc_hbm_traffic.txt", "r02d_pmc_hbm_traffic.txt", "r02c_pmc_hbm_traffic.txt", "r02a_pmc_hbm_traffic.txt", "r01j_pmc_hbm_traffic.txt"):
+
+    def stored_traffic(pattern):
+        """(bytes per launch, file) of the kernels whose name contains `pattern` in the newest committed PMC summary
+        (calls-weighted over the matching lines), or (None, None)."""
+        for fn in ("r04m_pmc_hbm_traffic.txt",):
+            try:
+                tot, calls = 0.0, 0
+                for ln in open(os.path.join(here, "profiles", fn)):
+                    f = ln.split()
+                    if pattern in ln and len(f) > 5:
+                        tot += int(f[1]) * (float(f[2]) + float(f[3])) * 1e6
+                        calls += int(f[1])
+                if calls:
+                    return tot / calls, "profiles/" + fn
+            except (OSError, ValueError):
+                pass
+        return None, None
+
+    def stored_rocprof_avg_ms(pattern):
+        """average duration (ms) of the kernels whose name contains `pattern` in the committed rocprofv3 --kernel-trace --stats
+        summary of this command (the replayed step: in-graph durations), or None."""
+        import csv
+
+        try:
+            tot, calls = 0.0, 0
+            for r in csv.DictReader(open(os.path.join(here, "profiles", "r04m_bench_kernel_stats.csv"))):
+                if pattern in r["Name"]:
+                    tot += float(r["TotalDurationNs"])
+                    calls += int(r["Calls"])
+            return tot / calls / 1e6 if calls else None
+        except (OSError, ValueError, KeyError):
+            return None
+
+    for fn in ("r04m_pmc_hbm_traffic.txt", "r03k_pmc_hbm_traffic.txt", "r03_pmc_hbm_traffic.txt", "r02d_pmc_hbm_traffic.txt", "r02c_pmc_hbm_traffic.txt", "r02a_pmc_hbm_traffic.txt", "r01j_pmc_hbm_traffic.txt"):
         try:
             for line in open(os.path.join(here, "profiles", fn)):
                 f = line.split()
@@ -632,7 +676,7 @@ def main():
         "achieved_isolated_zero_operands": achieved_isolated_zero,
         "frac_isolated_zero_operands": achieved_isolated_zero / peak,
         "power_note": "the *_zero_operands figures are the same launches on zero-filled tensors: identical instruction stream, lower switching power, higher sustained clock - the gap to *_isolated is set by the part's power limit under random fp16 operands, not by the kernel's schedule (profiles/r03j_zero_vs_random.txt; the guide's own best plain-HIP bf16 GEMM sustains 0.53-0.59 of the dense peak on random data)",
-        "note": ("achieved/frac: events around every launch of this kernel " + ("in %d eager re-runs of the step right after the timed region (the timed steps are hipGraph replays: events cannot bracket graph nodes; rocprofv3 --kernel-trace of this command gives the in-graph durations, profiles/)" % profiled_eager if profiled_eager else "during the timed steps") + ", while the text / key-encoder / weight-gradient streams share the CUs; *_isolated: the same kernel on the five layer2-4 3x3 shapes with the GPU to itself"),
+        "note": ("achieved/frac: events around every launch of this kernel " + ("in %d eager re-runs of the step right after the timed region, all kernels on ONE stream (the timed steps are hipGraph replays: events cannot bracket graph nodes; with the product's four streams an event pair also counts the wait for CUs held by another stream's kernel; rocprofv3 --kernel-trace of this command gives the in-graph durations: rocprof_in_graph)" % profiled_eager if profiled_eager else "during the timed steps, while the text / key-encoder / weight-gradient streams share the CUs") + "; *_isolated: the same kernel on the five layer2-4 3x3 shapes with the GPU to itself"),
         "peak_note": peak_note,
         "launches": nlaunch,
         "avg_launch_ms": ms / max(nlaunch, 1),
@@ -650,8 +694,17 @@ def main():
         "launches": nlaunch2,
         "avg_launch_ms": ms2 / max(nlaunch2, 1),
         "algorithmic_gflop_per_launch": flops2 / max(nlaunch2, 1) / 1e9,
-        "note": "live events around every launch of this kernel " + ("in the %d eager re-runs of the step right after the timed region" % profiled_eager if profiled_eager else "during the timed steps") + " (all streams running)",
+        "note": "live events around every launch of this kernel " + ("in the %d one-stream eager re-runs of the step right after the timed region" % profiled_eager if profiled_eager else "during the timed steps (all streams running)"),
     }
+    t1, t1_src = stored_traffic("gemm_p16_kernel<0, 128, 128, 2, 4, 2, 2") if p16 else (None, None)
+    roofline_1x1["traffic"], roofline_1x1["traffic_source"] = t1, t1_src
+    if p16:  # the rocprofv3 view of the same kernels inside the REPLAYED step (stored summary of this command)
+        for obj, pat in ((roofline, "gemm_p16_kernel<2, 128, 128, 2, 4, 2, 2"), (roofline_1x1, "gemm_p16_kernel<0, 128, 128, 2, 4, 2, 2")):
+            ms_r = stored_rocprof_avg_ms(pat)
+            if ms_r and obj["launches"]:
+                gf = obj["algorithmic_gflop_per_launch"]
+                obj["rocprof_in_graph"] = {"avg_launch_ms": ms_r, "achieved": gf / ms_r, "frac": gf / ms_r / peak,
+                                           "source": "profiles/r04m_bench_kernel_stats.csv: average duration of this template inside the replayed step x the algorithmic GFLOP per launch of the live events"}
     # the two MFMA-bound tile kernels as equals, the one with the larger total per step first; and the HBM-bound streaming kernel
     nrun = max(profiled_eager, 1) if runner is not None else args.steps
     roofline["total_ms_per_step"] = ms / nrun
@@ -665,12 +718,13 @@ def main():
         "peak": 8000.0,
         "unit": "GB/s",
         "frac": (bytes3 / (ms3 * 1e-3) / 1e9 / 8000.0) if ms3 > 0 else 0.0,
-        "traffic": None,
+        "traffic": stored_traffic("gemm_p16_stream_kernel")[0],
+        "traffic_source": stored_traffic("gemm_p16_stream_kernel")[1],
         "launches": nlaunch3,
         "avg_launch_ms": ms3 / max(nlaunch3, 1),
         "algorithmic_MB_per_launch": bytes3 / max(nlaunch3, 1) / 1e6,
         "total_ms_per_step": ms3 / nrun,
-        "note": "algorithmic bytes = activations once + output once (read and written when accumulating) + filter, over live event time, all streams running; HBM peak 8 TB/s (a float4 copy reaches 6.29: MI355X_MICROARCH.md)",
+        "note": "algorithmic bytes = activations once + output once (read and written when accumulating) + filter, over live event time (one-stream eager re-runs); HBM peak 8 TB/s (a float4 copy reaches 6.29: MI355X_MICROARCH.md)",
     }
     retr = None
     if not args.no_retrieval:
