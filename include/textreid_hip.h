@@ -131,13 +131,26 @@ int trid_gemm_p16(const trid_gemm_desc* d, int variant, void* stream);
 /* The same product for SHORT reductions (K = 64 / 128 / 256: the expand 1x1 convolutions conv3 / downsample of layer1-3,
  * m_resnet.py:26,41-47, and the data gradients of conv1) as a streaming kernel (csrc/gemm_stream.hip): persistent
  * workgroups, the [32][K] filter panel of a wave in registers, activation tiles by LDS-DMA, stores straight from the
- * accumulators; bit-identical to trid_gemm_p16.  A P16 [M][K], B P16 [N][K] (N % 32 == 0), C fp32 [M][ldc]; accumulate:
- * C += A . B^T; stats (may be NULL, not with accumulate): [ceil(M / rows)][N][4] = (mean, M2, min, max) per `rows` rows,
+ * accumulators; bit-identical to trid_gemm_p16.  A P16 [M][K], B P16 [N][K] (N % 32 == 0), C fp32 [M][ldc] (NULL with stats: a statistics-only pass, nothing
+ * is stored but the partials); accumulate: C += A . B^T; stats (may be NULL, not with accumulate): [ceil(M / rows)][N][4] = (mean, M2, min, max) per `rows` rows,
  * rows = trid_gemm_p16_stream_rows(M, N, K, accumulate) (0 there: shape not covered, use trid_gemm_p16).  c_mask (NULL, or
  * with accumulate, ldc == N and N % 256 == 0): as trid_gemm_desc.c_mask, C = A . B^T + (bit ? C : 0). */
 int trid_gemm_p16_stream_rows(int M, int N, int K, int accumulate);
+int trid_gemm_p16_stream_stats_rows(int M, int N, int K); /* rows per partial of the statistics-only pass (C == NULL) */
 int trid_gemm_p16_stream(const void* A, const float* a_amax, const void* B, const float* b_amax, float* C, long long ldc,
                          float* stats, int M, int N, int K, int accumulate, const uint64_t* c_mask, void* stream);
+/* conv3 + bn3 + identity + ReLU of an identity bottleneck block (m_resnet.py:57-66: out = relu(bn3(conv3(a)) + x)) in ONE
+ * pass over the activations, once the BatchNorm statistics are known (a first trid_gemm_p16_stream pass with C = NULL and
+ * stats given, then trid_bn_finalize_minmax_f32): the 1x1 convolution is recomputed - K = 64 / 128 input channels: 4 K bytes
+ * per row - instead of storing y (4 N bytes) and reading it back.  A P16 [M][K], B P16 [N][K], res P16 [M][N] (scale from
+ * res_amax), out P16 [M][N] with the scale of bound_a + bound_b (published in bound_sum), relu_mask (may be NULL) as
+ * trid_bn_apply_p16_f32 writes it, y (may be NULL; fp32 [M][N]): the raw convolution output, kept when a backward pass
+ * needs it.  Results are bit-identical to trid_gemm_p16_stream + trid_bn_apply_p16_f32.  _ok: shapes covered. */
+int trid_conv1x1_bn_res_p16_ok(int M, int N, int K);
+int trid_conv1x1_bn_res_p16(const void* A, const float* a_amax, const void* B, const float* b_amax, float* y,
+                            const float* bn_scale, const float* bn_shift, const void* res, const float* res_amax,
+                            void* out, const float* bound_a, const float* bound_b, float* bound_sum,
+                            uint64_t* relu_mask, int M, int N, int K, int relu, void* stream);
 /* Weight gradients on P16 operands: C[M][N] = alpha * sum_k A[k][m] * B[k][n] with A = dL/dy [K pixels][M] and
  * B = the layer input [K pixels][N] (b_mode TRID_B_NC) or its 3x3 gather (TRID_B_CONV: N = 9*Cin, the NHWC image
  * [K pixels][Cin]); the K-major operands are transposed by the LDS read (ds_read_b64_tr_b16).  splits > 1 writes

@@ -276,6 +276,43 @@ def test_gemm_p16_stream(ops, M_, N, K):
     assert abs(float(bound) - float(z.abs().max())) <= 1e-4 * float(z.abs().max())
 
 
+@pytest.mark.parametrize("M_,N,K", [(3072, 256, 64), (768 * 2 + 40, 512, 128), (64 * 7, 256, 128), (200, 512, 64)])
+@pytest.mark.parametrize("keep_y", [False, True])
+def test_conv1x1_bn_res_fused(ops, M_, N, K, keep_y):
+    """csrc/gemm_stream.hip FUSE: conv3 + bn3 + identity + ReLU of an identity block in one pass over the activations (the
+    1x1 convolution recomputed after a statistics-only pass) BIT for bit against conv_p16 + bn_finalize_minmax + bn_apply_p16:
+    output planes, output scale, ReLU bit mask, raw conv output; ragged row counts."""
+    import torch as T
+
+    x, w = T.relu(R("fx%d" % K, M_, K)), R("fw%d" % N, N, K, scale=0.2)
+    ident = T.relu(R("fi%d" % N, M_, N))
+    gamma, beta = R("fg", N).abs() + 0.5, R("fb", N)
+    xp, wp, ip = ops.p16_pack(dev(x)), ops.p16_pack(dev(w)), ops.p16_pack(dev(ident))
+    # the two-pass reference: store y, read it back
+    y_ref, st_ref = ops.conv_p16(xp, wp)
+    b_ref = ops.amax_slot(y_ref.device)
+    fin_ref = ops.bn_finalize_minmax(st_ref, M_, dev(gamma), dev(beta), None, None, False, b_ref)
+    out_ref, mask_ref = ops.bn_apply_p16(y_ref, fin_ref, b_ref, relu=True, res=ip, bound_res=ip.amax, want_mask=True)
+    # statistics-only pass + fused pass
+    assert ops.conv1x1_bn_res_ok(M_, N, K)
+    st = ops.conv1x1_stats_p16(xp, wp)
+    if st.rows_per_part == st_ref.rows_per_part:
+        assert T.equal(st, st_ref)
+    b = ops.amax_slot(y_ref.device)
+    fin = ops.bn_finalize_minmax(st, M_, dev(gamma), dev(beta), None, None, False, b)
+    assert rel(fin.scale, fin_ref.scale) < 1e-6 and rel(fin.shift, fin_ref.shift) < 1e-6 and abs(float(b) - float(b_ref)) <= 1e-6 * float(b_ref)
+    # the fused pass against the three-kernel form on the SAME coefficients: bit for bit
+    out, mask, y = ops.conv1x1_bn_res_p16(xp, wp, fin_ref, b_ref, ip, relu=True, want_mask=True, keep_y=keep_y)
+    assert T.equal(out.amax, out_ref.amax)
+    assert T.equal(out.data, out_ref.data)
+    assert T.equal(mask, mask_ref)
+    assert (y is None) == (not keep_y) and (y is None or T.equal(y, y_ref))
+    out2, mask2, _ = ops.conv1x1_bn_res_p16(xp, wp, fin_ref, b_ref, ip, relu=True, want_mask=False)
+    assert mask2 is None and T.equal(out2.data, out_ref.data)
+    want = T.relu(T.nn.functional.batch_norm((x.double() @ w.double().t()), None, None, gamma.double(), beta.double(), True, 0.1, 1e-5) + ident.double())
+    assert rel(out.unpack(), want) < 2e-6
+
+
 def _relu_mask_words(keep):
     """bool [M, N] -> the relu_mask words of bn_apply (quad q = element / 4: four 64-bit words per 64 quads, one per component
     element % 4, bit q % 64)."""

@@ -444,10 +444,23 @@ def block_forward_p16(blk, x, WP, dev, training, save, nbt, masks=None):
     yb, pb = ops.conv_p16(aa, WP[id(blk.conv2.weight)], conv3=True)
     stb, a_ab = fin(blk.bn2, pb, Ma, True)
     ab = ops.bn_apply_pool2_p16(yb, stb, a_ab, relu=True, fmt=fmt) if stride > 1 else ops.bn_apply_p16(yb, stb, a_ab, relu=True, fmt=fmt)
-    yc, pc = ops.conv_p16(ab, WP[id(blk.conv3.weight)])
-    Mc = yc.numel() // yc.shape[-1]
-    stc, a_c = fin(blk.bn3, pc, Mc, False)
+    Mc = ab.data.numel() // ab.shape[-1]
     xd = yd = std = None
+    if blk.downsample is None and fmt == 1 and not save and ops.conv1x1_bn_res_ok(Mc, blk.conv3.out_channels, ab.shape[-1]):
+        # identity blocks of layer1 / layer2 (K = 64 / 128) in the KEY encoder (nothing is kept for a backward pass): y =
+        # conv3(ab) is 4 N bytes per row to write and read back against 4 K to read ab again - a statistics-only pass, then
+        # conv3 + bn3 + identity + ReLU in one kernel that never stores y (layer1: 259 us instead of 307, layer2: 129 / 167).
+        # With y kept (the query encoder: its BatchNorm backward needs it) the fused pass is no faster than GEMM + apply
+        # (346 vs 326 us, 166 vs 174: tools/exp/fused_bench.py), so that side stays on the three-kernel form
+        pc = ops.conv1x1_stats_p16(ab, WP[id(blk.conv3.weight)])
+        stc, a_c = fin(blk.bn3, pc, Mc, False)
+        out, rmask, yc = ops.conv1x1_bn_res_p16(ab, WP[id(blk.conv3.weight)], stc, a_c, x, relu=True, want_mask=save, keep_y=save)
+        rec = (x, ya, sta, aa, yb, stb, ab, yc, stc, xd, yd, std, rmask) if save else None
+        if masks is not None:
+            masks.extend([aa.unpack() > 0, ab.unpack() > 0, out.unpack() > 0])
+        return out, rec
+    yc, pc = ops.conv_p16(ab, WP[id(blk.conv3.weight)])
+    stc, a_c = fin(blk.bn3, pc, Mc, False)
     if blk.downsample is not None:
         xd = ops.bn_apply_pool2_p16(x, None, x.amax, fmt=fmt) if stride > 1 else x
         yd, pd = ops.conv_p16(xd, WP[id(blk.downsample[1].weight)])

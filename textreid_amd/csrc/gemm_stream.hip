@@ -68,13 +68,36 @@ struct StreamParams {
     int tiles;       // ceil(M / RB)
     int nt_a, nt_c;  // non-temporal activation loads / output stores
     const unsigned* cmask;  // accumulate only, ldc == N, N % 256 == 0: bit mask over C (bn_apply's relu_mask layout) gating the OLD values
+    // FUSE (trid_conv1x1_bn_res_p16): the BatchNorm + identity residual + ReLU of bn_apply_kernel<1, 1> in the epilogue
+    const float* bn_scale;   // [N]
+    const float* bn_shift;   // [N]
+    const char* res;         // P16 [M][N]: the identity branch
+    const float* res_amax;
+    char* out;               // P16 [M][N]
+    const float* oa;         // bound of max|bn(y)| and of the residual: the output's scale comes from their sum ...
+    const float* ob;
+    float* osum;             // ... which is published here
+    unsigned char* mask;     // relu_mask words of the output (1 bit per element), or null
+    int relu;
+    int nt_o;
 };
+
+__device__ __forceinline__ void lds_store1(const void* p, float v) {
+    asm volatile("ds_write_b32 %0, %1" ::"v"((unsigned)(uintptr_t)p), "v"(v) : "memory");
+}
 
 }  // namespace
 
 // K: reduction length; CW: column waves (each 32 columns); TM: 32-row blocks per wave and step.  8 waves = CW x RW.
-template <int K, int CW, int TM, bool ACC>
+// FUSE (CW = 8, no accumulate): 0 = store C; 1 = C is not stored, the tile goes through BatchNorm + residual + ReLU and is
+// written as a P16 tensor (+ ReLU bit mask); 2 = both (the raw conv output is kept for the backward pass).
+template <int K, int CW, int TM, bool ACC, int FUSE = 0>
 __global__ __launch_bounds__(512, 2) void gemm_p16_stream_kernel(StreamParams p) {
+    static_assert(FUSE == 0 || (CW == 8 && !ACC), "the fused epilogue is built for the 8-column-wave, non-accumulating form");
+    // FUSE == 3: the statistics-only pass (nothing is stored but the partials).  Without the output stream a step is over in
+    // a fraction of the HBM latency, so one tile in flight per workgroup starves it (66 us for 100 MB): THREE stages, two
+    // tiles in flight.  (With C stores in between the 6-bit in-order vmcnt could not tell the older DMA from the newer one.)
+    constexpr int NS = FUSE == 3 ? 3 : 2;
     constexpr int NW = 8, RW = NW / CW;
     constexpr int RB = RW * TM * 32;          // rows per step
     constexpr int ROWB = K * 4;               // bytes of one A row
@@ -87,7 +110,9 @@ __global__ __launch_bounds__(512, 2) void gemm_p16_stream_kernel(StreamParams p)
     static_assert(NCH % NW == 0, "stage must split evenly over the waves");
     extern __shared__ __attribute__((aligned(16))) uint4 smem[];
     char* const ring = reinterpret_cast<char*>(smem);
-    float4* const sstat = reinterpret_cast<float4*>(ring + 2 * STAGE);  // RW > 1: [2][NW][32]
+    float4* const sstat = reinterpret_cast<float4*>(ring + NS * STAGE);  // RW > 1: [2][NW][32]
+    constexpr int TP = 36;                                                 // FUSE: row pitch (floats) of a wave's transposition tile
+    float* const tbuf = reinterpret_cast<float*>(sstat + 2 * NW * 32);     // FUSE: [NW][32][TP]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -124,6 +149,26 @@ __global__ __launch_bounds__(512, 2) void gemm_p16_stream_kernel(StreamParams p)
     const __amdgpu_buffer_rsrc_t rsM = __builtin_amdgcn_make_buffer_rsrc((void*)(p.cmask != nullptr ? (const void*)p.cmask : (const void*)p.C), 0, (unsigned)((size_t)p.M * p.N / 8), 0x00020000);
     constexpr unsigned OOB = 0x80000000u;
 
+    // FUSE: this lane's 8 channels (octet oc of the wave's 32 columns; the same in both halves of a tile) and their coefficients
+    constexpr bool FEPI = FUSE == 1 || FUSE == 2;
+    const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc((void*)(FEPI ? (const void*)p.res : (const void*)p.C), 0, (unsigned)((size_t)p.M * p.N * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc((void*)(FEPI ? (void*)p.out : (void*)p.C), 0, (unsigned)((size_t)p.M * p.N * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)((FEPI && p.mask != nullptr) ? (void*)p.mask : (void*)p.C), 0, (unsigned)((size_t)p.M * p.N / 8), 0x00020000);
+    float fsc[8], fsh[8];
+    float oscale = 1.f, rinv = 1.f;
+    if constexpr (FUSE == 1 || FUSE == 2) {
+        const int c0 = (col_live ? n0 : 0) + 8 * (lane & 3);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            fsc[j] = p.bn_scale[c0 + j];
+            fsh[j] = p.bn_shift[c0 + j];
+        }
+        const float bound = (p.oa != nullptr ? *p.oa : 0.f) + (p.ob != nullptr ? *p.ob : 0.f);
+        if (p.osum != nullptr && blockIdx.x == 0 && tid == 0) *p.osum = bound;
+        oscale = f16_scale_of(bound);
+        rinv = 1.f / f16_scale_of(*p.res_amax);
+    }
+
     // loader: chunk c (1 KB = RPC rows) of a stage; lane -> (row, stored unit j); source unit = j ^ (row & 15).  The per-chunk
     // offsets are re-derived from the lane index in every step (`zero` is opaque to the compiler): kept across the loop
     // they would cost DPW x 2 VGPRs of a budget that the filter panel (K/2) and the accumulators already fill
@@ -148,17 +193,32 @@ __global__ __launch_bounds__(512, 2) void gemm_p16_stream_kernel(StreamParams p)
 
     int t = worker;
     if (t < p.tiles) issue(t, 0, 0);
+    if (NS == 3 && t + p.workers < p.tiles) issue(t + p.workers, 1, 0);
     int stage = 0;
     bool first = true;
-    for (; t < p.tiles; t += p.workers, stage ^= 1) {
+    for (; t < p.tiles; t += p.workers, stage = (NS == 2 ? stage ^ 1 : (stage == NS - 1 ? 0 : stage + 1))) {
         // the DMA of this tile was issued before this wave's stores of the previous step: vmcnt retires in order
         // (the counter has 6 bits: with 64 stores per step the oldest two are waited for as well)
-        constexpr int NST = TM * 16 + 1 > 63 ? 63 : TM * 16 + 1, NSC = TM * 16 > 63 ? 63 : TM * 16;
-        if (first) wait_vm<0>();
-        else if (p.stats != nullptr && RW == 1) wait_vm<NST>();
-        else wait_vm<NSC>();
+        // FUSE: at least TM * 4 P16 stores (+ TM * 16 stores of the raw output, FUSE == 2) follow the DMA - a count below the
+        // real one (the optional mask stores) only waits for a few of the oldest stores as well
+        constexpr int NFU = TM * 4 + (FUSE == 2 ? TM * 16 : 0);
+        constexpr int NST = TM * 16 + 1 > 63 ? 63 : TM * 16 + 1, NSC = FUSE ? NFU : (TM * 16 > 63 ? 63 : TM * 16);
+        static_assert(NFU <= 63, "s_waitcnt vmcnt has six bits");
+        if constexpr (NS == 3) {
+            // younger than this tile's DMA: the next tile's DMA, if there is one, and at most two partial stores (one counted)
+            if (t + p.workers < p.tiles) {
+                if (first) wait_vm<DPW>();
+                else wait_vm<DPW + 1>();
+            } else {
+                wait_vm<0>();
+            }
+        } else {
+            if (first) wait_vm<0>();
+            else if (p.stats != nullptr && RW == 1) wait_vm<NST>();
+            else wait_vm<NSC>();
+        }
         lds_barrier();
-        const int tn = t + p.workers;
+        const int tn = t + (NS - 1) * p.workers;
         // RW > 1: the previous step's BatchNorm partials, merged by the first lanes of the workgroup (one column each)
         if (RW > 1 && p.stats != nullptr && !first && tid < CW * 32) {
             const float4* src = sstat + (stage ^ 1) * NW * 32;
@@ -211,9 +271,24 @@ __global__ __launch_bounds__(512, 2) void gemm_p16_stream_kernel(StreamParams p)
                         mw[i][r] = __builtin_amdgcn_raw_buffer_load_b32(rsM, mbase + (unsigned)(i * 32 + (r & 3) + 8 * (r >> 2)) * rowb, 0, 0);
             }
         }
+        // FUSE: the identity branch of this step's rows, 8 channels per lane and tile half (hi and lo planes: 2 x 16 bytes),
+        // fetched under the MFMAs like the old C values above
+        v4u rhi[FUSE ? TM : 1][2], rlo[FUSE ? TM : 1][2];
+        if constexpr (FUSE == 1 || FUSE == 2) {
+            const unsigned rowb = (unsigned)p.N * 4u;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const unsigned row = (unsigned)t * RB + (unsigned)(rw * TM + i) * 32u + (unsigned)((lane + 64 * h) >> 2);
+                    const unsigned off = col_live ? row * rowb + (unsigned)(n0 >> 5) * 128u + (unsigned)(lane & 3) * 16u : OOB;
+                    rhi[i][h] = __builtin_amdgcn_raw_buffer_load_b128(rsR, off, 0, 0);
+                    rlo[i][h] = __builtin_amdgcn_raw_buffer_load_b128(rsR, col_live ? off + 64u : OOB, 0, 0);
+                }
+        }
         int zero = 0;
         asm volatile("" : "+v"(zero));
-        if (tn < p.tiles) issue(tn, stage ^ 1, zero);
+        if (tn < p.tiles) issue(tn, NS == 2 ? (stage ^ 1) : (stage == 0 ? NS - 1 : stage - 1), zero);
 
         // ---- MFMAs of this tile: per 16-deep k step 2 fragment reads per row block, 3 products
         v16f acc[TM];
@@ -326,15 +401,98 @@ __global__ __launch_bounds__(512, 2) void gemm_p16_stream_kernel(StreamParams p)
         {
             // 32-bit byte offsets (the tensor stays below 2 GB); rows >= M lie beyond the descriptor's range: dropped.  A wave
             // whose columns do not exist stores everything out of range
+            // (no C - the statistics-only pass: every store is out of range, the instruction count the waits rely on stays)
             const unsigned ldcb = (unsigned)p.ldc * 4u;
-            const unsigned base = col_live ? (unsigned)row0 * ldcb + 4u * khalf * ldcb + (unsigned)(n0 + (lane & 31)) * 4u : OOB;
+            const unsigned base = (col_live && p.C != nullptr) ? (unsigned)row0 * ldcb + 4u * khalf * ldcb + (unsigned)(n0 + (lane & 31)) * 4u : OOB;
+            if constexpr (FUSE != 1 && FUSE != 3) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float v = acc[i][r];
+                        store_c(__float_as_uint(v), rsC, base + (unsigned)(i * 32 + (r & 3) + 8 * (r >> 2)) * ldcb, p.nt_c != 0);
+                    }
+            }
+        }
+        if constexpr (FUSE == 1 || FUSE == 2) {
+            // out = relu(y * scale + shift + identity) as a P16 tensor, the arithmetic of bn_apply_kernel<1, 1> (bn_pool.hip).
+            // The tile is transposed through a wave-private LDS tile (accumulator layout: one column per lane; P16 rows want
+            // 8 consecutive channels per lane: 16 bytes of the hi plane, 16 of the lo plane).  The LDS stores are inline asm
+            // (beside the LDS-DMA in flight hipcc would order a visible ds_write behind s_waitcnt vmcnt(0)) and take the
+            // accumulators after a VALU instruction (the unscale above), not straight from the MFMA.
+            wait_vm<DPW + (FUSE == 2 ? TM * 16 : 0)>();  // the identity branch (older than this step's DMA and C stores)
+            float* const tw = tbuf + wave * (32 * TP);
+            const unsigned rowb = (unsigned)p.N * 4u;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float v = acc[i][r];
-                    store_c(__float_as_uint(v), rsC, base + (unsigned)(i * 32 + (r & 3) + 8 * (r >> 2)) * ldcb, p.nt_c != 0);
+                    lds_store1(tw + ((r & 3) + 8 * (r >> 2) + 4 * khalf) * TP + (lane & 31), v);
                 }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                unsigned long long bal[2][8];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int rl = (lane + 64 * h) >> 2, oc = lane & 3;
+                    const float4 y0 = *reinterpret_cast<const float4*>(tw + rl * TP + 8 * oc);
+                    const float4 y1 = *reinterpret_cast<const float4*>(tw + rl * TP + 8 * oc + 4);
+                    const float yv[8] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w};
+                    float v[8];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {  // dword q of a plane = channels 2q, 2q + 1
+                        const unsigned hw = rhi[i][h][q], lw = rlo[i][h][q];  // (a bit_cast of the vector ELEMENT itself reads element 0)
+                        const f16x2 hh = __builtin_bit_cast(f16x2, hw), ll = __builtin_bit_cast(f16x2, lw);
+                        const float r0 = ((float)hh.x + (float)ll.x) * rinv, r1 = ((float)hh.y + (float)ll.y) * rinv;
+                        v[2 * q] = fmaf(yv[2 * q], fsc[2 * q], fsh[2 * q]) + r0;
+                        v[2 * q + 1] = fmaf(yv[2 * q + 1], fsc[2 * q + 1], fsh[2 * q + 1]) + r1;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) bal[h][j] = __ballot(v[j] > 0.f);
+                    if (p.relu) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+                    }
+                    v4u oh, ol;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        unsigned hq, lq;
+                        f16_split2(v[2 * q] * oscale, v[2 * q + 1] * oscale, hq, lq);
+                        oh[q] = hq;
+                        ol[q] = lq;
+                    }
+                    const unsigned row = (unsigned)t * RB + (unsigned)(rw * TM + i) * 32u + (unsigned)rl;
+                    const unsigned off = col_live ? row * rowb + (unsigned)(n0 >> 5) * 128u + (unsigned)oc * 16u : OOB;
+                    if (p.nt_o) {
+                        __builtin_amdgcn_raw_buffer_store_b128(oh, rsO, off, 0, 2);
+                        __builtin_amdgcn_raw_buffer_store_b128(ol, rsO, col_live ? off + 64u : OOB, 0, 2);
+                    } else {
+                        __builtin_amdgcn_raw_buffer_store_b128(oh, rsO, off, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(ol, rsO, col_live ? off + 64u : OOB, 0, 0);
+                    }
+                }
+                if (p.mask != nullptr) {
+                    // ReLU bits in bn_apply's layout: quad q of a 256-column group -> bit q of the word of its component; this
+                    // wave's 8 quads of a row are byte (n0 / 32) % 8 of the row's four words.  Lane L writes the byte of
+                    // (row L / 4 of the half, component L % 4): from the two ballots that hold that component (channel j = k
+                    // of an octet is quad 2 oc, j = k + 4 quad 2 oc + 1), 4 octet bits of the row each, interleaved
+                    const int rr = lane >> 2, k = lane & 3;
+                    const unsigned cq0 = (unsigned)(n0 >> 2);
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const unsigned long long b0 = k == 0 ? bal[h][0] : k == 1 ? bal[h][1] : k == 2 ? bal[h][2] : bal[h][3];
+                        const unsigned long long b1 = k == 0 ? bal[h][4] : k == 1 ? bal[h][5] : k == 2 ? bal[h][6] : bal[h][7];
+                        const unsigned n0b = (unsigned)(b0 >> (4 * rr)) & 15u, n1b = (unsigned)(b1 >> (4 * rr)) & 15u;
+                        const unsigned e0 = (n0b & 1u) | ((n0b & 2u) << 1) | ((n0b & 4u) << 2) | ((n0b & 8u) << 3);
+                        const unsigned e1 = (n1b & 1u) | ((n1b & 2u) << 1) | ((n1b & 4u) << 2) | ((n1b & 8u) << 3);
+                        const unsigned byte = e0 | (e1 << 1);
+                        const unsigned row = (unsigned)t * RB + (unsigned)(rw * TM + i) * 32u + (unsigned)(16 * h + rr);
+                        const unsigned grp = row * ((unsigned)p.N >> 8) + (cq0 >> 6);
+                        const unsigned off = col_live ? grp * 32u + (unsigned)k * 8u + ((cq0 & 63u) >> 3) : OOB;
+                        __builtin_amdgcn_raw_buffer_store_b8((unsigned char)byte, rsK, off, 0, 0);
+                    }
+                }
+            }
         }
         first = false;
     }
@@ -366,14 +524,15 @@ __global__ __launch_bounds__(512, 2) void gemm_p16_stream_kernel(StreamParams p)
     }
 }
 
-template <int K, int CW, int TM, bool ACC>
+template <int K, int CW, int TM, bool ACC, int FUSE = 0>
 static int launch_stream(StreamParams& p, hipStream_t stream) {
     constexpr int RW = 8 / CW, RB = RW * TM * 32;
-    const size_t lds = (size_t)2 * RB * K * 4 + (RW > 1 ? 2 * 8 * 32 * sizeof(float4) : 0);
+    constexpr bool FEPI = FUSE == 1 || FUSE == 2;
+    const size_t lds = (size_t)(FUSE == 3 ? 3 : 2) * RB * K * 4 + ((RW > 1 || FEPI) ? 2 * 8 * 32 * sizeof(float4) : 0) + (FEPI ? (size_t)8 * 32 * 36 * 4 : 0);
     static std::once_flag once;
     static hipError_t attr_err = hipSuccess;
     std::call_once(once, [] {
-        attr_err = hipFuncSetAttribute((const void*)gemm_p16_stream_kernel<K, CW, TM, ACC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_err = hipFuncSetAttribute((const void*)gemm_p16_stream_kernel<K, CW, TM, ACC, FUSE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
     if (attr_err != hipSuccess) {
         set_error("trid_gemm_p16_stream: cannot reserve LDS: %s", hipGetErrorString(attr_err));
@@ -387,7 +546,7 @@ static int launch_stream(StreamParams& p, hipStream_t stream) {
     int need = (p.tiles + 7) / 8 * 8;  // no more workers than tiles
     p.workers = std::min(per, need);
     const int grid = p.workers * p.panels;
-    hipLaunchKernelGGL((gemm_p16_stream_kernel<K, CW, TM, ACC>), dim3(grid), dim3(512), lds, stream, p);
+    hipLaunchKernelGGL((gemm_p16_stream_kernel<K, CW, TM, ACC, FUSE>), dim3(grid), dim3(512), lds, stream, p);
     return check_launch("trid_gemm_p16_stream");
 }
 
@@ -399,6 +558,10 @@ static int pick_stream(StreamParams& p, hipStream_t stream) {
         if (acc || p.N <= 128) return TRID_E_UNSUPPORTED;
         return launch_stream<K, 8, 2, false>(p, stream);
     } else {
+        if (p.N > 128 && !acc && p.C == nullptr) {  // statistics only: three stages (K = 128: 64-row steps, 3 x 32 KB)
+            if constexpr (K == 64) return launch_stream<K, 8, 4, false, 3>(p, stream);
+            else return launch_stream<K, 8, 2, false, 3>(p, stream);
+        }
         if (p.N > 128) return acc ? launch_stream<K, 8, 2, true>(p, stream) : launch_stream<K, 8, 4, false>(p, stream);
         if (p.N > 64) return acc ? launch_stream<K, 4, 2, true>(p, stream) : launch_stream<K, 4, 2, false>(p, stream);
         return acc ? launch_stream<K, 2, 1, true>(p, stream) : launch_stream<K, 2, 1, false>(p, stream);
@@ -418,9 +581,15 @@ extern "C" int trid_gemm_p16_stream_rows(int M, int N, int K, int accumulate) {
     return 128;
 }
 
+// ... of the statistics-only pass (C == NULL)
+extern "C" int trid_gemm_p16_stream_stats_rows(int M, int N, int K) {
+    if (N > 128 && K == 128) return 64;
+    return trid_gemm_p16_stream_rows(M, N, K, 0);
+}
+
 extern "C" int trid_gemm_p16_stream(const void* A, const float* a_amax, const void* B, const float* b_amax, float* C, long long ldc,
                                     float* stats, int M, int N, int K, int accumulate, const uint64_t* c_mask, void* stream) {
-    TRID_REQUIRE(A && B && C && a_amax && b_amax, "trid_gemm_p16_stream: null operand");
+    TRID_REQUIRE(A && B && (C || (stats && !accumulate)) && a_amax && b_amax, "trid_gemm_p16_stream: null operand (C may be null only for a statistics-only pass)");
     TRID_REQUIRE(trid_gemm_p16_stream_rows(M, N, K, accumulate) > 0, "trid_gemm_p16_stream: needs K in {64, 128, 256} and N %% 32 == 0 (M=%d N=%d K=%d)", M, N, K);
     TRID_REQUIRE(aligned16(A) && aligned16(B) && aligned16(C) && (!stats || aligned16(stats)), "trid_gemm_p16_stream: operands must be 16-byte aligned");
     TRID_REQUIRE(ldc >= N && !(stats && accumulate), "trid_gemm_p16_stream: ldc >= N; BatchNorm partials only without accumulate");
@@ -442,4 +611,37 @@ extern "C" int trid_gemm_p16_stream(const void* A, const float* a_amax, const vo
     if (K == 64) return pick_stream<64>(p, s);
     if (K == 128) return pick_stream<128>(p, s);
     return pick_stream<256>(p, s);
+}
+
+// shapes the fused conv3 + BatchNorm + identity + ReLU kernel covers (K = planes of layer1 / layer2, N = 4 planes)
+extern "C" int trid_conv1x1_bn_res_p16_ok(int M, int N, int K) {
+    return (K == 64 || K == 128) && N > 0 && N % 256 == 0 && M > 0 && (long long)M * N * 4 < (1ll << 31);
+}
+
+extern "C" int trid_conv1x1_bn_res_p16(const void* A, const float* a_amax, const void* B, const float* b_amax, float* y,
+                                       const float* bn_scale, const float* bn_shift, const void* res, const float* res_amax,
+                                       void* out, const float* bound_a, const float* bound_b, float* bound_sum,
+                                       uint64_t* relu_mask, int M, int N, int K, int relu, void* stream) {
+    TRID_REQUIRE(A && B && a_amax && b_amax && bn_scale && bn_shift && res && res_amax && out && bound_a, "trid_conv1x1_bn_res_p16: null operand");
+    TRID_REQUIRE(trid_conv1x1_bn_res_p16_ok(M, N, K), "trid_conv1x1_bn_res_p16: needs K in {64, 128}, N %% 256 == 0, tensors below 2 GB (M=%d N=%d K=%d)", M, N, K);
+    TRID_REQUIRE(aligned16(A) && aligned16(B) && aligned16(res) && aligned16(out) && (!y || aligned16(y)) && (!relu_mask || aligned16(relu_mask)),
+                 "trid_conv1x1_bn_res_p16: operands must be 16-byte aligned");
+    StreamParams p;
+    memset(&p, 0, sizeof(p));
+    p.A = (const char*)A; p.B = (const char*)B; p.C = y;
+    p.a_amax = a_amax; p.b_amax = b_amax;
+    p.M = M; p.N = N; p.ldc = N;
+    p.bn_scale = bn_scale; p.bn_shift = bn_shift;
+    p.res = (const char*)res; p.res_amax = res_amax;
+    p.out = (char*)out; p.oa = bound_a; p.ob = bound_b; p.osum = bound_sum;
+    p.mask = reinterpret_cast<unsigned char*>(relu_mask);
+    p.relu = relu;
+    static const int nt_env = getenv("TRID_STREAM_NT") ? atoi(getenv("TRID_STREAM_NT")) : -1;
+    const bool big = (long long)M * N * 4 >= STREAM_NT_MIN_BYTES;
+    p.nt_a = 0;
+    p.nt_c = nt_env >= 0 ? ((nt_env >> 1) & 1) : big;
+    p.nt_o = nt_env >= 0 ? ((nt_env >> 1) & 1) : big;
+    hipStream_t s = (hipStream_t)stream;
+    if (K == 64) return y ? launch_stream<64, 8, 2, false, 2>(p, s) : launch_stream<64, 8, 2, false, 1>(p, s);
+    return y ? launch_stream<128, 8, 2, false, 2>(p, s) : launch_stream<128, 8, 2, false, 1>(p, s);
 }

@@ -444,6 +444,43 @@ def bn_apply_p16(y, st, bound, relu=True, res=None, res_st=None, bound_res=None,
     return (o, mask) if want_mask else o
 
 
+USE_FUSED_EXPAND = __import__("os").environ.get("TRID_FUSED_EXPAND", "1") != "0"  # identity blocks of layer1 / layer2: conv3 + bn3 + residual in one pass (0: A/B runs)
+
+
+def conv1x1_bn_res_ok(M, N, K):
+    return USE_FUSED_EXPAND and USE_STREAM and bool(L.load().trid_conv1x1_bn_res_p16_ok(int(M), int(N), int(K)))
+
+
+def conv1x1_stats_p16(x, w):
+    """BatchNorm partials of the 1x1 convolution y = x . w^T WITHOUT storing y (the first of the two passes of
+    conv1x1_bn_res_p16): [steps][N][4] = (mean, M2, min, max), `rows_per_part` set."""
+    C = x.shape[-1]
+    M = x.data.numel() // C
+    N = w.shape[0]
+    rows = int(L.load().trid_gemm_p16_stream_stats_rows(int(M), int(N), int(C)))
+    st = empty(((M + rows - 1) // rows, N, 4), x.data)
+    call("trid_gemm_p16_stream", _p(x.data), _p(x.amax), _p(w.data), _p(w.amax), None, N, _p(st), M, N, C, 0, None, stream())
+    st.rows_per_part = rows
+    return st
+
+
+def conv1x1_bn_res_p16(x, w, st, bound, res, relu=True, want_mask=False, keep_y=False):
+    """relu(bn(x . w^T) + res) as a P16 tensor, the convolution recomputed inside the pass (csrc/gemm_stream.hip, FUSE):
+    x P16 [..., K], w P16 [N, K], st / bound from bn_finalize_minmax on conv1x1_stats_p16's partials, res P16 [..., N] (the
+    identity branch).  Returns (out P16, relu mask or None, y fp32 or None); bit-identical to conv_p16 + bn_apply_p16."""
+    C = x.shape[-1]
+    M = x.data.numel() // C
+    N = w.shape[0]
+    shape = tuple(x.shape[:-1]) + (N,)
+    out = p16_empty(shape, x.data, 1)
+    y = empty(shape, x.data) if keep_y else None
+    mask = torch.empty(((M * N // 4 + 63) // 64) * 4, dtype=torch.int64, device=x.data.device) if want_mask else None
+    osum = amax_slot(x.data.device)
+    call("trid_conv1x1_bn_res_p16", _p(x.data), _p(x.amax), _p(w.data), _p(w.amax), _p(y), _p(st.scale), _p(st.shift), _p(res.data), _p(res.amax),
+         _p(out), _p(bound), _p(res.amax), _p(osum), _p(mask), M, N, C, 1 if relu else 0, stream())
+    return P16(out, osum, 1), mask, y
+
+
 def bn_apply_pool2_p16(y, st, bound, relu=True, fmt=1):
     """avgpool2(act(bn(y))) -> P16; y: raw conv output fp32 (st given) or a P16 tensor (st None: plain pooling, the
     output keeps the input's scale)."""
