@@ -554,8 +554,9 @@ static int launch_stream(StreamParams& p, hipStream_t stream) {
 template <int K>
 static int pick_stream(StreamParams& p, hipStream_t stream) {
     const bool acc = p.accumulate != 0;
-    if constexpr (K == 256) {  // (the 128-VGPR filter panel leaves no room for the old C values: no accumulate form)
-        if (acc || p.N <= 128) return TRID_E_UNSUPPORTED;
+    if constexpr (K == 256) {  // (beside the 128-VGPR filter panel the old C values fit for ONE row block per wave and step)
+        if (p.N <= 128) return TRID_E_UNSUPPORTED;
+        if (acc) return launch_stream<K, 8, 1, true>(p, stream);
         return launch_stream<K, 8, 2, false>(p, stream);
     } else {
         if (p.N > 128 && !acc && p.C == nullptr) {  // statistics only: three stages (K = 128: 64-row steps, 3 x 32 KB)
@@ -575,7 +576,8 @@ using namespace trid;
 // rows per BatchNorm partial (= rows per step) of the streaming kernel for this shape, 0 when it does not apply
 extern "C" int trid_gemm_p16_stream_rows(int M, int N, int K, int accumulate) {
     if (!(K == 64 || K == 128 || K == 256) || N <= 0 || N % 32 != 0 || M <= 0) return 0;
-    if (K == 256 && (accumulate || N <= 128)) return 0;  // (256 -> 128 measured no faster than the tile kernel: 146 vs 142 us)
+    if (K == 256 && N <= 128) return 0;  // (256 -> 128 measured no faster than the tile kernel: 146 vs 142 us)
+    if (K == 256 && accumulate) return 32;
     if (N > 128) return (accumulate || K == 256) ? 64 : 128;
     if (N > 64) return K == 256 ? 64 : 128;
     return 128;
