@@ -180,6 +180,16 @@ int trid_stem_conv1_f32(const float* img, const float* w, float* y, float* stats
 /* ... and its weight gradient (autograd of that nn.Conv2d): dw [32][27] = sum over output pixels of dy [B][Ho][Wo][32] (fp32)
  * times the image values under the 27 taps, gathered from the NCHW image (no im2col tensor), exact fp32 MFMA; slabs: scratch
  * of trid_stem_conv1_wgrad_slabs() * 864 floats (per-workgroup partial gradients, folded in a fixed order). */
+/* Weight gradient of the same 3x3 convolutions (autograd of nn.Conv2d(C, N, 3, padding=1): stem conv2 / conv3, layer1's
+ * conv2) with every pixel of x and dy staged once (rings of image rows in LDS, nine shifted transposing fragment reads): dy =
+ * P16 NHWC [B][H][W][Cout], x = P16 NHWC [B][H][W][Cin], dw fp32 [Cout][9 * Cin] (column = tap * Cin + c, as
+ * trid_gemm_p16_wgrad with TRID_B_CONV); slabs: scratch of trid_conv3x3_wgrad_halo_slabs() * Cout * 9 * Cin floats.
+ * trid_conv3x3_wgrad_halo_rows: image rows per step, 0 = geometry not covered ((Cin, Cout) in {(32,32), (32,64), (64,64)},
+ * W % 16 == 0) - use trid_gemm_p16_wgrad then. */
+int trid_conv3x3_wgrad_halo_rows(int H, int W, int Cin, int Cout);
+int trid_conv3x3_wgrad_halo_slabs(void);
+int trid_conv3x3_wgrad_halo_p16(const void* dy, const float* dy_amax, const void* x, const float* x_amax, float* dw, float* slabs,
+                                int B, int H, int W, int Cin, int Cout, void* stream);
 int trid_stem_conv1_wgrad_slabs(void);
 int trid_stem_conv1_wgrad_f32(const float* img, const float* dy, float* dw, float* slabs, int B, int Hi, int Wi, void* stream);
 /* 3x3 / stride 1 / pad 1 convolution (nn.Conv2d(C, N, 3, padding=1, bias=False): stem conv2 / conv3,

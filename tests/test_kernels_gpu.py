@@ -197,6 +197,23 @@ def test_conv3x3_halo_p16(ops, B, C, H, W, N, cpi):
         assert rel(dx.permute(0, 3, 1, 2), xr.grad) < TOL
 
 
+# (B, C, H, W, N): the stem's conv2 / conv3 and layer1's conv2 geometries, small and odd batch counts, several chunks per image
+@pytest.mark.parametrize("B,C,H,W,N", [(2, 32, 192, 64, 32), (3, 32, 48, 32, 32), (2, 32, 192, 64, 64), (5, 32, 24, 16, 64), (2, 64, 96, 32, 64), (3, 64, 16, 16, 64)])
+def test_conv3x3_wgrad_halo_p16(ops, B, C, H, W, N):
+    """csrc/stem_conv.hip: the 3x3 weight gradient with rings of x and dy rows in LDS (each pixel staged once, nine shifted
+    transposing fragment reads) against autograd and against the transposing GEMM kernel it replaces; two runs: same bits."""
+    x, w, gy = R("gx", B, C, H, W), R("gw", N, C, 3, 3, scale=0.1), R("gg", B, N, H, W)
+    wr = w.clone().requires_grad_(True)
+    F.conv2d(x, wr, padding=1).backward(gy)
+    want = wr.grad.permute(0, 2, 3, 1).reshape(N, 9 * C)  # [N][tap][c]
+    assert ops.conv3x3_wgrad_halo_rows(H, W, C, N) > 0
+    xp, gp = ops.p16_pack(dev(nhwc(x))), ops.p16_pack(dev(nhwc(gy)))
+    dw = ops.conv3x3_wgrad_halo_p16(gp, xp)
+    assert dw.shape == (N, 9 * C) and rel(dw, want) < 2e-6
+    assert rel(dw, ops.wgrad_p16(gp, xp, conv=(H, W, C))) < 2e-6
+    assert torch.equal(dw, ops.conv3x3_wgrad_halo_p16(gp, xp))
+
+
 @pytest.mark.parametrize("B,H,W", [(3, 24, 16), (2, 384, 128), (5, 96, 32), (1, 22, 10), (2, 23, 11)])
 def test_stem_conv1_wgrad_direct(ops, B, H, W):
     """csrc/stem_conv.hip: the weight gradient of the 3 -> 32 channel, stride-2 convolution straight from the NCHW image

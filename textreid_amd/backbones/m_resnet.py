@@ -320,6 +320,9 @@ def stem_backward_p16(mod, rec, g, WPT, ws, G):
     Bi, H, W, _ = y3.shape
 
     def wgrad(dy, act, C):
+        if ops.conv3x3_wgrad_halo_rows(H, W, C, dy.shape[-1]):  # every pixel staged once (csrc/stem_conv.hip)
+            return ws.run(lambda d_, x_: ops.conv3x3_wgrad_halo_p16(ops.P16(d_, dy.amax), ops.P16(x_, act.amax)), dy.data, act.data,
+                          keep=(dy.amax, act.amax))
         return ws.run(lambda d_, x_: ops.wgrad_p16(ops.P16(d_, dy.amax), ops.P16(x_, act.amax), conv=(H, W, C)), dy.data, act.data,
                       keep=(dy.amax, act.amax))
 
@@ -497,6 +500,9 @@ def block_backward_p16(blk, rec, g, WPT, ws, G):
     fmt = x.fmt
 
     def wgrad(dy, act, conv=None):
+        if conv is not None and fmt == 1 and ops.conv3x3_wgrad_halo_rows(conv[0], conv[1], conv[2], dy.shape[-1]):  # layer1's conv2
+            return ws.run(lambda d_, x_: ops.conv3x3_wgrad_halo_p16(ops.P16(d_, dy.amax), ops.P16(x_, act.amax)), dy.data, act.data,
+                          keep=(dy.amax, act.amax))
         return ws.run(lambda d_, x_: ops.wgrad_p16(ops.P16(d_, dy.amax, fmt), ops.P16(x_, act.amax, fmt), conv=conv), dy.data, act.data,
                       keep=(dy.amax, act.amax))
 

@@ -714,6 +714,10 @@ __global__ __launch_bounds__(512, 4) void gemm_p16_wgrad_kernel(GemmParams p) {
         }
     };
 
+    // a wave whose 32 x 32 sub-tile lies outside [M] x [N] (32 output channels in a 64-row tile: the stem's conv2; the last
+    // column tile of 9 * 32 = 288 columns) only loads and synchronises: its MFMAs would take half of its SIMD's matrix
+    // pipe from the wave that has work
+    const bool wave_live = (m0 + wm * (32 * TM) < p.M) && (n0 + wn * 32 < p.N);
     {
 #pragma unroll
         for (int s = 0; s < STAGES - 1; ++s)
@@ -726,7 +730,7 @@ __global__ __launch_bounds__(512, 4) void gemm_p16_wgrad_kernel(GemmParams p) {
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             if (t + STAGES - 1 < nk) issue(t + STAGES - 1, istage);
-            compute(stage);
+            if (wave_live) compute(stage);
             stage = (stage + 1 == STAGES) ? 0 : stage + 1;
             istage = (istage + 1 == STAGES) ? 0 : istage + 1;
         }

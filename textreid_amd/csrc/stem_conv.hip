@@ -70,6 +70,7 @@ struct HaloParams {
     int chunks_per_image;
     int nchunks;
     FastDiv fdW;
+    FastDiv fd_cpr;       // DMA chunk -> ring row
     int nt;               // non-temporal image loads / output stores (tensors far beyond the Infinity Cache)
 };
 
@@ -138,7 +139,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_p16_kernel(HaloParams p) 
     auto issue_rows = [&](int b, int y_first, int nrows, int slot_first) {
         const int total = nrows * cpr;
         for (int i = wave; i < total; i += NW) {
-            const int rr = i / cpr, c = i - rr * cpr;
+            const int rr = (int)fdiv((uint32_t)i, p.fd_cpr), c = i - rr * cpr;
             const int y = y_first + rr;
             int slot = slot_first + rr;
             slot = slot >= R ? slot - R : slot;
@@ -487,6 +488,168 @@ __global__ __launch_bounds__(256) void stem_conv1_wgrad_kernel(Conv1WgradParams 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------- 3x3 weight gradients
+// dW[n][tap][c] = sum over pixels of dy[pixel][n] * x[pixel + tap offset][c] for the same layers (32 / 64 channels, the
+// largest maps).  The transposing GEMM kernel (gemm_p16.hip) stages the shifted image once per TAP: nine passes of x through
+// the L2 -> LDS path (3.5 GB per launch for the stem's conv2, 15 TB/s: its limit).  Here the rings of the forward kernel
+// return: TH + 2 rows of x (with the zero padding as data) and TH rows of dy in LDS, each pixel staged ONCE, and the nine
+// taps are nine shifted TRANSPOSING fragment reads (ds_read_b64_tr_b16: a lane gets 4 consecutive pixels of its channel)
+// of the same x image against one dy fragment.  The reduction runs over pixels (16 per MFMA), the OUTPUT tile of a wave -
+// 32 dy channels x 32 x channels x 9 taps - lives in 144 accumulator VGPRs for the whole launch; waves split the pixels
+// of a step, meet in LDS at the end, and every workgroup writes one [N][9 C] slab (folded by trid_slab_reduce_f32 in a fixed
+// order).  LDS row image: [32-channel group][pixel slot][128 B], 16-byte slot s of pixel slot q stored at
+// s ^ (4 * ((q >> 1) & 1)) - the reader applies the swizzle of the slot it actually reads, so any tap shift stays
+// conflict-free (rows q and q + 2 of a 4-pixel tile share banks and differ in that bit).
+struct HaloWgradParams {
+    const char* x;        // P16 NHWC [B][H][W][CIN]
+    const char* dy;       // P16 NHWC [B][H][W][COUT]
+    float* slabs;         // [gridDim.x][COUT][9 * CIN]
+    const float* x_amax;
+    const float* dy_amax;
+    int B, H, W, TH;
+    int xcpg;             // 1-KB DMA chunks per channel group of an x ring row: ceil((W + 2) / 8)
+    int rg_per_chunk, chunks_per_image, nchunks;
+    FastDiv fd_xrow, fd_xcpg, fd_drow, fd_dcpg, fdW;  // chunk -> (row, group, pixel block); pixel -> (row, column)
+};
+
+typedef __fp16 h4v_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
+__device__ __forceinline__ f16x8 tr_frag8(const char* lds_addr) {  // 8 pixels of this lane's channel: two 4-pixel transposing reads
+    typedef __attribute__((address_space(3))) h4v_t* lp;
+    const h4v_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lp)(lds_addr));
+    const h4v_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lp)(lds_addr + 512));
+    f16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+}
+
+// 8 waves = (COUT / 32 dy-channel blocks) x (CIN / 32 x-channel blocks) x PG pixel groups
+template <int CIN, int COUT>
+__global__ __launch_bounds__(512, 2) void conv3x3_wgrad_halo_p16_kernel(HaloWgradParams p) {
+    constexpr int NW = 8, NB = COUT / 32, CBK = CIN / 32, PG = NW / (NB * CBK);
+    extern __shared__ __attribute__((aligned(16))) uint4 smem[];
+    const int W = p.W, H = p.H, TH = p.TH;
+    const int RX = 2 * TH + 2;
+    const int xgs = p.xcpg * 1024, xrowb = CBK * xgs;  // x ring: bytes per channel-group plane / per row
+    const int dgs = W * 128, drowb = NB * dgs;          // dy ring
+    char* const xring = reinterpret_cast<char*>(smem);
+    char* const dring = xring + (size_t)RX * xrowb;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nb = wave / (CBK * PG), cbk = (wave / PG) % CBK, pg = wave % PG;
+    // transposing-read lane constants: 16-channel half h, pixel r4 of the 4 x 16 tile, 8-byte chunk c8, k half kh
+    const int h = (lane >> 4) & 1, r4 = (lane & 15) >> 2, c8 = lane & 3, kh = lane >> 5;
+
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (unsigned)((size_t)p.B * H * W * CIN * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, (unsigned)((size_t)p.B * H * W * COUT * 4), 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+
+    // x rows [y_first, y_first + nrows) of image b -> ring slots slot_first .. (mod RX); slot q of a row is image column q - 1
+    auto issue_x = [&](int b, int y_first, int nrows, int slot_first) {
+        const int per_row = CBK * p.xcpg;
+        for (int i = wave; i < nrows * per_row; i += NW) {
+            const int rr = (int)fdiv((uint32_t)i, p.fd_xrow), c = i - rr * per_row;
+            const int g = CBK == 1 ? 0 : (int)fdiv((uint32_t)c, p.fd_xcpg), q = 8 * (c - g * p.xcpg) + (lane >> 3);
+            int slot = slot_first + rr;
+            slot = slot >= RX ? slot - RX : slot;
+            const int y = y_first + rr, xx = q - 1;
+            const int su = (lane & 7) ^ (((q >> 1) & 1) << 2);
+            const bool ok = (y >= 0) && (y < H) && (xx >= 0) && (xx < W);
+            const unsigned vo = ok ? (unsigned)((((size_t)b * H + y) * W + xx) * (CIN * 4) + g * 128 + su * 16) : OOB;
+            dma16(rsX, xring + (size_t)slot * xrowb + c * 1024, vo, false);
+        }
+    };
+    // dy rows [y_first, y_first + TH) -> ring rows half * TH ..
+    auto issue_d = [&](int b, int y_first, int half) {
+        const int cpg = W / 8, per_row = NB * cpg;
+        for (int i = wave; i < TH * per_row; i += NW) {
+            const int rr = (int)fdiv((uint32_t)i, p.fd_drow), c = i - rr * per_row;
+            const int g = NB == 1 ? 0 : (int)fdiv((uint32_t)c, p.fd_dcpg), q = 8 * (c - g * cpg) + (lane >> 3);
+            const int su = (lane & 7) ^ (((q >> 1) & 1) << 2);
+            const unsigned vo = (unsigned)((((size_t)b * H + (y_first + rr)) * W + q) * (COUT * 4) + g * 128 + su * 16);
+            dma16(rsD, dring + (size_t)(half * TH + rr) * drowb + c * 1024, vo, false);
+        }
+    };
+
+    v16f acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    const int ksteps = TH * W / 16;      // 16-pixel reduction steps per step tile
+    const int kper = ksteps / PG;        // ... of this wave (the host guarantees divisibility)
+    // byte offset of this lane's fragment piece inside a pixel's 128-byte line: slot (plane, half, chunk), swizzled by the pixel slot
+    auto piece = [&](int q, int pl) { return q * 128 + ((((pl * 4 + h * 2 + (c8 >> 1))) ^ (((q >> 1) & 1) << 2)) << 4) + 8 * (c8 & 1); };
+
+    for (int chunk = blockIdx.x; chunk < p.nchunks; chunk += gridDim.x) {
+        const int b = chunk / p.chunks_per_image;
+        int y0 = (chunk - b * p.chunks_per_image) * p.rg_per_chunk * TH;
+        int slot0 = 0;  // ring slot of image row y0 - 1
+        issue_x(b, y0 - 1, TH + 2, 0);
+        issue_d(b, y0, 0);
+        for (int s = 0; s < p.rg_per_chunk; ++s) {
+            wait_vm<0>();  // (no stores in this loop: everything this wave has in flight are the rows of this step)
+            lds_barrier();
+            if (s + 1 < p.rg_per_chunk) {
+                int sl = slot0 + TH + 2;
+                sl = sl >= RX ? sl - RX : sl;
+                issue_x(b, y0 + TH + 1, TH, sl);
+                issue_d(b, y0 + TH, (s + 1) & 1);
+            }
+            const char* dbase = dring + (size_t)((s & 1) * TH) * drowb + nb * dgs;
+            for (int kk = 0; kk < kper; ++kk) {
+                const int pix = (pg * kper + kk) * 16;       // first pixel of this k step inside the step tile
+                const int ty = (int)fdiv((uint32_t)pix, p.fdW), x0 = pix - ty * W;
+                const int qd = x0 + 8 * kh + r4;
+                const f16x8 ah = tr_frag8(dbase + (size_t)ty * drowb + piece(qd, 0));
+                const f16x8 al = tr_frag8(dbase + (size_t)ty * drowb + piece(qd, 1));
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    int rs = slot0 + ty + ky;
+                    rs = rs >= RX ? rs - RX : rs;
+                    rs = rs >= RX ? rs - RX : rs;
+                    const char* xb = xring + (size_t)rs * xrowb + cbk * xgs;
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const int qx = x0 + kx + 8 * kh + r4;
+                        const f16x8 bh = tr_frag8(xb + piece(qx, 0));
+                        const f16x8 bl = tr_frag8(xb + piece(qx, 1));
+                        const int t = ky * 3 + kx;
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[t], 0, 0, 0);
+                    }
+                }
+            }
+            y0 += TH;
+            slot0 += TH;
+            slot0 = slot0 >= RX ? slot0 - RX : slot0;
+        }
+        lds_barrier();  // every wave is done with the rings before the next chunk primes them
+    }
+
+    // ---- the pixel groups of a (dy block, x block) pair meet in LDS, tap by tap; one slab per workgroup
+    const float f = 1.f / (f16_scale_of(*p.x_amax) * f16_scale_of(*p.dy_amax));
+    float* const tile = reinterpret_cast<float*>(smem);  // [NW][32][33]
+    float* const out = p.slabs + (size_t)blockIdx.x * (COUT * 9 * CIN);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tile[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh) * 33 + (lane & 31)] = f * acc[t][r];
+        __syncthreads();
+        for (int e = tid; e < NB * CBK * 1024; e += 512) {
+            const int pair = e >> 10, i = (e >> 5) & 31, j = e & 31;  // pair = nb * CBK + cbk
+            float v = 0.f;
+#pragma unroll
+            for (int g = 0; g < PG; ++g) v += tile[((pair * PG + g) * 32 + i) * 33 + j];
+            out[(size_t)((pair / CBK) * 32 + i) * (9 * CIN) + t * CIN + (pair % CBK) * 32 + j] = v;
+        }
+        __syncthreads();
+    }
+}
+
 template <int CIN, int COUT>
 static int launch_halo(HaloParams& p, hipStream_t stream) {
     constexpr int NW = 8, CB = COUT / 32, KG = CIN / 32, PB = NW / (CB * KG);
@@ -555,6 +718,7 @@ extern "C" int trid_conv3x3_halo_p16(const void* x, const float* x_amax, const v
     p.rg_per_chunk = rg / cpi;
     p.nchunks = B * cpi;
     p.fdW = make_fastdiv((uint32_t)W);
+    p.fd_cpr = make_fastdiv((uint32_t)(p.rowb >> 10));
     static const int nt_env = getenv("TRID_STREAM_NT") ? atoi(getenv("TRID_STREAM_NT")) : -1;
     p.nt = nt_env >= 0 ? (nt_env != 0) : ((long long)B * H * W * std::min(Cin, Cout) * 4 >= STREAM_NT_MIN_BYTES);
     hipStream_t s = (hipStream_t)stream;
@@ -562,6 +726,77 @@ extern "C" int trid_conv3x3_halo_p16(const void* x, const float* x_amax, const v
     if (Cin == 32 && Cout == 64) return launch_halo<32, 64>(p, s);
     if (Cin == 64 && Cout == 64) return launch_halo<64, 64>(p, s);  // (layer1's conv2, m_resnet.py:22)
     return launch_halo<64, 32>(p, s);
+}
+
+// rows per step of the ring-of-rows weight-gradient kernel, 0 when it does not cover the geometry
+static int halo_wgrad_rows(int H, int W, int Cin, int Cout) {
+    if (!((Cin == 32 && (Cout == 32 || Cout == 64)) || (Cin == 64 && Cout == 64)) || W <= 0 || W % 16 != 0) return 0;
+    const int pg = 8 / ((Cin / 32) * (Cout / 32));
+    for (int th = 4; th >= 1; th >>= 1) {
+        if (H % th != 0 || (th * W / 16) % pg != 0) continue;
+        const size_t xrowb = (size_t)(Cin / 32) * ((W + 2 + 7) / 8) * 1024, drowb = (size_t)(Cout / 32) * W * 128;
+        if ((2 * th + 2) * xrowb + 2 * th * drowb <= 160 * 1024) return th;
+    }
+    return 0;
+}
+
+constexpr int HWG_SLABS = 256;
+
+extern "C" int trid_conv3x3_wgrad_halo_rows(int H, int W, int Cin, int Cout) { return halo_wgrad_rows(H, W, Cin, Cout); }
+extern "C" int trid_conv3x3_wgrad_halo_slabs(void) { return HWG_SLABS; }
+
+template <int CIN, int COUT>
+static int launch_halo_wgrad(HaloWgradParams& p, int grid, hipStream_t stream) {
+    const size_t lds = std::max((size_t)(2 * p.TH + 2) * (CIN / 32) * p.xcpg * 1024 + (size_t)2 * p.TH * (COUT / 32) * p.W * 128, (size_t)8 * 32 * 33 * 4);
+    static std::once_flag once;
+    static hipError_t attr_err = hipSuccess;
+    std::call_once(once, [] {
+        attr_err = hipFuncSetAttribute((const void*)conv3x3_wgrad_halo_p16_kernel<CIN, COUT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    });
+    if (attr_err != hipSuccess) {
+        set_error("trid_conv3x3_wgrad_halo_p16: cannot reserve LDS: %s", hipGetErrorString(attr_err));
+        return (int)attr_err;
+    }
+    hipLaunchKernelGGL((conv3x3_wgrad_halo_p16_kernel<CIN, COUT>), dim3(grid), dim3(512), lds, stream, p);
+    return check_launch("trid_conv3x3_wgrad_halo_p16");
+}
+
+extern "C" int trid_conv3x3_wgrad_halo_p16(const void* dy, const float* dy_amax, const void* x, const float* x_amax, float* dw, float* slabs,
+                                           int B, int H, int W, int Cin, int Cout, void* stream) {
+    TRID_REQUIRE(dy && x && dw && slabs && dy_amax && x_amax && B > 0 && H > 0 && W > 0, "trid_conv3x3_wgrad_halo_p16: bad arguments");
+    TRID_REQUIRE(aligned16(dy) && aligned16(x) && aligned16(dw) && aligned16(slabs), "trid_conv3x3_wgrad_halo_p16: operands must be 16-byte aligned");
+    const int th = halo_wgrad_rows(H, W, Cin, Cout);
+    TRID_REQUIRE(th > 0, "trid_conv3x3_wgrad_halo_p16: geometry H=%d W=%d Cin=%d Cout=%d is not covered (trid_conv3x3_wgrad_halo_rows() == 0)", H, W, Cin, Cout);
+    TRID_REQUIRE((long long)B * H * W * std::max(Cin, Cout) * 4 < (1ll << 31), "trid_conv3x3_wgrad_halo_p16: tensors must stay below 2 GB (31-bit buffer offsets)");
+    HaloWgradParams p;
+    memset(&p, 0, sizeof(p));
+    p.x = (const char*)x; p.dy = (const char*)dy; p.slabs = slabs;
+    p.x_amax = x_amax; p.dy_amax = dy_amax;
+    p.B = B; p.H = H; p.W = W; p.TH = th;
+    p.xcpg = (W + 2 + 7) / 8;
+    p.fd_xrow = make_fastdiv((uint32_t)((Cin / 32) * p.xcpg));
+    p.fd_xcpg = make_fastdiv((uint32_t)p.xcpg);
+    p.fd_drow = make_fastdiv((uint32_t)((Cout / 32) * (W / 8)));
+    p.fd_dcpg = make_fastdiv((uint32_t)(W / 8));
+    p.fdW = make_fastdiv((uint32_t)W);
+    const int rg = H / th;
+    int cpi = rg;  // chunks per image: the smallest divisor of the step count that gives the chip >= 256 chunks
+    for (int d = 1; d <= rg; ++d)
+        if (rg % d == 0 && (long long)B * d >= HWG_SLABS) {
+            cpi = d;
+            break;
+        }
+    p.chunks_per_image = cpi;
+    p.rg_per_chunk = rg / cpi;
+    p.nchunks = B * cpi;
+    const int grid = std::min(p.nchunks, HWG_SLABS);
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    if (Cin == 32 && Cout == 32) rc = launch_halo_wgrad<32, 32>(p, grid, s);
+    else if (Cin == 32) rc = launch_halo_wgrad<32, 64>(p, grid, s);
+    else rc = launch_halo_wgrad<64, 64>(p, grid, s);
+    if (rc) return rc;
+    return trid_slab_reduce_f32(slabs, dw, (long long)Cout * 9 * Cin, grid, (long long)Cout * 9 * Cin, 0, stream);
 }
 
 extern "C" int trid_stem_conv1_wgrad_slabs(void) { return C1W_SLABS; }

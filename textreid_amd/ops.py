@@ -400,6 +400,26 @@ def stem_conv1(images, w, stats=True):
     return (y, st) if stats else y
 
 
+USE_HALO_WGRAD = __import__("os").environ.get("TRID_HALO_WGRAD", "1") != "0"  # 3x3 weight gradients with 32 / 64 channels on the ring-of-rows kernel (0: A/B runs)
+
+
+def conv3x3_wgrad_halo_rows(H, W, Cin, Cout):
+    return int(L.load().trid_conv3x3_wgrad_halo_rows(int(H), int(W), int(Cin), int(Cout))) if USE_HALO_WGRAD else 0
+
+
+def conv3x3_wgrad_halo_p16(dy, x):
+    """Weight gradient of a 3x3 / stride 1 / pad 1 convolution with 32 / 64 channels: dy P16 [B,H,W,N], x P16 [B,H,W,C] -> dw fp32
+    [N, 9*C] (column = tap * C + c, as wgrad_p16(conv=...)); every pixel staged once (csrc/stem_conv.hip)."""
+    Bi, H, W, C = x.shape
+    N = dy.shape[-1]
+    if dy.fmt != 1 or x.fmt != 1 or not conv3x3_wgrad_halo_rows(H, W, C, N):
+        raise RuntimeError("conv3x3_wgrad_halo_p16: geometry H=%d W=%d Cin=%d Cout=%d (or a non-P16 operand) is not covered" % (H, W, C, N))
+    dw = empty((N, 9 * C), x.data)
+    slabs = empty((int(L.load().trid_conv3x3_wgrad_halo_slabs()), N * 9 * C), x.data)
+    call("trid_conv3x3_wgrad_halo_p16", _p(dy.data), _p(dy.amax), _p(x.data), _p(x.amax), _p(dw), _p(slabs), Bi, H, W, C, N, stream())
+    return dw
+
+
 def stem_conv1_wgrad(images, dy):
     """Weight gradient of the stem's first convolution: dw [32, 3, 3, 3] from the NCHW image batch and dy fp32 [B,Ho,Wo,32]
     (exact fp32 MFMA, no im2col tensor)."""

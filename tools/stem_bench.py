@@ -75,7 +75,15 @@ for (C, N, tag) in ((32, 32, "wgrad conv2"), (32, 64, "wgrad conv3")):
     line("%s: dy[M,%d]^T x gather(x[M,%d]) library default (old: %s)" % (tag, N, C, "exact fp32" if N == 32 else "split"),
          t(lambda: ops.conv3x3_wgrad(dy, x) if N == 32 else ops.conv3x3_wgrad(dy, x, prec=16, aa=ad, ba=ax), reps=5), nb)
     line("%s: transposing P16 kernel" % tag, t(lambda: ops.wgrad_p16(dp, xp, conv=(H, W, C)), reps=5), nb)
+    line("%s: ring-of-rows kernel + slab fold" % tag, t(lambda: ops.conv3x3_wgrad_halo_p16(dp, xp), reps=5), nb)
     del x, dy, xp, dp
+x = torch.relu(torch.randn(B, 96, 32, 64, generator=g)).to(dev)
+dy = torch.randn(B, 96, 32, 64, generator=g).to(dev)
+xp, dp = ops.p16_pack(x), ops.p16_pack(dy)
+nb = B * 96 * 32 * 128 * 4
+line("wgrad layer1 conv2 64->64 (96x32): transposing P16 kernel", t(lambda: ops.wgrad_p16(dp, xp, conv=(96, 32, 64)), reps=5), nb)
+line("wgrad layer1 conv2 64->64 (96x32): ring-of-rows kernel + slab fold", t(lambda: ops.conv3x3_wgrad_halo_p16(dp, xp), reps=5), nb)
+del x, dy, xp, dp
 
 # ---- the BatchNorm passes of the stem (for the byte budget)
 y = torch.randn(B, H, W, 32, generator=g).to(dev)
