@@ -293,7 +293,7 @@ def test_gemm_p16_stream(ops, M_, N, K):
     assert abs(float(bound) - float(z.abs().max())) <= 1e-4 * float(z.abs().max())
 
 
-@pytest.mark.parametrize("M_,N,K", [(3072, 256, 64), (768 * 2 + 40, 512, 128), (64 * 7, 256, 128), (200, 512, 64)])
+@pytest.mark.parametrize("M_,N,K", [(3072, 256, 64), (768 * 2 + 40, 512, 128), (64 * 7, 256, 128), (200, 512, 64), (192 * 3 + 20, 1024, 256)])
 @pytest.mark.parametrize("keep_y", [False, True])
 def test_conv1x1_bn_res_fused(ops, M_, N, K, keep_y):
     """csrc/gemm_stream.hip FUSE: conv3 + bn3 + identity + ReLU of an identity block in one pass over the activations (the
@@ -311,7 +311,7 @@ def test_conv1x1_bn_res_fused(ops, M_, N, K, keep_y):
     fin_ref = ops.bn_finalize_minmax(st_ref, M_, dev(gamma), dev(beta), None, None, False, b_ref)
     out_ref, mask_ref = ops.bn_apply_p16(y_ref, fin_ref, b_ref, relu=True, res=ip, bound_res=ip.amax, want_mask=True)
     # statistics-only pass + fused pass
-    assert ops.conv1x1_bn_res_ok(M_, N, K)
+    assert ops.conv1x1_bn_res_ok(M_, N, K) == (K <= 128)  # (K = 256: covered by the kernel, not used by the model)
     st = ops.conv1x1_stats_p16(xp, wp)
     if st.rows_per_part == st_ref.rows_per_part:
         assert T.equal(st, st_ref)

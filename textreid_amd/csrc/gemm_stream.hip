@@ -557,6 +557,7 @@ static int pick_stream(StreamParams& p, hipStream_t stream) {
     if constexpr (K == 256) {  // (beside the 128-VGPR filter panel the old C values fit for ONE row block per wave and step)
         if (p.N <= 128) return TRID_E_UNSUPPORTED;
         if (acc) return launch_stream<K, 8, 1, true>(p, stream);
+        if (p.C == nullptr) return launch_stream<K, 8, 1, false, 3>(p, stream);  // statistics only: three stages of 32 rows
         return launch_stream<K, 8, 2, false>(p, stream);
     } else {
         if (p.N > 128 && !acc && p.C == nullptr) {  // statistics only: three stages (K = 128: 64-row steps, 3 x 32 KB)
@@ -586,6 +587,7 @@ extern "C" int trid_gemm_p16_stream_rows(int M, int N, int K, int accumulate) {
 // ... of the statistics-only pass (C == NULL)
 extern "C" int trid_gemm_p16_stream_stats_rows(int M, int N, int K) {
     if (N > 128 && K == 128) return 64;
+    if (N > 128 && K == 256) return 32;
     return trid_gemm_p16_stream_rows(M, N, K, 0);
 }
 
@@ -615,9 +617,9 @@ extern "C" int trid_gemm_p16_stream(const void* A, const float* a_amax, const vo
     return pick_stream<256>(p, s);
 }
 
-// shapes the fused conv3 + BatchNorm + identity + ReLU kernel covers (K = planes of layer1 / layer2, N = 4 planes)
+// shapes the fused conv3 + BatchNorm + identity + ReLU kernel covers (K = planes of layer1 - layer3, N = 4 planes)
 extern "C" int trid_conv1x1_bn_res_p16_ok(int M, int N, int K) {
-    return (K == 64 || K == 128) && N > 0 && N % 256 == 0 && M > 0 && (long long)M * N * 4 < (1ll << 31);
+    return (K == 64 || K == 128 || K == 256) && N > 0 && N % 256 == 0 && M > 0 && (long long)M * N * 4 < (1ll << 31);
 }
 
 extern "C" int trid_conv1x1_bn_res_p16(const void* A, const float* a_amax, const void* B, const float* b_amax, float* y,
@@ -625,7 +627,7 @@ extern "C" int trid_conv1x1_bn_res_p16(const void* A, const float* a_amax, const
                                        void* out, const float* bound_a, const float* bound_b, float* bound_sum,
                                        uint64_t* relu_mask, int M, int N, int K, int relu, void* stream) {
     TRID_REQUIRE(A && B && a_amax && b_amax && bn_scale && bn_shift && res && res_amax && out && bound_a, "trid_conv1x1_bn_res_p16: null operand");
-    TRID_REQUIRE(trid_conv1x1_bn_res_p16_ok(M, N, K), "trid_conv1x1_bn_res_p16: needs K in {64, 128}, N %% 256 == 0, tensors below 2 GB (M=%d N=%d K=%d)", M, N, K);
+    TRID_REQUIRE(trid_conv1x1_bn_res_p16_ok(M, N, K), "trid_conv1x1_bn_res_p16: needs K in {64, 128, 256}, N %% 256 == 0, tensors below 2 GB (M=%d N=%d K=%d)", M, N, K);
     TRID_REQUIRE(aligned16(A) && aligned16(B) && aligned16(res) && aligned16(out) && (!y || aligned16(y)) && (!relu_mask || aligned16(relu_mask)),
                  "trid_conv1x1_bn_res_p16: operands must be 16-byte aligned");
     StreamParams p;
@@ -645,5 +647,6 @@ extern "C" int trid_conv1x1_bn_res_p16(const void* A, const float* a_amax, const
     p.nt_o = nt_env >= 0 ? ((nt_env >> 1) & 1) : big;
     hipStream_t s = (hipStream_t)stream;
     if (K == 64) return y ? launch_stream<64, 8, 2, false, 2>(p, s) : launch_stream<64, 8, 2, false, 1>(p, s);
-    return y ? launch_stream<128, 8, 2, false, 2>(p, s) : launch_stream<128, 8, 2, false, 1>(p, s);
+    if (K == 128) return y ? launch_stream<128, 8, 2, false, 2>(p, s) : launch_stream<128, 8, 2, false, 1>(p, s);
+    return y ? launch_stream<256, 8, 1, false, 2>(p, s) : launch_stream<256, 8, 1, false, 1>(p, s);  // (one row block per wave: the 128-VGPR filter panel)
 }

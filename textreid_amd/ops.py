@@ -468,7 +468,9 @@ USE_FUSED_EXPAND = __import__("os").environ.get("TRID_FUSED_EXPAND", "1") != "0"
 
 
 def conv1x1_bn_res_ok(M, N, K):
-    return USE_FUSED_EXPAND and USE_STREAM and bool(L.load().trid_conv1x1_bn_res_p16_ok(int(M), int(N), int(K)))
+    """Does the fused conv3 + bn3 + identity pass pay for this shape?  (K = 256 - layer3 - is built and tested but measured
+    no faster than GEMM + apply: 104 vs 103 us, its statistics-only pass is compute-bound; tools/exp/fused_bench.py)"""
+    return USE_FUSED_EXPAND and USE_STREAM and K <= 128 and bool(L.load().trid_conv1x1_bn_res_p16_ok(int(M), int(N), int(K)))
 
 
 def conv1x1_stats_p16(x, w):

@@ -12,7 +12,7 @@ def t(fn, reps=20):
     for _ in range(reps): fn()
     e1.record(); T.cuda.synchronize()
     return e0.elapsed_time(e1) / reps * 1e3
-for (M, N, K) in ((393216, 256, 64), (98304, 512, 128)):
+for (M, N, K) in ((393216, 256, 64), (98304, 512, 128), (24576, 1024, 256)):
     x, w, ident = T.relu(T.randn(M, K, device=dev)), T.randn(N, K, device=dev) * 0.2, T.relu(T.randn(M, N, device=dev))
     xp, wp, ip = ops.p16_pack(x), ops.p16_pack(w), ops.p16_pack(ident)
     del x, ident
