@@ -183,7 +183,7 @@ def p16_eligible(mod, mult=32):
     return cache[mult]
 
 
-def p16_weights(mod, WA, transposed, fmt=1):
+def p16_weights(mod, WA, transposed, fmt=1, stem_only=False):
     """{id(conv weight): ops.P16} for every residual-block filter of `mod`, ONE multi-tensor launch: the forward
     operands [N][taps*C] (filters as stored: 3x3 in OHWI) or, transposed, the data-gradient operands [C][taps*N] with
     the taps reversed.  fmt 1: P16 (scaled by WA's amax scalars); fmt 2: plain bf16.  Destination buffers and the
@@ -194,9 +194,11 @@ def p16_weights(mod, WA, transposed, fmt=1):
     mine = [m.weight for blk in blocks for m in blk.modules() if isinstance(m, nn.Conv2d)]
     if fmt == 1 and hasattr(mod, "blocks") and stem_p16_channels(mod):
         mine = [mod.conv2.weight, mod.conv3.weight] + mine  # the stem's 3x3 convolutions run on P16 operands too (stem_forward_p16)
+    if stem_only:  # bf16 mode: the residual blocks read bf16 filters, the stem stays fp32-class on ITS two P16 filters
+        mine = [mod.conv2.weight, mod.conv3.weight]
     key = tuple(w.data_ptr() for w in mine)
     plans = mod.__dict__.setdefault("_p16_plans", {})
-    plan = plans.get((transposed, fmt))
+    plan = plans.get((transposed, fmt, stem_only))
     if plan is None or plan[0] != key:
         dev = mine[0].device
         dsts, rows = [], []
@@ -208,7 +210,7 @@ def p16_weights(mod, WA, transposed, fmt=1):
             dsts.append(d)
             rows.append([w.data_ptr(), d.data_ptr(), N, T, C, index[id(w)]])
         plan = (key, torch.tensor(rows, dtype=torch.int64, device=dev), dsts)
-        plans[(transposed, fmt)] = plan
+        plans[(transposed, fmt, stem_only)] = plan
     ops.call("trid_p16_pack_multi_f32", ops._p(plan[1]), ops._p(WA["all"]), len(mine), 1 if transposed else 0, fmt, ops.stream())
     return {id(w): ops.P16(d, WA[id(w)] if fmt == 1 else None, fmt) for w, d in zip(mine, plan[2])}
 
@@ -288,7 +290,7 @@ def stem_p16_ok(mod, images):
             and all(ops.conv3x3_halo_rows(Ho, Wo, ci, co) > 0 for ci, co in ((32, 32), (32, 64), (64, 32))))
 
 
-def stem_forward_p16(mod, images, WP, dev, nbt, masks=None):
+def stem_forward_p16(mod, images, WP, dev, nbt, masks=None, out_fmt=1):
     """The stem (m_resnet.py:199-207) as bandwidth-shaped kernels on pre-split operands: conv1 straight from the NCHW
     image (exact fp32 MFMA, no im2col tensor), conv2 / conv3 on the ring-of-rows kernel with their inputs written as
     P16 tensors by the BatchNorm passes (bounds from the conv epilogues' column extremes), and the pooled output handed
@@ -305,7 +307,8 @@ def stem_forward_p16(mod, images, WP, dev, nbt, masks=None):
     y3, p3, rpp3 = ops.conv3x3_halo_p16(a2, WP[id(mod.conv3.weight)])
     b3 = ops.amax_slot(dev)
     st3 = _finalize_minmax(mod.bn3, p3, M, True, b3, nbt, rpp3)
-    x = ops.bn_apply_pool2_p16(y3, st3, b3, relu=True)  # (an average never exceeds the maximum: b3 bounds the pooled tensor)
+    # (an average never exceeds the maximum: b3 bounds the pooled tensor; out_fmt 2 - bf16 mode - hands the blocks a bf16 tensor)
+    x = ops.bn_apply_pool2_p16(y3, st3, b3, relu=True, fmt=out_fmt)
     if masks is not None:
         masks.extend([a1.unpack() > 0, a2.unpack() > 0, _pre_mask(y3, st3)])
     return x, (images, y1, st1, a1, y2, st2, a2, y3, st3)
@@ -707,9 +710,12 @@ class ModifiedResNet(nn.Module):
         p16 = ops.USE_P16 and training and ar.PB in (16, 1) and p16_eligible(self, 32 if ar.PB == 16 else 64)
         fmt = (1 if ar.PB == 16 else 2) if p16 else 0
         WP = p16_weights(self, ar.WA, False, fmt) if p16 else None  # every filter the pass multiplies with, ONE launch
-        stem16 = fmt == 1 and ops.USE_P16_STEM and stem_p16_ok(self, images)
+        # the stem's bandwidth-shaped kernels are fp32-class (P16 operands, exact fp32 conv1) in BOTH modes: in the bf16 mode
+        # (configs[3]) the stem, like BatchNorm and the weight gradients, keeps fp32 arithmetic and hands over a bf16 tensor
+        stem16 = fmt in (1, 2) and ops.USE_P16_STEM and stem_p16_ok(self, images)
         if stem16:
-            x, srec = stem_forward_p16(self, images, WP, images.device, nbt, masks)
+            WPs = WP if fmt == 1 else p16_weights(self, ar.WA, False, 1, stem_only=True)
+            x, srec = stem_forward_p16(self, images, WPs, images.device, nbt, masks, out_fmt=fmt)
         else:
             x, ax, srec = stem_forward(self, images, ar, training, nbt, masks)
         if save:
@@ -885,7 +891,7 @@ class ModifiedResNet(nn.Module):
         S["blocks"] = None
         g = g.float()  # the stem's BatchNorm passes take fp32 gradients in every mode
         if S.get("stem_p16"):
-            stem_backward_p16(self, S["stem"], g, WPT, ws, G)
+            stem_backward_p16(self, S["stem"], g, WPT if p16 == 1 else p16_weights(self, ar.WA, True, 1, stem_only=True), ws, G)
         else:
             stem_backward(self, S["stem"], g, ar, ws, G)
         ws.join()
