@@ -330,28 +330,21 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 && STAGES == 2) ? 2 : (W
     auto emit_stats = [&]() {
         // BatchNorm partials per 128-row slab of the tile: column (mean, M2) over the slab's rows < M; with
         // stats_w == 4 also the column (min, max): the consumer derives max|BatchNorm(y)| - the fp16 scale of the
-        // NEXT operand - from them before the apply pass runs (an affine map takes extremes to extremes)
+        // NEXT operand - from them before the apply pass runs (an affine map takes extremes to extremes).
+        // Two levels, TWO barriers per tile (the one-level form - slab mean, then squared deviations from it - needed a
+        // barrier pair per reduction: seven per tile, 3-13 % of the short-K layers): every wave takes (mean, M2, min, max)
+        // of ITS 32 * TM rows in registers (its own mean: only means are subtracted), the waves of a slab meet in LDS once,
+        // and one of them merges the wave partials in wave order with Chan's formula.
         __syncthreads();
-        float* red = reinterpret_cast<float*>(smem);  // [WM][BN] (+ [WM][BN] for the second value of a pair)
+        float4* red = reinterpret_cast<float4*>(smem);  // [WM][BN]
         constexpr int WPS = 128 / (32 * TM);            // waves (along M) per slab
+        constexpr int WR = 32 * TM;                     // rows per wave
         const int slab = wm / WPS;
-        const int rows_left = p.M - (m0 + 128 * slab);
-        const int cnt = rows_left < 128 ? rows_left : 128;
-        const float inv = cnt > 0 ? 1.f / (float)cnt : 0.f;
-        auto column_total = [&](float s, int cl) {  // sum over the slab's 128 rows of a per-lane partial
-            s += __shfl_xor(s, 32, 64);
-            if (khalf == 0) red[wm * BN + cl] = s;
-            __syncthreads();
-            float t = 0.f;
-#pragma unroll
-            for (int w = 0; w < WPS; ++w) t += red[(slab * WPS + w) * BN + cl];
-            __syncthreads();
-            return t;
-        };
+        const int nw_i = min(max(p.M - (m0 + wm * WR), 0), WR);
+        const float inv_nw = nw_i > 0 ? 1.f / (float)nw_i : 0.f;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int cl = wn * (32 * TN) + 32 * j + (lane & 31);
-            const int col = n0 + cl;
             float s = 0.f, lo = INFINITY, hi = -INFINITY;
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -364,39 +357,50 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 && STAGES == 2) ? 2 : (W
                         hi = fmaxf(hi, acc[i][j][r]);
                     }
                 }
-            const float mean = column_total(s, cl) * inv;
-            s = 0.f;
+            s += __shfl_xor(s, 32, 64);
+            lo = fminf(lo, __shfl_xor(lo, 32, 64));
+            hi = fmaxf(hi, __shfl_xor(hi, 32, 64));
+            const float mean = s * inv_nw;
+            float q = 0.f;
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = row_base + i * 32 + (r & 3) + 8 * (r >> 2);
                     const float d = acc[i][j][r] - mean;
-                    if (row < p.M) s += d * d;
+                    if (row < p.M) q += d * d;
                 }
-            const float m2 = column_total(s, cl);
-            if (p.stats_w == 4) {
-                lo = fminf(lo, __shfl_xor(lo, 32, 64));
-                hi = fmaxf(hi, __shfl_xor(hi, 32, 64));
-                if (khalf == 0) {
-                    red[wm * BN + cl] = lo;
-                    red[(WM + wm) * BN + cl] = hi;
-                }
-                __syncthreads();
+            q += __shfl_xor(q, 32, 64);
+            if (khalf == 0) red[wm * BN + cl] = make_float4(mean, q, lo, hi);
+        }
+        __syncthreads();
+        if ((wm % WPS) == 0 && khalf == 0) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int cl = wn * (32 * TN) + 32 * j + (lane & 31);
+                const int col = n0 + cl;
+                float cnt = 0.f, mean = 0.f, m2 = 0.f, lo = INFINITY, hi = -INFINITY;
 #pragma unroll
                 for (int w = 0; w < WPS; ++w) {
-                    lo = fminf(lo, red[(slab * WPS + w) * BN + cl]);
-                    hi = fmaxf(hi, red[(WM + slab * WPS + w) * BN + cl]);
+                    const int nb_i = min(max(p.M - (m0 + (slab * WPS + w) * WR), 0), WR);
+                    if (nb_i > 0) {
+                        const float4 v = red[(slab * WPS + w) * BN + cl];
+                        const float nb = (float)nb_i, nt = cnt + nb, d = v.x - mean;
+                        mean += d * (nb / nt);
+                        m2 += v.y + d * d * (cnt * nb / nt);
+                        cnt = nt;
+                        lo = fminf(lo, v.z);
+                        hi = fmaxf(hi, v.w);
+                    }
                 }
-                __syncthreads();
-            }
-            if ((wm % WPS) == 0 && khalf == 0 && col < p.N && cnt > 0) {
-                float* dst = p.stats + (((long long)mb * (BM / 128) + slab) * p.N + col) * p.stats_w;
-                dst[0] = mean;
-                dst[1] = m2;
-                if (p.stats_w == 4) {
-                    dst[2] = lo;
-                    dst[3] = hi;
+                if (col < p.N && cnt > 0.f) {
+                    float* dst = p.stats + (((long long)mb * (BM / 128) + slab) * p.N + col) * p.stats_w;
+                    dst[0] = mean;
+                    dst[1] = m2;
+                    if (p.stats_w == 4) {
+                        dst[2] = lo;
+                        dst[3] = hi;
+                    }
                 }
             }
         }
