@@ -479,6 +479,35 @@ def main():
         step(n_prep + i)
         torch.cuda.synchronize()
         log("warmup step %d done" % i)
+    # recorded or eager?  Both run the same kernels on the same streams with bit-identical results (tests/test_match_state_gpu.py);
+    # which is faster depends on the box: the replay saves host time (one hipGraphLaunch instead of ~1000 launches) but its
+    # executor adds a dependency edge per node (~0.3 ms per step), the eager step needs the host to stay ahead of a 44 ms GPU
+    # step.  A short probe of each decides; both figures go into the line (TRID_BENCH_LAUNCH=graph / eager forces one).
+    launch_probe = None
+    use_eager = False
+    if runner is not None and runner.graph is not None:
+        def probe(fn, n=4):
+            torch.cuda.synchronize()
+            t0p = time.perf_counter()
+            for j in range(n):
+                fn(j)
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0p) / n * 1e3
+
+        base = n_prep + args.warmup
+        probe(lambda j: runner._eager(*batch(base + j)), 2)  # (the eager path's own warm-up after the recording)
+        ms_graph = probe(lambda j: step(base + 2 + j))
+        ms_eager = probe(lambda j: runner._eager(*batch(base + 6 + j)))
+        forced = os.environ.get("TRID_BENCH_LAUNCH", "")
+        use_eager = forced == "eager" or (forced != "graph" and ms_eager < 0.995 * ms_graph)
+        launch_probe = {"hipgraph_replay_ms_per_step": ms_graph, "eager_ms_per_step": ms_eager, "chosen": "eager" if use_eager else "hipgraph replay"}
+        if world > 1:  # every rank must take the same path: rank 0 decides
+            flag = torch.tensor([1 if use_eager else 0], device=device)
+            dist.broadcast(flag, 0)
+            use_eager = bool(flag.item())
+        log("launch probe: replay %.2f ms, eager %.2f ms per step -> %s" % (ms_graph, ms_eager, "eager" if use_eager else "replay"))
+        n_prep += 10
+    timed_step = (lambda i: runner._eager(*batch(i))) if use_eager else step
     # live roofline of the dominant kernel: 3x3 implicit-GEMM conv, 128x128 tiles
     split = ops.GEMM_PRECISION in (1, 3, 6)
     dom = (ops.A_CONV, ops.B_KC, 128, 128, split)
@@ -492,7 +521,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        last = step(n_prep + args.warmup + i)
+        last = timed_step(n_prep + args.warmup + i)
     t_host = time.perf_counter() - t0
     torch.cuda.synchronize()
     if world > 1:
@@ -676,7 +705,7 @@ def main():
         "achieved_isolated_zero_operands": achieved_isolated_zero,
         "frac_isolated_zero_operands": achieved_isolated_zero / peak,
         "power_note": "the *_zero_operands figures are the same launches on zero-filled tensors: identical instruction stream, lower switching power, higher sustained clock - the gap to *_isolated is set by the part's power limit under random fp16 operands, not by the kernel's schedule (profiles/r03j_zero_vs_random.txt; the guide's own best plain-HIP bf16 GEMM sustains 0.53-0.59 of the dense peak on random data)",
-        "note": ("achieved/frac: events around every launch of this kernel " + ("in %d eager re-runs of the step right after the timed region, all kernels on ONE stream (the timed steps are hipGraph replays: events cannot bracket graph nodes; with the product's four streams an event pair also counts the wait for CUs held by another stream's kernel; rocprofv3 --kernel-trace of this command gives the in-graph durations: rocprof_in_graph)" % profiled_eager if profiled_eager else "during the timed steps, while the text / key-encoder / weight-gradient streams share the CUs") + "; *_isolated: the same kernel on the five layer2-4 3x3 shapes with the GPU to itself"),
+        "note": ("achieved/frac: events around every launch of this kernel " + ("in %d eager re-runs of the step right after the timed region, all kernels on ONE stream (events cannot bracket the nodes of a replayed graph, and with the product's four streams an event pair also counts the wait for CUs held by another stream's kernel; rocprofv3 --kernel-trace of this command gives the durations inside the timed step: rocprof_in_graph)" % profiled_eager if profiled_eager else "during the timed steps, while the text / key-encoder / weight-gradient streams share the CUs") + "; *_isolated: the same kernel on the five layer2-4 3x3 shapes with the GPU to itself"),
         "peak_note": peak_note,
         "launches": nlaunch,
         "avg_launch_ms": ms / max(nlaunch, 1),
@@ -736,7 +765,7 @@ def main():
         log("retrieval: %.1f M gallery imgs/s" % (retr["value"] / 1e6))
     qsim = [queue_similarity_bench(device, B=B, K=k) for k in sorted({args.queue, 65536})]
     qsim.append(queue_similarity_bench(device, B=B, K=65536, bf16=True))
-    step_launch = "hipGraph replay (one launch per step)" if runner is not None else "eager (%d rank(s)%s)" % (world, ": RCCL collectives inside backward" if world > 1 else "")
+    step_launch = ("eager launches, four streams (chosen by the probe over the recorded step)" if use_eager else "hipGraph replay (one launch per step)") if runner is not None else "eager (%d rank(s)%s)" % (world, ": RCCL collectives inside backward" if world > 1 else "")
     c3 = None
     if world == 1 and not args.no_configs3 and ops.conv_precision() == 16 and args.model == "m_resnet50":
         del model, opt, runner
@@ -764,6 +793,7 @@ def main():
                 "parallelism": "dp%d" % world,
                 "optimizer": "Adam (fused multi-tensor)",
                 "step_launch": step_launch,
+                "launch_probe": launch_probe,
                 "host_enqueue_ms_per_step": t_host / args.steps * 1e3,
                 "gemm_arithmetic": arith,
                 "final_loss": loss_val,
