@@ -310,9 +310,16 @@ def gemm_p16(A, B, C, M, N, K, ldc, conv=None, alpha=1.0, accumulate=False, bias
 USE_STREAM = __import__("os").environ.get("TRID_STREAM_1X1", "1") != "0"  # short-K 1x1 convolutions on csrc/gemm_stream.hip (0: A/B runs)
 
 
+@__import__("functools").lru_cache(maxsize=None)
+def _query(name, *ints):
+    """A pure shape query of the library (cached: the same few shapes come back every step, and a ctypes call costs ~2 us of the
+    host time an eager step has to stay under)."""
+    return int(getattr(L.load(), name)(*ints))
+
+
 def gemm_p16_stream_rows(M, N, K, accumulate=False):
     """Rows per step (= per BatchNorm partial) of the streaming short-K kernel for this shape; 0: not covered."""
-    return int(L.load().trid_gemm_p16_stream_rows(int(M), int(N), int(K), 1 if accumulate else 0))
+    return _query("trid_gemm_p16_stream_rows", int(M), int(N), int(K), 1 if accumulate else 0)
 
 
 def gemm_p16_stream(A, B, C, M, N, K, ldc, accumulate=False, stats=None, cmask=None):
@@ -368,7 +375,7 @@ def conv_p16(x, w, conv3=False, stats=True):
 def conv3x3_halo_rows(H, W, Cin, Cout):
     """Image rows per step of the stem's ring-of-rows convolution kernel for this geometry (csrc/stem_conv.hip), 0 when
     the kernel does not cover it (channel counts other than 32 / 64, a width that does not tile 128 / 256 pixels)."""
-    return int(L.load().trid_conv3x3_halo_rows(int(H), int(W), int(Cin), int(Cout)))
+    return _query("trid_conv3x3_halo_rows", int(H), int(W), int(Cin), int(Cout))
 
 
 def conv3x3_halo_p16(x, w, stats=True, chunks_per_image=0):
@@ -404,7 +411,7 @@ USE_HALO_WGRAD = __import__("os").environ.get("TRID_HALO_WGRAD", "1") != "0"  # 
 
 
 def conv3x3_wgrad_halo_rows(H, W, Cin, Cout):
-    return int(L.load().trid_conv3x3_wgrad_halo_rows(int(H), int(W), int(Cin), int(Cout))) if USE_HALO_WGRAD else 0
+    return _query("trid_conv3x3_wgrad_halo_rows", int(H), int(W), int(Cin), int(Cout)) if USE_HALO_WGRAD else 0
 
 
 def conv3x3_wgrad_halo_p16(dy, x):
@@ -415,7 +422,7 @@ def conv3x3_wgrad_halo_p16(dy, x):
     if dy.fmt != 1 or x.fmt != 1 or not conv3x3_wgrad_halo_rows(H, W, C, N):
         raise RuntimeError("conv3x3_wgrad_halo_p16: geometry H=%d W=%d Cin=%d Cout=%d (or a non-P16 operand) is not covered" % (H, W, C, N))
     dw = empty((N, 9 * C), x.data)
-    slabs = empty((int(L.load().trid_conv3x3_wgrad_halo_slabs()), N * 9 * C), x.data)
+    slabs = empty((_query("trid_conv3x3_wgrad_halo_slabs"), N * 9 * C), x.data)
     call("trid_conv3x3_wgrad_halo_p16", _p(dy.data), _p(dy.amax), _p(x.data), _p(x.amax), _p(dw), _p(slabs), Bi, H, W, C, N, stream())
     return dw
 
@@ -427,7 +434,7 @@ def stem_conv1_wgrad(images, dy):
     if Cin != 3 or dy.shape[-1] != 32 or dy.dtype != torch.float32 or not dy.is_contiguous() or not images.is_contiguous():
         raise RuntimeError("stem_conv1_wgrad: a contiguous [B,3,H,W] image batch and a contiguous fp32 [B,Ho,Wo,32] gradient are needed")
     dw = empty((32, 3, 3, 3), images)
-    slabs = empty((int(L.load().trid_stem_conv1_wgrad_slabs()), 32 * 27), images)
+    slabs = empty((_query("trid_stem_conv1_wgrad_slabs"), 32 * 27), images)
     call("trid_stem_conv1_wgrad_f32", _p(images), _p(dy), _p(dw), _p(slabs), Bi, Hi, Wi, stream())
     return dw
 
@@ -470,7 +477,7 @@ USE_FUSED_EXPAND = __import__("os").environ.get("TRID_FUSED_EXPAND", "1") != "0"
 def conv1x1_bn_res_ok(M, N, K):
     """Does the fused conv3 + bn3 + identity pass pay for this shape?  (K = 256 - layer3 - is built and tested but measured
     no faster than GEMM + apply: 104 vs 103 us, its statistics-only pass is compute-bound; tools/exp/fused_bench.py)"""
-    return USE_FUSED_EXPAND and USE_STREAM and K <= 128 and bool(L.load().trid_conv1x1_bn_res_p16_ok(int(M), int(N), int(K)))
+    return USE_FUSED_EXPAND and USE_STREAM and K <= 128 and bool(_query("trid_conv1x1_bn_res_p16_ok", int(M), int(N), int(K)))
 
 
 def conv1x1_stats_p16(x, w):
@@ -479,7 +486,7 @@ def conv1x1_stats_p16(x, w):
     C = x.shape[-1]
     M = x.data.numel() // C
     N = w.shape[0]
-    rows = int(L.load().trid_gemm_p16_stream_stats_rows(int(M), int(N), int(C)))
+    rows = _query("trid_gemm_p16_stream_stats_rows", int(M), int(N), int(C))
     st = empty(((M + rows - 1) // rows, N, 4), x.data)
     call("trid_gemm_p16_stream", _p(x.data), _p(x.amax), _p(w.data), _p(w.amax), None, N, _p(st), M, N, C, 0, None, stream())
     st.rows_per_part = rows
