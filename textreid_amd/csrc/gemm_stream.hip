@@ -242,7 +242,8 @@ __global__ __launch_bounds__(512, 2) void gemm_p16_stream_kernel(StreamParams p)
             const int col = panel * (CW * 32) + tid;
             if (col < p.N) reinterpret_cast<float4*>(p.stats)[(long long)(t - p.workers) * p.N + col] = make_float4(mean, m2, lo, hi);
         }
-        if (RW > 1 && p.stats != nullptr && !first && wave < (CW * 32 + 63) / 64) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // (the partial store above is OLDER than everything issued below: the counted waits - which leave only the youngest
+        // stores in flight - cover it; no drain here)
         // accumulate: the old C values of this step, fetched under the MFMAs (issued BEFORE the DMA so that a counted
         // wait retires them without waiting for the next tile)
         float oldc[ACC ? TM : 1][16];

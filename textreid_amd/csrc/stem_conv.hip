@@ -182,7 +182,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_p16_kernel(HaloParams p) 
                 }
                 const long long part = ((long long)b * H + (y0 - TH)) / TH;
                 reinterpret_cast<float4*>(p.stats)[part * COUT + lane] = make_float4(mean, m2, lo, hi);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (keeps the counted wait below exact: nothing of wave 0's is left in flight but the DMA that follows)
+                // (no wait here: this store is OLDER than the row DMA issued next, and vmcnt retires in order - the counted wait at
+                // the top of the next step, which leaves only the 16 output stores issued after that DMA in flight, covers it.
+                // Draining it on the spot cost wave 0 a memory round trip per step while seven waves waited at the barrier)
             }
             if (s + 1 < p.rg_per_chunk) {
                 int sl = slot0 + TH + 2;
