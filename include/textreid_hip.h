@@ -126,8 +126,11 @@ int trid_p16_pack_wt_f32(const float* w, int N, int T, int C, int flip, const fl
 int trid_p16_pack_multi_f32(const long long* table, const float* amax, int n_tensors, int transposed, int fmt, void* stream);
 /* C = alpha * A . B^T (+ epilogues of trid_gemm_f32: bias, accumulate, residual, relu, split-K slabs, BatchNorm
  * partials) with A ([M][K], or an NHWC image for a_mode TRID_A_CONV) and B ([N][K]) in P16; lda / ldb = row pitch
- * in elements; a_amax / b_amax = the scalars the operands were packed with.  variant: tile shape (0 = default). */
+ * in elements; a_amax / b_amax = the scalars the operands were packed with.  variant: tile shape; < 0 = the library's
+ * choice (128 x 128 tiles of 8 waves; 9 = 96 x 128 tiles of 6 waves, an experiment kept for the record).  The BatchNorm
+ * partials `stats` cover trid_gemm_p16_rows(M, N, precision, variant) rows each (128; 96 for variant 9). */
 int trid_gemm_p16(const trid_gemm_desc* d, int variant, void* stream);
+int trid_gemm_p16_rows(int M, int N, int precision, int variant);
 /* The same product for SHORT reductions (K = 64 / 128 / 256: the expand 1x1 convolutions conv3 / downsample of layer1-3,
  * m_resnet.py:26,41-47, and the data gradients of conv1) as a streaming kernel (csrc/gemm_stream.hip): persistent
  * workgroups, the [32][K] filter panel of a wave in registers, activation tiles by LDS-DMA, stores straight from the

@@ -254,9 +254,10 @@ if r == 0:
 else:
     assert out is None
 # a rank with no samples at all still takes part
-out = _gather_predictions(pred if r == 0 else {})
+out = _gather_predictions(pred if r == 0 else {}, device="cpu")  # (the empty rank allocates on ITS device, not on rank 0's)
 if r == 0:
     assert sorted(out) == sorted(mine)
+    assert all(v.device.type == "cpu" and t.device.type == "cpu" for v, t in out.values())
 print("rank", r, "ok")
 dist.destroy_process_group()
 """

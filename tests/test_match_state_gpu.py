@@ -489,6 +489,13 @@ def test_failed_capture_falls_back_to_eager(gpu):
             torch.zeros(4, device=gpu).sum().item()  # a host read inside a capture: the runtime refuses it
 
     runner._capture = boom
+    # host state an aborted recording leaves behind: collectives staged inside the dead capture
+    from textreid_amd.parallel import GradReducer
+
+    runner.reducer = GradReducer()
+    runner.reducer._stages.append((None, torch.zeros(1, device=gpu), [], []))
+    runner.reducer._pending.append((None, torch.zeros(1, device=gpu), []))
+    runner.reducer._staged.add(123)
     out = []
     for s in range(3):
         images, tokens, lengths, ids = bench.synth_batch(4, s, gpu, 3, vocab=1000)
@@ -496,6 +503,7 @@ def test_failed_capture_falls_back_to_eager(gpu):
         out.append(float(sum(ld.values())))
     torch.cuda.synchronize()
     assert runner.disabled and runner.graph is None and all(np.isfinite(out))
+    assert runner.reducer._stages == [] and runner.reducer._pending == [] and runner.reducer._staged == set()
     assert {int(opt.state[p]["step"]) for g_ in opt.param_groups for p in g_["params"]} == {3}  # three real optimizer steps
 
 

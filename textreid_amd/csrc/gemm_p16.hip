@@ -46,7 +46,7 @@ __device__ __forceinline__ void dma16(const __amdgpu_buffer_rsrc_t& rs, uint4* l
 // tensors their producers already wrote in bf16 - half the operand bytes, a third of the matrix work.
 // PP: the two wave halves of the workgroup run the K loop half a tile apart ("ping-pong", see the main loop).
 template <int AMODE, int BM, int BN, int WM, int WN, int STAGES, int PL, bool PP = false>
-__global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 && STAGES == 2) ? 2 : (WM * WN == 8 && (BM + BN) * 128 * STAGES <= 80 * 1024 ? 4 : 2)) void gemm_p16_kernel(GemmParams p) {
+__global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 && STAGES == 2) ? 2 : (WM * WN == 8 && (BM + BN) * 128 * STAGES <= 80 * 1024 ? 4 : (WM * WN == 6 ? 3 : 2))) void gemm_p16_kernel(GemmParams p) {
     constexpr int NW = WM * WN;
     constexpr int BKE = PL == 2 ? 32 : 64;  // K elements per 128-byte row chunk = per K tile
     constexpr int EB = PL == 2 ? 4 : 2;     // bytes per element of a row
@@ -328,7 +328,8 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 && STAGES == 2) ? 2 : (W
 
     // BatchNorm partials from the FINAL values held in acc (accumulator layout)
     auto emit_stats = [&]() {
-        // BatchNorm partials per 128-row slab of the tile: column (mean, M2) over the slab's rows < M; with
+        // BatchNorm partials per 128-row slab of the tile (per TILE when BM is not a multiple of 128: the 96-row tiles,
+        // whose partials cover 96 rows each - trid_gemm_p16_rows): column (mean, M2) over the slab's rows < M; with
         // stats_w == 4 also the column (min, max): the consumer derives max|BatchNorm(y)| - the fp16 scale of the
         // NEXT operand - from them before the apply pass runs (an affine map takes extremes to extremes).
         // Two levels, TWO barriers per tile (the one-level form - slab mean, then squared deviations from it - needed a
@@ -337,7 +338,8 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 && STAGES == 2) ? 2 : (W
         // and one of them merges the wave partials in wave order with Chan's formula.
         __syncthreads();
         float4* red = reinterpret_cast<float4*>(smem);  // [WM][BN]
-        constexpr int WPS = 128 / (32 * TM);            // waves (along M) per slab
+        constexpr int SR = (BM % 128 == 0) ? 128 : BM;  // rows per slab = per partial
+        constexpr int WPS = SR / (32 * TM);             // waves (along M) per slab
         constexpr int WR = 32 * TM;                     // rows per wave
         const int slab = wm / WPS;
         const int nw_i = min(max(p.M - (m0 + wm * WR), 0), WR);
@@ -394,7 +396,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 && STAGES == 2) ? 2 : (W
                     }
                 }
                 if (col < p.N && cnt > 0.f) {
-                    float* dst = p.stats + (((long long)mb * (BM / 128) + slab) * p.N + col) * p.stats_w;
+                    float* dst = p.stats + (((long long)mb * (BM / SR) + slab) * p.N + col) * p.stats_w;
                     dst[0] = mean;
                     dst[1] = m2;
                     if (p.stats_w == 4) {
@@ -428,9 +430,9 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 && STAGES == 2) ? 2 : (W
                             acc[i][j][r] = p.c_fmt == 2 ? __builtin_bit_cast(float, cvt_pk_bf16(v, 0.f) << 16) : v;
                         }
                 }
-                emit_stats();  // (ends with a barrier: the partial buffers in LDS are free again)
+                emit_stats();
             }
-            __syncthreads();  // every wave is done with the operand stages
+            __syncthreads();  // every wave is done with the operand stages - and with emit_stats' `red` (it does NOT end with a barrier)
             float* Ct = reinterpret_cast<float*>(smem);  // [BM][BN]
 #pragma unroll
             for (int j = 0; j < TN; ++j)
@@ -904,6 +906,7 @@ static int pick_p16(GemmParams& p, int variant, int planes, hipStream_t stream) 
     }
     if (p.N <= 32) return launch_p16<AMODE, 256, 32, 4, 1, 3>(p, stream);
     if (p.N <= 64) return launch_p16<AMODE, 128, 64, 2, 2, 3>(p, stream);
+    if (variant < 0) variant = 3;
     switch (variant) {
         case 1: return launch_p16<AMODE, 128, 128, 2, 2, 3>(p, stream);   // 4 waves of 64x64, 3 stages (96 KB): 1 WG / CU
         case 2: return launch_p16<AMODE, 256, 128, 4, 2, 3>(p, stream);   // 8 waves of 64x64, 3 stages (144 KB)
@@ -911,6 +914,10 @@ static int pick_p16(GemmParams& p, int variant, int planes, hipStream_t stream) 
         case 4: return launch_p16<AMODE, 256, 128, 4, 2, 2>(p, stream);   // 8 waves of 64x64, 2 stages (96 KB)
         case 5: return launch_p16<AMODE, 128, 128, 2, 4, 3>(p, stream);   // 8 waves of 64x32, 3 stages (96 KB)
         case 8: return launch_p16<AMODE, 128, 64, 2, 2, 2>(p, stream);    // 4 waves of 64x32, 2 stages (48 KB): 3 WG / CU
+        // 96-row tiles (6 waves of 32x64, 56 KB, 2 WG / CU): M = 24 576 x N = 256 becomes 512 workgroups = one full round of the
+        // chip instead of 384 - measured 20-35 % SLOWER on every shape, balanced or not (profiles/r05a_tile96.txt: with 12
+        // instead of 16 waves per CU the K loop hides less); kept selectable for that record, never chosen
+        case 9: return launch_p16<AMODE, 96, 128, 3, 2, 2>(p, stream);
         case 6: return launch_p16<AMODE, 128, 128, 2, 4, 2, 2, true>(p, stream);  // variant 3 with the ping-pong schedule
         case 7: return launch_p16<AMODE, 256, 128, 4, 2, 2, 2, true>(p, stream);  // variant 4 with the ping-pong schedule
         default: return launch_p16<AMODE, 128, 128, 2, 2, 2>(p, stream);  // 4 waves of 64x64, 2 stages (64 KB): 2 WG / CU
@@ -1017,6 +1024,12 @@ extern "C" int trid_p16_pack_multi_f32(const long long* table, const float* amax
     TRID_REQUIRE(table && (amax || fmt == 2) && n_tensors > 0 && (fmt == 1 || fmt == 2), "trid_p16_pack_multi_f32: bad arguments");
     hipLaunchKernelGGL(p16_pack_multi_kernel, dim3(64, (unsigned)n_tensors), dim3(256), 0, (hipStream_t)stream, table, amax, transposed, fmt);
     return check_launch("trid_p16_pack_multi_f32");
+}
+
+extern "C" int trid_gemm_p16_rows(int M, int N, int precision, int variant) {
+    (void)M;
+    if (precision == 1 || N <= 64) return 128;
+    return variant == 9 ? 96 : 128;
 }
 
 extern "C" int trid_gemm_p16(const trid_gemm_desc* d, int variant, void* stream_) {

@@ -142,7 +142,7 @@ class MoCoHead(nn.Module):
 
     # ---------------------------------------------------------------- forward
     def _side_stream(self, device, which="_text_stream"):
-        if os.environ.get("TRID_SERIAL", "0") == "1":  # experiment (tools/r04_trace.sh): one stream, un-overlapped kernel durations
+        if os.environ.get("TRID_SERIAL", "0") == "1":  # experiment (tools/exp/r04_trace.sh): one stream, un-overlapped kernel durations
             return torch.cuda.current_stream(device)
         st = getattr(self, which, None)
         if st is None or st.device != device:

@@ -125,25 +125,63 @@ class CapturedTrainStep:
         self.grads = []
 
     def _try_capture(self, images, cb):
-        """Record the step; on ANY failure (a non-capturable call, an invalidated capture) keep training eagerly - eager
-        is the documented fall-back for everything else, a failed recording must not end the run at step 3."""
+        """Record the step; when the RECORDING fails (a non-capturable call, an invalidated capture) keep training eagerly -
+        eager is the documented fall-back for everything else, a failed recording must not end the run at step 3.  Only
+        capture failures are absorbed: an out-of-memory error, or a device that still refuses a probe launch after the
+        aborted recording was torn down (a real kernel fault, a sticky HIP error), is re-raised.  Under data parallelism
+        the ranks agree on the outcome (one MAX all-reduce of the failure flag): either all replay or all stay eager."""
+        from .. import ops
+
         saved = [(p, p.grad) for p in self.model.parameters()]
+        ok = True
         try:
             self._capture(images, cb)
-            return True
-        except Exception as e:  # noqa: BLE001 - whatever the runtime raised mid-capture
+        except torch.cuda.OutOfMemoryError:
+            raise
+        except RuntimeError as e:  # what torch / the library raise for a failed or invalidated stream capture
+            ok = False
             self.log.warning("train step: hipGraph capture failed (%s: %s) - the step stays eager for the rest of the run",
                              type(e).__name__, str(e).splitlines()[0] if str(e) else "")
-            try:
-                torch.cuda.synchronize()
-            except Exception:  # noqa: BLE001
-                pass
-            for p, g in saved:
-                p.grad = g
-            self.graph = self.static = self.out = self.signature = None
-            self.grads = []
+            self._abort_capture(saved)
+            # is the device itself still healthy?  (a capture error leaves it usable; a kernel fault does not)
+            torch.cuda.synchronize()
+            probe = ops.amax_slot(images.device)
+            ops.call("trid_amax_f32", ops._p(self.static_probe(images)), 1, ops._p(probe), ops.stream())
+            torch.cuda.synchronize()
+        if dp_active():
+            import torch.distributed as dist
+
+            flag = torch.tensor([0.0 if ok else 1.0], device=images.device if dist.get_backend() != "gloo" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            if ok and float(flag.item()) > 0:
+                self.log.warning("train step: another rank could not record the step - dropping this rank's graph, all ranks stay eager")
+                self._abort_capture(saved)
+                ok = False
+        if not ok:
             self.disabled = True
-            return False
+        return ok
+
+    @staticmethod
+    def static_probe(images):
+        return images.reshape(-1)[:1].float().contiguous()
+
+    def _abort_capture(self, saved_grads):
+        """Tear down everything an aborted (or discarded) recording left on the host: the reducer's Work handles and flat
+        buffers were created inside the invalidated capture (waiting on them, or merging their slices, would crash or corrupt
+        the next eager backward), the amax / finalize pools of the capture hold slots of its dead memory pool."""
+        from .. import ops
+
+        try:
+            torch.cuda.synchronize()
+        except RuntimeError:
+            pass
+        for p, g in saved_grads:
+            p.grad = g
+        if self.reducer is not None:
+            self.reducer.abort()
+        ops.begin_capture()  # (clears the capture-private pools)
+        self.graph = self.static = self.out = self.signature = None
+        self.grads = []
 
     def __call__(self, images, captions):
         cb = CaptionBatch.from_list(captions)

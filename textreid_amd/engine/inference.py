@@ -52,11 +52,12 @@ def compute_on_dataset(model, data_loader, device, dedupe=True):
     return results
 
 
-def _gather_predictions(pred):
+def _gather_predictions(pred, device=None):
     """{dataset_idx: [v[C], t[C]]} of every rank -> the merged dict on rank 0 (None elsewhere): ONE packed all-gather of
     [n_max, 2C + 2] rows per rank instead of the reference's pickled dicts (`lib/utils/comm.py:47-87`,
     `lib/engine/inference.py:28-45`).  The dataset index travels as its own bits (an int64 = two fp32 lanes, exact for
-    any index), the pack is one stack per rank and the unpack one host transfer - no per-sample launches or syncs."""
+    any index), the pack is one stack per rank and the unpack one host transfer - no per-sample launches or syncs.
+    The merged embeddings live where the local ones do (`device` for a rank without samples), on every world size."""
     if world_size() == 1:
         return pred
     import torch.distributed as dist
@@ -70,16 +71,22 @@ def _gather_predictions(pred):
     nmax = max(sizes)
     if nmax == 0:
         return {} if rank() == 0 else None
-    # (a rank without samples still takes part; width / device then come from a rank that has some)
+    # a rank without samples still takes part: the embedding width comes from a rank that has some, the device is ITS OWN
+    # (the collective runs on this rank's GPU; another rank's device string names a GPU this rank does not own)
     if keys:
         v = torch.stack([pred[k][0].reshape(-1) for k in keys]).float()
         t = torch.stack([pred[k][1].reshape(-1) for k in keys]).float()
         C, dev = v.shape[1], v.device
-    metas = [None] * W
-    dist.all_gather_object(metas, (C, str(dev)) if keys else None)
+    widths = [None] * W
+    dist.all_gather_object(widths, C if keys else None)
     if not keys:
-        C, devs = next(m for m in metas if m is not None)
-        dev = torch.device(devs)
+        C = next(c for c in widths if c is not None)
+        if device is not None:
+            dev = torch.device(device)
+            if dev.type == "cuda" and dev.index is None:
+                dev = torch.device("cuda", torch.cuda.current_device())
+        else:
+            dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
         v = t = torch.zeros(0, C, device=dev)
     idx = torch.tensor(keys, dtype=torch.int64, device=dev).view(-1, 1).view(torch.float32)  # [n, 2] bit lanes
     packed = torch.zeros(nmax, 2 * C + 2, device=dev)
@@ -87,13 +94,12 @@ def _gather_predictions(pred):
     out = all_gather_rows(packed)
     if rank() != 0:
         return None
-    out = out.cpu()
+    all_keys = out[:, :2].contiguous().view(torch.int64).view(-1).tolist()  # ONE host read for every rank's block
     merged = {}
     for w, n in enumerate(sizes):
-        blk = out[w * nmax : w * nmax + n]
-        ks = blk[:, :2].contiguous().view(torch.int64).view(-1).tolist()  # one host read per rank block
-        for j, k in enumerate(ks):
-            merged[k] = [blk[j, 2 : C + 2], blk[j, C + 2 :]]
+        for j in range(n):
+            row = w * nmax + j
+            merged[all_keys[row]] = [out[row, 2 : C + 2], out[row, C + 2 :]]
     return merged
 
 
@@ -103,7 +109,7 @@ def inference(model, data_loader, dataset_name="cuhkpedes-test", device="cuda", 
     dataset = data_loader.dataset
     logger.info("Start evaluation on %s dataset(%d images).", dataset_name, len(dataset))
     t0 = time.time()
-    predictions = _gather_predictions(compute_on_dataset(model, data_loader, torch.device(device)))
+    predictions = _gather_predictions(compute_on_dataset(model, data_loader, torch.device(device)), device=device)
     logger.info("Total inference time: %.1fs", time.time() - t0)
     if predictions is None:
         return None

@@ -238,7 +238,25 @@ class P16:
         return out
 
 
-P16_VARIANT = int(__import__("os").environ.get("TRID_P16_VARIANT", "3"))  # tile shape of trid_gemm_p16 (experiments)
+P16_VARIANT = int(__import__("os").environ.get("TRID_P16_VARIANT", "-1"))  # tile shape of trid_gemm_p16; < 0: the library's choice per shape
+
+
+class Partials:
+    """BatchNorm partials of a convolution epilogue with the number of rows each of them covers (the tile height of the
+    kernel that wrote them: 128, 96 or 64 rows, or whole image-row bands) - bn_finalize_minmax needs both."""
+
+    __slots__ = ("data", "rows")
+
+    def __init__(self, data, rows):
+        self.data, self.rows = data, int(rows)
+
+    @property
+    def shape(self):
+        return self.data.shape
+
+    @property
+    def rows_per_part(self):
+        return self.rows
 
 
 def p16_empty(shape, like, fmt):
@@ -294,6 +312,10 @@ def gemm_p16(A, B, C, M, N, K, ldc, conv=None, alpha=1.0, accumulate=False, bias
     d.stats_minmax = 1 if minmax else 0
     d.c_format = 2 if C.dtype == torch.bfloat16 else 0  # (data gradients of the bf16 mode are bf16 tensors)
     v = P16_VARIANT if variant is None else variant
+    if stats is not None:
+        rows = gemm_p16_rows(M, N, A.fmt, v)
+        if stats.shape[0] != (M + rows - 1) // rows:
+            raise RuntimeError("gemm_p16: the partials buffer must hold one entry per %d rows (gemm_p16_rows): %d parts for M=%d" % (rows, stats.shape[0], M))
     prof = PROFILE
     if prof is not None and N > 64:
         label = prof["match"]((A_CONV if conv is not None else A_KC, B_KC, 128, 128, True))
@@ -315,6 +337,12 @@ def _query(name, *ints):
     """A pure shape query of the library (cached: the same few shapes come back every step, and a ctypes call costs ~2 us of the
     host time an eager step has to stay under)."""
     return int(getattr(L.load(), name)(*ints))
+
+
+def gemm_p16_rows(M, N, fmt=1, variant=None):
+    """Rows per BatchNorm partial (= tile height) of trid_gemm_p16 for this shape: 128, or 96 where the library's dispatch picks
+    its 96-row tiles (an M x N grid that leaves the last round of resident workgroups partly empty)."""
+    return _query("trid_gemm_p16_rows", int(M), int(N), 16 if fmt == 1 else 1, P16_VARIANT if variant is None else int(variant))
 
 
 def gemm_p16_stream_rows(M, N, K, accumulate=False):
@@ -344,7 +372,8 @@ USE_HALO_BLOCKS = __import__("os").environ.get("TRID_HALO_BLOCKS", "1") != "0"  
 
 
 def conv_p16(x, w, conv3=False, stats=True):
-    """x: P16 [B,H,W,C] (or [M,C]); w: P16 [N, K] -> raw conv output y fp32 [.., N] (+ (mean, M2, min, max) partials)."""
+    """x: P16 [B,H,W,C] (or [M,C]); w: P16 [N, K] -> raw conv output y fp32 [.., N] (+ Partials: (mean, M2, min, max) per
+    column and row group, (mean, M2) for bf16 operands)."""
     C = x.shape[-1]
     M = x.data.numel() // C
     N = w.shape[0]
@@ -355,21 +384,19 @@ def conv_p16(x, w, conv3=False, stats=True):
         if rows:
             st = empty(((M + rows - 1) // rows, N, 4), x.data) if stats else None
             gemm_p16_stream(x, w, y, M, N, C, N, stats=st)
-            if stats:
-                st.rows_per_part = rows  # (bn_finalize_minmax reads it: 64-row partials for K = 256)
-            return (y, st) if stats else y
+            return (y, Partials(st, rows)) if stats else y  # (64-row partials for K = 256)
     if conv3 and x.fmt == 1 and USE_HALO_BLOCKS and y.dtype == torch.float32 and conv3x3_halo_rows(x.shape[1], x.shape[2], C, N):
         if not stats:  # 64-channel 3x3 convolutions at large maps (layer1's conv2): the stem's ring-of-rows kernel
             return conv3x3_halo_p16(x, w, stats=False)
         y, st, rows = conv3x3_halo_p16(x, w)
-        st.rows_per_part = rows
-        return y, st
-    st = empty(((M + STATS_ROWS - 1) // STATS_ROWS, N, 4 if mm else 2), x.data) if stats else None
+        return y, Partials(st, rows)
+    rows = gemm_p16_rows(M, N, x.fmt)
+    st = empty(((M + rows - 1) // rows, N, 4 if mm else 2), x.data) if stats else None
     if conv3:
         gemm_p16(x, w, y, M, N, 9 * C, N, conv=(x.shape[1], x.shape[2], C), stats=st, minmax=mm)
     else:
         gemm_p16(x, w, y, M, N, C, N, stats=st, minmax=mm)
-    return (y, st) if stats else y
+    return (y, Partials(st, rows)) if stats else y
 
 
 def conv3x3_halo_rows(H, W, Cin, Cout):
@@ -440,10 +467,12 @@ def stem_conv1_wgrad(images, dy):
 
 
 def bn_finalize_minmax(partials, M, gamma, beta, running_mean, running_var, relu, bound, momentum=BN_MOMENTUM, eps=BN_EPS, rows_per_part=STATS_ROWS):
-    """bn_finalize on (mean, M2, min, max) partials; `bound` (a zeroed amax_slot) receives max|act(BatchNorm(y))|."""
+    """bn_finalize on (mean, M2, min, max) partials (a Partials record, or a raw [parts][C][4] tensor with `rows_per_part`);
+    `bound` (a zeroed amax_slot) receives max|act(BatchNorm(y))|."""
     C = gamma.numel()
     st = BNState(C, gamma)
-    rows_per_part = getattr(partials, "rows_per_part", rows_per_part)  # (conv_p16 on the streaming kernel: its own step size)
+    if isinstance(partials, Partials):
+        partials, rows_per_part = partials.data, partials.rows
     call("trid_bn_finalize_minmax_f32", _p(partials), partials.shape[0], rows_per_part, M, C, _p(gamma), _p(beta),
          _p(running_mean), _p(running_var), momentum, eps, _p(st.mean), _p(st.invstd), _p(st.scale), _p(st.shift),
          1 if relu else 0, _p(bound), _p(bn_finalize_ws(partials.device)), stream())
@@ -489,8 +518,7 @@ def conv1x1_stats_p16(x, w):
     rows = _query("trid_gemm_p16_stream_stats_rows", int(M), int(N), int(C))
     st = empty(((M + rows - 1) // rows, N, 4), x.data)
     call("trid_gemm_p16_stream", _p(x.data), _p(x.amax), _p(w.data), _p(w.amax), None, N, _p(st), M, N, C, 0, None, stream())
-    st.rows_per_part = rows
-    return st
+    return Partials(st, rows)
 
 
 def conv1x1_bn_res_p16(x, w, st, bound, res, relu=True, want_mask=False, keep_y=False):
@@ -774,7 +802,10 @@ class BNState:
 def bn_finalize(partials, M, gamma, beta, running_mean, running_var, momentum=BN_MOMENTUM, eps=BN_EPS):
     C = gamma.numel()
     st = BNState(C, gamma)
-    call("trid_bn_finalize_f32", _p(partials), partials.shape[0], STATS_ROWS, M, C, _p(gamma), _p(beta),
+    rows = STATS_ROWS
+    if isinstance(partials, Partials):  # (bf16 mode: conv_p16's (mean, M2) partials with their tile height)
+        partials, rows = partials.data, partials.rows
+    call("trid_bn_finalize_f32", _p(partials), partials.shape[0], rows, M, C, _p(gamma), _p(beta),
          _p(running_mean), _p(running_var), momentum, eps, _p(st.mean), _p(st.invstd), _p(st.scale), _p(st.shift),
          _p(bn_finalize_ws(partials.device)), stream())
     if running_mean is not None:

@@ -128,6 +128,12 @@ class GradReducer:
         self.bytes_staged = self.bytes_post = self.steps = 0
         self._exposed = []
 
+    def abort(self):
+        """Forget every collective in flight WITHOUT waiting for it (engine.graph: a stream capture was invalidated - the
+        Work handles and flat buffers staged inside it belong to the dead recording)."""
+        self._stages, self._pending, self._staged = [], [], set()
+        self._t0 = None
+
     def stats(self):
         """{"allreduce_bytes_per_step", "staged_fraction", "exposed_ms_per_step"}; synchronises the device."""
         n = max(self.steps, 1)

@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of an environment switch on one box: tools/r04_run10.sh VAR  (VAR=0 vs VAR=1, two rounds)
+# A/B of an environment switch on one box: tools/exp/r04_run10.sh VAR  (VAR=0 vs VAR=1, two rounds)
 set -uo pipefail
 : "${GRAFT_REPO_ROOT:?}"
 cd "$GRAFT_REPO_ROOT"
