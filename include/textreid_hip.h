@@ -91,6 +91,21 @@ typedef struct trid_gemm_desc {
                             * element of C in the layout of trid_bn_apply_*'s relu_mask; C = A . B^T + (bit ? C : 0).  The data
                             * gradient of a residual block's conv1 lands on dL/d(block output) masked by that output's ReLU
                             * (m_resnet.py:49-66 backward: out = relu(bn3(..) + identity)) without a masked copy of it */
+    /* trid_gemm_p16 only, c_format == 1: the eval-mode epilogue (m_resnet.py:54-67 under model.eval(): BatchNorm of running
+     * statistics, residual add and ReLU fused into the convolution).  C is written as a P16 tensor [M][N] (ldc == N, N % 32
+     * == 0, batch == splits == 1, no accumulate / stats):
+     *     C = act(col_scale[n] * alpha * (A . B^T)[m][n] + bias[n] (+ res_p16[m][n])),   act = relu ? max(., 0) : identity
+     * scaled by the bound eval_coef[0] * *eval_tin + eval_coef[1] (+ *eval_tres) >= max|C|, which is published in *out_bound
+     * (the output tensor's amax scalar); the TRUE max|C| is folded into *out_tmax (zeroed by the caller), the `eval_tin` of
+     * the next layer.  eval_coef: trid_eval_bound_coefs_f32. */
+    const float* col_scale;  /* [N] or NULL (1) */
+    const void* res_p16;     /* P16 [M][N] or NULL */
+    const float* res_amax;   /* the scalar res_p16 was packed with */
+    const float* eval_coef;  /* device [2] */
+    const float* eval_tin;   /* device scalar: true max|A| (any upper bound is valid) */
+    const float* eval_tres;  /* device scalar: true max|res_p16|, NULL without a residual */
+    float* out_bound;        /* device scalar, written */
+    float* out_tmax;         /* device scalar, atomicMax'ed (bit pattern of a non-negative float) */
 } trid_gemm_desc;
 
 int trid_gemm_f32(const trid_gemm_desc* d, void* stream);
@@ -154,6 +169,14 @@ int trid_conv1x1_bn_res_p16(const void* A, const float* a_amax, const void* B, c
                             const float* bn_scale, const float* bn_shift, const void* res, const float* res_amax,
                             void* out, const float* bound_a, const float* bound_b, float* bound_sum,
                             uint64_t* relu_mask, int M, int N, int K, int relu, void* stream);
+/* eval mode (model.eval() of m_resnet.py:62-66): out = act(bn_scale * (A . B^T) + bn_shift (+ res)) as a P16 tensor in ONE pass,
+ * the streaming kernel with the fused epilogue above; res (the identity / downsample branch, P16, may be NULL).  The output's
+ * scale: the bound eval_coef[0] * *eval_tin + eval_coef[1] (+ *eval_tres), published in *out_bound; the true max|out| is
+ * atomicMax'ed into *out_tmax (zeroed by the caller).  Shapes: trid_conv1x1_bn_res_p16_ok. */
+int trid_conv1x1_eval_p16(const void* A, const float* a_amax, const void* B, const float* b_amax, const float* bn_scale,
+                          const float* bn_shift, const void* res, const float* res_amax, void* out, const float* eval_coef,
+                          const float* eval_tin, const float* eval_tres, float* out_bound, float* out_tmax, int M, int N, int K,
+                          int relu, void* stream);
 /* Weight gradients on P16 operands: C[M][N] = alpha * sum_k A[k][m] * B[k][n] with A = dL/dy [K pixels][M] and
  * B = the layer input [K pixels][N] (b_mode TRID_B_NC) or its 3x3 gather (TRID_B_CONV: N = 9*Cin, the NHWC image
  * [K pixels][Cin]); the K-major operands are transposed by the LDS read (ds_read_b64_tr_b16).  splits > 1 writes
@@ -226,6 +249,16 @@ int trid_bn_finalize_f32(const float* partials, int nparts, int rows_per_part, l
 /* eval mode: scale/shift from running statistics */
 int trid_bn_eval_coeffs_f32(const float* gamma, const float* beta, const float* running_mean,
                             const float* running_var, float eps, float* scale, float* shift, int C, void* stream);
+/* eval mode (model.eval() of m_resnet.py:57-66, BatchNorm on running statistics): max|act(y*scale[c]+shift[c])| of a conv
+ * output y from the [nparts][C][4] = (mean, M2, min, max) partials of the conv's epilogue, folded into *bound (device scalar,
+ * zeroed by the caller, integer atomicMax): the fp16 scale of the P16 tensor the apply pass writes, known before it runs */
+int trid_bn_eval_bound_f32(const float* partials, int nparts, int C, const float* scale, const float* shift, int relu,
+                           float* bound, void* stream);
+/* eval mode: per convolution i the pair coef[2i] = max_n |scale[n]| * sum_k |w[n][k]|, coef[2i+1] = max_n |shift[n]|, so that
+ * |scale[n] * (w[n] . x) + shift[n]| <= coef[2i] * max|x| + coef[2i+1]: the output bound of the fused eval epilogues
+ * (trid_gemm_desc.eval_coef, trid_conv1x1_eval_p16).  table (device) = n_tensors x {w, N, K, scale, shift} (int64; w fp32 with
+ * each output channel's K weights contiguous); coef (device, 2 * n_tensors floats) must be zero on entry. */
+int trid_eval_bound_coefs_f32(const long long* table, int n_tensors, float* coef, void* stream);
 /* out = act( y*scale[c]+shift[c] + (res ? (rscale ? res*rscale[c]+rshift[c] : res) : 0) ).
  * relu_mask (optional, M*C/8 bytes): 1 bit per element, set where the pre-activation value is > 0, for
  * trid_bn_bwd_* mask_mode 3.  Element quad i = (row*C + c)/4 -> 64-bit words (i/64)*4 + (c%4), bit i%64. */

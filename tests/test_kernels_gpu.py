@@ -293,6 +293,81 @@ def test_gemm_p16_stream(ops, M_, N, K):
     assert abs(float(bound) - float(z.abs().max())) <= 1e-4 * float(z.abs().max())
 
 
+EVAL_SHAPES = [
+    # (M or (B, H, W), N, K, conv3, residual): tile kernel 1x1 / 3x3 gather, N <= 64 and N <= 32 tiles, streaming kernel K = 64 / 128 / 256
+    (300, 128, 512, False, False), (2 * 128 + 7, 256, 1024, False, True), ((3, 12, 8), 128, 9 * 64, True, False),
+    ((2, 24, 8), 256, 9 * 32, True, False), (500, 64, 256, False, False), (260, 32, 64, False, False),
+    (128 * 3 + 20, 256, 64, False, True), (64 * 5 + 3, 512, 128, False, False), (64 * 5 + 3, 512, 128, False, True),
+    (32 * 7 + 5, 1024, 256, False, True), (200, 2048, 512, False, True),
+]
+
+
+@pytest.mark.parametrize("Msp,N,K,conv3,with_res", EVAL_SHAPES)
+@pytest.mark.parametrize("relu", [True, False])
+def test_conv_eval_p16(ops, Msp, N, K, conv3, with_res, relu):
+    """The eval-mode epilogues (csrc/gemm_p16.hip c_format 1, csrc/gemm_stream.hip trid_conv1x1_eval_p16): conv +
+    running-statistics BatchNorm (+ P16 residual) (+ ReLU) written as a P16 tensor whose scale comes from the analytic
+    bound coef[0] * max|x| + coef[1] (+ max|res|) - against an fp64 evaluation; the published bound really bounds the
+    output and stays within 2^9 of its maximum (the bits the two-plane format can spare), the folded true maximum IS the
+    output's maximum (bit for bit: it is what the next layer's bound is built on)."""
+    import torch as T
+
+    if conv3:
+        Bi, H, W = Msp
+        C = K // 9
+        x = T.relu(R("ex%d" % C, Bi, H, W, C))
+        w = R("ew%d" % N, N, 3, 3, C, scale=1.0 / (K ** 0.5))
+        ref = F.conv2d(x.double().permute(0, 3, 1, 2), w.double().permute(0, 3, 1, 2), padding=1).permute(0, 2, 3, 1)
+        w2 = w.reshape(N, K)
+        M_ = Bi * H * W
+    else:
+        M_, C = Msp, K
+        x = T.relu(R("ex%d" % K, M_, K))
+        w2 = R("ew%d" % N, N, K, scale=1.0 / (K ** 0.5))
+        ref = x.double() @ w2.double().t()
+    scale, shift = R("es", N) * 0.5 + 1.0, R("eh", N) * 0.3
+    res = T.relu(R("er%d" % N, *ref.shape)) * 2.0 if with_res else None
+    want = ref * scale.double() + shift.double() + (res.double() if with_res else 0.0)
+    want = T.relu(want) if relu else want
+    xp, wp = ops.p16_pack(dev(x)), ops.p16_pack(dev(w2))
+    rp = ops.p16_pack(dev(res)) if with_res else None
+    st = ops.BNState(N, xp.data)
+    st.scale.copy_(dev(scale)); st.shift.copy_(dev(shift))
+    coef = ops.eval_bound_coefs([(dev(w2), st.scale, st.shift)], xp.data.device)
+    c_ref = T.tensor([float((w2.double().abs().sum(1) * scale.double().abs()).max()), float(shift.abs().max())])
+    assert rel(coef[0], c_ref) < 2e-4 and bool((coef[0].cpu().double() >= c_ref * (1 - 1e-6)).all())
+    out = ops.conv_eval_p16(xp, wp, st, coef[0], relu=relu, res=rp, conv3=conv3)
+    got = out.unpack()
+    assert got.shape == want.shape
+    assert rel(got, want) < 2e-6, rel(got, want)
+    true_max = float(got.abs().max())
+    assert abs(float(out.tmax) - true_max) <= 1e-6 * true_max  # the folded maximum is that of the fp32 values the split was taken from
+    bound = float(out.amax)
+    assert bound >= float(want.abs().max()) and bound <= 512.0 * true_max, (bound, true_max)
+    # a loose input maximum (any upper bound is valid) only loosens the output's bound - the values stay
+    loose = ops.P16(xp.data, xp.amax, 1, xp.amax * 8.0)
+    out2 = ops.conv_eval_p16(loose, wp, st, coef[0], relu=relu, res=rp, conv3=conv3)
+    assert float(out2.amax) > bound and rel(out2.unpack(), want) < 2e-6 and abs(float(out2.tmax) - true_max) <= 1e-6 * true_max
+
+
+def test_bn_eval_bound(ops):
+    """trid_bn_eval_bound_f32: max|act(y * scale + shift)| from the conv epilogue's (min, max) partials and eval coefficients."""
+    import torch as T
+
+    M_, N, K = 128 * 5 + 9, 96, 64
+    x, w = R("bx", M_, K), R("bw", N, K, scale=0.2)
+    xp, wp = ops.p16_pack(dev(x)), ops.p16_pack(dev(w))
+    y, parts = ops.conv_p16(xp, wp)
+    st = ops.BNState(N, y)
+    scale, shift = R("bs", N), R("bh", N) * 0.4
+    st.scale.copy_(dev(scale)); st.shift.copy_(dev(shift))
+    z = y.double().cpu() * scale.double() + shift.double()
+    for relu in (True, False):
+        b = float(ops.bn_eval_bound(parts, st, relu))
+        t = float(T.relu(z).max()) if relu else float(z.abs().max())
+        assert abs(b - t) <= 1e-5 * t, (relu, b, t)
+
+
 @pytest.mark.parametrize("M_,N,K,conv", [(96 * 5, 256, 512, None), (96 * 3 + 50, 128, 1024, None), (2 * 24 * 8, 256, 9 * 64, (24, 8, 64)),
                                          (3 * 12 * 8, 512, 9 * 32, (12, 8, 32))])
 def test_gemm_p16_tile96(ops, M_, N, K, conv):

@@ -556,7 +556,11 @@ class _EncoderFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, images, mod, save, *params):
         if not mod.training and not save and mod.fold_eval_bn and getattr(mod, "_debug_taps", None) is None:
-            out, saved = mod._run_forward_folded(images), None
+            if (ops.USE_EVAL_P16 and ops.USE_P16 and ops.conv_precision() == 16 and p16_eligible(mod, 32) and stem_p16_ok(mod, images)
+                    and images.shape[0] * ((images.shape[2] + 1) // 2) * ((images.shape[3] + 1) // 2) * 64 * 4 < (1 << 31)):
+                out, saved = mod._run_forward_eval_p16(images), None  # CLIP geometries: the P16 kernels with fused eval epilogues
+            else:
+                out, saved = mod._run_forward_folded(images), None   # other widths / arithmetic modes: folded filters, on-the-fly split
         else:
             if save and not mod.training:
                 # eval-mode BatchNorm (running statistics) has a different backward (dy = g * scale, no batch terms);
@@ -631,6 +635,69 @@ class ModifiedResNet(nn.Module):
         params = list(self.parameters())
         save = torch.is_grad_enabled() and any(p.requires_grad for p in params)
         return _EncoderFn.apply(x, self, save, *params)
+
+    def _eval_plan(self, device):
+        """Everything of the eval-mode pass that depends on the parameters only, kept until a parameter or BatchNorm buffer is
+        replaced or written (ops.parameter_generation(): the library's own writers go through raw pointers): the P16 filters
+        (one pack launch), the running-statistics BatchNorm coefficients of the 55 / 106 layers and the output-bound
+        coefficients (max_n |scale_n| ||w_n||_1, max_n |shift_n|) of every convolution (one launch)."""
+        key = (device, ops.parameter_generation()) + tuple((t.data_ptr(), t._version) for t in list(self.parameters()) + list(self.buffers()))
+        plan = getattr(self, "_eval_plan_cache", None)
+        if plan is not None and plan[0] == key:
+            return plan[1]
+        WA = weight_amax(self)
+        WP = p16_weights(self, WA, False, 1)
+        pairs = [(self.conv2, self.bn2), (self.conv3, self.bn3)]
+        for blk in self.blocks():
+            pairs += [(blk.conv1, blk.bn1), (blk.conv2, blk.bn2), (blk.conv3, blk.bn3)]
+            if blk.downsample is not None:
+                pairs.append((blk.downsample[1], blk.downsample[2]))
+        sts = {id(bn): _bn_coeffs(bn, None, 0, False) for bn in [self.bn1] + [bn for _, bn in pairs]}
+        coef = ops.eval_bound_coefs([(conv.weight.detach(), sts[id(bn)].scale, sts[id(bn)].shift) for conv, bn in pairs], device)
+        E = {id(conv.weight): (WP[id(conv.weight)], sts[id(bn)], coef[i]) for i, (conv, bn) in enumerate(pairs)}
+        E["bn1"] = sts[id(self.bn1)]
+        self._eval_plan_cache = (key, E, WA, coef)  # (WA / coef own the scalars the P16 filters and rows refer to)
+        return E
+
+    def _run_forward_eval_p16(self, images):
+        """Eval mode (test_net.py / inference.py:14-26, head.py:178-183) on the pre-split (P16) kernels of the training pass:
+        every convolution of the residual blocks is ONE launch - LDS-DMA tile kernel (csrc/gemm_p16.hip) or the streaming
+        short-K kernel (csrc/gemm_stream.hip) - whose epilogue applies the running-statistics BatchNorm (scale, shift), adds
+        the P16 identity / downsample branch, clamps, and writes the next operand as a P16 tensor.  The output's fp16 scale
+        comes from an analytic bound (csrc/gemm_common.h EvalBound) on the TRUE maximum of the input, which each epilogue folds
+        into a device scalar while it writes: no amax pass, no fp32 activation, no elementwise pass except the three 2x2
+        average pools.  The stem and layer1's 64-channel 3x3 convolutions run on the ring-of-rows kernel (csrc/stem_conv.hip);
+        their BatchNorm + ReLU stays a separate pass that knows its output's exact maximum from the conv epilogue's extremes."""
+        E = self._eval_plan(images.device)
+
+        def ring(x_, conv, st, pool=False):
+            """3x3 conv on the ring-of-rows kernel -> BatchNorm + ReLU (-> 2x2 average) as a P16 tensor"""
+            y, parts, rows = ops.conv3x3_halo_p16(x_, E[id(conv.weight)][0])
+            b = ops.bn_eval_bound(ops.Partials(parts, rows), st, True)
+            return ops.bn_apply_pool2_p16(y, st, b, relu=True) if pool else ops.bn_apply_p16(y, st, b, relu=True)
+
+        y1, p1 = ops.stem_conv1(images, self.conv1.weight)
+        st1 = E["bn1"]
+        a1 = ops.bn_apply_p16(y1, st1, ops.bn_eval_bound(ops.Partials(p1, ops.STATS_ROWS), st1, True), relu=True)
+        a2 = ring(a1, self.conv2, E[id(self.conv2.weight)][1])
+        x = ring(a2, self.conv3, E[id(self.conv3.weight)][1], pool=True)
+        for blk in self.blocks():
+            stride = blk.stride
+            aa = ops.conv_eval_p16(x, *E[id(blk.conv1.weight)], relu=True)
+            planes = blk.conv2.out_channels
+            if ops.USE_HALO_BLOCKS and ops.conv3x3_halo_rows(aa.shape[1], aa.shape[2], planes, planes):
+                ab = ring(aa, blk.conv2, E[id(blk.conv2.weight)][1], pool=stride > 1)  # (layer1: 64 channels at 96 x 32)
+            else:
+                ab = ops.conv_eval_p16(aa, *E[id(blk.conv2.weight)], relu=True, conv3=True)
+                if stride > 1:
+                    ab = ops.bn_apply_pool2_p16(ab, None, ab.amax)
+            ident = x
+            if blk.downsample is not None:
+                xd = ops.bn_apply_pool2_p16(x, None, x.amax) if stride > 1 else x
+                ident = ops.conv_eval_p16(xd, *E[id(blk.downsample[1].weight)], relu=False)
+            x = ops.conv_eval_p16(ab, *E[id(blk.conv3.weight)], relu=True, res=ident)
+        feat, _ = self._attnpool_forward(x, False)
+        return feat
 
     def _run_forward_folded(self, images):
         """Eval mode (test_net.py / inference.py:14-26): BatchNorm uses running statistics, so it is

@@ -85,9 +85,45 @@ __global__ __launch_bounds__(256) void amax_multi_kernel(const float* const* __r
     }
 }
 
+// Eval-mode output bounds (gemm_common.h EvalBound): per convolution i the pair
+//     coef[2i] = max_n |scale_n| * ||w_n||_1,   coef[2i + 1] = max_n |shift_n|
+// so that |scale_n (w_n . x) + shift_n| <= coef[2i] * max|x| + coef[2i + 1] for every output channel n.  table[i] =
+// {w, N, K, scale, shift} (device, 5 x int64): w fp32 [N][K] with each output channel's K weights contiguous (both the
+// OIHW and the OHWI layouts), scale / shift [N] the eval-mode BatchNorm coefficients.  One wave per output channel;
+// `coef` must start at 0 (integer atomicMax on non-negative floats).
+__global__ __launch_bounds__(256) void eval_bound_coefs_kernel(const long long* __restrict__ table, unsigned* __restrict__ coef) {
+    const long long* e = table + 5 * (long long)blockIdx.y;
+    const float* __restrict__ w = reinterpret_cast<const float*>(e[0]);
+    const int N = (int)e[1], K = (int)e[2];
+    const float* __restrict__ scale = reinterpret_cast<const float*>(e[3]);
+    const float* __restrict__ shift = reinterpret_cast<const float*>(e[4]);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned c1 = 0, c2 = 0;
+    for (int n = blockIdx.x * 4 + wave; n < N; n += gridDim.x * 4) {
+        float s = 0.f;
+        for (int k = lane; k < K; k += 64) s += fabsf(w[(long long)n * K + k]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        const unsigned a = absbits(scale[n] * s * 1.0001f), b = absbits(shift[n]);  // (the slack covers the order of the sum)
+        c1 = a > c1 ? a : c1;
+        c2 = b > c2 ? b : c2;
+    }
+    if (lane == 0) {
+        if (c1 != 0) atomicMax(coef + 2 * blockIdx.y, c1);
+        if (c2 != 0) atomicMax(coef + 2 * blockIdx.y + 1, c2);
+    }
+}
+
 }  // namespace trid
 
 using namespace trid;
+
+extern "C" int trid_eval_bound_coefs_f32(const long long* table, int n_tensors, float* coef, void* stream) {
+    TRID_REQUIRE(table && coef && n_tensors > 0, "trid_eval_bound_coefs_f32: bad arguments");
+    hipLaunchKernelGGL(eval_bound_coefs_kernel, dim3(32, (unsigned)n_tensors), dim3(256), 0, (hipStream_t)stream, table,
+                       reinterpret_cast<unsigned*>(coef));
+    return check_launch("trid_eval_bound_coefs_f32");
+}
 
 extern "C" int trid_amax_f32(const float* x, long long n, float* out, void* stream) {
     TRID_REQUIRE(x && out && n > 0 && aligned16(x), "trid_amax_f32: bad arguments (x must be 16-byte aligned)");

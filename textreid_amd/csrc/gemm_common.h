@@ -22,6 +22,23 @@ struct GemmFilter {
     int* overflow;
 };
 
+// Eval-mode epilogues (BatchNorm of running statistics, ReLU, residual fused into the convolution: m_resnet.py:54-67 under
+// model.eval()) write their output as a P16 tensor, so its fp16 scale must be fixed before the first element is known.
+// It comes from a BOUND that needs no pass over anything:
+//     |out[m][n]| <= |scale_n| * ||w_n||_1 * max|in| + |shift_n| (+ max|res|)  <=  coef[0] * tin + coef[1] (+ tres)
+// with coef = (max_n |scale_n| ||w_n||_1, max_n |shift_n|) computed once per checkpoint (trid_eval_bound_coefs_f32) and
+// tin / tres the TRUE maxima of the input / residual tensors, which their producers folded into device scalars
+// (`tmax`, integer atomicMax) while writing them - the looseness of one layer's bound therefore never reaches the next.
+// A bound 2^h above the true maximum costs nothing for elements within 2^-(16-h) of the maximum (two 11-bit planes,
+// both normal) and leaves the others an absolute error of 2^-(38-h) of the maximum.
+struct EvalBound {
+    const float* coef;   // [2]
+    const float* tin;    // true max|A| (device scalar)
+    const float* tres;   // true max|res| or null
+    float* out_bound;    // published by workgroup 0: the bound the output was scaled by (= the output tensor's amax scalar)
+    float* out_tmax;     // atomicMax (bits of a non-negative float; zeroed by the caller): true max|out|
+};
+
 struct GemmParams {
     const float* A;
     const float* B;
@@ -52,6 +69,13 @@ struct GemmParams {
     int wide_epilogue;    // gemm_p16.hip: stores (and accumulate / res reads) as whole rows through LDS
     int xcd_split;        // weight gradients (gemm_p16.hip): 1-D grid, every XCD owns whole K splits
     const unsigned long long* cmask;  // gemm_p16.hip, accumulate: bit per element of C (relu_mask layout) gating the OLD values
+    // gemm_p16.hip, c_fmt == 1 (the eval-mode epilogue): C is written as a P16 tensor,
+    //     out = act(colscale[n] * (A . B^T)[m][n] + bias[n] (+ res16[m][n])),
+    // scaled by the bound eval_out_bound(ev) that every workgroup derives from device scalars before it stores anything
+    const float* colscale;  // [N] or null
+    const void* res16;      // P16 [M][N] (row pitch N) or null
+    const float* res16_amax;
+    EvalBound ev;
 };
 
 constexpr int BK = 32;

@@ -449,6 +449,55 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 && STAGES == 2) ? 2 : (W
             const int col = n0 + 4 * c4;
             float4 bv4 = make_float4(0.f, 0.f, 0.f, 0.f);
             if (!pre && bias != nullptr && col < p.N) bv4 = *reinterpret_cast<const float4*>(bias + col);
+            if (p.c_fmt == 1) {
+                // eval-mode epilogue: out = act(colscale * y + bias (+ P16 residual)) written as a P16 tensor whose scale comes
+                // from a bound every workgroup derives from the same device scalars (gemm_common.h EvalBound); the true
+                // maximum of what was written is folded into *out_tmax for the next layer's bound
+                const float bound = eval_out_bound(p.ev);
+                if (p.ev.out_bound != nullptr && blockIdx.x == 0 && blockIdx.z == 0 && tid == 0) *p.ev.out_bound = bound;
+                const float oscale = f16_scale_of(bound);
+                const float rinv = p.res16 != nullptr ? 1.f / f16_scale_of(*p.res16_amax) : 1.f;
+                float4 cs = make_float4(1.f, 1.f, 1.f, 1.f);
+                if (p.colscale != nullptr && col < p.N) cs = *reinterpret_cast<const float4*>(p.colscale + col);
+                char* const outb = reinterpret_cast<char*>(p.C);
+                const char* const resb = reinterpret_cast<const char*>(p.res16);
+                unsigned am = 0;
+#pragma unroll
+                for (int ps = 0; ps < BM / RG; ++ps) {
+                    const int rl = ps * RG + rg, row = m0 + rl;
+                    if (row >= p.M || col >= p.N) continue;
+                    float4 v = *reinterpret_cast<const float4*>(Ct + rl * BN + 4 * c4);
+                    v = make_float4(fmaf(v.x, cs.x, bv4.x), fmaf(v.y, cs.y, bv4.y), fmaf(v.z, cs.z, bv4.z), fmaf(v.w, cs.w, bv4.w));
+                    // P16 row: 128 bytes per 32-column group = [hi x 32 | lo x 32]; this lane's 4 columns = 8 bytes of each plane
+                    const long long at = (long long)row * p.N * 4 + (col >> 5) * 128 + (col & 31) * 2;
+                    if (resb != nullptr) {
+                        const uint2 h = *reinterpret_cast<const uint2*>(resb + at), l = *reinterpret_cast<const uint2*>(resb + at + 64);
+                        const f16x2 h0 = __builtin_bit_cast(f16x2, h.x), h1 = __builtin_bit_cast(f16x2, h.y);
+                        const f16x2 l0 = __builtin_bit_cast(f16x2, l.x), l1 = __builtin_bit_cast(f16x2, l.y);
+                        v.x += ((float)h0.x + (float)l0.x) * rinv; v.y += ((float)h0.y + (float)l0.y) * rinv;
+                        v.z += ((float)h1.x + (float)l1.x) * rinv; v.w += ((float)h1.y + (float)l1.y) * rinv;
+                    }
+                    if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                    am = absmax4u(am, v);
+                    unsigned q0h, q0l, q1h, q1l;
+                    f16_split2(v.x * oscale, v.y * oscale, q0h, q0l);
+                    f16_split2(v.z * oscale, v.w * oscale, q1h, q1l);
+                    *reinterpret_cast<uint2*>(outb + at) = make_uint2(q0h, q1h);
+                    *reinterpret_cast<uint2*>(outb + at + 64) = make_uint2(q0l, q1l);
+                }
+                am = wave_umax(am);
+                __syncthreads();  // every wave is done reading Ct
+                unsigned* redu = reinterpret_cast<unsigned*>(smem);
+                if (lane == 0) redu[wave] = am;
+                __syncthreads();
+                if (tid == 0 && p.ev.out_tmax != nullptr) {
+                    unsigned r = 0;
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) r = redu[w] > r ? redu[w] : r;
+                    if (r != 0) atomicMax(reinterpret_cast<unsigned*>(p.ev.out_tmax), r);
+                }
+                return;
+            }
 #pragma unroll
             for (int ps = 0; ps < BM / RG; ++ps) {
                 const int rl = ps * RG + rg, row = m0 + rl;
@@ -906,7 +955,7 @@ static int pick_p16(GemmParams& p, int variant, int planes, hipStream_t stream) 
     }
     if (p.N <= 32) return launch_p16<AMODE, 256, 32, 4, 1, 3>(p, stream);
     if (p.N <= 64) return launch_p16<AMODE, 128, 64, 2, 2, 3>(p, stream);
-    if (variant < 0) variant = 3;
+    if (variant < 0 || p.c_fmt == 1) variant = 3;  // (the eval epilogue lives in the staged-through-LDS store path of the default tile)
     switch (variant) {
         case 1: return launch_p16<AMODE, 128, 128, 2, 2, 3>(p, stream);   // 4 waves of 64x64, 3 stages (96 KB): 1 WG / CU
         case 2: return launch_p16<AMODE, 256, 128, 4, 2, 3>(p, stream);   // 8 waves of 64x64, 3 stages (144 KB)
@@ -1058,12 +1107,24 @@ extern "C" int trid_gemm_p16(const trid_gemm_desc* d, int variant, void* stream_
     p.stats_w = d->stats_minmax ? 4 : 2;
     p.c_fmt = d->c_format;
     p.cmask = reinterpret_cast<const unsigned long long*>(d->c_mask);
+    p.colscale = d->col_scale; p.res16 = d->res_p16; p.res16_amax = d->res_amax;
+    p.ev.coef = d->eval_coef; p.ev.tin = d->eval_tin; p.ev.tres = d->eval_tres;
+    p.ev.out_bound = d->out_bound; p.ev.out_tmax = d->out_tmax;
     TRID_REQUIRE(p.cmask == nullptr || (d->accumulate && d->batch == 1 && d->splits == 1 && d->ldc == d->N && d->N % 4 == 0 && !d->stats),
                  "trid_gemm_p16: c_mask needs accumulate, batch == splits == 1, ldc == N, N %% 4 == 0");
     static const int wide_env = getenv("TRID_GEMM_WIDE_EPILOGUE") ? atoi(getenv("TRID_GEMM_WIDE_EPILOGUE")) : 1;  // (0: A/B runs)
     p.wide_epilogue = wide_env;
-    TRID_REQUIRE(p.c_fmt == 0 || (p.c_fmt == 2 && d->batch == 1 && d->splits == 1),
-                 "trid_gemm_p16: c_format must be 0, or 2 with batch == splits == 1");
+    TRID_REQUIRE(p.c_fmt == 0 || ((p.c_fmt == 2 || p.c_fmt == 1) && d->batch == 1 && d->splits == 1),
+                 "trid_gemm_p16: c_format must be 0, or 1 / 2 with batch == splits == 1");
+    if (p.c_fmt == 1) {
+        TRID_REQUIRE(planes == 2 && !d->accumulate && !d->stats && !d->residual && d->ldc == d->N && d->N % 32 == 0 && (long long)d->M * d->N * 4 < (1ll << 31),
+                     "trid_gemm_p16: the eval epilogue (c_format 1) needs P16 operands, ldc == N, N %% 32 == 0, no accumulate / stats / fp32 residual (N=%d)", d->N);
+        TRID_REQUIRE(d->eval_coef && d->eval_tin && (!d->res_p16 || (d->res_amax && d->eval_tres && aligned16(d->res_p16))) && (!d->col_scale || aligned16(d->col_scale)) &&
+                     (!d->bias || aligned16(d->bias)), "trid_gemm_p16: the eval epilogue needs eval_coef / eval_tin (and res_amax / eval_tres with a residual), 16-byte aligned vectors");
+        p.wide_epilogue = 1;  // (the only form of this epilogue)
+    } else {
+        TRID_REQUIRE(!d->col_scale && !d->res_p16, "trid_gemm_p16: col_scale / res_p16 belong to the eval epilogue (c_format 1)");
+    }
     if (d->a_mode == A_CONV) {
         TRID_REQUIRE(d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cin % bke == 0 && d->K == 9 * d->Cin && d->M % (d->H * d->W) == 0 && d->splits == 1,
                      "trid_gemm_p16: A_CONV needs Cin %% %d == 0, K == 9*Cin, M a multiple of H*W, splits == 1", bke);

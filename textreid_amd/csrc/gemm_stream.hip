@@ -80,6 +80,7 @@ struct StreamParams {
     unsigned char* mask;     // relu_mask words of the output (1 bit per element), or null
     int relu;
     int nt_o;
+    EvalBound ev;            // eval mode (trid_conv1x1_eval_p16; ev.coef != null): the output's scale from the analytic bound, res optional
 };
 
 __device__ __forceinline__ void lds_store1(const void* p, float v) {
@@ -163,11 +164,18 @@ __global__ __launch_bounds__(512, 2) void gemm_p16_stream_kernel(StreamParams p)
             fsc[j] = p.bn_scale[c0 + j];
             fsh[j] = p.bn_shift[c0 + j];
         }
-        const float bound = (p.oa != nullptr ? *p.oa : 0.f) + (p.ob != nullptr ? *p.ob : 0.f);
-        if (p.osum != nullptr && blockIdx.x == 0 && tid == 0) *p.osum = bound;
+        float bound;
+        if (p.ev.coef != nullptr) {
+            bound = eval_out_bound(p.ev);
+            if (p.ev.out_bound != nullptr && blockIdx.x == 0 && tid == 0) *p.ev.out_bound = bound;
+        } else {
+            bound = (p.oa != nullptr ? *p.oa : 0.f) + (p.ob != nullptr ? *p.ob : 0.f);
+            if (p.osum != nullptr && blockIdx.x == 0 && tid == 0) *p.osum = bound;
+        }
         oscale = f16_scale_of(bound);
-        rinv = 1.f / f16_scale_of(*p.res_amax);
+        rinv = p.res != nullptr ? 1.f / f16_scale_of(*p.res_amax) : 1.f;
     }
+    unsigned tmax_bits = 0;  // eval mode: true max|out| of everything this lane wrote
 
     // loader: chunk c (1 KB = RPC rows) of a stage; lane -> (row, stored unit j); source unit = j ^ (row & 15).  The per-chunk
     // offsets are re-derived from the lane index in every step (`zero` is opaque to the compiler): kept across the loop
@@ -282,9 +290,10 @@ __global__ __launch_bounds__(512, 2) void gemm_p16_stream_kernel(StreamParams p)
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const unsigned row = (unsigned)t * RB + (unsigned)(rw * TM + i) * 32u + (unsigned)((lane + 64 * h) >> 2);
-                    const unsigned off = col_live ? row * rowb + (unsigned)(n0 >> 5) * 128u + (unsigned)(lane & 3) * 16u : OOB;
+                    const bool res_live = col_live && p.res != nullptr;  // (no identity branch: out-of-range loads return zeros)
+                    const unsigned off = res_live ? row * rowb + (unsigned)(n0 >> 5) * 128u + (unsigned)(lane & 3) * 16u : OOB;
                     rhi[i][h] = __builtin_amdgcn_raw_buffer_load_b128(rsR, off, 0, 0);
-                    rlo[i][h] = __builtin_amdgcn_raw_buffer_load_b128(rsR, col_live ? off + 64u : OOB, 0, 0);
+                    rlo[i][h] = __builtin_amdgcn_raw_buffer_load_b128(rsR, res_live ? off + 64u : OOB, 0, 0);
                 }
         }
         int zero = 0;
@@ -464,6 +473,13 @@ __global__ __launch_bounds__(512, 2) void gemm_p16_stream_kernel(StreamParams p)
                     }
                     const unsigned row = (unsigned)t * RB + (unsigned)(rw * TM + i) * 32u + (unsigned)rl;
                     const unsigned off = col_live ? row * rowb + (unsigned)(n0 >> 5) * 128u + (unsigned)oc * 16u : OOB;
+                    if (p.ev.out_tmax != nullptr && col_live && row < (unsigned)p.M) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const unsigned a = __builtin_bit_cast(unsigned, v[j]) & 0x7fffffffu;
+                            tmax_bits = a > tmax_bits ? a : tmax_bits;
+                        }
+                    }
                     if (p.nt_o) {
                         __builtin_amdgcn_raw_buffer_store_b128(oh, rsO, off, 0, 2);
                         __builtin_amdgcn_raw_buffer_store_b128(ol, rsO, col_live ? off + 64u : OOB, 0, 2);
@@ -496,6 +512,21 @@ __global__ __launch_bounds__(512, 2) void gemm_p16_stream_kernel(StreamParams p)
             }
         }
         first = false;
+    }
+    if constexpr (FUSE == 1 || FUSE == 2) {
+        if (p.ev.out_tmax != nullptr) {  // one atomic per workgroup
+            tmax_bits = wave_umax(tmax_bits);
+            lds_barrier();
+            unsigned* redu = reinterpret_cast<unsigned*>(sstat);
+            if (lane == 0) redu[wave] = tmax_bits;
+            __syncthreads();
+            if (tid == 0) {
+                unsigned r = 0;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) r = redu[w] > r ? redu[w] : r;
+                if (r != 0) atomicMax(reinterpret_cast<unsigned*>(p.ev.out_tmax), r);
+            }
+        }
     }
     if (RW > 1 && p.stats != nullptr && !first) {  // the last step's partials
         lds_barrier();
@@ -621,6 +652,36 @@ extern "C" int trid_gemm_p16_stream(const void* A, const float* a_amax, const vo
 // shapes the fused conv3 + BatchNorm + identity + ReLU kernel covers (K = planes of layer1 - layer3, N = 4 planes)
 extern "C" int trid_conv1x1_bn_res_p16_ok(int M, int N, int K) {
     return (K == 64 || K == 128 || K == 256) && N > 0 && N % 256 == 0 && M > 0 && (long long)M * N * 4 < (1ll << 31);
+}
+
+// eval mode: out = act(scale * (A . B^T) + shift (+ res)) as a P16 tensor on the fused streaming kernel, the output's scale from
+// the analytic bound (gemm_common.h EvalBound), its true maximum folded into *out_tmax
+extern "C" int trid_conv1x1_eval_p16(const void* A, const float* a_amax, const void* B, const float* b_amax, const float* bn_scale,
+                                     const float* bn_shift, const void* res, const float* res_amax, void* out, const float* eval_coef,
+                                     const float* eval_tin, const float* eval_tres, float* out_bound, float* out_tmax, int M, int N, int K,
+                                     int relu, void* stream) {
+    TRID_REQUIRE(A && B && a_amax && b_amax && bn_scale && bn_shift && out && eval_coef && eval_tin && out_bound, "trid_conv1x1_eval_p16: null operand");
+    TRID_REQUIRE(!res || (res_amax && eval_tres), "trid_conv1x1_eval_p16: a residual needs its amax scalar and its true maximum");
+    TRID_REQUIRE(trid_conv1x1_bn_res_p16_ok(M, N, K), "trid_conv1x1_eval_p16: needs K in {64, 128, 256}, N %% 256 == 0, tensors below 2 GB (M=%d N=%d K=%d)", M, N, K);
+    TRID_REQUIRE(aligned16(A) && aligned16(B) && (!res || aligned16(res)) && aligned16(out), "trid_conv1x1_eval_p16: operands must be 16-byte aligned");
+    StreamParams p;
+    memset(&p, 0, sizeof(p));
+    p.A = (const char*)A; p.B = (const char*)B; p.C = nullptr;
+    p.a_amax = a_amax; p.b_amax = b_amax;
+    p.M = M; p.N = N; p.ldc = N;
+    p.bn_scale = bn_scale; p.bn_shift = bn_shift;
+    p.res = (const char*)res; p.res_amax = res_amax;
+    p.out = (char*)out;
+    p.ev.coef = eval_coef; p.ev.tin = eval_tin; p.ev.tres = res ? eval_tres : nullptr;
+    p.ev.out_bound = out_bound; p.ev.out_tmax = out_tmax;
+    p.relu = relu;
+    static const int nt_env = getenv("TRID_STREAM_NT") ? atoi(getenv("TRID_STREAM_NT")) : -1;
+    const bool big = (long long)M * N * 4 >= STREAM_NT_MIN_BYTES;
+    p.nt_o = nt_env >= 0 ? ((nt_env >> 1) & 1) : big;
+    hipStream_t s = (hipStream_t)stream;
+    if (K == 64) return launch_stream<64, 8, 2, false, 1>(p, s);
+    if (K == 128) return launch_stream<128, 8, 2, false, 1>(p, s);
+    return launch_stream<256, 8, 1, false, 1>(p, s);
 }
 
 extern "C" int trid_conv1x1_bn_res_p16(const void* A, const float* a_amax, const void* B, const float* b_amax, float* y,

@@ -146,6 +146,29 @@ __device__ __forceinline__ void split_store_wide_f16(const float4 (&w)[4], float
     }
 }
 
+// bound of an eval-mode epilogue's output (gemm_common.h EvalBound); the factor covers the fp32 rounding of the sums
+__device__ __forceinline__ float eval_out_bound(const EvalBound& e) {
+    float b = fmaf(e.coef[0] * 1.001f, *e.tin, e.coef[1]);
+    if (e.tres != nullptr) b += *e.tres;
+    return b;
+}
+// running maximum of |v| as the bit pattern of a non-negative float
+__device__ __forceinline__ unsigned absmax4u(unsigned m, float4 v) {
+    const unsigned a = __builtin_bit_cast(unsigned, v.x) & 0x7fffffffu, b = __builtin_bit_cast(unsigned, v.y) & 0x7fffffffu;
+    const unsigned c = __builtin_bit_cast(unsigned, v.z) & 0x7fffffffu, d = __builtin_bit_cast(unsigned, v.w) & 0x7fffffffu;
+    const unsigned ab = a > b ? a : b, cd = c > d ? c : d;
+    const unsigned q = ab > cd ? ab : cd;
+    return q > m ? q : m;
+}
+__device__ __forceinline__ unsigned wave_umax(unsigned m) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned t = __shfl_xor(m, o, 64);
+        m = t > m ? t : m;
+    }
+    return m;
+}
+
 // ---------------------------------------------------------------- P16 (pre-split GEMM operand) element access
 // A [rows][C] tensor in P16 (gemm_p16.hip): per row and 32-channel group 128 bytes = [hi x 32 | lo x 32] fp16 of
 // x * 2^s.  These kernels work on channel QUADS (float4): quad cq of a row lives at 8-byte unit

@@ -52,6 +52,14 @@ class GemmDesc(ctypes.Structure):
         ("stats_minmax", ctypes.c_int32),
         ("c_format", ctypes.c_int32),
         ("c_mask", ctypes.c_void_p),
+        ("col_scale", ctypes.c_void_p),
+        ("res_p16", ctypes.c_void_p),
+        ("res_amax", ctypes.c_void_p),
+        ("eval_coef", ctypes.c_void_p),
+        ("eval_tin", ctypes.c_void_p),
+        ("eval_tres", ctypes.c_void_p),
+        ("out_bound", ctypes.c_void_p),
+        ("out_tmax", ctypes.c_void_p),
     ]
 
 

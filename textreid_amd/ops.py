@@ -218,12 +218,14 @@ class P16:
     then 32 fp16 low parts of x * 2^s (4 bytes per element, same shape / dtype as the fp32 tensor it replaces so it
     travels through the allocator unchanged); `amax` is the device scalar the scale s was derived from."""
 
-    __slots__ = ("data", "amax", "fmt")
+    __slots__ = ("data", "amax", "fmt", "tmax")
 
-    def __init__(self, data, amax, fmt=1):
+    def __init__(self, data, amax, fmt=1, tmax=None):
         """fmt 1: P16 proper (fp32-class).  fmt 2: a plain bf16 tensor (configs[3]'s arithmetic: the residual blocks'
-        convolutions read bf16 operands) - same producers / consumers, no scale, half the bytes."""
+        convolutions read bf16 operands) - same producers / consumers, no scale, half the bytes.
+        tmax (eval-mode flow): device scalar holding the TRUE max|x| where `amax` is only a bound of it."""
         self.data, self.amax, self.fmt = data, amax, fmt
+        self.tmax = tmax if tmax is not None else amax
 
     @property
     def shape(self):
@@ -500,6 +502,70 @@ def bn_apply_p16(y, st, bound, relu=True, res=None, res_st=None, bound_res=None,
     return (o, mask) if want_mask else o
 
 
+# --------------------------------------------------------------------------- eval mode: fused epilogues writing P16
+USE_EVAL_P16 = os.environ.get("TRID_EVAL_P16", "1") != "0"  # eval-mode image encoder on the P16 kernels (0: the folded on-the-fly-split path, A/B runs)
+
+
+def eval_bound_coefs(entries, device):
+    """[(w, scale, shift)] per convolution -> device tensor [n, 2]: (max_n |scale_n| ||w_n||_1, max_n |shift_n|), the output
+    bound coefficients of the eval-mode epilogues (csrc/gemm_common.h EvalBound).  w: the fp32 filter parameter (any layout
+    that keeps an output channel's weights contiguous), scale / shift: the running-statistics BatchNorm coefficients."""
+    rows = [[w.data_ptr(), w.shape[0], w.numel() // w.shape[0], sc.data_ptr(), sh.data_ptr()] for (w, sc, sh) in entries]
+    table = torch.tensor(rows, dtype=torch.int64, device=device)
+    coef = torch.zeros(len(rows), 2, dtype=torch.float32, device=device)
+    call("trid_eval_bound_coefs_f32", _p(table), len(rows), _p(coef), stream())
+    return coef
+
+
+def bn_eval_bound(partials, st, relu):
+    """Device scalar max|act(bn(y))| of a conv output from its epilogue's (mean, M2, min, max) Partials and the eval-mode
+    coefficients `st` (exact: an affine map takes extremes to extremes)."""
+    bound = amax_slot(partials.data.device)
+    call("trid_bn_eval_bound_f32", _p(partials.data), partials.data.shape[0], partials.data.shape[1], _p(st.scale), _p(st.shift),
+         1 if relu else 0, _p(bound), stream())
+    return bound
+
+
+def conv_eval_p16(x, w, st, coef, relu=True, res=None, conv3=False):
+    """Eval-mode conv + BatchNorm(running statistics) (+ residual) (+ ReLU) in ONE kernel, P16 in -> P16 out:
+    act(st.scale * conv(x, w) + st.shift (+ res)).  x: P16 [B,H,W,C] / [M,C] with its true maximum `x.tmax`; w: P16 [N, K];
+    coef: this convolution's row of eval_bound_coefs; res: P16 [.., N] or None.  The output's scale comes from the bound
+    coef[0] * max|x| + coef[1] (+ max|res|) - no pass over the output - and its true maximum is folded into `.tmax`."""
+    C = x.shape[-1]
+    M = x.data.numel() // C
+    N = w.shape[0]
+    K = 9 * C if conv3 else C
+    shape = tuple(x.shape[:-1]) + (N,)
+    out = p16_empty(shape, x.data, 1)
+    dev = x.data.device
+    bound, tmax = amax_slot(dev), amax_slot(dev)
+    if not conv3 and USE_STREAM and K in (64, 128, 256) and _query("trid_conv1x1_bn_res_p16_ok", int(M), int(N), int(K)):
+        call("trid_conv1x1_eval_p16", _p(x.data), _p(x.amax), _p(w.data), _p(w.amax), _p(st.scale), _p(st.shift),
+             _p(res.data) if res is not None else None, _p(res.amax) if res is not None else None, _p(out), _p(coef), _p(x.tmax),
+             _p(res.tmax) if res is not None else None, _p(bound), _p(tmax), M, N, K, 1 if relu else 0, stream())
+        return P16(out, bound, 1, tmax)
+    d = GemmDesc()
+    d.A, d.B, d.C = _p(x.data), _p(w.data), _p(out)
+    d.M, d.N, d.K = M, N, K
+    d.lda, d.ldb, d.ldc = C, K, N
+    d.batch, d.splits = 1, 1
+    d.a_mode, d.b_mode = (A_CONV if conv3 else A_KC), B_KC
+    d.alpha = 1.0
+    if conv3:
+        d.H, d.W, d.Cin = x.shape[1], x.shape[2], C
+    d.precision = 16
+    d.a_amax, d.b_amax = _p(x.amax), _p(w.amax)
+    d.relu = 1 if relu else 0
+    d.c_format = 1
+    d.col_scale, d.bias = _p(st.scale), _p(st.shift)
+    if res is not None:
+        d.res_p16, d.res_amax, d.eval_tres = _p(res.data), _p(res.amax), _p(res.tmax)
+    d.eval_coef, d.eval_tin = _p(coef), _p(x.tmax)
+    d.out_bound, d.out_tmax = _p(bound), _p(tmax)
+    call("trid_gemm_p16", ctypes.addressof(d), -1, stream())
+    return P16(out, bound, 1, tmax)
+
+
 USE_FUSED_EXPAND = __import__("os").environ.get("TRID_FUSED_EXPAND", "1") != "0"  # identity blocks of layer1 / layer2: conv3 + bn3 + residual in one pass (0: A/B runs)
 
 
@@ -547,7 +613,8 @@ def bn_apply_pool2_p16(y, st, bound, relu=True, fmt=1):
     call("trid_bn_apply_pool2_p16_f32", _p(src), _p(st.scale) if st else None, _p(st.shift) if st else None,
          y.fmt if isinstance(y, P16) else (2 if y.dtype == torch.bfloat16 else 0), _p(y.amax) if isinstance(y, P16) else None, _p(out), fmt, Bi, H, W, C,
          1 if (relu and st is not None) else 0, _p(bound), stream())
-    return P16(out, bound if fmt == 1 else None, fmt)
+    # (plain pooling of a P16 tensor: an average never exceeds the maximum - the input's true maximum still bounds the output)
+    return P16(out, bound if fmt == 1 else None, fmt, y.tmax if (isinstance(y, P16) and st is None and fmt == 1) else None)
 
 
 def bn_bwd_p16(g, y, st, mask_mode, act=None, pooled=False, want_dres=False, fmt=1):
