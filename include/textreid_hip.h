@@ -203,6 +203,12 @@ int trid_stem_im2col_f32(const float* img, float* col, int B, int Cin, int H, in
  * stored; stats (may be NULL): [ceil(M/128)][32][4] = per-128-row (mean, M2, min, max) BatchNorm partials
  * (trid_bn_finalize_minmax_f32 with rows_per_part 128). */
 int trid_stem_conv1_f32(const float* img, const float* w, float* y, float* stats, int B, int Hi, int Wi, void* stream);
+/* eval mode (model.eval(): m_resnet.py:199-201 with BatchNorm on running statistics): the same kernel with the fused epilogue
+ * out = act(bn_scale[c] * conv1(img) + bn_shift[c]) written as a P16 tensor [B][Ho][Wo][32]; scale / maximum scalars as in
+ * trid_gemm_desc's eval fields (eval_tin = max|img|). */
+int trid_stem_conv1_eval_p16(const float* img, const float* w, const float* bn_scale, const float* bn_shift, void* out,
+                             const float* eval_coef, const float* eval_tin, float* out_bound, float* out_tmax, int B, int Hi, int Wi,
+                             int relu, void* stream);
 /* ... and its weight gradient (autograd of that nn.Conv2d): dw [32][27] = sum over output pixels of dy [B][Ho][Wo][32] (fp32)
  * times the image values under the 27 taps, gathered from the NCHW image (no im2col tensor), exact fp32 MFMA; slabs: scratch
  * of trid_stem_conv1_wgrad_slabs() * 864 floats (per-workgroup partial gradients, folded in a fixed order). */
@@ -230,6 +236,12 @@ int trid_stem_conv1_wgrad_f32(const float* img, const float* dy, float* dw, floa
 int trid_conv3x3_halo_rows(int H, int W, int Cin, int Cout);
 int trid_conv3x3_halo_p16(const void* x, const float* x_amax, const void* w, const float* w_amax, float* y, float* stats,
                           int B, int H, int W, int Cin, int Cout, int chunks_per_image, void* stream);
+/* eval mode: the ring-of-rows kernel with the fused epilogue out = act(bn_scale[c] * conv(x, w) + bn_shift[c]) written as a
+ * P16 tensor [B][H][W][Cout] (the stem's conv2, layer1's conv2 under model.eval(): m_resnet.py:22,57-60,202-204) - no fp32
+ * output, no apply pass.  eval_coef / eval_tin / out_bound / out_tmax: as trid_gemm_desc's eval fields. */
+int trid_conv3x3_halo_eval_p16(const void* x, const float* x_amax, const void* w, const float* w_amax, const float* bn_scale,
+                               const float* bn_shift, void* out, const float* eval_coef, const float* eval_tin, float* out_bound,
+                               float* out_tmax, int B, int H, int W, int Cin, int Cout, int relu, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * BatchNorm2d (train: batch statistics + running update; eval: running stats),

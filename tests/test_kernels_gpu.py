@@ -350,6 +350,58 @@ def test_conv_eval_p16(ops, Msp, N, K, conv3, with_res, relu):
     assert float(out2.amax) > bound and rel(out2.unpack(), want) < 2e-6 and abs(float(out2.tmax) - true_max) <= 1e-6 * true_max
 
 
+@pytest.mark.parametrize("B,C,H,W,N", [(3, 32, 8, 64, 32), (2, 32, 4, 64, 64), (5, 64, 12, 32, 64), (2, 64, 8, 16, 32)])
+@pytest.mark.parametrize("relu", [True, False])
+def test_conv3x3_halo_eval_p16(ops, B, C, H, W, N, relu):
+    """csrc/stem_conv.hip, eval instantiation of the ring-of-rows kernel: conv + running-statistics BatchNorm (+ ReLU) written as a
+    P16 tensor straight from the accumulators (lane pairs exchange fp16 planes: one dword per pixel and lane) against fp64."""
+    import torch as T
+
+    x = T.relu(R("hex%d" % C, B, H, W, C))
+    w = R("hew%d" % N, N, 3, 3, C, scale=1.0 / ((9 * C) ** 0.5))
+    scale, shift = R("hes", N) * 0.5 + 1.0, R("heh", N) * 0.3
+    want = F.conv2d(x.double().permute(0, 3, 1, 2), w.double().permute(0, 3, 1, 2), padding=1).permute(0, 2, 3, 1) * scale.double() + shift.double()
+    want = T.relu(want) if relu else want
+    assert ops.conv3x3_halo_rows(H, W, C, N) > 0
+    xp, wp = ops.p16_pack(dev(x)), ops.p16_pack(dev(w.reshape(N, 9 * C)))
+    st = ops.BNState(N, xp.data)
+    st.scale.copy_(dev(scale)); st.shift.copy_(dev(shift))
+    coef = ops.eval_bound_coefs([(dev(w.reshape(N, 9 * C)), st.scale, st.shift)], xp.data.device)
+    out = ops.conv_eval_p16(xp, wp, st, coef[0], relu=relu, conv3=True)
+    got = out.unpack()
+    assert rel(got, want) < 2e-6, rel(got, want)
+    tm = float(got.abs().max())
+    assert abs(float(out.tmax) - tm) <= 1e-6 * tm and float(out.amax) >= float(want.abs().max()) and float(out.amax) <= 512.0 * tm
+    # the same values as the tile kernel's eval epilogue
+    old = ops.USE_HALO_BLOCKS
+    try:
+        ops.USE_HALO_BLOCKS = False
+        ref = ops.conv_eval_p16(xp, wp, st, coef[0], relu=relu, conv3=True)
+    finally:
+        ops.USE_HALO_BLOCKS = old
+    assert T.equal(ref.amax, out.amax) and rel(ref.unpack(), got) < 1e-6
+
+
+@pytest.mark.parametrize("B,Hi,Wi", [(2, 16, 16), (3, 24, 10), (1, 384, 128)])
+def test_stem_conv1_eval_p16(ops, B, Hi, Wi):
+    """trid_stem_conv1_eval_p16: conv1 (3 -> 32, stride 2, exact fp32 MFMA) + BatchNorm + ReLU straight from the NCHW batch as a P16
+    tensor - against F.conv2d in fp64; ragged last tile (rows beyond M stay out of the maximum)."""
+    import torch as T
+
+    img, w = R("c1i", B, 3, Hi, Wi), R("c1w", 32, 3, 3, 3, scale=0.3)
+    scale, shift = R("c1s", 32) * 0.5 + 1.0, R("c1h", 32) * 0.3
+    want = T.relu(F.conv2d(img.double(), w.double(), stride=2, padding=1).permute(0, 2, 3, 1) * scale.double() + shift.double())
+    st = ops.BNState(32, dev(img))
+    st.scale.copy_(dev(scale)); st.shift.copy_(dev(shift))
+    wd, imd = dev(w), dev(img)
+    coef = ops.eval_bound_coefs([(wd, st.scale, st.shift)], imd.device)
+    out = ops.stem_conv1_eval_p16(imd, wd, st, coef[0], ops.amax(imd))
+    got = out.unpack()
+    assert got.shape == want.shape and rel(got, want) < 2e-6, rel(got, want)
+    tm = float(got.abs().max())
+    assert abs(float(out.tmax) - tm) <= 1e-6 * tm and float(out.amax) >= float(want.abs().max())
+
+
 def test_bn_eval_bound(ops):
     """trid_bn_eval_bound_f32: max|act(y * scale + shift)| from the conv epilogue's (min, max) partials and eval coefficients."""
     import torch as T

@@ -647,15 +647,15 @@ class ModifiedResNet(nn.Module):
             return plan[1]
         WA = weight_amax(self)
         WP = p16_weights(self, WA, False, 1)
-        pairs = [(self.conv2, self.bn2), (self.conv3, self.bn3)]
+        pairs = [(self.conv1, self.bn1), (self.conv2, self.bn2), (self.conv3, self.bn3)]
         for blk in self.blocks():
             pairs += [(blk.conv1, blk.bn1), (blk.conv2, blk.bn2), (blk.conv3, blk.bn3)]
             if blk.downsample is not None:
                 pairs.append((blk.downsample[1], blk.downsample[2]))
-        sts = {id(bn): _bn_coeffs(bn, None, 0, False) for bn in [self.bn1] + [bn for _, bn in pairs]}
+        sts = {id(bn): _bn_coeffs(bn, None, 0, False) for _, bn in pairs}
         coef = ops.eval_bound_coefs([(conv.weight.detach(), sts[id(bn)].scale, sts[id(bn)].shift) for conv, bn in pairs], device)
-        E = {id(conv.weight): (WP[id(conv.weight)], sts[id(bn)], coef[i]) for i, (conv, bn) in enumerate(pairs)}
-        E["bn1"] = sts[id(self.bn1)]
+        # (conv1 multiplies its fp32 filter as stored: no P16 copy)
+        E = {id(conv.weight): (WP.get(id(conv.weight)), sts[id(bn)], coef[i]) for i, (conv, bn) in enumerate(pairs)}
         self._eval_plan_cache = (key, E, WA, coef)  # (WA / coef own the scalars the P16 filters and rows refer to)
         return E
 
@@ -666,31 +666,23 @@ class ModifiedResNet(nn.Module):
         the P16 identity / downsample branch, clamps, and writes the next operand as a P16 tensor.  The output's fp16 scale
         comes from an analytic bound (csrc/gemm_common.h EvalBound) on the TRUE maximum of the input, which each epilogue folds
         into a device scalar while it writes: no amax pass, no fp32 activation, no elementwise pass except the three 2x2
-        average pools.  The stem and layer1's 64-channel 3x3 convolutions run on the ring-of-rows kernel (csrc/stem_conv.hip);
-        their BatchNorm + ReLU stays a separate pass that knows its output's exact maximum from the conv epilogue's extremes."""
+        average pools.  The stem (conv1 straight from the NCHW batch) and layer1's 64-channel 3x3 convolutions run on the
+        bandwidth-shaped kernels of csrc/stem_conv.hip with the same fused epilogue."""
         E = self._eval_plan(images.device)
-
-        def ring(x_, conv, st, pool=False):
-            """3x3 conv on the ring-of-rows kernel -> BatchNorm + ReLU (-> 2x2 average) as a P16 tensor"""
-            y, parts, rows = ops.conv3x3_halo_p16(x_, E[id(conv.weight)][0])
-            b = ops.bn_eval_bound(ops.Partials(parts, rows), st, True)
-            return ops.bn_apply_pool2_p16(y, st, b, relu=True) if pool else ops.bn_apply_p16(y, st, b, relu=True)
-
-        y1, p1 = ops.stem_conv1(images, self.conv1.weight)
-        st1 = E["bn1"]
-        a1 = ops.bn_apply_p16(y1, st1, ops.bn_eval_bound(ops.Partials(p1, ops.STATS_ROWS), st1, True), relu=True)
-        a2 = ring(a1, self.conv2, E[id(self.conv2.weight)][1])
-        x = ring(a2, self.conv3, E[id(self.conv3.weight)][1], pool=True)
+        _, st1, c1 = E[id(self.conv1.weight)]
+        a1 = ops.stem_conv1_eval_p16(images, self.conv1.weight, st1, c1, ops.amax(images))
+        a2 = ops.conv_eval_p16(a1, *E[id(self.conv2.weight)], relu=True, conv3=True)  # (ring-of-rows kernel)
+        # conv3 is followed by the 2x2 average: its BatchNorm + ReLU + pool stays one separate pass over the raw output (fusing
+        # the pool needs pixels of two image rows = two waves of the ring kernel), whose scale is exact (the epilogue's extremes)
+        wp3, st3, _ = E[id(self.conv3.weight)]
+        y3, parts, rows = ops.conv3x3_halo_p16(a2, wp3)
+        x = ops.bn_apply_pool2_p16(y3, st3, ops.bn_eval_bound(ops.Partials(parts, rows), st3, True), relu=True)
         for blk in self.blocks():
             stride = blk.stride
             aa = ops.conv_eval_p16(x, *E[id(blk.conv1.weight)], relu=True)
-            planes = blk.conv2.out_channels
-            if ops.USE_HALO_BLOCKS and ops.conv3x3_halo_rows(aa.shape[1], aa.shape[2], planes, planes):
-                ab = ring(aa, blk.conv2, E[id(blk.conv2.weight)][1], pool=stride > 1)  # (layer1: 64 channels at 96 x 32)
-            else:
-                ab = ops.conv_eval_p16(aa, *E[id(blk.conv2.weight)], relu=True, conv3=True)
-                if stride > 1:
-                    ab = ops.bn_apply_pool2_p16(ab, None, ab.amax)
+            ab = ops.conv_eval_p16(aa, *E[id(blk.conv2.weight)], relu=True, conv3=True)  # (layer1: the ring-of-rows kernel)
+            if stride > 1:
+                ab = ops.bn_apply_pool2_p16(ab, None, ab.amax)
             ident = x
             if blk.downsample is not None:
                 xd = ops.bn_apply_pool2_p16(x, None, x.amax) if stride > 1 else x

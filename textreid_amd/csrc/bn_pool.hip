@@ -241,27 +241,28 @@ static int bn_finalize_launch(const float* partials, int nparts, int rows_per_pa
 }
 
 // eval mode: max|act(y * scale + shift)| of a conv output from the (mean, M2, min, max) partials of its epilogue and the
-// running-statistics coefficients (an affine map takes extremes to extremes) -> atomicMax into *bound (zeroed by the caller)
-__global__ __launch_bounds__(256) void bn_eval_bound_kernel(const float4* __restrict__ partials, int nparts, int C,
+// running-statistics coefficients -> atomicMax into *bound (zeroed by the caller).  An affine map takes the extremes of a
+// set to extremes, and the largest act(.) over a channel is reached at the (min or max) of one of its parts - so every
+// (part, channel) entry is processed on its own and only a global maximum is folded: no per-channel reduction.
+__global__ __launch_bounds__(256) void bn_eval_bound_kernel(const float4* __restrict__ partials, long long total, int C,
                                                             const float* __restrict__ scale, const float* __restrict__ shift,
                                                             int relu, float* __restrict__ bound) {
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int slot = threadIdx.x >> 6;
-    float lo = INFINITY, hi = -INFINITY;
-    if (c < C)
-        for (int b = blockIdx.y * 4 + slot; b < nparts; b += gridDim.y * 4) {
-            const float4 v = partials[(long long)b * C + c];
-            lo = fminf(lo, v.z);
-            hi = fmaxf(hi, v.w);
-        }
     float m = 0.f;
-    if (c < C && lo <= hi) {
-        const float zl = fmaf(lo, scale[c], shift[c]), zh = fmaf(hi, scale[c], shift[c]);
-        m = relu ? fmaxf(fmaxf(zl, zh), 0.f) : fmaxf(fabsf(zl), fabsf(zh));
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const int c = (int)(e % C);
+        const float4 v = partials[e];
+        const float zl = fmaf(v.z, scale[c], shift[c]), zh = fmaf(v.w, scale[c], shift[c]);
+        m = fmaxf(m, relu ? fmaxf(zl, zh) : fmaxf(fabsf(zl), fabsf(zh)));
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(reinterpret_cast<unsigned*>(bound), __builtin_bit_cast(unsigned, m));
+    __shared__ float red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        if (m > 0.f) atomicMax(reinterpret_cast<unsigned*>(bound), __builtin_bit_cast(unsigned, m));
+    }
 }
 
 __global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, const float* rm, const float* rv,
@@ -714,9 +715,9 @@ extern "C" int trid_bn_finalize_minmax_f32(const float* partials, int nparts, in
 extern "C" int trid_bn_eval_bound_f32(const float* partials, int nparts, int C, const float* scale, const float* shift, int relu,
                                       float* bound, void* stream) {
     TRID_REQUIRE(partials && scale && shift && bound && nparts > 0 && C > 0 && aligned16(partials), "trid_bn_eval_bound_f32: bad arguments");
-    const int gy = nparts >= 256 ? 16 : (nparts >= 16 ? 4 : 1);
-    hipLaunchKernelGGL(bn_eval_bound_kernel, dim3((C + 63) / 64, gy), dim3(256), 0, (hipStream_t)stream,
-                       reinterpret_cast<const float4*>(partials), nparts, C, scale, shift, relu, bound);
+    const long long total = (long long)nparts * C;
+    hipLaunchKernelGGL(bn_eval_bound_kernel, dim3(grid_for(total, 256 * 4, 1024)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const float4*>(partials), total, C, scale, shift, relu, bound);
     return check_launch("trid_bn_eval_bound_f32");
 }
 

@@ -59,6 +59,15 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 && STAGES == 2) ? 2 : (W
 
     const float scaleA = (PL == 2 && p.a_amax != nullptr) ? f16_scale_of(*p.a_amax) : 1.f;
     const float scaleB = (PL == 2 && p.b_amax != nullptr) ? f16_scale_of(*p.b_amax) : 1.f;
+    // eval epilogue (c_fmt 1): its device scalars are fetched here, under the K loop, not at the tile's tail
+    float ev_bound = 0.f, ev_rinv = 1.f;
+    unsigned ev_seen = 0;
+    if (p.c_fmt == 1) {
+        ev_bound = eval_out_bound(p.ev);
+        ev_rinv = p.res16 != nullptr ? 1.f / f16_scale_of(*p.res16_amax) : 1.f;
+        // what earlier workgroups folded so far (device-scope load: the atomics live beyond the per-XCD L2)
+        if (p.ev.out_tmax != nullptr) ev_seen = __hip_atomic_load(reinterpret_cast<const unsigned*>(p.ev.out_tmax), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -453,10 +462,10 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 && STAGES == 2) ? 2 : (W
                 // eval-mode epilogue: out = act(colscale * y + bias (+ P16 residual)) written as a P16 tensor whose scale comes
                 // from a bound every workgroup derives from the same device scalars (gemm_common.h EvalBound); the true
                 // maximum of what was written is folded into *out_tmax for the next layer's bound
-                const float bound = eval_out_bound(p.ev);
+                const float bound = ev_bound;
                 if (p.ev.out_bound != nullptr && blockIdx.x == 0 && blockIdx.z == 0 && tid == 0) *p.ev.out_bound = bound;
                 const float oscale = f16_scale_of(bound);
-                const float rinv = p.res16 != nullptr ? 1.f / f16_scale_of(*p.res16_amax) : 1.f;
+                const float rinv = ev_rinv;
                 float4 cs = make_float4(1.f, 1.f, 1.f, 1.f);
                 if (p.colscale != nullptr && col < p.N) cs = *reinterpret_cast<const float4*>(p.colscale + col);
                 char* const outb = reinterpret_cast<char*>(p.C);
@@ -485,6 +494,10 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 && STAGES == 2) ? 2 : (W
                     *reinterpret_cast<uint2*>(outb + at) = make_uint2(q0h, q1h);
                     *reinterpret_cast<uint2*>(outb + at + 64) = make_uint2(q0l, q1l);
                 }
+                // ONE atomic per workgroup, and only when it saw something above what the scalar held when it started (after the
+                // first round of resident workgroups nearly none does).  Same-address device-scope atomics retire one by one,
+                // ~15 ns each: one per wave (3072 tiles x 8) put 60 us of serialized atomics on a 180 us launch
+                // (profiles/r05b_eval_calls.txt)
                 am = wave_umax(am);
                 __syncthreads();  // every wave is done reading Ct
                 unsigned* redu = reinterpret_cast<unsigned*>(smem);
@@ -494,7 +507,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 && STAGES == 2) ? 2 : (W
                     unsigned r = 0;
 #pragma unroll
                     for (int w = 0; w < NW; ++w) r = redu[w] > r ? redu[w] : r;
-                    if (r != 0) atomicMax(reinterpret_cast<unsigned*>(p.ev.out_tmax), r);
+                    if (r > ev_seen) atomicMax(reinterpret_cast<unsigned*>(p.ev.out_tmax), r);
                 }
                 return;
             }

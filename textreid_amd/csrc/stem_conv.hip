@@ -55,6 +55,43 @@ __device__ __forceinline__ void lds_store1(const void* p, float v) {
     asm volatile("ds_write_b32 %0, %1" ::"v"(lds_off(p)), "v"(v) : "memory");
 }
 
+// Eval-mode epilogue of the kernels below, whose accumulator layout gives a lane ONE output channel (lane & 31 of a 32-channel
+// group = one 128-byte P16 line per pixel: [hi x 32 | lo x 32] fp16) and 16 pixels: v = act(acc * scale + shift) is split into
+// its two fp16 planes in the lane, neighbouring lanes exchange one plane each (channel pairs make a dword), and every lane
+// stores ONE dword per pixel - even lanes the high parts of channels (n, n + 1), odd lanes the low parts of (n - 1, n): the
+// same 16 stores per lane as the fp32 form, 32 lanes = one full line.  Returns the running maximum of |v| (bits).
+// off16[r]: byte offset of pixel r's line (32-channel group included); rows beyond the tensor lie beyond rs's range.
+template <bool NT, int PITCH>
+__device__ __forceinline__ unsigned store_p16_rows(const v16f& acc, float sc, float sh, int relu, float oscale, const __amdgpu_buffer_rsrc_t& rs,
+                                                   unsigned base, int lane, unsigned tmax, unsigned rowmask = 0xffffu) {
+    // base: byte offset of accumulator row 0's line (32-channel group included); row r lies (r & 3) + 8 (r >> 2) pixels further
+    const int n = lane & 31;
+    const bool even = (n & 1) == 0;
+    base += even ? 2u * (unsigned)n : 64u + 2u * (unsigned)(n - 1);
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+        float v0 = fmaf(acc[r], sc, sh), v1 = fmaf(acc[r + 1], sc, sh);
+        if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+        // (rowmask: rows that exist - a ragged last tile's other rows are dropped by the store but must not reach the maximum)
+        const unsigned a0 = ((rowmask >> r) & 1u) ? (__builtin_bit_cast(unsigned, v0) & 0x7fffffffu) : 0u;
+        const unsigned a1 = ((rowmask >> (r + 1)) & 1u) ? (__builtin_bit_cast(unsigned, v1) & 0x7fffffffu) : 0u;
+        tmax = a0 > tmax ? a0 : tmax;
+        tmax = a1 > tmax ? a1 : tmax;
+        unsigned h2, l2;  // (hi_r | hi_r+1 << 16), (lo_r | lo_r+1 << 16)
+        f16_split2(v0 * oscale, v1 * oscale, h2, l2);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const unsigned mine = k == 0 ? ((h2 & 0xffffu) | (l2 << 16)) : ((h2 >> 16) | (l2 & 0xffff0000u));  // (hi | lo << 16) of row r + k
+            const unsigned nbr = (unsigned)__shfl_xor((int)mine, 1, 64);
+            const unsigned outw = even ? ((mine & 0xffffu) | (nbr << 16)) : ((nbr >> 16) | (mine & 0xffff0000u));
+            const unsigned off = base + (unsigned)((((r + k) & 3) + 8 * ((r + k) >> 2)) * PITCH);
+            if (NT) __builtin_amdgcn_raw_buffer_store_b32(outw, rs, off, 0, 2);
+            else __builtin_amdgcn_raw_buffer_store_b32(outw, rs, off, 0, 0);
+        }
+    }
+    return tmax;
+}
+
 struct HaloParams {
     const char* x;        // P16 NHWC [B][H][W][CIN]
     const char* w;        // P16 [COUT][9 * CIN] (k = tap * CIN + c)
@@ -72,6 +109,13 @@ struct HaloParams {
     FastDiv fdW;
     FastDiv fd_cpr;       // DMA chunk -> ring row
     int nt;               // non-temporal image loads / output stores (tensors far beyond the Infinity Cache)
+    // eval mode (out16 != null; y / stats unused): out16 = act(y * bn_scale[c] + bn_shift[c]) as a P16 tensor [B][H][W][COUT]
+    // scaled by the analytic bound of gemm_common.h EvalBound; the true maximum is folded into *ev.out_tmax
+    char* out16;
+    const float* bn_scale;
+    const float* bn_shift;
+    int relu;
+    EvalBound ev;
 };
 
 // 16-byte unit u of pixel slot q is stored at unit u ^ swz(q) of that pixel's LDS line(s): the 16-lane groups of a
@@ -85,7 +129,8 @@ __device__ __forceinline__ int swz(int q) {
 
 // CIN, COUT in {32, 64}.  8 waves = PB pixel blocks x (COUT / 32) column blocks x (CIN / 32) channel groups;
 // a wave multiplies its 32 pixels x 32 input channels x 9 taps into 32 output channels.
-template <int CIN, int COUT>
+// EVAL: the eval-mode epilogue (its own instantiation: the training kernel keeps its register budget)
+template <int CIN, int COUT, bool EVAL = false>
 __global__ __launch_bounds__(512, 2) void conv3x3_halo_p16_kernel(HaloParams p) {
     constexpr int NW = 8, CB = COUT / 32, KG = CIN / 32, PB = NW / (CB * KG);
     constexpr int PIXB = CIN * 4;           // bytes of one pixel in LDS / HBM
@@ -104,6 +149,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_p16_kernel(HaloParams p) 
     const int cpr = rowb >> 10;  // DMA chunks per ring row
 
     const float unscale = 1.f / (f16_scale_of(*p.x_amax) * f16_scale_of(*p.w_amax));
+    // eval mode: this lane's channel coefficients, the output scale from the analytic bound
+    float e_sc = 1.f, e_sh = 0.f, e_oscale = 1.f;
+    unsigned e_tmax = 0;
+    if constexpr (EVAL) {
+        e_sc = p.bn_scale[cb * 32 + (lane & 31)];
+        e_sh = p.bn_shift[cb * 32 + (lane & 31)];
+        const float bound = eval_out_bound(p.ev);
+        if (p.ev.out_bound != nullptr && blockIdx.x == 0 && tid == 0) *p.ev.out_bound = bound;
+        e_oscale = f16_scale_of(bound);
+    }
 
     // ---- this wave's filter slice: B fragments [tap][k step][plane], 144 VGPRs, loaded once
     f16x8 bf[9][2][2];
@@ -131,7 +186,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_p16_kernel(HaloParams p) 
     }
 
     const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (unsigned)((size_t)p.B * H * W * PIXB), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, (unsigned)((size_t)p.B * H * W * COUT * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(EVAL ? (void*)p.out16 : (void*)p.y, 0, (unsigned)((size_t)p.B * H * W * COUT * 4), 0x00020000);
     constexpr unsigned OOB = 0x80000000u;
 
     // rows [y_first, y_first + nrows) of image b -> ring slots slot_first ... (mod R); rows outside the image and the
@@ -166,7 +221,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_p16_kernel(HaloParams p) 
             else wait_vm<0>();
             lds_barrier();
             // previous step's BatchNorm partials: merged by the first lanes of wave 0 (one column each)
-            if (p.stats != nullptr && s > 0 && wave == 0 && lane < COUT) {
+            if (!EVAL && p.stats != nullptr && s > 0 && wave == 0 && lane < COUT) {
                 const float4* src = sstat + ((s - 1) & 1) * NW * 32;
                 const int c2 = lane >> 5, n = lane & 31;
                 float cnt = 0.f, mean = 0.f, m2 = 0.f, lo = INFINITY, hi = -INFINITY;
@@ -245,7 +300,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_p16_kernel(HaloParams p) 
                 }
             }
             if (KG == 1 || kg == 0) {
-                if (p.stats != nullptr) {
+                if (!EVAL && p.stats != nullptr) {
                     float sum = 0.f, lo = INFINITY, hi = -INFINITY;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
@@ -267,13 +322,19 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_p16_kernel(HaloParams p) 
                     if (khalf == 0) lds_store4(sstat + (s & 1) * NW * 32 + wave * 32 + (lane & 31), make_float4(mean, m2, lo, hi));
                 }
                 const size_t m0 = ((size_t)b * H + y0) * W + pb * 32 + 4 * khalf;
-                const unsigned col = (unsigned)(cb * 32 + (lane & 31)) * 4u;
+                if constexpr (EVAL) {  // BatchNorm (running statistics) + ReLU, written as the next operand (16 stores per lane as well)
+                    const unsigned base = (unsigned)(m0 * (COUT * 4)) + (unsigned)cb * 128u;
+                    e_tmax = p.nt ? store_p16_rows<true, COUT * 4>(acc, e_sc, e_sh, p.relu, e_oscale, rsY, base, lane, e_tmax)
+                                  : store_p16_rows<false, COUT * 4>(acc, e_sc, e_sh, p.relu, e_oscale, rsY, base, lane, e_tmax);
+                } else {
+                    const unsigned col = (unsigned)(cb * 32 + (lane & 31)) * 4u;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const unsigned off = (unsigned)((m0 + (r & 3) + 8 * (r >> 2)) * (COUT * 4)) + col;
-                    const float v = acc[r];  // (a bit_cast of the vector ELEMENT itself stores element 0 sixteen times)
-                    if (p.nt) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsY, off, 0, 2);
-                    else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsY, off, 0, 0);
+                    for (int r = 0; r < 16; ++r) {
+                        const unsigned off = (unsigned)((m0 + (r & 3) + 8 * (r >> 2)) * (COUT * 4)) + col;
+                        const float v = acc[r];  // (a bit_cast of the vector ELEMENT itself stores element 0 sixteen times)
+                        if (p.nt) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsY, off, 0, 2);
+                        else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsY, off, 0, 0);
+                    }
                 }
             }
             y0 += TH;
@@ -283,7 +344,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_p16_kernel(HaloParams p) 
         // chunk end: the last step's partials, and every wave is done with the ring before the next chunk primes it
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         lds_barrier();
-        if (p.stats != nullptr && wave == 0 && lane < COUT) {
+        if (!EVAL && p.stats != nullptr && wave == 0 && lane < COUT) {
             const int s = p.rg_per_chunk;
             const float4* src = sstat + ((s - 1) & 1) * NW * 32;
             const int c2 = lane >> 5, n = lane & 31;
@@ -303,6 +364,18 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_p16_kernel(HaloParams p) 
         }
         lds_barrier();
     }
+    if (EVAL && p.ev.out_tmax != nullptr) {  // one atomic per (persistent) workgroup
+        e_tmax = wave_umax(e_tmax);
+        unsigned* redu = reinterpret_cast<unsigned*>(sstat);
+        if (lane == 0) redu[wave] = e_tmax;
+        lds_barrier();
+        if (tid == 0) {
+            unsigned r = 0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) r = redu[w] > r ? redu[w] : r;
+            if (r != 0) atomicMax(reinterpret_cast<unsigned*>(p.ev.out_tmax), r);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------- conv1
@@ -320,8 +393,15 @@ struct Conv1Params {
     long long M;        // B * Ho * Wo
     int nslabs;
     FastDiv fdWo, fdHo;
+    // eval mode (out16 != null; y / stats unused): out16 = act(y * bn_scale + bn_shift) as a P16 tensor [B][Ho][Wo][32]
+    char* out16;
+    const float* bn_scale;
+    const float* bn_shift;
+    int relu;
+    EvalBound ev;
 };
 
+template <bool EVAL>
 __global__ __launch_bounds__(256) void stem_conv1_kernel(Conv1Params p) {
     __shared__ float4 sstat[2][4][32];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -335,8 +415,17 @@ __global__ __launch_bounds__(256) void stem_conv1_kernel(Conv1Params p) {
     }
     const size_t img_bytes = (size_t)p.B * 3 * p.Hi * p.Wi * 4;
     const __amdgpu_buffer_rsrc_t rsI = __builtin_amdgcn_make_buffer_rsrc((void*)p.img, 0, (unsigned)img_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, (unsigned)(p.M * 128), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(EVAL ? (void*)p.out16 : (void*)p.y, 0, (unsigned)(p.M * 128), 0x00020000);
     constexpr unsigned OOB = 0x80000000u;
+    float e_sc = 1.f, e_sh = 0.f, e_oscale = 1.f;
+    unsigned e_tmax = 0;
+    if constexpr (EVAL) {
+        e_sc = p.bn_scale[n];
+        e_sh = p.bn_shift[n];
+        const float bound = eval_out_bound(p.ev);
+        if (p.ev.out_bound != nullptr && blockIdx.x == 0 && tid == 0) *p.ev.out_bound = bound;
+        e_oscale = f16_scale_of(bound);
+    }
     int it = 0;
     for (int slab = blockIdx.x; slab < p.nslabs; slab += gridDim.x, ++it) {
         const long long m = (long long)slab * 128 + wave * 32 + (lane & 31);
@@ -368,7 +457,7 @@ __global__ __launch_bounds__(256) void stem_conv1_kernel(Conv1Params p) {
         // rows of this wave that exist
         const long long row0 = (long long)slab * 128 + wave * 32;
         const int cnt_w = (int)(p.M - row0 < 32 ? (p.M - row0 > 0 ? p.M - row0 : 0) : 32);
-        if (p.stats != nullptr) {
+        if (!EVAL && p.stats != nullptr) {
             float sum = 0.f, lo = INFINITY, hi = -INFINITY;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -393,13 +482,21 @@ __global__ __launch_bounds__(256) void stem_conv1_kernel(Conv1Params p) {
             hi = fmaxf(hi, __shfl_xor(hi, 32, 64));
             if (kh == 0) sstat[it & 1][wave][n] = make_float4(mean, m2, lo, hi);
         }
+        if constexpr (EVAL) {
+            // rows beyond M: their stores are dropped (descriptor range), and they are kept out of the maximum
+            unsigned rowmask = 0;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {  // (rows beyond M lie beyond the descriptor's range: the store is dropped)
-            const unsigned off = (unsigned)((row0 + (r & 3) + 8 * (r >> 2) + 4 * kh) * 128 + n * 4);
-            const float v = acc[r];
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsY, off, 0, 0);
+            for (int r = 0; r < 16; ++r) rowmask |= (((r & 3) + 8 * (r >> 2) + 4 * kh) < cnt_w ? 1u : 0u) << r;
+            e_tmax = store_p16_rows<false, 128>(acc, e_sc, e_sh, p.relu, e_oscale, rsY, (unsigned)((row0 + 4 * kh) * 128), lane, e_tmax, rowmask);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {  // (rows beyond M lie beyond the descriptor's range: the store is dropped)
+                const unsigned off = (unsigned)((row0 + (r & 3) + 8 * (r >> 2) + 4 * kh) * 128 + n * 4);
+                const float v = acc[r];
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsY, off, 0, 0);
+            }
         }
-        if (p.stats != nullptr) {
+        if (!EVAL && p.stats != nullptr) {
             __syncthreads();  // (double-buffered: the next slab's partials go to the other half)
             if (wave == 0 && lane < 32) {
                 float cnt = 0.f, mean = 0.f, m2 = 0.f, lo = INFINITY, hi = -INFINITY;
@@ -419,6 +516,18 @@ __global__ __launch_bounds__(256) void stem_conv1_kernel(Conv1Params p) {
                 }
                 reinterpret_cast<float4*>(p.stats)[(long long)slab * 32 + lane] = make_float4(mean, m2, lo, hi);
             }
+        }
+    }
+    if (EVAL && p.ev.out_tmax != nullptr) {  // one atomic per workgroup (at most 2048 of them)
+        e_tmax = wave_umax(e_tmax);
+        __syncthreads();
+        unsigned* redu = reinterpret_cast<unsigned*>(&sstat[0][0][0]);
+        if (lane == 0) redu[wave] = e_tmax;
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned a = redu[0] > redu[1] ? redu[0] : redu[1], b = redu[2] > redu[3] ? redu[2] : redu[3];
+            const unsigned r = a > b ? a : b;
+            if (r != 0) atomicMax(reinterpret_cast<unsigned*>(p.ev.out_tmax), r);
         }
     }
 }
@@ -652,22 +761,27 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_halo_p16_kernel(HaloWgra
     }
 }
 
-template <int CIN, int COUT>
-static int launch_halo(HaloParams& p, hipStream_t stream) {
+template <int CIN, int COUT, bool EVAL>
+static int launch_halo_t(HaloParams& p, hipStream_t stream) {
     constexpr int NW = 8, CB = COUT / 32, KG = CIN / 32, PB = NW / (CB * KG);
     const size_t lds = (size_t)p.R * p.rowb + 2 * NW * 32 * sizeof(float4) + (KG == 2 ? (size_t)PB * CB * 16 * 64 * 4 : 0);
     static std::once_flag once;
     static hipError_t attr_err = hipSuccess;
     std::call_once(once, [] {
-        attr_err = hipFuncSetAttribute((const void*)conv3x3_halo_p16_kernel<CIN, COUT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_err = hipFuncSetAttribute((const void*)conv3x3_halo_p16_kernel<CIN, COUT, EVAL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
     if (attr_err != hipSuccess) {
         set_error("trid_conv3x3_halo_p16: cannot reserve LDS: %s", hipGetErrorString(attr_err));
         return (int)attr_err;
     }
     const int grid = std::min(p.nchunks, 256);
-    hipLaunchKernelGGL((conv3x3_halo_p16_kernel<CIN, COUT>), dim3(grid), dim3(512), lds, stream, p);
+    hipLaunchKernelGGL((conv3x3_halo_p16_kernel<CIN, COUT, EVAL>), dim3(grid), dim3(512), lds, stream, p);
     return check_launch("trid_conv3x3_halo_p16");
+}
+
+template <int CIN, int COUT>
+static int launch_halo(HaloParams& p, hipStream_t stream) {
+    return p.out16 != nullptr ? launch_halo_t<CIN, COUT, true>(p, stream) : launch_halo_t<CIN, COUT, false>(p, stream);
 }
 
 }  // namespace trid
@@ -690,17 +804,10 @@ static int halo_rows_per_step(int H, int W, int Cin, int Cout) {
 
 extern "C" int trid_conv3x3_halo_rows(int H, int W, int Cin, int Cout) { return halo_rows_per_step(H, W, Cin, Cout); }
 
-extern "C" int trid_conv3x3_halo_p16(const void* x, const float* x_amax, const void* w, const float* w_amax, float* y, float* stats,
-                                     int B, int H, int W, int Cin, int Cout, int chunks_per_image, void* stream) {
-    TRID_REQUIRE(x && w && y && x_amax && w_amax && B > 0 && H > 0 && W > 0, "trid_conv3x3_halo_p16: bad arguments");
-    TRID_REQUIRE(aligned16(x) && aligned16(w) && aligned16(y) && (!stats || aligned16(stats)), "trid_conv3x3_halo_p16: operands must be 16-byte aligned");
+static int halo_dispatch(HaloParams& p, int B, int H, int W, int Cin, int Cout, int chunks_per_image, const char* who, hipStream_t s) {
     const int th = halo_rows_per_step(H, W, Cin, Cout);
-    TRID_REQUIRE(th > 0, "trid_conv3x3_halo_p16: geometry H=%d W=%d Cin=%d Cout=%d is not covered (trid_conv3x3_halo_rows() == 0)", H, W, Cin, Cout);
-    TRID_REQUIRE((long long)B * H * W * std::max(Cin, Cout) * 4 < (1ll << 31), "trid_conv3x3_halo_p16: tensors must stay below 2 GB (31-bit buffer offsets)");
-    HaloParams p;
-    memset(&p, 0, sizeof(p));
-    p.x = (const char*)x; p.w = (const char*)w; p.y = y; p.stats = stats;
-    p.x_amax = x_amax; p.w_amax = w_amax;
+    TRID_REQUIRE(th > 0, "%s: geometry H=%d W=%d Cin=%d Cout=%d is not covered (trid_conv3x3_halo_rows() == 0)", who, H, W, Cin, Cout);
+    TRID_REQUIRE((long long)B * H * W * std::max(Cin, Cout) * 4 < (1ll << 31), "%s: tensors must stay below 2 GB (31-bit buffer offsets)", who);
     p.B = B; p.H = H; p.W = W;
     p.TH = th;
     p.R = 2 * th + 2;
@@ -713,7 +820,7 @@ extern "C" int trid_conv3x3_halo_p16(const void* x, const float* x_amax, const v
             break;
         }
     if (chunks_per_image > 0) {
-        TRID_REQUIRE(rg % chunks_per_image == 0, "trid_conv3x3_halo_p16: chunks_per_image must divide the %d steps of an image", rg);
+        TRID_REQUIRE(rg % chunks_per_image == 0, "%s: chunks_per_image must divide the %d steps of an image", who, rg);
         cpi = chunks_per_image;
     }
     p.chunks_per_image = cpi;
@@ -723,11 +830,36 @@ extern "C" int trid_conv3x3_halo_p16(const void* x, const float* x_amax, const v
     p.fd_cpr = make_fastdiv((uint32_t)(p.rowb >> 10));
     static const int nt_env = getenv("TRID_STREAM_NT") ? atoi(getenv("TRID_STREAM_NT")) : -1;
     p.nt = nt_env >= 0 ? (nt_env != 0) : ((long long)B * H * W * std::min(Cin, Cout) * 4 >= STREAM_NT_MIN_BYTES);
-    hipStream_t s = (hipStream_t)stream;
     if (Cin == 32 && Cout == 32) return launch_halo<32, 32>(p, s);
     if (Cin == 32 && Cout == 64) return launch_halo<32, 64>(p, s);
     if (Cin == 64 && Cout == 64) return launch_halo<64, 64>(p, s);  // (layer1's conv2, m_resnet.py:22)
     return launch_halo<64, 32>(p, s);
+}
+
+extern "C" int trid_conv3x3_halo_p16(const void* x, const float* x_amax, const void* w, const float* w_amax, float* y, float* stats,
+                                     int B, int H, int W, int Cin, int Cout, int chunks_per_image, void* stream) {
+    TRID_REQUIRE(x && w && y && x_amax && w_amax && B > 0 && H > 0 && W > 0, "trid_conv3x3_halo_p16: bad arguments");
+    TRID_REQUIRE(aligned16(x) && aligned16(w) && aligned16(y) && (!stats || aligned16(stats)), "trid_conv3x3_halo_p16: operands must be 16-byte aligned");
+    HaloParams p;
+    memset(&p, 0, sizeof(p));
+    p.x = (const char*)x; p.w = (const char*)w; p.y = y; p.stats = stats;
+    p.x_amax = x_amax; p.w_amax = w_amax;
+    return halo_dispatch(p, B, H, W, Cin, Cout, chunks_per_image, "trid_conv3x3_halo_p16", (hipStream_t)stream);
+}
+
+extern "C" int trid_conv3x3_halo_eval_p16(const void* x, const float* x_amax, const void* w, const float* w_amax, const float* bn_scale,
+                                          const float* bn_shift, void* out, const float* eval_coef, const float* eval_tin, float* out_bound,
+                                          float* out_tmax, int B, int H, int W, int Cin, int Cout, int relu, void* stream) {
+    TRID_REQUIRE(x && w && out && x_amax && w_amax && bn_scale && bn_shift && eval_coef && eval_tin && out_bound && B > 0 && H > 0 && W > 0,
+                 "trid_conv3x3_halo_eval_p16: bad arguments");
+    TRID_REQUIRE(aligned16(x) && aligned16(w) && aligned16(out), "trid_conv3x3_halo_eval_p16: operands must be 16-byte aligned");
+    HaloParams p;
+    memset(&p, 0, sizeof(p));
+    p.x = (const char*)x; p.w = (const char*)w;
+    p.x_amax = x_amax; p.w_amax = w_amax;
+    p.out16 = (char*)out; p.bn_scale = bn_scale; p.bn_shift = bn_shift; p.relu = relu;
+    p.ev.coef = eval_coef; p.ev.tin = eval_tin; p.ev.out_bound = out_bound; p.ev.out_tmax = out_tmax;
+    return halo_dispatch(p, B, H, W, Cin, Cout, 0, "trid_conv3x3_halo_eval_p16", (hipStream_t)stream);
 }
 
 // rows per step of the ring-of-rows weight-gradient kernel, 0 when it does not cover the geometry
@@ -824,20 +956,38 @@ extern "C" int trid_stem_conv1_wgrad_f32(const float* img, const float* dy, floa
     return trid_slab_reduce_f32(slabs, dw, 32 * 27, C1W_SLABS, 32 * 27, 0, stream);
 }
 
-extern "C" int trid_stem_conv1_f32(const float* img, const float* w, float* y, float* stats, int B, int Hi, int Wi, void* stream) {
-    TRID_REQUIRE(img && w && y && B > 0 && Hi > 0 && Wi > 0, "trid_stem_conv1_f32: bad arguments");
-    TRID_REQUIRE((long long)B * 3 * Hi * Wi * 4 < (1ll << 31), "trid_stem_conv1_f32: the image batch must stay below 2 GB");
-    Conv1Params p;
-    memset(&p, 0, sizeof(p));
-    p.img = img; p.w = w; p.y = y; p.stats = stats;
+static int conv1_dispatch(Conv1Params& p, int B, int Hi, int Wi, const char* who, hipStream_t stream) {
+    TRID_REQUIRE((long long)B * 3 * Hi * Wi * 4 < (1ll << 31), "%s: the image batch must stay below 2 GB", who);
     p.B = B; p.Hi = Hi; p.Wi = Wi;
     p.Ho = (Hi + 1) / 2; p.Wo = (Wi + 1) / 2;
     p.M = (long long)B * p.Ho * p.Wo;
-    TRID_REQUIRE(p.M * 128 < (1ll << 31), "trid_stem_conv1_f32: the output must stay below 2 GB (31-bit buffer offsets)");
+    TRID_REQUIRE(p.M * 128 < (1ll << 31), "%s: the output must stay below 2 GB (31-bit buffer offsets)", who);
     p.nslabs = (int)((p.M + 127) / 128);
     p.fdWo = make_fastdiv((uint32_t)p.Wo);
     p.fdHo = make_fastdiv((uint32_t)p.Ho);
     const int grid = std::min(p.nslabs, 256 * 8);
-    hipLaunchKernelGGL(stem_conv1_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
-    return check_launch("trid_stem_conv1_f32");
+    if (p.out16 != nullptr) hipLaunchKernelGGL(stem_conv1_kernel<true>, dim3(grid), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL(stem_conv1_kernel<false>, dim3(grid), dim3(256), 0, stream, p);
+    return check_launch(who);
+}
+
+extern "C" int trid_stem_conv1_f32(const float* img, const float* w, float* y, float* stats, int B, int Hi, int Wi, void* stream) {
+    TRID_REQUIRE(img && w && y && B > 0 && Hi > 0 && Wi > 0, "trid_stem_conv1_f32: bad arguments");
+    Conv1Params p;
+    memset(&p, 0, sizeof(p));
+    p.img = img; p.w = w; p.y = y; p.stats = stats;
+    return conv1_dispatch(p, B, Hi, Wi, "trid_stem_conv1_f32", (hipStream_t)stream);
+}
+
+extern "C" int trid_stem_conv1_eval_p16(const float* img, const float* w, const float* bn_scale, const float* bn_shift, void* out,
+                                        const float* eval_coef, const float* eval_tin, float* out_bound, float* out_tmax, int B, int Hi, int Wi,
+                                        int relu, void* stream) {
+    TRID_REQUIRE(img && w && bn_scale && bn_shift && out && eval_coef && eval_tin && out_bound && B > 0 && Hi > 0 && Wi > 0 && aligned16(out),
+                 "trid_stem_conv1_eval_p16: bad arguments");
+    Conv1Params p;
+    memset(&p, 0, sizeof(p));
+    p.img = img; p.w = w;
+    p.out16 = (char*)out; p.bn_scale = bn_scale; p.bn_shift = bn_shift; p.relu = relu;
+    p.ev.coef = eval_coef; p.ev.tin = eval_tin; p.ev.out_bound = out_bound; p.ev.out_tmax = out_tmax;
+    return conv1_dispatch(p, B, Hi, Wi, "trid_stem_conv1_eval_p16", (hipStream_t)stream);
 }

@@ -526,6 +526,31 @@ def bn_eval_bound(partials, st, relu):
     return bound
 
 
+def conv3x3_halo_eval_p16(x, w, st, coef, relu=True):
+    """conv_eval_p16 for the 32 / 64-channel 3x3 convolutions at large maps (the stem's conv2, layer1's conv2) on the
+    ring-of-rows kernel (csrc/stem_conv.hip): x P16 [B,H,W,Cin], w P16 [Cout, 9*Cin] -> act(bn(conv)) P16 [B,H,W,Cout]."""
+    Bi, H, W, C = x.shape
+    N = w.shape[0]
+    out = p16_empty((Bi, H, W, N), x.data, 1)
+    bound, tmax = amax_slot(x.data.device), amax_slot(x.data.device)
+    call("trid_conv3x3_halo_eval_p16", _p(x.data), _p(x.amax), _p(w.data), _p(w.amax), _p(st.scale), _p(st.shift), _p(out), _p(coef), _p(x.tmax),
+         _p(bound), _p(tmax), Bi, H, W, C, N, 1 if relu else 0, stream())
+    return P16(out, bound, 1, tmax)
+
+
+def stem_conv1_eval_p16(images, w, st, coef, img_amax, relu=True):
+    """Eval-mode stem conv1 (3 -> 32, stride 2) + BatchNorm + ReLU straight from the NCHW batch -> P16 [B,Ho,Wo,32]; img_amax: device
+    scalar >= max|images| (ops.amax)."""
+    Bi, Cin, Hi, Wi = images.shape
+    if Cin != 3 or w.shape[0] != 32 or not w.is_contiguous() or not images.is_contiguous():
+        raise RuntimeError("stem_conv1_eval_p16: a contiguous [B,3,H,W] image batch and contiguous [32,3,3,3] filters are needed")
+    out = p16_empty((Bi, (Hi + 1) // 2, (Wi + 1) // 2, 32), images, 1)
+    bound, tmax = amax_slot(images.device), amax_slot(images.device)
+    call("trid_stem_conv1_eval_p16", _p(images), _p(w), _p(st.scale), _p(st.shift), _p(out), _p(coef), _p(img_amax), _p(bound), _p(tmax),
+         Bi, Hi, Wi, 1 if relu else 0, stream())
+    return P16(out, bound, 1, tmax)
+
+
 def conv_eval_p16(x, w, st, coef, relu=True, res=None, conv3=False):
     """Eval-mode conv + BatchNorm(running statistics) (+ residual) (+ ReLU) in ONE kernel, P16 in -> P16 out:
     act(st.scale * conv(x, w) + st.shift (+ res)).  x: P16 [B,H,W,C] / [M,C] with its true maximum `x.tmax`; w: P16 [N, K];
@@ -538,6 +563,8 @@ def conv_eval_p16(x, w, st, coef, relu=True, res=None, conv3=False):
     shape = tuple(x.shape[:-1]) + (N,)
     out = p16_empty(shape, x.data, 1)
     dev = x.data.device
+    if conv3 and res is None and USE_HALO_BLOCKS and conv3x3_halo_rows(x.shape[1], x.shape[2], C, N):
+        return conv3x3_halo_eval_p16(x, w, st, coef, relu)
     bound, tmax = amax_slot(dev), amax_slot(dev)
     if not conv3 and USE_STREAM and K in (64, 128, 256) and _query("trid_conv1x1_bn_res_p16_ok", int(M), int(N), int(K)):
         call("trid_conv1x1_eval_p16", _p(x.data), _p(x.amax), _p(w.data), _p(w.amax), _p(st.scale), _p(st.shift),

@@ -8,7 +8,8 @@ import oracle.visual as OV
 from textreid_amd import ops
 from textreid_amd.backbones.m_resnet import ModifiedResNet
 spec = OV.RN101 if (len(sys.argv) > 1 and sys.argv[1] == "rn101") else OV.RN50
-sizes = [int(a) for a in sys.argv[2:]] or [128]
+sizes = [int(a) for a in sys.argv[2:] if a.isdigit()] or [128]
+ONLY_P16 = "--only-p16" in sys.argv  # (profiling runs)
 torch.manual_seed(0)
 m = ModifiedResNet(list(spec.layers), spec.output_dim, spec.heads, spec.last_stride, (spec.height, spec.in_width), spec.width).cuda()
 with torch.no_grad():
@@ -19,7 +20,7 @@ with torch.no_grad():
     for B in sizes:
         x = torch.randn(B, 3, 384, 128, device="cuda")
         outs = {}
-        for name, fold, p16 in (("unfolded", False, False), ("folded (r02)", True, False), ("P16 eval", True, True)) * 2:
+        for name, fold, p16 in ((("P16 eval", True, True),) if ONLY_P16 else (("unfolded", False, False), ("folded (r02)", True, False), ("P16 eval", True, True)) * 2):
             m.fold_eval_bn, ops.USE_EVAL_P16 = fold, p16
             outs[name] = m(x); torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -28,6 +29,8 @@ with torch.no_grad():
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
             print("B %4d %-13s %7.2f ms/batch (host enqueue %6.2f)  %7.0f imgs/s" % (B, name, dt * 100, th * 100, 10 * B / dt), flush=True)
+        if ONLY_P16:
+            continue
         ref = outs["unfolded"].double()
         for k in ("folded (r02)", "P16 eval"):
             print("   %-13s vs unfolded: max rel err %.1e" % (k, float((outs[k].double() - ref).abs().max() / ref.abs().max())))
