@@ -553,6 +553,18 @@ int trid_enqueue_f32(float* v_queue, float* t_queue, int64_t* id_queue, int64_t*
 long long trid_topk_ws_floats(int Q, int G, int k);
 int trid_sim_topk_f32(const float* q, const float* g, float* out_val, int64_t* out_idx, int Q, int G, int C,
                       int k, long long idx_offset, int precision, const float* q_amax, const float* g_amax, float* ws, void* stream);
+/* The same with the operands ALSO given pre-split (C == 256): q16 = P16 [ceil32(Q)][256] (padding rows zero), g16 = P16 [G][256],
+ * packed with q_amax / g_amax (trid_p16_pack_f32).  The gallery embeddings are written once and scored against every query
+ * panel: split once instead of once per panel, and the admission-filter pass runs on the streaming kernel with 256 queries
+ * resident in a workgroup's registers (csrc/gemm_stream.hip) - the gallery crosses LDS once per 256 queries, nothing is
+ * stored but candidates.  Results as trid_sim_topk_f32 with precision 16 (same arithmetic; values agree to the last bits).
+ * mode 0: as trid_sim_topk_f32 (the overflow fall-back passes are enqueued behind the fused pass, gated on a device flag).
+ * mode 1: without them - the caller reads the int at ws[trid_topk_ws_flag_offset(Q, G)] afterwards and, when it is non-zero (a
+ * candidate list overflowed: an adversarially ordered gallery), calls mode 2 (q16 / g16 unused), which redoes the columns
+ * beyond the first panel densely.  One 4-byte read instead of ~2 G / 8192 gated no-op launches (1.4 of 17 ms at G = 1e6). */
+int trid_sim_topk_p16(const float* q, const float* g, const void* q16, const void* g16, float* out_val, int64_t* out_idx, int Q, int G,
+                      int k, long long idx_offset, const float* q_amax, const float* g_amax, float* ws, int mode, void* stream);
+long long trid_topk_ws_flag_offset(int Q, int G);
 
 /* per-row top-k of a given similarity matrix (rank(get_mAP=False), evaluation.py:17-19) */
 int trid_topk_rows_f32(const float* sim, int ld, int Q, int G, int k, float* out_val, int64_t* out_idx,

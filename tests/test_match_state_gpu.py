@@ -114,6 +114,58 @@ def test_fused_similarity_topk_shape_edges(gpu, Q, G, k):
     assert torch.allclose(vals.cpu(), rv, atol=2e-6)
 
 
+@pytest.mark.parametrize("Q,G,k", [(1, 8193, 3), (70, 8192 + 64 + 5, 10), (130, 8192 * 3 + 5, 16), (300, 8192 + 40000, 10), (33, 8192 + 63, 1)])
+def test_fused_similarity_topk_presplit_operands(gpu, Q, G, k):
+    """C = 256 embeddings: queries and gallery are split into their fp16 planes once and the admission-filter pass runs on the
+    streaming kernel with the queries resident in registers (trid_sim_topk_p16) - query counts that are not multiples of the
+    32-column wave panel (zero padding rows must never produce candidates), a ragged last gallery tile, k = 1 / 16; against the
+    dense product, and against the on-the-fly-split path it replaces (same arithmetic, another summation order: last-bit
+    differences, 6e-8 measured - the indices agree wherever two neighbours are further apart than that)."""
+    import textreid_amd.evaluation as E
+
+    te, ie = OF.randn("tkp:q%d" % Q, (Q, 256), 4), OF.randn("tkp:g%d" % G, (G, 256), 4)
+    assert E.USE_SIM_P16
+    vals, idx = E.similarity_topk(te.to(gpu), ie.to(gpu), k)
+    rv, ri = torch.topk(OE.similarity(te, ie), k, dim=1)
+    assert torch.allclose(vals.cpu(), rv, atol=2e-6)
+    clear = torch.ones_like(ri, dtype=torch.bool)  # (neighbours closer than the arithmetic's last bits may swap)
+    clear[:, :-1] &= (rv[:, :-1] - rv[:, 1:]) > 1e-6
+    clear[:, 1:] &= (rv[:, :-1] - rv[:, 1:]) > 1e-6
+    assert torch.equal(idx.cpu()[clear], ri[clear]) and float(clear.float().mean()) > 0.9
+    try:
+        E.USE_SIM_P16 = False
+        v0, i0 = E.similarity_topk(te.to(gpu), ie.to(gpu), k)
+    finally:
+        E.USE_SIM_P16 = True
+    assert torch.allclose(v0, vals, atol=3e-7, rtol=0)
+    gap_ok = torch.ones_like(idx, dtype=torch.bool)
+    gap_ok[:, :-1] &= (vals[:, :-1] - vals[:, 1:]) > 3e-7
+    gap_ok[:, 1:] &= (vals[:, :-1] - vals[:, 1:]) > 3e-7
+    assert torch.equal(i0[gap_ok], idx[gap_ok])
+
+
+def test_fused_similarity_topk_presplit_overflow_and_negative_thresholds(gpu):
+    """The pre-split path on the orders a threshold filter is weakest on: a gallery ascending along its index (every later row
+    beats the first chunk's thresholds: the lists overflow, the gated dense passes must answer), and queries whose best
+    similarities are all NEGATIVE (the zero rows a ragged tile reads must not be admitted as 0 >= threshold)."""
+    from textreid_amd.evaluation import similarity_topk
+
+    G, Q, C = 8192 * 2 + 1234, 96, 256
+    gen = torch.Generator().manual_seed(3)
+    gal = torch.zeros(G, C)
+    gal[:, 0] = torch.arange(G, dtype=torch.float32) * 1e-4
+    gal[:, 1] = torch.randn(G, generator=gen)
+    gal[:, 2] = -torch.rand(G, generator=gen) - 0.5               # strictly negative
+    q = torch.zeros(Q, C)
+    q[:32, 0] = 1.0            # ascending with the index: overflow
+    q[32:64, 1] = 1.0          # random order
+    q[64:, 2] = 1.0            # every similarity negative
+    vals, idx = similarity_topk(q.to(gpu), gal.to(gpu), 10, normalize=False)
+    order = torch.sort(q @ gal.t(), dim=1, descending=True, stable=True)
+    assert torch.equal(idx.cpu(), order.indices[:, :10])
+    assert torch.allclose(vals.cpu(), order.values[:, :10], rtol=1e-6, atol=0)
+
+
 def test_rank_full_argsort_beyond_the_lds_sort(gpu):
     """rank(get_mAP=True) on a gallery wider than the in-LDS bitonic sort (G > 16384: ICFG-PEDES i2t has 19 848
     captions): packed keys + segmented radix sort (argsort_large.hip).  Index-exact against a stable descending sort,

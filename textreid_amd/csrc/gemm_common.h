@@ -86,6 +86,12 @@ int gemm_bf16_dispatch(GemmParams& p, int a_mode, int b_mode, int precision, hip
 
 }  // namespace trid
 
+namespace trid {
+// retrieval (gemm_stream.hip): the admission-filter pass on pre-split operands, queries resident in registers
+int stream_topk_filter(const void* g16, const float* g_amax, const void* q16, const float* q_amax, int G, int Q, const GemmFilter& filt,
+                       hipStream_t stream);
+}  // namespace trid
+
 // trid_gemm_f32 plus the internal extras (either may be null).  With a filter the call returns
 // TRID_E_UNSUPPORTED when the shape / precision does not run on the split kernel.
 int trid_gemm_launch(const trid_gemm_desc* d, const trid::GemmFilter* filt, const int* gate, hipStream_t stream);

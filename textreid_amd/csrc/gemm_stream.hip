@@ -81,6 +81,10 @@ struct StreamParams {
     int relu;
     int nt_o;
     EvalBound ev;            // eval mode (trid_conv1x1_eval_p16; ev.coef != null): the output's scale from the analytic bound, res optional
+    // FUSE == 4 (retrieval, stream_topk_filter): nothing is stored but the elements that reach their COLUMN's threshold
+    // (columns = queries, rows = gallery rows): appended to the column's candidate list through an atomic counter
+    GemmFilter filt;
+    int n_real;              // columns that exist (N is padded to a multiple of 32)
 };
 
 __device__ __forceinline__ void lds_store1(const void* p, float v) {
@@ -95,6 +99,9 @@ __device__ __forceinline__ void lds_store1(const void* p, float v) {
 template <int K, int CW, int TM, bool ACC, int FUSE = 0>
 __global__ __launch_bounds__(512, 2) void gemm_p16_stream_kernel(StreamParams p) {
     static_assert(FUSE == 0 || (CW == 8 && !ACC), "the fused epilogue is built for the 8-column-wave, non-accumulating form");
+    // FUSE == 4: the top-k admission filter of the retrieval match (evaluation.py:117-120, 17-19): the QUERIES are the column
+    // panel a wave keeps in registers (32 queries x K = 256 in 128 VGPRs), the gallery streams through the LDS ring once per
+    // 256 queries, and an element leaves the chip only when it reaches its query's admission threshold (one register)
     // FUSE == 3: the statistics-only pass (nothing is stored but the partials).  Without the output stream a step is over in
     // a fraction of the HBM latency, so one tile in flight per workgroup starves it (66 us for 100 MB): THREE stages, two
     // tiles in flight.  (With C stores in between the 6-bit in-order vmcnt could not tell the older DMA from the newer one.)
@@ -176,6 +183,11 @@ __global__ __launch_bounds__(512, 2) void gemm_p16_stream_kernel(StreamParams p)
         rinv = p.res != nullptr ? 1.f / f16_scale_of(*p.res_amax) : 1.f;
     }
     unsigned tmax_bits = 0;  // eval mode: true max|out| of everything this lane wrote
+    float f_thr = INFINITY;  // FUSE == 4: this lane's column (query) threshold
+    if constexpr (FUSE == 4) {
+        const int col = n0 + (lane & 31);
+        if (col_live && col < p.n_real) f_thr = p.filt.thr[(long long)col * p.filt.thr_stride];
+    }
 
     // loader: chunk c (1 KB = RPC rows) of a stage; lane -> (row, stored unit j); source unit = j ^ (row & 15).  The per-chunk
     // offsets are re-derived from the lane index in every step (`zero` is opaque to the compiler): kept across the loop
@@ -220,6 +232,8 @@ __global__ __launch_bounds__(512, 2) void gemm_p16_stream_kernel(StreamParams p)
             } else {
                 wait_vm<0>();
             }
+        } else if constexpr (FUSE == 4) {
+            wait_vm<0>();  // (the only vector-memory traffic besides this tile's DMA: the rare candidate appends of the last step)
         } else {
             if (first) wait_vm<0>();
             else if (p.stats != nullptr && RW == 1) wait_vm<NST>();
@@ -414,13 +428,48 @@ __global__ __launch_bounds__(512, 2) void gemm_p16_stream_kernel(StreamParams p)
             // (no C - the statistics-only pass: every store is out of range, the instruction count the waits rely on stays)
             const unsigned ldcb = (unsigned)p.ldc * 4u;
             const unsigned base = (col_live && p.C != nullptr) ? (unsigned)row0 * ldcb + 4u * khalf * ldcb + (unsigned)(n0 + (lane & 31)) * 4u : OOB;
-            if constexpr (FUSE != 1 && FUSE != 3) {
+            if constexpr (FUSE != 1 && FUSE != 3 && FUSE != 4) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const float v = acc[i][r];
                         store_c(__float_as_uint(v), rsC, base + (unsigned)(i * 32 + (r & 3) + 8 * (r >> 2)) * ldcb, p.nt_c != 0);
+                    }
+            }
+        }
+        if constexpr (FUSE == 4) {
+            // top-k admission filter: rows beyond M (a ragged last tile read zeros) are taken out first; then ONE comparison
+            // of the lane's maximum tells whether any of its TM * 16 elements is a candidate (~k / Gc of them are)
+            const long long rb = row0 + 4 * khalf;
+            if ((long long)(t + 1) * RB > p.M) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (rb + i * 32 + (r & 3) + 8 * (r >> 2) >= p.M) acc[i][r] = -INFINITY;
+            }
+            float mx = -INFINITY;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, acc[i][r]);
+            if (mx >= f_thr) {
+                const int col = n0 + (lane & 31);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float v = acc[i][r];
+                        if (v >= f_thr) {
+                            const int slot = atomicAdd(p.filt.cnt + col, 1);
+                            if (slot < p.filt.cap) {
+                                float2* dst = reinterpret_cast<float2*>(p.filt.cand) + (long long)col * p.filt.cap + slot;
+                                *dst = make_float2(v, __int_as_float((int)(rb + i * 32 + (r & 3) + 8 * (r >> 2)) + p.filt.col0));
+                            } else {
+                                *p.filt.overflow = 1;
+                            }
+                        }
                     }
             }
         }
@@ -647,6 +696,43 @@ extern "C" int trid_gemm_p16_stream(const void* A, const float* a_amax, const vo
     if (K == 64) return pick_stream<64>(p, s);
     if (K == 128) return pick_stream<128>(p, s);
     return pick_stream<256>(p, s);
+}
+
+// Retrieval: candidates of Q queries (P16 [Qp][256], Qp = Q rounded up to 32, padding rows zero) against G gallery rows (P16
+// [G][256]): every similarity >= thr[query * thr_stride] is appended to the query's list (value, gallery row + col0).
+// 1280 persistent workgroups = 5 full rounds of the chip for Q = 1e4 (40 query panels x 32 workers; the panels of one worker
+// index share an XCD and walk the same gallery tiles: the gallery crosses the fabric once per XCD, not once per panel).
+int trid::stream_topk_filter(const void* g16, const float* g_amax, const void* q16, const float* q_amax, int G, int Q, const GemmFilter& filt,
+                             hipStream_t stream) {
+    const int Qp = (Q + 31) / 32 * 32;
+    TRID_REQUIRE(g16 && q16 && g_amax && q_amax && G > 0 && Q > 0 && filt.thr && filt.cnt && filt.cand && filt.overflow, "stream_topk_filter: null operand");
+    TRID_REQUIRE(aligned16(g16) && aligned16(q16) && (long long)G * 1024 < (1ll << 31), "stream_topk_filter: 16-byte aligned operands, gallery shard below 2 GB");
+    StreamParams p;
+    memset(&p, 0, sizeof(p));
+    p.A = (const char*)g16; p.B = (const char*)q16; p.C = nullptr;
+    p.a_amax = g_amax; p.b_amax = q_amax;
+    p.M = G; p.N = Qp; p.ldc = Qp;
+    p.filt = filt; p.n_real = Q;
+    constexpr int K = 256, CW = 8, TM = 2, RB = TM * 32;
+    const size_t lds = (size_t)2 * RB * K * 4 + 2 * 8 * 32 * sizeof(float4);
+    static std::once_flag once;
+    static hipError_t attr_err = hipSuccess;
+    std::call_once(once, [] {
+        attr_err = hipFuncSetAttribute((const void*)gemm_p16_stream_kernel<K, CW, TM, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    });
+    if (attr_err != hipSuccess) {
+        set_error("stream_topk_filter: cannot reserve LDS: %s", hipGetErrorString(attr_err));
+        return (int)attr_err;
+    }
+    p.panels = (Qp + CW * 32 - 1) / (CW * 32);
+    p.tiles = (G + RB - 1) / RB;
+    // workers per panel: whole rounds of the chip's 256 CUs, >= 64 tiles per worker
+    int workers = 8;
+    while (workers < 256 && (long long)p.panels * workers < 1024 && p.tiles / (workers * 2) >= 64) workers *= 2;
+    while ((long long)p.panels * workers % 256 != 0 && workers < 256 && p.tiles / (workers + 8) >= 64) workers += 8;
+    p.workers = std::min(workers, (p.tiles + 7) / 8 * 8);
+    hipLaunchKernelGGL((gemm_p16_stream_kernel<K, CW, TM, false, 4>), dim3(p.workers * p.panels), dim3(512), lds, stream, p);
+    return check_launch("stream_topk_filter");
 }
 
 // shapes the fused conv3 + BatchNorm + identity + ReLU kernel covers (K = planes of layer1 - layer3, N = 4 planes)

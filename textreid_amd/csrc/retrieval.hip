@@ -276,10 +276,14 @@ static void launch_cands(const float* cand, const int* cnt, int cap, int Q, long
 // step 4 (panel GEMM + scan per chunk, each a no-op unless the overflow flag is set) redo columns >= Gc,
 // so the result is exact for any input.  Shapes / precisions the split kernel does not cover run the
 // dense passes unconditionally.
-extern "C" int trid_sim_topk_f32(const float* q, const float* g, float* out_val, int64_t* out_idx, int Q, int G, int C,
-                                 int k, long long idx_offset, int precision, const float* q_amax, const float* g_amax, float* ws,
-                                 void* stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
+// q16 / g16 (may be null): the same operands pre-split (P16 [ceil32(Q)][256] with zero padding rows, P16 [G][256], packed with
+// q_amax / g_amax): step 2 then runs on the streaming kernel with the queries resident in registers (gemm_stream.hip FUSE 4)
+// mode 0: everything (the gated dense passes of step 4 are enqueued behind the fused pass: no host round trip);
+// mode 1: steps 1-3 only - the CALLER reads the overflow flag (ws[trid_topk_ws_flag_offset]) and runs mode 2 when it is set
+//         (one 4-byte read instead of ~250 gated no-op launches = 1.4 ms of a 17 ms match at Q = 1e4, G = 1e6);
+// mode 2: the dense passes over the columns >= Gc, unconditionally (after a mode-1 call whose lists overflowed).
+static int sim_topk(const float* q, const float* g, const void* q16, const void* g16, float* out_val, int64_t* out_idx, int Q, int G, int C,
+                    int k, long long idx_offset, int precision, const float* q_amax, const float* g_amax, float* ws, int mode, hipStream_t stream) {
     TRID_REQUIRE(q && g && out_val && out_idx && ws, "trid_sim_topk_f32: null pointer");
     TRID_REQUIRE(Q > 0 && G > 0 && C > 0 && C % 4 == 0, "trid_sim_topk_f32: bad shape (C%%4)");
     TRID_REQUIRE(k >= 1 && k <= TOPK_MAX && k <= G, "trid_sim_topk_f32: k must be in [1,%d] and <= G", TOPK_MAX);
@@ -313,11 +317,12 @@ extern "C" int trid_sim_topk_f32(const float* q, const float* g, float* out_val,
         return check_launch("trid_sim_topk_f32");
     };
 
-    int rc = dense_pass(0, nullptr);
+    int rc = TRID_OK;
+    if (mode != 2) rc = dense_pass(0, nullptr);
     if (rc || G <= Gc) return rc;
 
     bool fused = false;
-    {
+    if (mode != 2) {
         hipError_t e = hipMemsetAsync(cnt, 0, (size_t)(Q + 1) * sizeof(int), stream);
         if (e != hipSuccess) { set_error("trid_sim_topk_f32: memset failed: %s", hipGetErrorString(e)); return (int)e; }
         trid_gemm_desc d;
@@ -332,7 +337,10 @@ extern "C" int trid_sim_topk_f32(const float* q, const float* g, float* out_val,
         GemmFilter f;
         f.thr = out_val + (k - 1); f.thr_stride = k;
         f.cnt = cnt; f.cand = ws; f.cap = cap; f.col0 = Gc; f.overflow = overflow;
-        rc = trid_gemm_launch(&d, &f, nullptr, stream);
+        if (q16 != nullptr && g16 != nullptr)
+            rc = stream_topk_filter(reinterpret_cast<const char*>(g16) + (size_t)Gc * 1024, g_amax, q16, q_amax, G - Gc, Q, f, stream);
+        else
+            rc = trid_gemm_launch(&d, &f, nullptr, stream);
         if (rc == TRID_OK) {
             fused = true;
 #define TRID_CALL(KK) launch_cands<KK>(ws, cnt, cap, Q, idx_offset, out_val, out_idx, overflow, stream)
@@ -345,11 +353,33 @@ extern "C" int trid_sim_topk_f32(const float* q, const float* g, float* out_val,
         }
     }
     // dense passes over the remaining chunks: unconditional without the fused path, gated on overflow with it
+    if (mode == 1 && fused) return TRID_OK;
+    if (mode == 1) {  // (the fused pass did not apply: the dense passes are the result - tell the caller not to redo them)
+        hipError_t e = hipMemsetAsync(overflow, 0, sizeof(int), stream);
+        if (e != hipSuccess) { set_error("trid_sim_topk: memset failed: %s", hipGetErrorString(e)); return (int)e; }
+    }
     for (int c0 = Gc; c0 < G; c0 += Gc) {
-        rc = dense_pass(c0, fused ? overflow : nullptr);
+        rc = dense_pass(c0, (fused && mode == 0) ? overflow : nullptr);
         if (rc) return rc;
     }
     return TRID_OK;
+}
+
+extern "C" long long trid_topk_ws_flag_offset(int Q, int G) { return (long long)Q * topk_chunk_cols(G) + Q; }
+
+extern "C" int trid_sim_topk_f32(const float* q, const float* g, float* out_val, int64_t* out_idx, int Q, int G, int C,
+                                 int k, long long idx_offset, int precision, const float* q_amax, const float* g_amax, float* ws,
+                                 void* stream_) {
+    return sim_topk(q, g, nullptr, nullptr, out_val, out_idx, Q, G, C, k, idx_offset, precision, q_amax, g_amax, ws, 0, (hipStream_t)stream_);
+}
+
+extern "C" int trid_sim_topk_p16(const float* q, const float* g, const void* q16, const void* g16, float* out_val, int64_t* out_idx, int Q, int G,
+                                 int k, long long idx_offset, const float* q_amax, const float* g_amax, float* ws, int mode, void* stream_) {
+    TRID_REQUIRE(mode >= 0 && mode <= 2, "trid_sim_topk_p16: mode must be 0, 1 or 2");
+    if (mode == 2) return sim_topk(q, g, nullptr, nullptr, out_val, out_idx, Q, G, 256, k, idx_offset, 16, q_amax, g_amax, ws, 2, (hipStream_t)stream_);
+    TRID_REQUIRE(q16 && g16 && q_amax && g_amax && aligned16(q16) && aligned16(g16), "trid_sim_topk_p16: the pre-split operands and their amax scalars are needed");
+    TRID_REQUIRE((long long)G * 1024 < (1ll << 31), "trid_sim_topk_p16: the gallery shard must stay below 2 GB (G <= 2097151 rows of 256)");
+    return sim_topk(q, g, q16, g16, out_val, out_idx, Q, G, 256, k, idx_offset, 16, q_amax, g_amax, ws, mode, (hipStream_t)stream_);
 }
 
 extern "C" int trid_topk_rows_f32(const float* sim, int ld, int Q, int G, int k, float* out_val, int64_t* out_idx,

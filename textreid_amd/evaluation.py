@@ -82,6 +82,33 @@ def _sim_precision(q, g):
     return 16, ops.amax(q), ops.amax(g)
 
 
+USE_SIM_P16 = os.environ.get("TRID_SIM_P16", "1") != "0"  # retrieval match on pre-split operands (0: the on-the-fly split GEMM, A/B runs)
+
+
+def _sim_topk_call(q, g, vals, idx, k, offset, ws):
+    """The fused similarity + top-k launch sequence.  C == 256 embeddings in the fp32-class default arithmetic: the gallery (written
+    once, scored against every query panel) and the queries are split into their fp16 planes ONCE (p16_pack) and the
+    admission-filter pass runs on the streaming kernel with the queries resident in registers (trid_sim_topk_p16)."""
+    Q, C = q.shape
+    G = g.shape[0]
+    prec, qa, ga = _sim_precision(q, g)
+    if USE_SIM_P16 and prec == 16 and C == 256 and G > 8192 and G * 1024 < (1 << 31):
+        q16 = torch.zeros((Q + 31) // 32 * 32, C, dtype=torch.float32, device=q.device)
+        call("trid_p16_pack_f32", _p(q), Q, C, C, _p(qa), _p(q16), 1, stream())
+        g16 = torch.empty_like(g)
+        call("trid_p16_pack_f32", _p(g), G, C, C, _p(ga), _p(g16), 1, stream())
+        if torch.cuda.is_current_stream_capturing():  # (no host read inside a capture: the device-gated fall-back passes)
+            call("trid_sim_topk_p16", _p(q), _p(g), _p(q16), _p(g16), _p(vals), _p(idx), Q, G, k, offset, _p(qa), _p(ga), _p(ws), 0, stream())
+            return
+        call("trid_sim_topk_p16", _p(q), _p(g), _p(q16), _p(g16), _p(vals), _p(idx), Q, G, k, offset, _p(qa), _p(ga), _p(ws), 1, stream())
+        # a candidate list overflowed (adversarially ordered gallery)?  One 4-byte read; the dense passes only then
+        flag = ws[ops.L.load().trid_topk_ws_flag_offset(Q, G):][:1].view(torch.int32)
+        if int(flag.item()) != 0:
+            call("trid_sim_topk_p16", _p(q), _p(g), None, None, _p(vals), _p(idx), Q, G, k, offset, _p(qa), _p(ga), _p(ws), 2, stream())
+        return
+    call("trid_sim_topk_f32", _p(q), _p(g), _p(vals), _p(idx), Q, G, C, k, offset, prec, _p(qa), _p(ga), _p(ws), stream())
+
+
 def similarity_topk(text_embed, image_embed, k=10, normalize=True):
     """Per-query top-k of text @ image.T without materialising [Q,G]; gallery rows
     sharded across ranks when torch.distributed is initialised (each rank passes
@@ -105,8 +132,7 @@ def similarity_topk(text_embed, image_embed, k=10, normalize=True):
 
         sizes = all_gather_rows(torch.tensor([G], dtype=torch.int64, device=q.device))
         offset = int(sizes[: dist_rank()].sum())
-    prec, qa, ga = _sim_precision(q, g)
-    call("trid_sim_topk_f32", _p(q), _p(g), _p(vals), _p(idx), Q, G, C, k, offset, prec, _p(qa), _p(ga), _p(ws), stream())
+    _sim_topk_call(q, g, vals, idx, k, offset, ws)
     if not dp:
         return vals, idx
     # per-shard lists -> every rank: [W*Q, k] rank-major, then one row top-k over the W*k candidates
@@ -126,8 +152,7 @@ def _topk_neighbours(q, g, k):
     vals = torch.empty(Q, k, dtype=torch.float32, device=q.device)
     idx = torch.empty(Q, k, dtype=torch.int64, device=q.device)
     ws = ops.empty((ops.L.load().trid_topk_ws_floats(Q, G, k),), q)
-    prec, qa, ga = _sim_precision(q, g)
-    call("trid_sim_topk_f32", _p(q), _p(g), _p(vals), _p(idx), Q, G, C, k, 0, prec, _p(qa), _p(ga), _p(ws), stream())
+    _sim_topk_call(q, g, vals, idx, k, 0, ws)
     return idx
 
 
