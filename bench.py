@@ -27,6 +27,8 @@ sys.path.insert(0, ROOT)
 
 F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak
+F16_SPLIT_PEAK_TFLOPS = 2500.0 / 3  # fp32-class two-plane fp16 arithmetic: 3 dense fp16 MFMA products per multiply-add
+VISUAL_FWD_GFLOP = {"m_resnet50": 17.24, "m_resnet101": 24.51}  # algorithmic forward work per image (convs + token-0 attention pool)
 
 
 def log(msg):
@@ -251,9 +253,9 @@ def configs3_bench(device, B=128, K=65536, steps=6, warmup=3):
     return out
 
 
-def encode_bench(model, images, tokens, lengths, reps=5):
+def encode_bench(model, images, tokens, lengths, reps=5, arch="m_resnet50"):
     """Eval-mode encode rates (test_net.py path: running-stat BatchNorm, no key encoders): gallery images/s
-    and query captions/s of ONE GPU at the training batch size."""
+    and query captions/s of ONE GPU at the training batch size; `gallery_encode` carries the MFMA roofline of the image pass."""
     from textreid_amd.caption import CaptionBatch
 
     head = model.embed_model
@@ -272,6 +274,25 @@ def encode_bench(model, images, tokens, lengths, reps=5):
             torch.cuda.synchronize()
             out[name] = reps * images.shape[0] / (time.perf_counter() - t0)
     model.train(was_training)
+    gf = VISUAL_FWD_GFLOP.get(arch)
+    if gf:
+        tfl = out["gallery_encode_imgs_per_s"] * gf / 1e3
+        roof = {
+            "bound": "mfma",
+            "kernel": "the eval-mode image encoder as a whole (inference.py:14-26): P16 tile / streaming / ring-of-rows kernels with the running-statistics BatchNorm, residual and ReLU fused into their epilogues",
+            "achieved": tfl,
+            "peak": F16_SPLIT_PEAK_TFLOPS,
+            "unit": "TFLOP/s",
+            "frac": tfl / F16_SPLIT_PEAK_TFLOPS,
+            "traffic": None,
+            "algorithmic_gflop_per_image": gf,
+            "note": "images/s x algorithmic forward GFLOP per image (SURVEY.md 8d) over the whole pass's wall time, launch gaps and the HBM-bound stem / layer1 kernels included",
+        }
+        for label, pat in (("tile_3x3", "gemm_p16_kernel<2, 128, 128, 2, 4, 2, 2"), ("tile_1x1", "gemm_p16_kernel<0, 128, 128, 2, 4, 2, 2"), ("stream_1x1", "gemm_p16_stream_kernel")):
+            k_ms, k_src = stored_kernel_avg_ms(pat, "_eval_encode_kernel_stats.csv")
+            if k_ms:
+                roof.setdefault("rocprof_kernels", {})[label] = {"avg_launch_ms": k_ms, "source": k_src}
+        out["gallery_encode"] = {"value": out["gallery_encode_imgs_per_s"], "unit": "imgs/s", "batch": int(images.shape[0]), "roofline": roof}
     return out
 
 
@@ -305,7 +326,23 @@ def retrieval_bench(device, world, rank, G_total=1000000, Q=10000, k=10, shard_r
         dist.all_reduce(tm, op=dist.ReduceOp.MAX)
         dt = float(tm.item())
     scored = shard * world
+    tfl = 2.0 * Q * scored * 256 / dt / 1e12
+    k_ms, k_src = stored_kernel_avg_ms("gemm_p16_stream_kernel<256, 8, 2, false, 4>", "_retrieval_kernel_stats.csv")
+    roof = {
+        "bound": "mfma",
+        "kernel": "trid::gemm_p16_stream_kernel<256, 8, 2, false, 4> (similarity of pre-split operands with the top-k admission filter as epilogue: 256 queries resident in a workgroup's registers, the gallery streamed through LDS once per query panel; fp16 two-plane arithmetic, 3 MFMA products per multiply-add)",
+        "achieved": tfl / world,
+        "peak": F16_SPLIT_PEAK_TFLOPS,
+        "unit": "TFLOP/s",
+        "frac": tfl / world / F16_SPLIT_PEAK_TFLOPS,
+        "traffic": None,
+        "note": "achieved = algorithmic FLOPs of the WHOLE match (2 Q G C, per GPU) / wall time of the whole call (amax + split of both operands, first-panel GEMM + row scan, filter pass, list merge, one 4-byte host read): the kernel itself is ~98 % of it",
+    }
+    if k_ms and shard_rows is None and world == 1:
+        gf = 2.0 * Q * (shard - 8192) * 256 / 1e9
+        roof["rocprof_kernel"] = {"avg_launch_ms": k_ms, "achieved": gf / k_ms, "frac": gf / k_ms / F16_SPLIT_PEAK_TFLOPS, "source": k_src + ": average duration of this kernel in rocprofv3 --kernel-trace --stats of tools/retrieval_time.py (same Q, G)"}
     return {
+        "roofline": roof,
         "metric": "gallery imgs/sec (retrieval: similarity + top-10, Q=1e4 queries)",
         "value": scored / dt,
         "unit": "gallery imgs/s",
@@ -314,10 +351,39 @@ def retrieval_bench(device, world, rank, G_total=1000000, Q=10000, k=10, shard_r
         "gallery_shard_per_gpu": shard,
         "queries": Q,
         "seconds": dt,
-        "tflops": 2.0 * Q * scored * 256 / dt / 1e12,
+        "tflops": tfl,
         "algorithmic_bytes_per_gpu": shard * 256 * 4 + Q * 256 * 4 + Q * k * 12,
-        "note": "fp32 embeddings, fp16 two-plane split (fp32-class) similarity GEMM, exact top-10: first 8192 gallery rows via a [Q,8192] panel + streaming scan, the rest via the GEMM's admission-filter epilogue (no similarity matrix in HBM)",
+        "note": "fp32 embeddings in, split ONCE into fp16 planes (fp32-class two-plane arithmetic), exact top-10: first 8192 gallery rows via a [Q,8192] panel + streaming scan, the rest via the admission-filter epilogue of the streaming kernel (no similarity matrix in HBM)",
     }
+
+
+def newest_profiles(suffix):
+    """File names under profiles/ that end in `suffix`, newest round first (names are r<round><letter>_...: descending name order)."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    try:
+        return sorted((f for f in os.listdir(os.path.join(here, "profiles")) if f.endswith(suffix) and f.startswith("r")), reverse=True)
+    except OSError:
+        return []
+
+
+def stored_kernel_avg_ms(pattern, suffix):
+    """(average duration in ms, file) of the kernels whose name contains `pattern` in the newest committed rocprofv3
+    --kernel-trace --stats summary profiles/r*<suffix> that lists them, or (None, None)."""
+    import csv
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    for fn in newest_profiles(suffix):
+        try:
+            tot, calls = 0.0, 0
+            for r in csv.DictReader(open(os.path.join(here, "profiles", fn))):
+                if pattern in r["Name"]:
+                    tot += float(r["TotalDurationNs"])
+                    calls += int(r["Calls"])
+            if calls:
+                return tot / calls / 1e6, "profiles/" + fn
+        except (OSError, ValueError, KeyError):
+            pass
+    return None, None
 
 
 def visible_gpus():
@@ -644,9 +710,9 @@ def main():
     here = os.path.dirname(os.path.abspath(__file__))
 
     def stored_traffic(pattern):
-        """(bytes per launch, file) of the kernels whose name contains `pattern` in the newest committed PMC summary
-        (calls-weighted over the matching lines), or (None, None)."""
-        for fn in ("r04m_pmc_hbm_traffic.txt",):
+        """(bytes per launch, file) of the kernels whose name contains `pattern` in the NEWEST committed PMC summary that
+        lists them (profiles/r*_pmc_hbm_traffic.txt, newest round first by name; calls-weighted over the matching lines), or (None, None)."""
+        for fn in newest_profiles("_pmc_hbm_traffic.txt"):
             try:
                 tot, calls = 0.0, 0
                 for ln in open(os.path.join(here, "profiles", fn)):
@@ -661,21 +727,11 @@ def main():
         return None, None
 
     def stored_rocprof_avg_ms(pattern):
-        """average duration (ms) of the kernels whose name contains `pattern` in the committed rocprofv3 --kernel-trace --stats
-        summary of this command (the replayed step: in-graph durations), or None."""
-        import csv
+        """(average duration in ms, file) of the kernels whose name contains `pattern` in the newest committed rocprofv3
+        --kernel-trace --stats summary of this command (profiles/r*_bench_kernel_stats.csv), or (None, None)."""
+        return stored_kernel_avg_ms(pattern, "_bench_kernel_stats.csv")
 
-        try:
-            tot, calls = 0.0, 0
-            for r in csv.DictReader(open(os.path.join(here, "profiles", "r04m_bench_kernel_stats.csv"))):
-                if pattern in r["Name"]:
-                    tot += float(r["TotalDurationNs"])
-                    calls += int(r["Calls"])
-            return tot / calls / 1e6 if calls else None
-        except (OSError, ValueError, KeyError):
-            return None
-
-    for fn in ("r04m_pmc_hbm_traffic.txt", "r03k_pmc_hbm_traffic.txt", "r03_pmc_hbm_traffic.txt", "r02d_pmc_hbm_traffic.txt", "r02c_pmc_hbm_traffic.txt", "r02a_pmc_hbm_traffic.txt", "r01j_pmc_hbm_traffic.txt"):
+    for fn in newest_profiles("_pmc_hbm_traffic.txt"):
         try:
             for line in open(os.path.join(here, "profiles", fn)):
                 f = line.split()
@@ -729,11 +785,11 @@ def main():
     roofline_1x1["traffic"], roofline_1x1["traffic_source"] = t1, t1_src
     if p16:  # the rocprofv3 view of the same kernels inside the REPLAYED step (stored summary of this command)
         for obj, pat in ((roofline, "gemm_p16_kernel<2, 128, 128, 2, 4, 2, 2"), (roofline_1x1, "gemm_p16_kernel<0, 128, 128, 2, 4, 2, 2")):
-            ms_r = stored_rocprof_avg_ms(pat)
+            ms_r, src_r = stored_rocprof_avg_ms(pat)
             if ms_r and obj["launches"]:
                 gf = obj["algorithmic_gflop_per_launch"]
                 obj["rocprof_in_graph"] = {"avg_launch_ms": ms_r, "achieved": gf / ms_r, "frac": gf / ms_r / peak,
-                                           "source": "profiles/r04m_bench_kernel_stats.csv: average duration of this template inside the replayed step x the algorithmic GFLOP per launch of the live events"}
+                                           "source": "%s: average duration of this template inside the timed step x the algorithmic GFLOP per launch of the live events" % src_r}
     # the two MFMA-bound tile kernels as equals, the one with the larger total per step first; and the HBM-bound streaming kernel
     nrun = max(profiled_eager, 1) if runner is not None else args.steps
     roofline["total_ms_per_step"] = ms / nrun
@@ -761,7 +817,7 @@ def main():
         if world == 1:  # the per-GPU work of configs[4]'s 8-GPU form: one 125 000-row shard
             sh = retrieval_bench(device, world, rank, shard_rows=125000)
             retr["one_of_8_shards"] = {k: sh[k] for k in ("value", "unit", "gallery_rows_scored", "seconds", "tflops")}
-        retr.update(encode_bench(model, batches[0][0], batches[0][1], batches[0][2]))
+        retr.update(encode_bench(model, batches[0][0], batches[0][1], batches[0][2], arch=args.model))
         log("retrieval: %.1f M gallery imgs/s" % (retr["value"] / 1e6))
     qsim = [queue_similarity_bench(device, B=B, K=k) for k in sorted({args.queue, 65536})]
     qsim.append(queue_similarity_bench(device, B=B, K=65536, bf16=True))
@@ -807,6 +863,7 @@ def main():
             # the fraction of them issued from INSIDE backward (overlapped) and the device time left exposed after it
             out["data_parallel"] = dict(dp_stats, rccl_ranks=world, backend=dist.get_backend(),
                                         embedding_allgather_bytes_per_rank=B * (4 * 256 + 2) * 4)
+        out["gallery_encode"] = retr.pop("gallery_encode", None) if retr else None
         out["retrieval"] = retr
         out["queue_similarity"] = qsim
         out["configs3_1gpu"] = c3
