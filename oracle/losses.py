@@ -21,13 +21,17 @@ def label_smooth_ce(logits, labels, epsilon):
     return (-t * logp).mean(0).sum()
 
 
-def instance_loss(projection, v_embed, t_embed, labels, epsilon=0.0):
-    # losses.py:42-62 with scale=1, norm=False (the call at moco_head/loss.py:23-29)
+def instance_loss(projection, v_embed, t_embed, labels, epsilon=0.0, scale=1, norm=False):
+    # losses.py:42-62 (moco_head/loss.py:23-29 calls it with scale=1, norm=False).  Quirk kept: the reference constructs
+    # CrossEntropyLabelSmooth(num_classes=...) without handing its `epsilon` on (losses.py:56), so ANY epsilon > 0 smooths
+    # with that class's default weight 0.1 (losses.py:18)
+    if norm:
+        v_embed, t_embed = F.normalize(v_embed, p=2, dim=-1), F.normalize(t_embed, p=2, dim=-1)
     pn = F.normalize(projection, p=2, dim=0)
-    lv = v_embed @ pn
-    lt = t_embed @ pn
+    lv = scale * (v_embed @ pn)
+    lt = scale * (t_embed @ pn)
     if epsilon > 0:
-        return label_smooth_ce(lv, labels, epsilon) + label_smooth_ce(lt, labels, epsilon)
+        return label_smooth_ce(lv, labels, 0.1) + label_smooth_ce(lt, labels, 0.1)
     return F.cross_entropy(lv, labels) + F.cross_entropy(lt, labels)
 
 

@@ -12,7 +12,11 @@ pre-gather gradients staged from inside backward) on its 128-row shard.  Checked
      1024 x 65536 contrastive matrices as the reference would form them;
   3. rank 0's REDUCED gradients against a single-process evaluation of the same global batch: the shards run through
      the encoders one after another (own BatchNorm statistics each, as `broadcast_buffers=False`,
-     `train_net.py:54-55`), the embeddings are concatenated and the losses taken once - no collective anywhere.
+     `train_net.py:54-55`), the embeddings are concatenated and the losses taken once - no collective anywhere;
+  4. the POST-GATHER gradients against the fp64 CPU ORACLE (not against the HIP path itself): dL/d(v_embed), dL/d(t_embed) of
+     the whole 512- / 1024-row global batch and `projection.grad`, by autograd through `oracle.head.losses_from_embeddings`
+     on the gathered blocks (normalisation included) - the arithmetic of the global contrastive / instance / alignment
+     losses at the size the reference would form them, pinned independently of the kernels under test.
 """
 import hashlib
 import os
@@ -71,8 +75,10 @@ def main():
     seen = {}
     fused = head.loss_evaluator.forward_fused
 
-    def spy(*a):  # the gathered blocks the losses are evaluated on
+    def spy(*a):  # the gathered blocks the losses are evaluated on, and the gradients that come back to them
         seen["args"] = [x.detach().clone() for x in a[:7]]
+        a[0].register_hook(lambda g: seen.__setitem__("d_v_embed", g.detach().clone()))
+        a[1].register_hook(lambda g: seen.__setitem__("d_t_embed", g.detach().clone()))
         return fused(*a)
 
     head.loss_evaluator.forward_fused = spy
@@ -119,6 +125,19 @@ def main():
         ost = {k: (st[k].double() if st[k].dtype.is_floating_point else st[k]) for k in ("loss_evaluator.projection", "t_queue", "v_queue", "id_queue")}
         old = OH.losses_from_embeddings(ost, v_embed.double(), t_embed.double(), v_q.double(), t_q.double(), v_k.double(), t_k.double(), gid, 0.1)
         errs = {"loss:" + k: _rel(dp_losses[k], old[k]) for k in old}
+        # ---- 4. post-gather gradients vs the ORACLE: autograd through the fp64 head on the gathered blocks
+        import torch.nn.functional as F_
+
+        ove, ote = v_embed.double().requires_grad_(True), t_embed.double().requires_grad_(True)
+        opr = st["loss_evaluator.projection"].double().clone().requires_grad_(True)
+        ost2 = dict(ost)
+        ost2["loss_evaluator.projection"] = opr
+        og = OH.losses_from_embeddings(ost2, ove, ote, F_.normalize(ove, dim=1), F_.normalize(ote, dim=1), v_k.double(), t_k.double(), gid, 0.1)
+        sum(og.values()).backward()
+        # (the gather's backward hands every rank the gradient of the WHOLE global batch; rank 0's copy is checked)
+        errs["oracle_grad:v_embed"] = _rel(seen["d_v_embed"], ove.grad)
+        errs["oracle_grad:t_embed"] = _rel(seen["d_t_embed"], ote.grad)
+        errs["oracle_grad:projection"] = _rel(dp_grads["loss_evaluator.projection"], opr.grad)
         # ---- 3. reduced gradients vs the single-process evaluation of the global batch (per-shard BatchNorm)
         head.load_state_dict({k: v.clone() for k, v in st.items()})
         head.v_encoder_q.grad_sync = None

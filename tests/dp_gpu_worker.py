@@ -115,6 +115,65 @@ def main():
     if r == 0:
         print("DP_REPLICAS_IDENTICAL")
         print("DP_TRANSPORT backend=%s world=%d staged_bytes=%d post_bytes=%d" % (dist.get_backend(), W, red.bytes_staged, red.bytes_post))
+    # ---- engine.trainer.do_train under data parallelism: ranks whose models were drawn from DIFFERENT seeds are made replicas by
+    # the initial broadcast (DDP's broadcast at wrap, train_net.py:50-56), train on their shards of the same global batches and
+    # end bit-identical; the periodic replica digest (log_period = 1 here) passes on every step
+    if os.environ.get("TRID_DP_TRAINER", "0") == "1":
+        import hashlib
+
+        from textreid_amd.engine.trainer import do_train
+        from textreid_amd.solver import FusedAdam
+
+        torch.manual_seed(1000 + r)
+        head.load_state_dict(filled)
+        for p_ in head.parameters():  # every rank its own weights (rank 0 keeps the filled ones) ...
+            p_.data.add_(0.02 * r * torch.randn_like(p_) * p_.abs().mean())
+        head.v_queue.copy_(F.normalize(torch.rand_like(head.v_queue), dim=0))  # ... its own queues, ids and pointer
+        head.id_queue.fill_(7 + r)
+        head.queue_ptr.fill_(Bl * r)
+        head.v_encoder_q.grad_sync = None
+        for p_ in head.parameters():
+            p_.grad = None
+
+        class Wrapper(torch.nn.Module):  # (textreid_amd.model.Model's surface: `embed_model` + forward)
+            def __init__(self, h):
+                super().__init__()
+                self.embed_model = h
+
+            def forward(self, images, captions):
+                return self.embed_model(images, captions)
+
+        wrapper = Wrapper(head)
+        opt = FusedAdam([{"params": [p_], "lr": 1e-3} for p_ in head.parameters() if p_.requires_grad], lr=1e-3)
+
+        class Loader:
+            dataset = list(range(3))
+
+            def __len__(self):
+                return 3
+
+            def __iter__(self):
+                for i in range(3):
+                    yield x[sl].roll(i, 0), CaptionBatch(tok[sl].roll(i, 0), ln[sl].roll(i, 0), (ids[sl] + i) % NC), None
+
+        class Sched:
+            def step(self):
+                pass
+
+        do_train(wrapper, Loader(), None, opt, Sched(), None, None, dev, checkpoint_period=10, evaluate_period=10,
+                 arguments={"max_epoch": 1, "epoch": 0, "iteration": 0}, log_period=1, capture=False)
+        torch.cuda.synchronize()
+        sha = hashlib.sha256()
+        for k_, v_ in head.state_dict().items():
+            if "running" in k_:
+                continue  # (BatchNorm statistics are rank-local by design, as `broadcast_buffers=False`)
+            sha.update(v_.detach().contiguous().cpu().numpy().tobytes())
+        allh = [None] * W
+        dist.all_gather_object(allh, sha.hexdigest())
+        assert all(h == allh[0] for h in allh), "ranks that started from different seeds did not end as replicas"
+        assert int(head.queue_ptr) == (3 * Bg) % K
+        if r == 0:
+            print("DP_TRAINER_REPLICAS_IDENTICAL")
     # ---- the data-parallel step RECORDED as one hipGraph (engine.graph.CapturedTrainStep with the run's GradReducer): the packed
     # all-gather of the forward, the all-reduces staged from inside backward, the bucketed ones after it and the fused Adam
     # step, replayed - bit for bit the eager data-parallel step (RCCL only: a host-staged transport cannot be recorded)

@@ -492,6 +492,10 @@ def gen_losses(seed=11):
     out = {"v": v.numpy(), "t": t.numpy(), "proj": proj.numpy(), "labels": lab.numpy()}
     out["instance"] = ref_losses.instance_loss(proj, v, t, lab, epsilon=0.1).numpy()
     out["instance_eps0"] = ref_losses.instance_loss(proj, v, t, lab, epsilon=0.0).numpy()
+    # the non-default forms of the signature (losses.py:42-54) and its epsilon quirk (any epsilon > 0 smooths with 0.1: losses.py:56,18)
+    out["instance_s28_norm"] = ref_losses.instance_loss(proj, v, t, lab, scale=28, norm=True, epsilon=0.1).numpy()
+    out["instance_s5"] = ref_losses.instance_loss(proj, v, t, lab, scale=5, norm=False, epsilon=0.0).numpy()
+    out["instance_eps03"] = ref_losses.instance_loss(proj, v, t, lab, epsilon=0.3).numpy()
     out["global_align"] = ref_losses.global_align_loss(v, t, lab).numpy()
     vp, tp = OF.randn("l:vp", (B, 1), seed), OF.randn("l:tp", (B, 1), seed)
     vn, tn = OF.randn("l:vn", (B, K), seed), OF.randn("l:tn", (B, K), seed)
@@ -499,6 +503,9 @@ def gen_losses(seed=11):
     out["infonce"] = ref_losses.infonce_loss(vp, vn, tp, tn, 0.07).numpy()
     check("instance", OL.instance_loss(proj, v, t, lab, 0.1), torch.from_numpy(out["instance"]))
     check("instance eps0", OL.instance_loss(proj, v, t, lab, 0.0), torch.from_numpy(out["instance_eps0"]))
+    check("instance s28 norm", OL.instance_loss(proj, v, t, lab, 0.1, scale=28, norm=True), torch.from_numpy(out["instance_s28_norm"]))
+    check("instance s5", OL.instance_loss(proj, v, t, lab, 0.0, scale=5), torch.from_numpy(out["instance_s5"]))
+    check("instance eps 0.3", OL.instance_loss(proj, v, t, lab, 0.3), torch.from_numpy(out["instance_eps03"]))
     check("global_align", OL.global_align_loss(v, t, lab), torch.from_numpy(out["global_align"]))
     check("infonce", OL.infonce_loss(vp, vn, tp, tn, 0.07), torch.from_numpy(out["infonce"]))
     np.savez_compressed(os.path.join(HERE, "losses.npz"), **out)

@@ -47,6 +47,14 @@ def test_dp_two_ranks_match_global_batch_oracle(fc):
     _run_ranks(2, TRID_DIST_BACKEND="gloo", TRID_TEST_FC=fc)
 
 
+def test_dp_do_train_broadcasts_and_keeps_replicas():
+    """engine.trainer.do_train with two ranks whose models start from DIFFERENT seeds: the initial broadcast of parameters and
+    buffers (train_net.py:50-56) makes them replicas, three optimizer steps on sharded batches keep them bit-identical, the
+    replica digest check runs on every step."""
+    out = _run_ranks(2, TRID_DIST_BACKEND="gloo", TRID_DP_TRAINER="1")
+    assert "DP_TRAINER_REPLICAS_IDENTICAL" in out
+
+
 def test_dp_collectives_execute_on_rccl():
     """The SAME step with backend `nccl` (= RCCL on ROCm) in a ONE-rank group with TRID_DP_FORCE=1: the packed
     `all_gather_into_tensor` inside the forward, the asynchronous SUM all-reduce of staged flats issued from inside

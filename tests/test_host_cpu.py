@@ -279,6 +279,72 @@ def test_inference_prediction_gather_gloo_world2(tmp_path):
         assert "rank %d ok" % r in o
 
 
+REPLICA_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from textreid_amd.parallel import broadcast_module_state, check_replicas, replica_digest
+dist.init_process_group("gloo", init_method="env://")
+W, r = dist.get_world_size(), dist.get_rank()
+torch.manual_seed(100 + r)  # DIFFERENT seeds: the ranks draw different weights, statistics and queues
+class M(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.conv = torch.nn.Conv2d(3, 8, 3)
+        self.bn = torch.nn.BatchNorm2d(8)
+        self.register_buffer("v_queue", torch.nn.functional.normalize(torch.rand(16, 64), dim=0))
+        self.register_buffer("id_queue", torch.randint(0, 1000, (1, 64)))
+        self.register_buffer("queue_ptr", torch.tensor([8 * r], dtype=torch.long))
+m = M()
+m.bn.running_mean.add_(float(r))
+before = [t.detach().clone() for t in list(m.parameters()) + list(m.buffers())]
+watch = [("queue_ptr", m.queue_ptr), ("id_queue", m.id_queue), ("parameter conv.weight", m.conv.weight)]
+try:
+    check_replicas(watch, "before the broadcast")
+    raise SystemExit("ranks drawn from different seeds passed the replica check")
+except RuntimeError as e:
+    assert "diverged" in str(e) and "id_queue" in str(e), str(e)
+nbytes = broadcast_module_state(m)
+assert nbytes == sum(t.numel() * t.element_size() for t in before)
+state = [t.detach().clone() for t in list(m.parameters()) + list(m.buffers())]
+ref = [None] * W
+dist.all_gather_object(ref, [t.numpy().tobytes() for t in state])
+assert ref[0] == ref[1]                      # bit-identical replicas ...
+if r == 0:
+    assert all(torch.equal(a, b) for a, b in zip(before, state))   # ... equal to what rank 0 had
+check_replicas(watch, "after the broadcast")
+# a replica that drifts in ONE element of the id queue is caught on every rank
+if r == 1:
+    m.id_queue[0, 5] += 1
+try:
+    check_replicas(watch, "after a drift")
+    raise SystemExit("a drifted replica passed the check")
+except RuntimeError as e:
+    assert "id_queue" in str(e) and "conv.weight" not in str(e), str(e)
+# digests: wrap-around sums of the words, exact for int64 and float tensors
+d = replica_digest([torch.tensor([2 ** 62, 2 ** 62, 2 ** 62, 2 ** 62]), torch.tensor([1.0, -1.0])])
+assert int(d[0]) == 0 and int(d[1]) == (0x3F800000 + (0xBF800000 - (1 << 32)))
+print("rank", r, "ok")
+dist.destroy_process_group()
+"""
+
+
+def test_replicas_broadcast_and_digest_gloo_world2(tmp_path):
+    """parallel.broadcast_module_state / check_replicas (engine.trainer.do_train under data parallelism; DDP's broadcast at wrap,
+    train_net.py:50-56): two gloo ranks that start from DIFFERENT seeds end bit-identical to rank 0, the digest check passes
+    then, fails before, and fails - naming the tensor - after one rank drifts in one element."""
+    script = tmp_path / "replica_worker.py"
+    script.write_text(REPLICA_WORKER % ROOT)
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="2")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o
+        assert "rank %d ok" % r in o
+
+
 def test_lr_schedule_values():
     from textreid_amd.solver import LRSchedulerWithWarmup
 

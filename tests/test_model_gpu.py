@@ -263,6 +263,9 @@ def test_losses(gpu, golden_dir):
     for name, fn, ofn, args, gold in [
         ("instance", lambda p_, v_, t_: L.instance_loss(p_, v_, t_, lab, epsilon=0.1), lambda p_, v_, t_: OL.instance_loss(p_, v_, t_, lab.cpu(), 0.1), (p, v, t), g["instance"]),
         ("instance_eps0", lambda p_, v_, t_: L.instance_loss(p_, v_, t_, lab, epsilon=0.0), lambda p_, v_, t_: OL.instance_loss(p_, v_, t_, lab.cpu(), 0.0), (p, v, t), g["instance_eps0"]),
+        ("instance_s28_norm", lambda p_, v_, t_: L.instance_loss(p_, v_, t_, lab, scale=28, norm=True, epsilon=0.1), lambda p_, v_, t_: OL.instance_loss(p_, v_, t_, lab.cpu(), 0.1, scale=28, norm=True), (p, v, t), g["instance_s28_norm"]),
+        ("instance_s5", lambda p_, v_, t_: L.instance_loss(p_, v_, t_, lab, scale=5, epsilon=0.0), lambda p_, v_, t_: OL.instance_loss(p_, v_, t_, lab.cpu(), 0.0, scale=5), (p, v, t), g["instance_s5"]),
+        ("instance_eps03", lambda p_, v_, t_: L.instance_loss(p_, v_, t_, lab, epsilon=0.3), lambda p_, v_, t_: OL.instance_loss(p_, v_, t_, lab.cpu(), 0.3), (p, v, t), g["instance_eps03"]),
         ("global_align", lambda v_, t_: L.global_align_loss(v_, t_, lab), lambda v_, t_: OL.global_align_loss(v_, t_, lab.cpu()), (v, t), g["global_align"]),
     ]:
         a = [x.clone().requires_grad_(True) for x in args]

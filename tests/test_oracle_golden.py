@@ -37,6 +37,9 @@ def test_losses(golden_dir):
     v, t, p, lab = (torch.from_numpy(g[k]) for k in ("v", "t", "proj", "labels"))
     assert rel(OL.instance_loss(p, v, t, lab, 0.1), g["instance"]) < 1e-6
     assert rel(OL.instance_loss(p, v, t, lab, 0.0), g["instance_eps0"]) < 1e-6
+    assert rel(OL.instance_loss(p, v, t, lab, 0.1, scale=28, norm=True), g["instance_s28_norm"]) < 1e-6
+    assert rel(OL.instance_loss(p, v, t, lab, 0.0, scale=5), g["instance_s5"]) < 1e-6
+    assert rel(OL.instance_loss(p, v, t, lab, 0.3), g["instance_eps03"]) < 1e-6  # (the reference smooths with 0.1 for any epsilon > 0)
     assert rel(OL.global_align_loss(v, t, lab), g["global_align"]) < 1e-6
     args = [torch.from_numpy(g[k]) for k in ("v_pos", "v_neg", "t_pos", "t_neg")]
     assert rel(OL.infonce_loss(*args, 0.07), g["infonce"]) < 1e-6

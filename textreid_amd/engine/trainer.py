@@ -13,7 +13,7 @@ import time
 
 import torch
 
-from ..parallel import GradReducer, dp_active, world_size
+from ..parallel import GradReducer, broadcast_module_state, check_replicas, dp_active, world_size
 from ..parallel import _backend as parallel_backend
 from .inference import inference
 
@@ -42,6 +42,19 @@ def do_train(model, data_loader, data_loader_val, optimizer, scheduler, checkpoi
     pre_gather = [p for n, p in model.named_parameters() if p.requires_grad and "loss_evaluator" not in n][::-1]
     if dp_active() and hasattr(getattr(model, "embed_model", None), "v_encoder_q"):
         model.embed_model.v_encoder_q.grad_sync = reducer  # conv gradients all-reduced from inside backward
+    watch = []
+    if dp_active():
+        # every rank starts from rank 0's parameters, BatchNorm statistics, queues, ids and pointer (DDP's broadcast at wrap,
+        # train_net.py:50-56) - the replicated queues must never depend on the ranks having drawn the same seeds
+        nb = broadcast_module_state(model)
+        logger.info("data parallel: %.1f MB of parameters and buffers broadcast from rank 0", nb / 2 ** 20)
+        em = getattr(model, "embed_model", None)
+        watch = [(n, getattr(em, n)) for n in ("queue_ptr", "id_queue") if hasattr(em, n)]
+        if pre_gather:
+            watch.append(("parameter %s" % next(n for n, p in model.named_parameters() if p is pre_gather[0]), pre_gather[0]))
+        post = [(n, p) for n, p in model.named_parameters() if "loss_evaluator" in n]
+        watch += [("parameter " + post[0][0], post[0][1])] if post else []
+        check_replicas(watch, "after the initial broadcast")
     # data parallel: the step is recorded with its RCCL collectives only on request (TRID_DP_CAPTURE=1) - a recorded step is
     # no faster than the eager one while the step is GPU-bound, and the multi-rank recording cannot be exercised on a one-GPU
     # build box (one rank: tests/test_dp_gpu.py)
@@ -82,6 +95,8 @@ def do_train(model, data_loader, data_loader_val, optimizer, scheduler, checkpoi
                 losses = sum(loss_dict.values())
             else:
                 loss_dict, losses = train_step(model, optimizer, images, captions, reducer, pre_gather)
+            if watch and iteration % log_period == 0:
+                check_replicas(watch, "at iteration %d" % iteration)  # (data parallel: a 64-bit digest per watched tensor)
             if meters is not None:
                 # every step counts (trainer.py:92-93 updates the meters per step): kept on device, one read per period
                 with torch.no_grad():

@@ -41,7 +41,7 @@ def _check(*ts):
 
 class _InstanceLossFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, projection, v, t, labels, epsilon):
+    def forward(ctx, projection, v, t, labels, epsilon, scale, norm):
         C, N = projection.shape
         B = v.shape[0]
         ldn = _pad16(N)
@@ -50,15 +50,19 @@ class _InstanceLossFn(torch.autograd.Function):
         invn = ops.empty((N,), v)
         call("trid_colnorm_f32", _p(proj), None, _p(pnt), _p(invn), C, N, ldn, stream())
         E2 = torch.cat([v.detach(), t.detach()], dim=0).contiguous()
-        logits = ops.linear(E2, pnt)  # [2B, ldn]
+        if norm:  # losses.py:45-47: the embeddings L2-normalised as well
+            E2, inv_e = ops.l2norm_rows(E2)
+        logits = ops.linear(E2, pnt, alpha=float(scale))  # [2B, ldn] (losses.py:52-53: scale * embed @ normalize(projection))
         labels2 = torch.cat([labels, labels]).long().contiguous()
         rows = ops.empty((2 * B,), v)
         call("trid_smooth_ce_rows_f32", _p(logits), _p(labels2), _p(rows), 2 * B, N, ldn, float(epsilon), 1.0 / B,
              stream())
         loss = ops.empty((1,), v)
         ops.sum_to(rows, loss, 1.0 / B)
-        dE2 = ops.matmul_nn(logits, pnt)
-        dpnt = ops.matmul_tn(logits, E2)
+        dE2 = ops.matmul_nn(logits, pnt, alpha=float(scale))
+        dpnt = ops.matmul_tn(logits, E2, alpha=float(scale))
+        if norm:
+            dE2 = ops.l2norm_rows_bwd(dE2, E2, inv_e)
         dproj = ops.empty((C, N), v)
         call("trid_colnorm_bwd_f32", _p(dpnt), _p(pnt), _p(invn), _p(dproj), C, N, ldn, stream())
         ctx.saved = (dproj, dE2, B)
@@ -68,14 +72,15 @@ class _InstanceLossFn(torch.autograd.Function):
     def backward(ctx, g):
         dproj, dE2, B = ctx.saved
         ctx.saved = None
-        return _scaled(g, dproj), _scaled(g, dE2[:B]), _scaled(g, dE2[B:]), None, None
+        return _scaled(g, dproj), _scaled(g, dE2[:B]), _scaled(g, dE2[B:]), None, None, None, None
 
 
 def instance_loss(projection, visual_embed, textual_embed, labels, scale=1, norm=False, epsilon=0.0):
-    if scale != 1 or norm:
-        raise NotImplementedError("instance_loss: only scale=1, norm=False (the call at moco_head/loss.py:23-29)")
+    """lib/models/losses.py:42-62.  The reference builds CrossEntropyLabelSmooth(num_classes=...) WITHOUT passing its own
+    `epsilon` on (losses.py:56): any epsilon > 0 smooths with that class's default weight 0.1 (losses.py:18) - reproduced."""
     _check(projection, visual_embed, textual_embed, labels)
-    return _InstanceLossFn.apply(projection, visual_embed, textual_embed, labels, epsilon)
+    eps_eff = 0.1 if epsilon > 0 else 0.0
+    return _InstanceLossFn.apply(projection, visual_embed, textual_embed, labels, eps_eff, scale, bool(norm))
 
 
 class _GlobalAlignFn(torch.autograd.Function):

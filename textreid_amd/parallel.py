@@ -65,6 +65,71 @@ def all_reduce_sum_(t):
     return dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True)
 
 
+def broadcast_module_state(module, src=0):
+    """Every parameter and buffer of `module` from rank `src` to all ranks, once (what DistributedDataParallel does when it
+    wraps the model: train_net.py:50-56 - with `broadcast_buffers=False` the buffers are synchronised at construction only).
+    The replicated-queue design needs every rank to START from the same weights, BatchNorm statistics, queues,
+    ids and pointer; equal seeds give that by convention, this gives it by construction.  One flat buffer per dtype."""
+    if not dp_active():
+        return 0
+    groups = {}
+    for t in list(module.parameters()) + list(module.buffers()):
+        groups.setdefault((t.dtype, t.device), []).append(t.data)
+    nbytes = 0
+    for (dtype, device), ts in groups.items():
+        flat = torch.cat([t.reshape(-1) for t in ts])
+        if _backend() == "gloo" and flat.is_cuda:
+            h = flat.cpu()
+            dist.broadcast(h, src)
+            flat.copy_(h)
+        else:
+            dist.broadcast(flat, src)
+        off = 0
+        for t in ts:
+            n = t.numel()
+            t.copy_(flat[off : off + n].view_as(t))
+            off += n
+        nbytes += flat.numel() * flat.element_size()
+    if any(t.is_cuda for t in module.parameters()):
+        from . import ops
+
+        ops.note_parameter_write()  # (caches keyed on parameter values: the eval path's folded filters / plans)
+    return nbytes
+
+
+def replica_digest(tensors):
+    """One int64 per tensor: the wrap-around sum of its 32-bit words (64-bit tensors: of their 64-bit words) - bit-identical
+    replicas have identical digests, and a replica that drifted in ANY element differs with probability 1 - 2^-32."""
+    out = []
+    for t in tensors:
+        b = t.detach().contiguous().reshape(-1)
+        if b.element_size() == 8:
+            w = b.view(torch.int64)
+        elif b.element_size() == 4:
+            w = b.view(torch.int32).to(torch.int64)
+        else:
+            w = b.view(torch.uint8).to(torch.int64)
+        out.append(w.sum())
+    return torch.stack(out)
+
+
+def check_replicas(named_tensors, where=""):
+    """Raise when the replicated state differs between ranks: a MIN and a MAX all-reduce of the digests (two tiny collectives);
+    `named_tensors` = [(name, tensor)] - the MoCo queue pointer, the id queue and a parameter, engine.trainer.do_train."""
+    if not dp_active():
+        return
+    d = replica_digest([t for _, t in named_tensors])
+    if _backend() == "gloo" and d.is_cuda:
+        d = d.cpu()
+    lo, hi = d.clone(), d.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    if not torch.equal(lo, hi):
+        bad = [n for (n, _), a, b in zip(named_tensors, lo.tolist(), hi.tolist()) if a != b]
+        raise RuntimeError("data-parallel replicas have diverged%s: %s differ between ranks (rank %d of %d) - every rank must push the "
+                           "same gathered keys and apply the same reduced gradients" % (" " + where if where else "", ", ".join(bad), rank(), world_size()))
+
+
 class _GatherRows(torch.autograd.Function):
     """all_gather along dim 0; backward returns the local rows of the gradient
     (no collective, no scaling: the loss is evaluated in full on every rank)."""
