@@ -155,8 +155,9 @@ def parity_vs_oracle(device, pref, tol=1e-3):
         "loss_rel_err": {k[5:]: v for k, v in errs.items() if k.startswith("loss:")},
         "tolerance": tol,
         "within_tolerance": bool(errs[worst] <= tol),
-        "case": "configs[1] at its exact size: CLIP-RN50 + BiGRU, B=%d, K=%d, margin-style state (oracle.fill seed %d), ragged captions; smallest |ReLU input| of the oracle's query encoder %.1e (floor %.0e)" % (
+        "case": "configs[1] at its exact size: CLIP-RN50 + BiGRU, B=%d, K=%d, margin-style state (oracle.fill seed %d: SELECTED for its ReLU margin by tools/pick_fullstep_seed.py - a well-conditioned step, on which two correct fp32 evaluations take the same side of every ReLU), ragged captions; smallest |ReLU input| of the oracle's query encoder %.1e (floor %.0e).  The complement - an UNSELECTED seed with He-style weights and 1.5e9 unstructured ReLU decisions at this size, in the decision-count form - is tests/test_model_gpu.py::test_config1_b128_unselected_seed_decision_count" % (
             B, K, PARITY_SEED, relu_min, relu_floor(B)),
+        "seed_selected_for_relu_margin": True,
     }
     del model, head, named, ld
     torch.cuda.empty_cache()
