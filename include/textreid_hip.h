@@ -372,6 +372,11 @@ int trid_colsum_f32(const float* x, float* out, long long M, int N, long long ld
 /* x[b*L + t, :] = table[tokens[b*ldtok + t], :]  for t < L */
 int trid_embedding_gather_f32(const float* table, const int64_t* tokens, float* x, int B, int L, int ldtok, int E,
                               long long vocab, void* stream);
+/* Gradient of a trainable token-embedding table (gru.py:23-24, `use_onehot == "yes"`: nn.Embedding(vocab, embed, padding_idx=0)):
+ * dtable[v] = sum over the positions whose token is v of dX[position] ([B*L][E], position = b * L + t), row padding_idx zero.
+ * Deterministic (no sort, no floating-point atomics): the first position of a token owns its row and adds in position order. */
+int trid_embedding_bwd_f32(const float* dX, const int64_t* tokens, int B, int L, int ldtok, int E, float* dtable,
+                           long long vocab, long long padding_idx, void* stream);
 /* One time step of both directions.  s = step index; direction d processes
  * t = s (d=0) or t = Lmax-1-s (d=1).  gi: [B*L, 2*3H] input projections (row
  * b*L+t, col d*3H + gate*H + j); gh: [2,B,3H]; h: [2,B,H] updated in place;

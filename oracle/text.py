@@ -53,10 +53,17 @@ def _direction(x, lengths, w_ih, w_hh, reverse, lmax):
 
 def text_forward(st, table, tokens, lengths):
     """tokens [B,Lpad] i64, lengths [B] i64, table [V,E] f32 (frozen, not a
-    parameter: gru.py:34) -> [B,2H]."""
+    parameter: gru.py:34) -> [B,2H].  The non-default input forms of gru.py:22-31,59-60: table None and "embed.weight"
+    [V,E] in `st` = a trainable nn.Embedding(padding_idx=0) (`use_onehot == "yes"`); "embed.weight" [E,V'] + "embed.bias"
+    in `st` beside a table [V,V'] = the frozen rows through nn.Linear(vocab_size, embed_size)."""
     lengths = lengths.view(-1)
     lmax = int(lengths.max())
-    x = table[tokens.reshape(-1)].reshape(tokens.shape[0], tokens.shape[1], -1)  # gru.py:55-58
+    if table is None:
+        x = torch.nn.functional.embedding(tokens, st["embed.weight"], padding_idx=0)  # gru.py:23-24,59-60
+    else:
+        x = table[tokens.reshape(-1)].reshape(tokens.shape[0], tokens.shape[1], -1)  # gru.py:55-58
+        if "embed.weight" in st:
+            x = torch.nn.functional.linear(x, st["embed.weight"], st["embed.bias"])  # gru.py:29-30,59-60
     of = _direction(x, lengths, st["gru.weight_ih_l0"], st["gru.weight_hh_l0"], False, lmax)
     ob = _direction(x, lengths, st["gru.weight_ih_l0_reverse"], st["gru.weight_hh_l0_reverse"], True, lmax)
     out = torch.cat([of, ob], dim=2)  # [B,lmax,2H]

@@ -331,6 +331,50 @@ def gen_text(seed=3):
     np.savez_compressed(os.path.join(HERE, "text.npz"), **out)
 
 
+def gen_text_embed(seed=4):
+    """The text encoder's non-default input forms (gru.py:22-31,59-60): a trainable nn.Embedding(padding_idx=0) (`use_onehot ==
+    "yes"`) and nn.Linear(vocab_size, embed_size) over the frozen table's rows (vocab_size != embed_size)."""
+    print("[text_embed]")
+    hidden, embed, vocab, Lpad, vdim = 64, 96, 120, 40, 48
+    lens = [40, 9, 33, 1, 17, 40, 25]
+    tok, ln = synth_tokens("tok:textemb", len(lens), lens, vocab, Lpad, seed)
+    tok[2, 5] = tok[2, 11] = tok[4, 3] = tok[0, 0]  # repeated tokens across captions: their embedding rows accumulate
+    out = {"tokens": tok.numpy(), "lengths": ln.numpy(), "seed": np.array(seed), "dims": np.array([hidden, embed, vocab, vdim])}
+    # form 1: nn.Embedding
+    g1 = ref_gru.GRU(hidden, vocab, embed, 1, 0.0, True, "yes", "./")
+    load_filled(g1, seed, "emb1.")
+    y1 = g1(make_captions(tok, ln))
+    w_out = OF.randn("gout:textemb", tuple(y1.shape), seed)
+    (y1 * w_out).sum().backward()
+    out["out_embedding"] = y1.detach().numpy()
+    for k, p in g1.named_parameters():
+        out["grad_embedding:" + k] = p.grad.numpy().copy()
+    st = {k: OF.fill("emb1." + k, tuple(v.shape), seed).requires_grad_(True) for k, v in g1.state_dict().items()}
+    yo = OT.text_forward(st, None, tok, ln)
+    check("embedding form: out", yo, y1)
+    (yo * w_out).sum().backward()
+    for k, p in g1.named_parameters():
+        check("embedding form: grad " + k, st[k].grad, p.grad, 1e-4)
+    assert float(g1.embed.weight.grad[0].abs().max()) == 0.0  # padding_idx
+    # form 2: nn.Linear over the frozen rows
+    table = OF.randn("vocab_table_lin", (vocab, vdim), seed, 0.5)
+    ref_gru.load_vocab_dict = lambda root, onehot: table.numpy()  # shim (ii)
+    g2 = ref_gru.GRU(hidden, vdim, embed, 1, 0.0, True, "clip_vit", "./")
+    load_filled(g2, seed, "emb2.")
+    y2 = g2(make_captions(tok, ln))
+    (y2 * w_out).sum().backward()
+    out["out_linear"] = y2.detach().numpy()
+    for k, p in g2.named_parameters():
+        out["grad_linear:" + k] = p.grad.numpy().copy()
+    st2 = {k: OF.fill("emb2." + k, tuple(v.shape), seed).requires_grad_(True) for k, v in g2.state_dict().items()}
+    yo2 = OT.text_forward(st2, table, tok, ln)
+    check("linear form: out", yo2, y2)
+    (yo2 * w_out).sum().backward()
+    for k, p in g2.named_parameters():
+        check("linear form: grad " + k, st2[k].grad, p.grad, 1e-4)
+    np.savez_compressed(os.path.join(HERE, "text_embed.npz"), **out)
+
+
 def ns(**kw):
     return types.SimpleNamespace(**kw)
 
@@ -585,7 +629,7 @@ def gen_ingest(seed=13):
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["losses", "rank", "text", "tiny", "head", "head_fc", "rn50", "rn101", "ingest"]
+    which = sys.argv[1:] or ["losses", "rank", "text", "text_embed", "tiny", "head", "head_fc", "rn50", "rn101", "ingest"]
     if "ingest" in which:
         gen_ingest()
     if "losses" in which:
@@ -594,6 +638,8 @@ if __name__ == "__main__":
         gen_rank()
     if "text" in which:
         gen_text()
+    if "text_embed" in which:
+        gen_text_embed()
     if "tiny" in which:
         gen_visual("tiny", OV.TINY, 4, 1, grads=("conv1.weight", "bn1.weight", "conv2.weight", "layer1.0.conv2.weight", "layer2.0.downsample.0.weight", "layer3.0.conv2.weight", "layer4.0.bn3.bias", "attnpool.k_proj.weight", "attnpool.q_proj.bias", "attnpool.positional_embedding", "attnpool.c_proj.weight"))
     if "head" in which:

@@ -345,6 +345,16 @@ def test_replicas_broadcast_and_digest_gloo_world2(tmp_path):
         assert "rank %d ok" % r in o
 
 
+def test_p16_flow_size_guard():
+    """The P16 kernels address operands with 31-bit offsets: per-GPU batches whose largest activation reaches 2 GB must not take
+    the P16 flow (about 640 images of 384 x 128) - a pure shape rule, checked on meta tensors."""
+    from textreid_amd.backbones.m_resnet import p16_fits
+
+    assert p16_fits(torch.empty(128, 3, 384, 128, device="meta")) and p16_fits(torch.empty(640, 3, 384, 128, device="meta"))
+    assert not p16_fits(torch.empty(683, 3, 384, 128, device="meta"))  # 683 x 192 x 64 x 64 x 4 B = 2 GB + 1 MB
+    assert p16_fits(torch.empty(2000, 3, 96, 32, device="meta"))
+
+
 def test_lr_schedule_values():
     from textreid_amd.solver import LRSchedulerWithWarmup
 

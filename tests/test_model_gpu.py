@@ -235,6 +235,44 @@ def test_text_encoder(gpu, golden_dir):
     assert not bad, bad
 
 
+@pytest.mark.parametrize("form", ["embedding", "linear"])
+def test_text_encoder_input_forms(gpu, golden_dir, form):
+    """The text encoder's non-default input forms (gru.py:22-31,59-60; no MoCo config uses them): a TRAINABLE
+    nn.Embedding(padding_idx=0) (`use_onehot == "yes"`: its gradient = rows of dX summed per token, deterministic, row 0 zero)
+    and nn.Linear(vocab_size, embed_size) over the frozen table's rows - outputs and every gradient against vectors captured
+    from the reference module, and run to run bit-identical."""
+    from textreid_amd.backbones.gru import GRU
+    from textreid_amd.caption import CaptionBatch
+
+    g = load(golden_dir, "text_embed.npz")
+    seed = int(g["seed"])
+    hidden, embed, vocab, vdim = (int(v) for v in g["dims"])
+    if form == "embedding":
+        m = GRU(hidden, vocab, embed, 1, 0.0, True, "yes", "./")
+        fill_module(m, seed, "emb1.")
+    else:
+        m = GRU(hidden, vdim, embed, 1, 0.0, True, "clip_vit", "./", vocab_dict=OF.randn("vocab_table_lin", (vocab, vdim), seed, 0.5))
+        fill_module(m, seed, "emb2.")
+    m.to(gpu)
+    cb = CaptionBatch(torch.from_numpy(g["tokens"]).to(gpu), torch.from_numpy(g["lengths"]).to(gpu))
+    grads = []
+    for _ in range(2):
+        for p in m.parameters():
+            p.grad = None
+        y = m(cb)
+        (y * OF.randn("gout:textemb", tuple(y.shape), seed).to(gpu)).sum().backward()
+        grads.append({k: p.grad.clone() for k, p in m.named_parameters()})
+    errs = {"out": rel(y, g["out_" + form])}
+    for k, gr in grads[0].items():
+        errs["grad:" + k] = rel(gr, g["grad_%s:%s" % (form, k)])
+        assert torch.equal(gr, grads[1][k]), k  # deterministic
+    if form == "embedding":
+        assert float(grads[0]["embed.weight"][0].abs().max()) == 0.0
+    print(form, {k: "%.1e" % v for k, v in errs.items()})
+    bad = {k: v for k, v in errs.items() if not v < TOL}
+    assert not bad, bad
+
+
 def test_text_encoder_accepts_reference_captions(gpu, golden_dir):
     """list[Caption] (reference container) and CaptionBatch give identical output."""
     from textreid_amd.backbones.gru import GRU

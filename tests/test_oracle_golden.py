@@ -80,6 +80,26 @@ def test_text(golden_dir):
     assert rel(y2, g["out2"]) < 1e-5
 
 
+def test_text_input_forms(golden_dir):
+    """The oracle's non-default text input forms (gru.py:22-31,59-60) against vectors captured from the reference module: a
+    trainable nn.Embedding(padding_idx=0) and nn.Linear over the frozen table's rows - outputs and every gradient."""
+    g = load(golden_dir, "text_embed.npz")
+    seed = int(g["seed"])
+    hidden, embed, vocab, vdim = (int(v) for v in g["dims"])
+    tok, ln = torch.from_numpy(g["tokens"]), torch.from_numpy(g["lengths"])
+    w_out = OF.randn("gout:textemb", (tok.shape[0], 2 * hidden), seed)
+    shapes = dict(OT.state_shapes(hidden, embed))
+    for form, pre, table, extra in (("embedding", "emb1.", None, {"embed.weight": (vocab, embed)}),
+                                    ("linear", "emb2.", OF.randn("vocab_table_lin", (vocab, vdim), seed, 0.5), {"embed.weight": (embed, vdim), "embed.bias": (embed,)})):
+        st = {k: OF.fill(pre + k, s, seed).requires_grad_(True) for k, s in dict(shapes, **extra).items()}
+        y = OT.text_forward(st, table, tok, ln)
+        assert rel(y, g["out_" + form]) < 1e-5
+        (y * w_out).sum().backward()
+        for k in st:
+            assert rel(st[k].grad, g["grad_%s:%s" % (form, k)]) < 1e-4, (form, k)
+    assert float(np.abs(g["grad_embedding:embed.weight"][0]).max()) == 0.0  # padding_idx = 0
+
+
 def test_text_zero_pad_enters_max():
     """gru.py:63 quirk: a caption shorter than the batch max gets max(.,0)."""
     st = filled(OT.state_shapes(16, 16), 0)

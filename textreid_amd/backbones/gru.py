@@ -33,23 +33,32 @@ FUSED_GRU_STEP = os.environ.get("TRID_FUSED_GRU", "1") != "0"  # A/B switch: 0 =
 
 class _GRUFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, mod, tokens, lengths, lmax, lmax_dev, save, w_ih_f, w_hh_f, w_ih_r, w_hh_r):
+    def forward(ctx, mod, tokens, lengths, lmax, lmax_dev, save, w_ih_f, w_hh_f, w_ih_r, w_hh_r, emb_w=None, emb_b=None):
         # `save` comes from the caller: ctx.needs_input_grad ignores torch.no_grad()
         B = tokens.shape[0]
         H = w_hh_f.shape[1]
         E = w_ih_f.shape[1]
         L = lmax
-        table = mod.vocab_dict
         st = ops.stream()
-        x = ops.empty((B * L, E), table)
-        ops.call("trid_embedding_gather_f32", ops._p(table), ops._p(tokens), ops._p(x), B, L, tokens.stride(0), E,
+        # the three input forms of gru.py:22-31,55-60: 0 = rows of the frozen table (every MoCo config); 1 = a TRAINABLE
+        # nn.Embedding (`use_onehot == "yes"`); 2 = rows of the frozen table through nn.Linear(vocab_size, embed_size)
+        mode = mod.embed_mode
+        table = emb_w.detach() if mode == 1 else mod.vocab_dict
+        x0 = None
+        x = ops.empty((B * L, table.shape[1]), table)
+        ops.call("trid_embedding_gather_f32", ops._p(table), ops._p(tokens), ops._p(x), B, L, tokens.stride(0), table.shape[1],
                  table.shape[0], st)
+        if mode == 2:
+            x0 = x
+            x = ops.linear(x0, emb_w.detach(), emb_b.detach())  # [B*L, E]
         gi = ops.empty((B * L, 6 * H), table)
         # fp16-split arithmetic for the big text GEMMs while that is the library's conv mode: every gathered row is a row
         # of the frozen table, so max|x| <= max|table| (computed once per table)
         P = 16 if ops.conv_precision() == 16 else None
         a_x = None
-        if P:
+        if P and mode != 0:
+            a_x = ops.amax(x)  # (a trained table / the Linear's output: no bound carries over from step to step)
+        elif P:
             if getattr(mod, "_table_amax", None) is None or mod._table_amax[0] is not table:
                 mod._table_amax = (table, ops.amax(table))
             a_x = mod._table_amax[1]
@@ -91,6 +100,7 @@ class _GRUFn(torch.autograd.Function):
                          L * B * 4 * H, L * B * H, st)
         if save:
             ctx.saved = (x, whh, gates, hprev, argt, lengths, B, H, E, L, fused, a_x)
+            ctx.embed = (mode, tokens, x0, table.shape[0], w_ih_f.detach(), w_ih_r.detach(), emb_w.detach() if emb_w is not None else None)
         return maxv
 
     @staticmethod
@@ -152,23 +162,43 @@ class _GRUFn(torch.autograd.Function):
             ops.gemm(dGi, x, slab, 3 * H, E, KK, 6 * H, E, E, a_mode=ops.A_MC, b_mode=ops.B_NC, batch=2,
                      strideA=3 * H, strideB=0, strideC=3 * H * E, splits=splits, strideSplit=n, **kw_ih)
             ops.call("trid_slab_reduce_f32", ops._p(slab), ops._p(dwih), n, splits, n, 0, st)
-        return None, None, None, None, None, None, dwih[0], dwhh[0], dwih[1], dwhh[1]
+        mode, tokens, x0, vocab, w_ih_f, w_ih_r, emb_w = ctx.embed
+        ctx.embed = None
+        d_emb_w = d_emb_b = None
+        if mode != 0:
+            # the input of the recurrence is itself a function of parameters: dX = dGi_fwd W_ih + dGi_rev W_ih_reverse
+            dX = ops.matmul_nn(dGi[:, : 3 * H], w_ih_f)
+            ops.matmul_nn(dGi[:, 3 * H :], w_ih_r, out=dX, accumulate=True)
+            if mode == 1:  # nn.Embedding(padding_idx=0): rows summed per token, deterministic (csrc/attn_text.hip)
+                d_emb_w = ops.empty((vocab, E), dout)
+                ops.call("trid_embedding_bwd_f32", ops._p(dX), ops._p(tokens), B, L, tokens.stride(0), E, ops._p(d_emb_w), vocab, 0, st)
+            else:          # nn.Linear on the frozen rows: dW = dX^T x0, db = column sums
+                d_emb_w = ops.matmul_tn(dX, x0)
+                d_emb_b = ops.colsum(dX)
+        return None, None, None, None, None, None, dwih[0], dwhh[0], dwih[1], dwhh[1], d_emb_w, d_emb_b
 
 
 class GRU(nn.Module):
     def __init__(self, hidden_dim, vocab_size, embed_size, num_layers, drop_out, bidirectional, use_onehot, root,
                  vocab_dict=None):
         super().__init__()
-        if use_onehot == "yes" or vocab_size != embed_size or num_layers != 1 or not bidirectional:
-            raise NotImplementedError("HIP text encoder covers the MoCo configs: frozen table, 1-layer BiGRU")
+        if num_layers != 1 or not bidirectional:
+            raise NotImplementedError("HIP text encoder covers the 1-layer bidirectional GRU of the shipped configs")
         self.use_onehot = use_onehot
-        self.embed = None
-        if vocab_dict is None:
-            vocab_dict = load_vocab_dict(root, use_onehot)
-        vocab_dict = torch.as_tensor(vocab_dict).float()
-        assert vocab_size == vocab_dict.shape[1]
-        dev = "cuda" if torch.cuda.is_available() else "cpu"
-        self.vocab_dict = vocab_dict.to(dev).contiguous()  # plain attribute, as gru.py:34
+        # word embedding: the three forms of gru.py:22-34
+        if use_onehot == "yes":
+            self.embed = nn.Embedding(vocab_size, embed_size, padding_idx=0)  # a trainable table (parameter holder: its forward is never called)
+            self.vocab_dict = None
+            self.embed_mode = 1
+        else:
+            self.embed = None if vocab_size == embed_size else nn.Linear(vocab_size, embed_size)
+            self.embed_mode = 0 if self.embed is None else 2
+            if vocab_dict is None:
+                vocab_dict = load_vocab_dict(root, use_onehot)
+            vocab_dict = torch.as_tensor(vocab_dict).float()
+            assert vocab_size == vocab_dict.shape[1]
+            dev = "cuda" if torch.cuda.is_available() else "cpu"
+            self.vocab_dict = vocab_dict.to(dev).contiguous()  # plain attribute, as gru.py:34
         self.gru = nn.GRU(embed_size, hidden_dim, num_layers=num_layers, dropout=drop_out,
                           bidirectional=bidirectional, bias=False)
         self.out_channels = hidden_dim * 2
@@ -177,15 +207,16 @@ class GRU(nn.Module):
         cb = CaptionBatch.from_list(captions)
         if not cb.tokens.is_cuda:
             raise RuntimeError("textreid_amd.GRU runs on the HIP kernel library only (CUDA tensors); no CPU fallback")
-        if self.vocab_dict.device != cb.tokens.device:
+        if self.vocab_dict is not None and self.vocab_dict.device != cb.tokens.device:
             self.vocab_dict = self.vocab_dict.to(cb.tokens.device)
         g = self.gru
         ws = (g.weight_ih_l0, g.weight_hh_l0, g.weight_ih_l0_reverse, g.weight_hh_l0_reverse)
-        save = torch.is_grad_enabled() and any(w.requires_grad for w in ws)
+        extra = () if self.embed is None else ((self.embed.weight, None) if self.embed_mode == 1 else (self.embed.weight, self.embed.bias))
+        save = torch.is_grad_enabled() and any(w.requires_grad for w in ws + tuple(e for e in extra if e is not None))
         # cb.max_len is the time-loop length; when it is only an upper BOUND of the batch maximum (bound_only: a recorded
         # step replayed on other captions) the zero-pad quirk of gru.py:63 takes the true maximum from the device
         lmax_dev = cb.lengths.max().reshape(1) if getattr(cb, "bound_only", False) else None
-        return _GRUFn.apply(self, cb.tokens.contiguous(), cb.lengths.contiguous(), cb.max_len, lmax_dev, save, *ws)
+        return _GRUFn.apply(self, cb.tokens.contiguous(), cb.lengths.contiguous(), cb.max_len, lmax_dev, save, *ws, *extra)
 
 
 def build_gru(cfg, bidirectional, vocab_dict=None):

@@ -283,10 +283,18 @@ def stem_p16_channels(mod):
     return (mod.conv1.in_channels, mod.conv1.out_channels, mod.conv2.out_channels, mod.conv3.out_channels) == (3, 32, 32, 64)
 
 
+def p16_fits(images, width=64):
+    """The P16 kernels address their operands with 31-bit buffer offsets: the largest activation of the pass - the stem's
+    conv3 output and layer1's block outputs, B x H/2 x W/2 x `width` x 4 bytes - must stay below 2 GB (about 640 images of
+    384 x 128 per GPU); larger per-GPU batches run the on-the-fly-split flow, whose kernels fall back per launch."""
+    Ho, Wo = (images.shape[2] + 1) // 2, (images.shape[3] + 1) // 2
+    return images.shape[0] * Ho * Wo * width * 4 < (1 << 31)
+
+
 def stem_p16_ok(mod, images):
     """... and the map sizes the ring-of-rows convolution kernel tiles (csrc/stem_conv.hip): 192x64 at 384x128 input."""
     Ho, Wo = (images.shape[2] + 1) // 2, (images.shape[3] + 1) // 2
-    return (stem_p16_channels(mod) and Ho % 2 == 0 and Wo % 2 == 0 and images.is_contiguous()
+    return (stem_p16_channels(mod) and Ho % 2 == 0 and Wo % 2 == 0 and images.is_contiguous() and p16_fits(images, mod.conv3.out_channels)
             and all(ops.conv3x3_halo_rows(Ho, Wo, ci, co) > 0 for ci, co in ((32, 32), (32, 64), (64, 32))))
 
 
@@ -556,8 +564,7 @@ class _EncoderFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, images, mod, save, *params):
         if not mod.training and not save and mod.fold_eval_bn and getattr(mod, "_debug_taps", None) is None:
-            if (ops.USE_EVAL_P16 and ops.USE_P16 and ops.conv_precision() == 16 and p16_eligible(mod, 32) and stem_p16_ok(mod, images)
-                    and images.shape[0] * ((images.shape[2] + 1) // 2) * ((images.shape[3] + 1) // 2) * 64 * 4 < (1 << 31)):
+            if ops.USE_EVAL_P16 and ops.USE_P16 and ops.conv_precision() == 16 and p16_eligible(mod, 32) and stem_p16_ok(mod, images):
                 out, saved = mod._run_forward_eval_p16(images), None  # CLIP geometries: the P16 kernels with fused eval epilogues
             else:
                 out, saved = mod._run_forward_folded(images), None   # other widths / arithmetic modes: folded filters, on-the-fly split
@@ -766,7 +773,7 @@ class ModifiedResNet(nn.Module):
         nbt = []  # num_batches_tracked buffers, incremented together at the end of the pass
         # ---- stem (m_resnet.py:199-207)
         masks = getattr(self, "_debug_masks", None)  # parity tests: every ReLU decision of the pass, in execution order
-        p16 = ops.USE_P16 and training and ar.PB in (16, 1) and p16_eligible(self, 32 if ar.PB == 16 else 64)
+        p16 = ops.USE_P16 and training and ar.PB in (16, 1) and p16_eligible(self, 32 if ar.PB == 16 else 64) and p16_fits(images, self.conv3.out_channels)
         fmt = (1 if ar.PB == 16 else 2) if p16 else 0
         WP = p16_weights(self, ar.WA, False, fmt) if p16 else None  # every filter the pass multiplies with, ONE launch
         # the stem's bandwidth-shaped kernels are fp32-class (P16 operands, exact fp32 conv1) in BOTH modes: in the bf16 mode

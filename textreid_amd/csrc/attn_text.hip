@@ -157,6 +157,48 @@ __global__ void embedding_gather_kernel(const float4* __restrict__ table, const 
     }
 }
 
+// Gradient of a TRAINABLE token-embedding table (gru.py:23-24: nn.Embedding(vocab, embed, padding_idx=0), the `use_onehot ==
+// "yes"` form): dT[v] = sum of dX[p] over the positions p whose token is v, row `pad` stays zero.  Deterministic without a
+// sort and without floating-point atomics: one workgroup per position; the workgroup of the FIRST position that holds a
+// token owns that token's row and adds the rows of the later positions in position order.  dT is zero-filled by the caller.
+__global__ __launch_bounds__(256) void embedding_bwd_kernel(const float* __restrict__ dX, const int64_t* __restrict__ tokens, int ldtok,
+                                                            int L, int N, int E, float* __restrict__ dT, long long vocab, long long pad) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int p = blockIdx.x;
+    const long long tok = tokens[(long long)(p / L) * ldtok + p % L];
+    if (tok == pad || tok < 0 || tok >= vocab) return;
+    __shared__ int earlier;
+    __shared__ unsigned long long bal[4];
+    if (tid == 0) earlier = 0;
+    __syncthreads();
+    for (int q = tid; q < p; q += 256)
+        if (tokens[(long long)(q / L) * ldtok + q % L] == tok) earlier = 1;  // (any writer writes 1)
+    __syncthreads();
+    if (earlier) return;
+    for (int c0 = 0; c0 < E; c0 += 256) {  // (E <= 256 * a few: the table rows are short)
+        const int c = c0 + tid;
+        float acc = c < E ? dX[(long long)p * E + c] : 0.f;
+        for (int q0 = p + 1; q0 < N; q0 += 256) {
+            const int q = q0 + tid;
+            const bool hit = q < N && tokens[(long long)(q / L) * ldtok + q % L] == tok;
+            const unsigned long long b = __ballot(hit);
+            if (lane == 0) bal[wave] = b;
+            __syncthreads();
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                unsigned long long m = bal[w];
+                while (m) {
+                    const int j = __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    if (c < E) acc += dX[(long long)(q0 + 64 * w + j) * E + c];
+                }
+            }
+            __syncthreads();
+        }
+        if (c < E) dT[tok * E + c] = acc;
+    }
+}
+
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-v)); }
 
 __global__ void gru_max_init_kernel(float* __restrict__ maxv, int32_t* __restrict__ argt,
@@ -309,6 +351,16 @@ extern "C" int trid_embedding_gather_f32(const float* table, const int64_t* toke
     hipLaunchKernelGGL(embedding_gather_kernel, dim3(grid_for(total, 256 * 2)), dim3(256), 0, (hipStream_t)stream,
                        (const float4*)table, tokens, (float4*)x, B, L, ldtok, E / 4, vocab);
     return check_launch("trid_embedding_gather_f32");
+}
+
+extern "C" int trid_embedding_bwd_f32(const float* dX, const int64_t* tokens, int B, int L, int ldtok, int E, float* dtable,
+                                      long long vocab, long long padding_idx, void* stream) {
+    TRID_REQUIRE(dX && tokens && dtable && B > 0 && L > 0 && ldtok >= L && E > 0 && vocab > 0, "trid_embedding_bwd_f32: bad arguments");
+    hipError_t e = hipMemsetAsync(dtable, 0, (size_t)vocab * E * sizeof(float), (hipStream_t)stream);
+    if (e != hipSuccess) { set_error("trid_embedding_bwd_f32: memset failed: %s", hipGetErrorString(e)); return (int)e; }
+    hipLaunchKernelGGL(embedding_bwd_kernel, dim3(B * L), dim3(256), 0, (hipStream_t)stream, dX, tokens, ldtok, L, B * L, E, dtable,
+                       vocab, padding_idx);
+    return check_launch("trid_embedding_bwd_f32");
 }
 
 extern "C" int trid_gru_max_init_f32(float* maxv, int32_t* argt, const int64_t* lengths, int Lmax, const int64_t* lmax_dev,

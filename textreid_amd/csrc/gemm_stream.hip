@@ -658,6 +658,8 @@ using namespace trid;
 // rows per BatchNorm partial (= rows per step) of the streaming kernel for this shape, 0 when it does not apply
 extern "C" int trid_gemm_p16_stream_rows(int M, int N, int K, int accumulate) {
     if (!(K == 64 || K == 128 || K == 256) || N <= 0 || N % 32 != 0 || M <= 0) return 0;
+    // (31-bit buffer offsets: operands of 2 GB and more - per-GPU batches beyond ~640 images at 384 x 128 - stay on the tile kernel)
+    if ((long long)M * K * 4 >= (1ll << 31) || (long long)M * N * 4 >= (1ll << 31)) return 0;
     if (K == 256 && N <= 128) return 0;  // (256 -> 128 measured no faster than the tile kernel: 146 vs 142 us)
     if (K == 256 && accumulate) return 32;
     if (N > 128) return (accumulate || K == 256) ? 64 : 128;

@@ -639,6 +639,7 @@ extern "C" int trid_queue_nce_f32(const float* v_q, const float* t_q, const floa
     TRID_REQUIRE(v_q && t_q && v_key && t_key && t_queue && v_queue && id_queue && ids && loss_rows && dq && ws,
                  "trid_queue_nce_f32: null pointer");
     TRID_REQUIRE(B > 0 && K > 0 && invT > 0.f && logit_bound > 0.f, "trid_queue_nce_f32: bad sizes / scalars");
+    TRID_REQUIRE((ticket == nullptr) == (loss == nullptr), "trid_queue_nce_f32: ticket and loss both or none");  // (before ANY launch)
     if (C != QC || K % QTILE != 0 || B > QMAXB) {
         set_error("trid_queue_nce_f32: built for C = %d, K %% %d == 0, B <= %d (got C = %d, K = %d, B = %d)", QC, QTILE, QMAXB, C, K, B);
         return TRID_E_UNSUPPORTED;
@@ -672,7 +673,7 @@ extern "C" int trid_queue_nce_f32(const float* v_q, const float* t_q, const floa
     const hipStream_t st = (hipStream_t)stream;
     const int rc = (precision == 1) ? launch_qnce<1>(p, nbb, st) : (precision == 3) ? launch_qnce<3>(p, nbb, st) : hashed ? launch_qnce_f16<true>(p, nbb, st) : launch_qnce_f16<false>(p, nbb, st);
     if (rc != TRID_OK) return rc;
-    TRID_REQUIRE((ticket == nullptr) == (loss == nullptr), "trid_queue_nce_f32: ticket and loss both or none");
+    static_assert(QC == 256, "queue_nce_finish_kernel folds exactly four waves (red[0..3] / red[4..7]): one thread per channel of C = 256");
     hipLaunchKernelGGL(queue_nce_finish_kernel, dim3(B, 2), dim3(QC), 0, st, p, t_key, v_key, loss_rows, dq, invT, shift,
                        gscale * invT / (float)B, ticket, loss, loss_scale);
     return check_launch("trid_queue_nce_f32(finish)");
