@@ -106,6 +106,9 @@ typedef struct trid_gemm_desc {
     const float* eval_tres;  /* device scalar: true max|res_p16|, NULL without a residual */
     float* out_bound;        /* device scalar, written */
     float* out_tmax;         /* device scalar, atomicMax'ed (bit pattern of a non-negative float) */
+    int32_t eval_pool_w;     /* c_format 1, a_mode TRID_A_CONV, no residual: != 0 (= W) writes AvgPool2d(2) of act(.) instead: C = P16 [M / 4][N]
+                              * (a stride-2 block's conv2 + bn2 + ReLU + avgpool, m_resnet.py:59-61); needs W | 128 with an even
+                              * number of image rows per 128-row tile, H * W % 128 == 0, N > 64 */
 } trid_gemm_desc;
 
 int trid_gemm_f32(const trid_gemm_desc* d, void* stream);
@@ -241,7 +244,10 @@ int trid_conv3x3_halo_p16(const void* x, const float* x_amax, const void* w, con
  * output, no apply pass.  eval_coef / eval_tin / out_bound / out_tmax: as trid_gemm_desc's eval fields. */
 int trid_conv3x3_halo_eval_p16(const void* x, const float* x_amax, const void* w, const float* w_amax, const float* bn_scale,
                                const float* bn_shift, void* out, const float* eval_coef, const float* eval_tin, float* out_bound,
-                               float* out_tmax, int B, int H, int W, int Cin, int Cout, int relu, void* stream);
+                               float* out_tmax, int B, int H, int W, int Cin, int Cout, int relu, int pool, void* stream);
+/* pool != 0 above: the output is the 2x2 average of act(.), P16 [B][H/2][W/2][Cout] - the stem's conv3 + bn3 + ReLU + AvgPool2d(2)
+ * (m_resnet.py:205-207) in one kernel; covered geometries (32 -> 64 channels, W % 64 == 0): */
+int trid_conv3x3_halo_eval_pool_ok(int H, int W, int Cin, int Cout);
 
 /* ------------------------------------------------------------------------- *
  * BatchNorm2d (train: batch statistics + running update; eval: running stats),

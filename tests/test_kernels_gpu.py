@@ -382,6 +382,58 @@ def test_conv3x3_halo_eval_p16(ops, B, C, H, W, N, relu):
     assert T.equal(ref.amax, out.amax) and rel(ref.unpack(), got) < 1e-6
 
 
+@pytest.mark.parametrize("B,H,W,C,N", [(2, 8, 32, 64, 128), (3, 16, 16, 32, 256), (1, 96, 32, 128, 128)])
+def test_conv_eval_p16_pooled(ops, B, H, W, C, N):
+    """The tile kernel's eval epilogue with AvgPool2d(2) fused (a stride-2 block's conv2 + bn2 + ReLU + avgpool, m_resnet.py:59-61):
+    the 128-row tile = whole image rows, its 32 pooled pixels averaged from the staged tile in LDS - against fp64 and against
+    the unfused form (convolution with the eval epilogue, then the pooling pass)."""
+    import torch as T
+
+    x = T.relu(R("tpx%d" % C, B, H, W, C))
+    w = R("tpw%d" % N, N, 3, 3, C, scale=1.0 / ((9 * C) ** 0.5))
+    scale, shift = R("tps", N) * 0.5 + 1.0, R("tph", N) * 0.3
+    full = T.relu(F.conv2d(x.double().permute(0, 3, 1, 2), w.double().permute(0, 3, 1, 2), padding=1) * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1))
+    want = F.avg_pool2d(full, 2).permute(0, 2, 3, 1)
+    assert ops.conv_eval_pool_ok(H, W, N)
+    xp, wp = ops.p16_pack(dev(x)), ops.p16_pack(dev(w.reshape(N, 9 * C)))
+    st = ops.BNState(N, xp.data)
+    st.scale.copy_(dev(scale)); st.shift.copy_(dev(shift))
+    coef = ops.eval_bound_coefs([(dev(w.reshape(N, 9 * C)), st.scale, st.shift)], xp.data.device)
+    out = ops.conv_eval_p16(xp, wp, st, coef[0], relu=True, conv3=True, pool=True)
+    got = out.unpack()
+    assert got.shape == want.shape and rel(got, want) < 2e-6, rel(got, want)
+    tm = float(got.abs().max())
+    assert abs(float(out.tmax) - tm) <= 1e-6 * tm and float(out.amax) >= float(full.abs().max())
+    unf = ops.conv_eval_p16(xp, wp, st, coef[0], relu=True, conv3=True)
+    two = ops.bn_apply_pool2_p16(unf, None, unf.amax)
+    assert rel(two.unpack(), got) < 1e-6
+
+
+@pytest.mark.parametrize("B,H,W", [(3, 8, 64), (2, 192, 64), (1, 6, 64)])
+def test_conv3x3_halo_eval_pooled(ops, B, H, W):
+    """The stem's conv3 + bn3 + ReLU + AvgPool2d(2) (m_resnet.py:205-207, eval mode) in ONE launch of the ring-of-rows kernel:
+    pixel pairs along x inside a lane, the two image rows of a pooled pixel in two waves that meet in LDS - against fp64."""
+    import torch as T
+
+    C, N = 32, 64
+    x = T.relu(R("px", B, H, W, C))
+    w = R("pw", N, 3, 3, C, scale=1.0 / ((9 * C) ** 0.5))
+    scale, shift = R("ps", N) * 0.5 + 1.0, R("ph", N) * 0.3
+    full = T.relu(F.conv2d(x.double().permute(0, 3, 1, 2), w.double().permute(0, 3, 1, 2), padding=1) * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1))
+    want = F.avg_pool2d(full, 2).permute(0, 2, 3, 1)
+    assert ops.conv3x3_halo_eval_pool_ok(H, W, C, N)
+    xp, wp = ops.p16_pack(dev(x)), ops.p16_pack(dev(w.reshape(N, 9 * C)))
+    st = ops.BNState(N, xp.data)
+    st.scale.copy_(dev(scale)); st.shift.copy_(dev(shift))
+    coef = ops.eval_bound_coefs([(dev(w.reshape(N, 9 * C)), st.scale, st.shift)], xp.data.device)
+    out = ops.conv3x3_halo_eval_p16(xp, wp, st, coef[0], relu=True, pool=True)
+    got = out.unpack()
+    assert got.shape == want.shape and rel(got, want) < 2e-6, rel(got, want)
+    tm = float(got.abs().max())
+    assert abs(float(out.tmax) - tm) <= 1e-6 * tm and float(out.amax) >= float(full.abs().max())
+    assert not ops.conv3x3_halo_eval_pool_ok(H, 32, C, N) and not ops.conv3x3_halo_eval_pool_ok(H, W, 64, 64)
+
+
 @pytest.mark.parametrize("B,Hi,Wi", [(2, 16, 16), (3, 24, 10), (1, 384, 128)])
 def test_stem_conv1_eval_p16(ops, B, Hi, Wi):
     """trid_stem_conv1_eval_p16: conv1 (3 -> 32, stride 2, exact fp32 MFMA) + BatchNorm + ReLU straight from the NCHW batch as a P16

@@ -76,6 +76,7 @@ struct GemmParams {
     const void* res16;      // P16 [M][N] (row pitch N) or null
     const float* res16_amax;
     EvalBound ev;
+    int pool_w;             // > 0: the epilogue output is the 2x2 average pool of act(.) over images of this width ([M / 4][N])
 };
 
 constexpr int BK = 32;

@@ -471,6 +471,37 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 && STAGES == 2) ? 2 : (W
                 char* const outb = reinterpret_cast<char*>(p.C);
                 const char* const resb = reinterpret_cast<const char*>(p.res16);
                 unsigned am = 0;
+                if (p.pool_w > 0) {
+                    // ... followed by AvgPool2d(2) (a stride-2 block's conv2: m_resnet.py:59-61 under eval), written pooled: the
+                    // tile's BM rows are BM / W whole image rows (W | BM, tiles start on even rows), i.e. BM / 4 pooled pixels that are
+                    // consecutive in the pooled tensor; a lane averages the four activated values of its 4 columns
+                    const int Wp = p.pool_w >> 1;
+#pragma unroll
+                    for (int ps = 0; ps < (BM / 4 + RG - 1) / RG; ++ps) {
+                        const int pl = ps * RG + rg;  // pooled pixel of the tile
+                        if (pl >= BM / 4 || col >= p.N) continue;
+                        const int py = pl / Wp, px = pl - py * Wp;
+                        const int r0 = 2 * py * p.pool_w + 2 * px;
+                        if (m0 + r0 >= p.M) continue;
+                        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int rl = r0 + (q >> 1) * p.pool_w + (q & 1);
+                            float4 v = *reinterpret_cast<const float4*>(Ct + rl * BN + 4 * c4);
+                            v = make_float4(fmaf(v.x, cs.x, bv4.x), fmaf(v.y, cs.y, bv4.y), fmaf(v.z, cs.z, bv4.z), fmaf(v.w, cs.w, bv4.w));
+                            if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+                        }
+                        a = make_float4(0.25f * a.x, 0.25f * a.y, 0.25f * a.z, 0.25f * a.w);
+                        am = absmax4u(am, a);
+                        const long long at = ((long long)(m0 >> 2) + pl) * p.N * 4 + (col >> 5) * 128 + (col & 31) * 2;
+                        unsigned q0h, q0l, q1h, q1l;
+                        f16_split2(a.x * oscale, a.y * oscale, q0h, q0l);
+                        f16_split2(a.z * oscale, a.w * oscale, q1h, q1l);
+                        *reinterpret_cast<uint2*>(outb + at) = make_uint2(q0h, q1h);
+                        *reinterpret_cast<uint2*>(outb + at + 64) = make_uint2(q0l, q1l);
+                    }
+                } else
 #pragma unroll
                 for (int ps = 0; ps < BM / RG; ++ps) {
                     const int rl = ps * RG + rg, row = m0 + rl;
@@ -1123,6 +1154,7 @@ extern "C" int trid_gemm_p16(const trid_gemm_desc* d, int variant, void* stream_
     p.colscale = d->col_scale; p.res16 = d->res_p16; p.res16_amax = d->res_amax;
     p.ev.coef = d->eval_coef; p.ev.tin = d->eval_tin; p.ev.tres = d->eval_tres;
     p.ev.out_bound = d->out_bound; p.ev.out_tmax = d->out_tmax;
+    p.pool_w = d->eval_pool_w;
     TRID_REQUIRE(p.cmask == nullptr || (d->accumulate && d->batch == 1 && d->splits == 1 && d->ldc == d->N && d->N % 4 == 0 && !d->stats),
                  "trid_gemm_p16: c_mask needs accumulate, batch == splits == 1, ldc == N, N %% 4 == 0");
     static const int wide_env = getenv("TRID_GEMM_WIDE_EPILOGUE") ? atoi(getenv("TRID_GEMM_WIDE_EPILOGUE")) : 1;  // (0: A/B runs)
@@ -1135,6 +1167,11 @@ extern "C" int trid_gemm_p16(const trid_gemm_desc* d, int variant, void* stream_
         TRID_REQUIRE(d->eval_coef && d->eval_tin && (!d->res_p16 || (d->res_amax && d->eval_tres && aligned16(d->res_p16))) && (!d->col_scale || aligned16(d->col_scale)) &&
                      (!d->bias || aligned16(d->bias)), "trid_gemm_p16: the eval epilogue needs eval_coef / eval_tin (and res_amax / eval_tres with a residual), 16-byte aligned vectors");
         p.wide_epilogue = 1;  // (the only form of this epilogue)
+        if (d->eval_pool_w) {
+            TRID_REQUIRE(d->a_mode == A_CONV && d->eval_pool_w == d->W && d->W % 2 == 0 && d->H % 2 == 0 && 128 % d->W == 0 && (128 / d->W) % 2 == 0 &&
+                         (d->H * d->W) % 128 == 0 && d->N > 64 && !d->res_p16,
+                         "trid_gemm_p16: the pooled eval epilogue needs a 3x3 convolution with W | 128, an even number of image rows per 128-row tile, H * W %% 128 == 0, N > 64, no residual (H=%d W=%d N=%d)", d->H, d->W, d->N);
+        }
     } else {
         TRID_REQUIRE(!d->col_scale && !d->res_p16, "trid_gemm_p16: col_scale / res_p16 belong to the eval epilogue (c_format 1)");
     }

@@ -115,6 +115,7 @@ struct HaloParams {
     const float* bn_scale;
     const float* bn_shift;
     int relu;
+    int pool;             // eval mode: the output is the 2x2 average of act(.) ([B][H/2][W/2][COUT]); 32 -> 64 channels, W % 64 == 0
     EvalBound ev;
 };
 
@@ -129,8 +130,10 @@ __device__ __forceinline__ int swz(int q) {
 
 // CIN, COUT in {32, 64}.  8 waves = PB pixel blocks x (COUT / 32) column blocks x (CIN / 32) channel groups;
 // a wave multiplies its 32 pixels x 32 input channels x 9 taps into 32 output channels.
-// EVAL: the eval-mode epilogue (its own instantiation: the training kernel keeps its register budget)
-template <int CIN, int COUT, bool EVAL = false>
+// EVAL: 1 = the eval-mode epilogue (its own instantiation: the training kernel keeps its register budget); 2 = ... followed by
+// the 2x2 average pool (the stem's conv3, m_resnet.py:205-207: avgpool(relu(bn3(conv3(x))))), written pooled: pixel pairs along x
+// are neighbouring accumulator rows of a lane, the two image rows of a pair are two waves that meet in LDS once per step
+template <int CIN, int COUT, int EVAL = 0>
 __global__ __launch_bounds__(512, 2) void conv3x3_halo_p16_kernel(HaloParams p) {
     constexpr int NW = 8, CB = COUT / 32, KG = CIN / 32, PB = NW / (CB * KG);
     constexpr int PIXB = CIN * 4;           // bytes of one pixel in LDS / HBM
@@ -186,8 +189,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_p16_kernel(HaloParams p) 
     }
 
     const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (unsigned)((size_t)p.B * H * W * PIXB), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(EVAL ? (void*)p.out16 : (void*)p.y, 0, (unsigned)((size_t)p.B * H * W * COUT * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(EVAL ? (void*)p.out16 : (void*)p.y, 0, (unsigned)((size_t)p.B * H * W * COUT * 4 / (EVAL == 2 ? 4 : 1)), 0x00020000);
     constexpr unsigned OOB = 0x80000000u;
+    static_assert(EVAL != 2 || KG == 1, "the pooled epilogue is built for 32 input channels (every wave holds final values)");
+    // EVAL == 2: this wave's image row inside the step (pixel blocks are 32 pixels: W / 32 of them per row) and its partner
+    const int wpb = W >> 5;
+    const int prow = EVAL == 2 ? pb / wpb : 0, pbx = EVAL == 2 ? pb - prow * wpb : 0;
+    const bool pool_owner = (prow & 1) == 0;  // even rows write the pooled pixels, odd rows hand their half over
 
     // rows [y_first, y_first + nrows) of image b -> ring slots slot_first ... (mod R); rows outside the image and the
     // pixel slots outside [1, W] become zeros (an out-of-range DMA lane writes zeros)
@@ -217,6 +225,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_p16_kernel(HaloParams p) 
         for (int s = 0; s < p.rg_per_chunk; ++s) {
             // rows y0-1 .. y0+TH were issued before this wave's stores of the previous step (vmcnt retires in order)
             if (s == 0) wait_vm<0>();
+            else if (EVAL == 2) { if (pool_owner) wait_vm<8>(); else wait_vm<0>(); }  // (8 pooled stores per lane, or none)
             else if (KG == 1 || kg == 0) wait_vm<16>();
             else wait_vm<0>();
             lds_barrier();
@@ -322,7 +331,55 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_p16_kernel(HaloParams p) 
                     if (khalf == 0) lds_store4(sstat + (s & 1) * NW * 32 + wave * 32 + (lane & 31), make_float4(mean, m2, lo, hi));
                 }
                 const size_t m0 = ((size_t)b * H + y0) * W + pb * 32 + 4 * khalf;
-                if constexpr (EVAL) {  // BatchNorm (running statistics) + ReLU, written as the next operand (16 stores per lane as well)
+                if constexpr (EVAL == 2) {
+                    // BatchNorm + ReLU, then the 2x2 average: along x in the lane (accumulator rows 2j, 2j + 1 are neighbouring
+                    // pixels), along y through LDS (the odd image rows' waves hand their sums to the even rows' waves)
+                    float hs[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        float v0 = fmaf(acc[2 * j], e_sc, e_sh), v1 = fmaf(acc[2 * j + 1], e_sc, e_sh);
+                        if (p.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+                        hs[j] = v0 + v1;
+                    }
+                    float* ex = reinterpret_cast<float*>(sstat);  // [NW][8][64] floats = 16 KB ... of which the odd rows' waves write
+                    if (!pool_owner) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const float v = hs[j];
+                            lds_store1(ex + (wave * 8 + j) * 64 + lane, v);
+                        }
+                    }
+                    lds_barrier();
+                    if (pool_owner) {
+                        const int partner = wave + wpb * CB * KG;  // the wave one image row below, same columns / channels
+                        v16f pv;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) pv[j] = 0.25f * (hs[j] + ex[(partner * 8 + j) * 64 + lane]);
+                        // pooled pixel of pair j: block of 16 pooled pixels per 32-pixel block, index 2 khalf + (j & 1) + 4 (j >> 1)
+                        const size_t pm0 = ((size_t)b * (H >> 1) + ((y0 + prow) >> 1)) * (W >> 1) + pbx * 16 + 2 * khalf;
+                        const unsigned base = (unsigned)(pm0 * (COUT * 4)) + (unsigned)cb * 128u;
+                        const int n = lane & 31;
+                        const bool even = (n & 1) == 0;
+                        const unsigned colb = base + (even ? 2u * (unsigned)n : 64u + 2u * (unsigned)(n - 1));
+#pragma unroll
+                        for (int j = 0; j < 8; j += 2) {
+                            const float v0 = pv[j], v1 = pv[j + 1];
+                            const unsigned a0 = __builtin_bit_cast(unsigned, v0) & 0x7fffffffu, a1 = __builtin_bit_cast(unsigned, v1) & 0x7fffffffu;
+                            e_tmax = a0 > e_tmax ? a0 : e_tmax;
+                            e_tmax = a1 > e_tmax ? a1 : e_tmax;
+                            unsigned h2, l2;
+                            f16_split2(v0 * e_oscale, v1 * e_oscale, h2, l2);
+#pragma unroll
+                            for (int k = 0; k < 2; ++k) {
+                                const unsigned mine = k == 0 ? ((h2 & 0xffffu) | (l2 << 16)) : ((h2 >> 16) | (l2 & 0xffff0000u));
+                                const unsigned nbr = (unsigned)__shfl_xor((int)mine, 1, 64);
+                                const unsigned outw = even ? ((mine & 0xffffu) | (nbr << 16)) : ((nbr >> 16) | (mine & 0xffff0000u));
+                                const unsigned off = colb + (unsigned)((((j + k) & 1) + 4 * ((j + k) >> 1)) * (COUT * 4));
+                                __builtin_amdgcn_raw_buffer_store_b32(outw, rsY, off, 0, 0);
+                            }
+                        }
+                    }
+                } else if constexpr (EVAL == 1) {  // BatchNorm (running statistics) + ReLU, written as the next operand (16 stores per lane as well)
                     const unsigned base = (unsigned)(m0 * (COUT * 4)) + (unsigned)cb * 128u;
                     e_tmax = p.nt ? store_p16_rows<true, COUT * 4>(acc, e_sc, e_sh, p.relu, e_oscale, rsY, base, lane, e_tmax)
                                   : store_p16_rows<false, COUT * 4>(acc, e_sc, e_sh, p.relu, e_oscale, rsY, base, lane, e_tmax);
@@ -761,10 +818,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_halo_p16_kernel(HaloWgra
     }
 }
 
-template <int CIN, int COUT, bool EVAL>
+template <int CIN, int COUT, int EVAL>
 static int launch_halo_t(HaloParams& p, hipStream_t stream) {
     constexpr int NW = 8, CB = COUT / 32, KG = CIN / 32, PB = NW / (CB * KG);
-    const size_t lds = (size_t)p.R * p.rowb + 2 * NW * 32 * sizeof(float4) + (KG == 2 ? (size_t)PB * CB * 16 * 64 * 4 : 0);
+    // (the [2][NW][32] float4 partials region = 8 KB; the pooled epilogue uses [NW][8][64] floats = 16 KB of exchange space there)
+    const size_t lds = (size_t)p.R * p.rowb + (EVAL == 2 ? 2 : 1) * 2 * NW * 32 * sizeof(float4) + (KG == 2 ? (size_t)PB * CB * 16 * 64 * 4 : 0);
     static std::once_flag once;
     static hipError_t attr_err = hipSuccess;
     std::call_once(once, [] {
@@ -781,7 +839,10 @@ static int launch_halo_t(HaloParams& p, hipStream_t stream) {
 
 template <int CIN, int COUT>
 static int launch_halo(HaloParams& p, hipStream_t stream) {
-    return p.out16 != nullptr ? launch_halo_t<CIN, COUT, true>(p, stream) : launch_halo_t<CIN, COUT, false>(p, stream);
+    if constexpr (CIN == 32 && COUT == 64) {
+        if (p.out16 != nullptr && p.pool) return launch_halo_t<CIN, COUT, 2>(p, stream);
+    }
+    return p.out16 != nullptr ? launch_halo_t<CIN, COUT, 1>(p, stream) : launch_halo_t<CIN, COUT, 0>(p, stream);
 }
 
 }  // namespace trid
@@ -847,9 +908,15 @@ extern "C" int trid_conv3x3_halo_p16(const void* x, const float* x_amax, const v
     return halo_dispatch(p, B, H, W, Cin, Cout, chunks_per_image, "trid_conv3x3_halo_p16", (hipStream_t)stream);
 }
 
+extern "C" int trid_conv3x3_halo_eval_pool_ok(int H, int W, int Cin, int Cout) {
+    const int th = halo_rows_per_step(H, W, Cin, Cout);
+    return Cin == 32 && Cout == 64 && th > 0 && th % 2 == 0 && W % 64 == 0 && H % 2 == 0;
+}
+
 extern "C" int trid_conv3x3_halo_eval_p16(const void* x, const float* x_amax, const void* w, const float* w_amax, const float* bn_scale,
                                           const float* bn_shift, void* out, const float* eval_coef, const float* eval_tin, float* out_bound,
-                                          float* out_tmax, int B, int H, int W, int Cin, int Cout, int relu, void* stream) {
+                                          float* out_tmax, int B, int H, int W, int Cin, int Cout, int relu, int pool, void* stream) {
+    TRID_REQUIRE(!pool || trid_conv3x3_halo_eval_pool_ok(H, W, Cin, Cout), "trid_conv3x3_halo_eval_p16: the pooled form covers 32 -> 64 channels, W %% 64 == 0 (H=%d W=%d Cin=%d Cout=%d)", H, W, Cin, Cout);
     TRID_REQUIRE(x && w && out && x_amax && w_amax && bn_scale && bn_shift && eval_coef && eval_tin && out_bound && B > 0 && H > 0 && W > 0,
                  "trid_conv3x3_halo_eval_p16: bad arguments");
     TRID_REQUIRE(aligned16(x) && aligned16(w) && aligned16(out), "trid_conv3x3_halo_eval_p16: operands must be 16-byte aligned");
@@ -857,7 +924,7 @@ extern "C" int trid_conv3x3_halo_eval_p16(const void* x, const float* x_amax, co
     memset(&p, 0, sizeof(p));
     p.x = (const char*)x; p.w = (const char*)w;
     p.x_amax = x_amax; p.w_amax = w_amax;
-    p.out16 = (char*)out; p.bn_scale = bn_scale; p.bn_shift = bn_shift; p.relu = relu;
+    p.out16 = (char*)out; p.bn_scale = bn_scale; p.bn_shift = bn_shift; p.relu = relu; p.pool = pool;
     p.ev.coef = eval_coef; p.ev.tin = eval_tin; p.ev.out_bound = out_bound; p.ev.out_tmax = out_tmax;
     return halo_dispatch(p, B, H, W, Cin, Cout, 0, "trid_conv3x3_halo_eval_p16", (hipStream_t)stream);
 }

@@ -60,6 +60,7 @@ class GemmDesc(ctypes.Structure):
         ("eval_tres", ctypes.c_void_p),
         ("out_bound", ctypes.c_void_p),
         ("out_tmax", ctypes.c_void_p),
+        ("eval_pool_w", ctypes.c_int32),
     ]
 
 

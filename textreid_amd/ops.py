@@ -526,15 +526,20 @@ def bn_eval_bound(partials, st, relu):
     return bound
 
 
-def conv3x3_halo_eval_p16(x, w, st, coef, relu=True):
-    """conv_eval_p16 for the 32 / 64-channel 3x3 convolutions at large maps (the stem's conv2, layer1's conv2) on the
-    ring-of-rows kernel (csrc/stem_conv.hip): x P16 [B,H,W,Cin], w P16 [Cout, 9*Cin] -> act(bn(conv)) P16 [B,H,W,Cout]."""
+def conv3x3_halo_eval_pool_ok(H, W, Cin, Cout):
+    return bool(_query("trid_conv3x3_halo_eval_pool_ok", int(H), int(W), int(Cin), int(Cout)))
+
+
+def conv3x3_halo_eval_p16(x, w, st, coef, relu=True, pool=False):
+    """conv_eval_p16 for the 32 / 64-channel 3x3 convolutions at large maps (the stem's conv2 / conv3, layer1's conv2) on the
+    ring-of-rows kernel (csrc/stem_conv.hip): x P16 [B,H,W,Cin], w P16 [Cout, 9*Cin] -> act(bn(conv)) P16 [B,H,W,Cout]; pool:
+    followed by the 2x2 average, written pooled ([B,H/2,W/2,Cout]: the stem's conv3; conv3x3_halo_eval_pool_ok)."""
     Bi, H, W, C = x.shape
     N = w.shape[0]
-    out = p16_empty((Bi, H, W, N), x.data, 1)
+    out = p16_empty((Bi, H // 2, W // 2, N) if pool else (Bi, H, W, N), x.data, 1)
     bound, tmax = amax_slot(x.data.device), amax_slot(x.data.device)
     call("trid_conv3x3_halo_eval_p16", _p(x.data), _p(x.amax), _p(w.data), _p(w.amax), _p(st.scale), _p(st.shift), _p(out), _p(coef), _p(x.tmax),
-         _p(bound), _p(tmax), Bi, H, W, C, N, 1 if relu else 0, stream())
+         _p(bound), _p(tmax), Bi, H, W, C, N, 1 if relu else 0, 1 if pool else 0, stream())
     return P16(out, bound, 1, tmax)
 
 
@@ -551,7 +556,12 @@ def stem_conv1_eval_p16(images, w, st, coef, img_amax, relu=True):
     return P16(out, bound, 1, tmax)
 
 
-def conv_eval_p16(x, w, st, coef, relu=True, res=None, conv3=False):
+def conv_eval_pool_ok(H, W, N):
+    """Can the tile kernel's eval epilogue write the 2x2 average pool of a 3x3 convolution's activated output directly?"""
+    return W % 2 == 0 and H % 2 == 0 and 128 % W == 0 and (128 // W) % 2 == 0 and (H * W) % 128 == 0 and N > 64
+
+
+def conv_eval_p16(x, w, st, coef, relu=True, res=None, conv3=False, pool=False):
     """Eval-mode conv + BatchNorm(running statistics) (+ residual) (+ ReLU) in ONE kernel, P16 in -> P16 out:
     act(st.scale * conv(x, w) + st.shift (+ res)).  x: P16 [B,H,W,C] / [M,C] with its true maximum `x.tmax`; w: P16 [N, K];
     coef: this convolution's row of eval_bound_coefs; res: P16 [.., N] or None.  The output's scale comes from the bound
@@ -561,9 +571,12 @@ def conv_eval_p16(x, w, st, coef, relu=True, res=None, conv3=False):
     N = w.shape[0]
     K = 9 * C if conv3 else C
     shape = tuple(x.shape[:-1]) + (N,)
+    if pool:  # (conv3 form only: the output is AvgPool2d(2) of the activated convolution)
+        assert conv3 and res is None and conv_eval_pool_ok(x.shape[1], x.shape[2], N)
+        shape = (x.shape[0], x.shape[1] // 2, x.shape[2] // 2, N)
     out = p16_empty(shape, x.data, 1)
     dev = x.data.device
-    if conv3 and res is None and USE_HALO_BLOCKS and conv3x3_halo_rows(x.shape[1], x.shape[2], C, N):
+    if conv3 and res is None and not pool and USE_HALO_BLOCKS and conv3x3_halo_rows(x.shape[1], x.shape[2], C, N):
         return conv3x3_halo_eval_p16(x, w, st, coef, relu)
     bound, tmax = amax_slot(dev), amax_slot(dev)
     if not conv3 and USE_STREAM and K in (64, 128, 256) and _query("trid_conv1x1_bn_res_p16_ok", int(M), int(N), int(K)):
@@ -589,6 +602,7 @@ def conv_eval_p16(x, w, st, coef, relu=True, res=None, conv3=False):
         d.res_p16, d.res_amax, d.eval_tres = _p(res.data), _p(res.amax), _p(res.tmax)
     d.eval_coef, d.eval_tin = _p(coef), _p(x.tmax)
     d.out_bound, d.out_tmax = _p(bound), _p(tmax)
+    d.eval_pool_w = x.shape[2] if pool else 0
     call("trid_gemm_p16", ctypes.addressof(d), -1, stream())
     return P16(out, bound, 1, tmax)
 
