@@ -676,29 +676,37 @@ class ModifiedResNet(nn.Module):
         average pools.  The stem (conv1 straight from the NCHW batch) and layer1's 64-channel 3x3 convolutions run on the
         bandwidth-shaped kernels of csrc/stem_conv.hip with the same fused epilogue."""
         E = self._eval_plan(images.device)
+        log = getattr(self, "_debug_eval_bounds", None)  # tools/eval_bounds.py: (layer, P16 output) of every fused epilogue
+
+        def note(name, t):
+            if log is not None:
+                log.append((name, t))
+            return t
+
         _, st1, c1 = E[id(self.conv1.weight)]
-        a1 = ops.stem_conv1_eval_p16(images, self.conv1.weight, st1, c1, ops.amax(images))
-        a2 = ops.conv_eval_p16(a1, *E[id(self.conv2.weight)], relu=True, conv3=True)  # (ring-of-rows kernel)
+        a1 = note("conv1", ops.stem_conv1_eval_p16(images, self.conv1.weight, st1, c1, ops.amax(images)))
+        a2 = note("conv2", ops.conv_eval_p16(a1, *E[id(self.conv2.weight)], relu=True, conv3=True))  # (ring-of-rows kernel)
         wp3, st3, c3 = E[id(self.conv3.weight)]
         if ops.conv3x3_halo_eval_pool_ok(a2.shape[1], a2.shape[2], a2.shape[3], wp3.shape[0]):
-            x = ops.conv3x3_halo_eval_p16(a2, wp3, st3, c3, relu=True, pool=True)  # conv3 + bn3 + ReLU + AvgPool2d(2) in one kernel
+            x = note("conv3+pool", ops.conv3x3_halo_eval_p16(a2, wp3, st3, c3, relu=True, pool=True))  # conv3 + bn3 + ReLU + AvgPool2d(2) in one kernel
         else:  # (other widths: BatchNorm + ReLU + pool as one pass over the raw output, scaled by the epilogue's exact extremes)
             y3, parts, rows = ops.conv3x3_halo_p16(a2, wp3)
             x = ops.bn_apply_pool2_p16(y3, st3, ops.bn_eval_bound(ops.Partials(parts, rows), st3, True), relu=True)
-        for blk in self.blocks():
+        for bi, blk in enumerate(self.blocks()):
             stride = blk.stride
-            aa = ops.conv_eval_p16(x, *E[id(blk.conv1.weight)], relu=True)
+            aa = note("block%d.conv1" % bi, ops.conv_eval_p16(x, *E[id(blk.conv1.weight)], relu=True))
             if stride > 1 and ops.conv_eval_pool_ok(aa.shape[1], aa.shape[2], blk.conv2.out_channels):
                 ab = ops.conv_eval_p16(aa, *E[id(blk.conv2.weight)], relu=True, conv3=True, pool=True)  # conv2 + bn2 + ReLU + AvgPool2d(2)
             else:
                 ab = ops.conv_eval_p16(aa, *E[id(blk.conv2.weight)], relu=True, conv3=True)  # (layer1: the ring-of-rows kernel)
                 if stride > 1:
                     ab = ops.bn_apply_pool2_p16(ab, None, ab.amax)
+            note("block%d.conv2" % bi, ab)
             ident = x
             if blk.downsample is not None:
                 xd = ops.bn_apply_pool2_p16(x, None, x.amax) if stride > 1 else x
-                ident = ops.conv_eval_p16(xd, *E[id(blk.downsample[1].weight)], relu=False)
-            x = ops.conv_eval_p16(ab, *E[id(blk.conv3.weight)], relu=True, res=ident)
+                ident = note("block%d.downsample" % bi, ops.conv_eval_p16(xd, *E[id(blk.downsample[1].weight)], relu=False))
+            x = note("block%d.conv3" % bi, ops.conv_eval_p16(ab, *E[id(blk.conv3.weight)], relu=True, res=ident))
         feat, _ = self._attnpool_forward(x, False)
         return feat
 
