@@ -732,6 +732,8 @@ int trid::stream_topk_filter(const void* g16, const float* g_amax, const void* q
     int workers = 8;
     while (workers < 256 && (long long)p.panels * workers < 1024 && p.tiles / (workers * 2) >= 64) workers *= 2;
     while ((long long)p.panels * workers % 256 != 0 && workers < 256 && p.tiles / (workers + 8) >= 64) workers += 8;
+    static const int w_env = getenv("TRID_TOPK_WORKERS") ? atoi(getenv("TRID_TOPK_WORKERS")) : 0;  // (experiments)
+    if (w_env > 0) workers = w_env;
     p.workers = std::min(workers, (p.tiles + 7) / 8 * 8);
     hipLaunchKernelGGL((gemm_p16_stream_kernel<K, CW, TM, false, 4>), dim3(p.workers * p.panels), dim3(512), lds, stream, p);
     return check_launch("stream_topk_filter");
