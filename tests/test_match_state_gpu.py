@@ -787,9 +787,16 @@ def test_inference_dedupes_image_encodes(gpu):
                 yield imgs[[image_ids[i] for i in idx]], CaptionBatch(tok[idx], ln[idx]), idx
 
     a = compute_on_dataset(model, Loader(), gpu, dedupe=True)
-    assert compute_on_dataset.last_stats == {"images_encoded": 4, "samples": N}
+    assert compute_on_dataset.last_stats == {"images_encoded": 4, "samples": N, "encoder_passes": 1}  # (coalesced across the 3 loader batches)
     b = compute_on_dataset(model, Loader(), gpu, dedupe=False)
     assert compute_on_dataset.last_stats["images_encoded"] == N
+    c = compute_on_dataset(model, Loader(), gpu, dedupe=True, encode_batch=0)  # one encoder pass per loader batch, as the reference
+    assert compute_on_dataset.last_stats == {"images_encoded": 4, "samples": N, "encoder_passes": 3}
+    d = compute_on_dataset(model, Loader(), gpu, dedupe=True, encode_batch=2)   # flushes in the middle of the run
+    assert compute_on_dataset.last_stats["images_encoded"] == 4 and sorted(d) == list(range(N))
+    for i in range(N):
+        assert torch.allclose(a[i][0], c[i][0], rtol=1e-5, atol=1e-6) and torch.equal(a[i][1], c[i][1])
+        assert torch.allclose(a[i][0], d[i][0], rtol=1e-5, atol=1e-6) and torch.equal(a[i][1], d[i][1])
     for i in range(N):
         # eval-mode BatchNorm is per-sample independent: identical up to GEMM tile-edge effects
         assert torch.allclose(a[i][0], b[i][0], rtol=1e-5, atol=1e-6) and torch.equal(a[i][1], b[i][1])
