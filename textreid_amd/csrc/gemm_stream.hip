@@ -21,6 +21,10 @@
 
 #include "split_common.h"
 
+#ifndef TRID_TOPK_PF
+#define TRID_TOPK_PF 1  // fragment prefetch distance of the retrieval filter instantiation (k steps); 2 measured the same (16.4 ms) at 256 VGPRs
+#endif
+
 namespace trid {
 
 namespace {
@@ -321,7 +325,10 @@ __global__ __launch_bounds__(512, 2) void gemm_p16_stream_kernel(StreamParams p)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
         const char* sA = ring + stage * STAGE;
-        f16x8 af[2][TM][2];
+        // fragment prefetch distance: 1 k step (two register sets).  (The retrieval filter runs two waves per SIMD - its 128-VGPR
+        // query panel - at 44 % MFMA-busy; a distance of 2 (three sets, 256 VGPRs) measured the same 16.4 ms: TRID_TOPK_PF)
+        constexpr int PF = FUSE == 4 ? TRID_TOPK_PF : 1;
+        f16x8 af[PF + 1][TM][2];
         auto fetch = [&](int q, f16x8(&dst)[TM][2]) {  // q = k group * 2 + k step
             const int g = q >> 1, ks = q & 1;
             const int u0 = g * 8 + 2 * ks + khalf;
@@ -331,17 +338,19 @@ __global__ __launch_bounds__(512, 2) void gemm_p16_stream_kernel(StreamParams p)
                 dst[i][1] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(sA + a_off[i] + (((u0 + 4) ^ rsw) << 4)));
             }
         };
-        fetch(0, af[0]);
+#pragma unroll
+        for (int q = 0; q < PF; ++q) fetch(q, af[q]);
 #pragma unroll
         for (int q = 0; q < 2 * KG; ++q) {
-            if (q + 1 < 2 * KG) fetch(q + 1, af[(q + 1) & 1]);
+            if (q + PF < 2 * KG) fetch(q + PF, af[(q + PF) % (PF + 1)]);
             const int g = q >> 1, ks = q & 1;
+            constexpr int NB = PF + 1;
 #pragma unroll
-            for (int i = 0; i < TM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[q & 1][i][0], bf[g][ks][1], acc[i], 0, 0, 0);
+            for (int i = 0; i < TM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[q % NB][i][0], bf[g][ks][1], acc[i], 0, 0, 0);
 #pragma unroll
-            for (int i = 0; i < TM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[q & 1][i][1], bf[g][ks][0], acc[i], 0, 0, 0);
+            for (int i = 0; i < TM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[q % NB][i][1], bf[g][ks][0], acc[i], 0, 0, 0);
 #pragma unroll
-            for (int i = 0; i < TM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[q & 1][i][0], bf[g][ks][0], acc[i], 0, 0, 0);
+            for (int i = 0; i < TM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[q % NB][i][0], bf[g][ks][0], acc[i], 0, 0, 0);
         }
 
         // ---- epilogue
