@@ -357,7 +357,9 @@ def retrieval_bench(device, world, rank, G_total=1000000, Q=10000, k=10, shard_r
         "peak": F16_SPLIT_PEAK_TFLOPS,
         "unit": "TFLOP/s",
         "frac": tfl / world / F16_SPLIT_PEAK_TFLOPS,
-        "traffic": None,
+        "traffic": stored_traffic("gemm_p16_stream_kernel<256, 8, 2, false, 4>")[0] if (shard_rows is None and world == 1) else None,
+        "traffic_source": stored_traffic("gemm_p16_stream_kernel<256, 8, 2, false, 4>")[1] if (shard_rows is None and world == 1) else None,
+        "traffic_note": "HBM-side bytes of the filter kernel per launch (stored PMC passes of tools/retrieval_time.py, same Q and G): the 1 GB gallery crosses the fabric about once per XCD (7.7 GB read) although 40 query panels stream it - the panels of one worker share an L2; the writes are the candidate appends and their atomics",
         "note": "achieved = algorithmic FLOPs of the WHOLE match (2 Q G C, per GPU) / wall time of the whole call (amax + split of both operands, first-panel GEMM + row scan, filter pass, list merge, one 4-byte host read): the kernel itself is ~98 % of it",
     }
     if k_ms and shard_rows is None and world == 1:
@@ -404,6 +406,26 @@ def stored_kernel_avg_ms(pattern, suffix):
             if calls:
                 return tot / calls / 1e6, "profiles/" + fn
         except (OSError, ValueError, KeyError):
+            pass
+    return None, None
+
+
+def stored_traffic(pattern):
+    """(HBM-side bytes per launch, file) of the kernels whose name contains `pattern` in the NEWEST committed PMC summary that
+    lists them (profiles/r*_pmc_hbm_traffic.txt, newest first by name; calls-weighted over the matching lines; separate
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes with the gfx950 2x FETCH_SIZE correction, tools/pmc_summary.py), or (None, None)."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    for fn in newest_profiles("_pmc_hbm_traffic.txt"):
+        try:
+            tot, calls = 0.0, 0
+            for ln in open(os.path.join(here, "profiles", fn)):
+                f = ln.split()
+                if pattern in ln and len(f) > 5:
+                    tot += int(f[1]) * (float(f[2]) + float(f[3])) * 1e6
+                    calls += int(f[1])
+            if calls:
+                return tot / calls, "profiles/" + fn
+        except (OSError, ValueError):
             pass
     return None, None
 
@@ -730,23 +752,6 @@ def main():
     # measurement of the committed build, not a counter read of this run: `traffic_source` names the file.
     traffic, traffic_note, traffic_src = None, None, None
     here = os.path.dirname(os.path.abspath(__file__))
-
-    def stored_traffic(pattern):
-        """(bytes per launch, file) of the kernels whose name contains `pattern` in the NEWEST committed PMC summary that
-        lists them (profiles/r*_pmc_hbm_traffic.txt, newest round first by name; calls-weighted over the matching lines), or (None, None)."""
-        for fn in newest_profiles("_pmc_hbm_traffic.txt"):
-            try:
-                tot, calls = 0.0, 0
-                for ln in open(os.path.join(here, "profiles", fn)):
-                    f = ln.split()
-                    if pattern in ln and len(f) > 5:
-                        tot += int(f[1]) * (float(f[2]) + float(f[3])) * 1e6
-                        calls += int(f[1])
-                if calls:
-                    return tot / calls, "profiles/" + fn
-            except (OSError, ValueError):
-                pass
-        return None, None
 
     def stored_rocprof_avg_ms(pattern):
         """(average duration in ms, file) of the kernels whose name contains `pattern` in the newest committed rocprofv3
