@@ -154,10 +154,24 @@ class ConvArith:
         return self.WA.get(id(conv.weight))
 
 
+def _conv_weights(mod):
+    """The conv filters under `mod` in module order (the order of weight_amax's scalars).  The module tree is static: walked once
+    (nn.Module.modules() cost 1.8 ms of host time per train step when walked on every pass)."""
+    ent = mod.__dict__.get("_conv_weight_list")
+    # (Parameter OBJECTS are stable under .to() / load_state_dict / optimizer steps; a caller that assigns new nn.Parameters
+    # is caught by the identity of the first and last filter)
+    if ent is None or ent[1].weight is not ent[0][0] or ent[2].weight is not ent[0][-1]:
+        cm = [m for m in mod.modules() if isinstance(m, nn.Conv2d)]
+        ent = ([m.weight for m in cm], cm[0], cm[-1])
+        mod.__dict__["_conv_weight_list"] = ent
+        mod.__dict__.pop("_block_conv_weight_list", None)
+    return ent[0]
+
+
 def weight_amax(mod):
     """{id(conv weight): device scalar max|w|} for every conv filter under `mod`, ONE multi-tensor launch (fp16-split
     arithmetic, ops.CONV_PRECISION == 16).  The pointer table is rebuilt only when a parameter moves."""
-    convs = [m.weight for m in mod.modules() if isinstance(m, nn.Conv2d)]
+    convs = _conv_weights(mod)
     key = tuple(w.data_ptr() for w in convs)
     plan = getattr(mod, "_wamax_plan", None)
     if plan is None or plan[0] != key:
@@ -188,10 +202,13 @@ def p16_weights(mod, WA, transposed, fmt=1, stem_only=False):
     operands [N][taps*C] (filters as stored: 3x3 in OHWI) or, transposed, the data-gradient operands [C][taps*N] with
     the taps reversed.  fmt 1: P16 (scaled by WA's amax scalars); fmt 2: plain bf16.  Destination buffers and the
     pointer table are persistent per module."""
-    convs = [m.weight for m in mod.modules() if isinstance(m, nn.Conv2d)]  # weight_amax's order
+    convs = _conv_weights(mod)  # weight_amax's order
     index = {id(w): i for i, w in enumerate(convs)}
-    blocks = mod.blocks() if hasattr(mod, "blocks") else [mod]  # (a single Bottleneck: per-block parity tests)
-    mine = [m.weight for blk in blocks for m in blk.modules() if isinstance(m, nn.Conv2d)]
+    mine = mod.__dict__.get("_block_conv_weight_list")
+    if mine is None:
+        blocks = mod.blocks() if hasattr(mod, "blocks") else [mod]  # (a single Bottleneck: per-block parity tests)
+        mine = [m.weight for blk in blocks for m in blk.modules() if isinstance(m, nn.Conv2d)]
+        mod.__dict__["_block_conv_weight_list"] = mine
     if fmt == 1 and hasattr(mod, "blocks") and stem_p16_channels(mod):
         mine = [mod.conv2.weight, mod.conv3.weight] + mine  # the stem's 3x3 convolutions run on P16 operands too (stem_forward_p16)
     if stem_only:  # bf16 mode: the residual blocks read bf16 filters, the stem stays fp32-class on ITS two P16 filters

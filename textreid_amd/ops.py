@@ -40,8 +40,19 @@ def conv_precision():
     return CONV_PRECISION if GEMM_PRECISION == 6 else GEMM_PRECISION
 
 
-def stream():
-    return torch.cuda.current_stream().cuda_stream
+_raw_stream = torch._C._cuda_getCurrentRawStream  # (the raw handle without building a torch.cuda.Stream object: ~0.3 us instead of ~7)
+_cur_device = torch._C._cuda_getDevice
+
+
+_SLOW_STREAM = os.environ.get("TRID_SLOW_STREAM", "0") == "1"  # (A/B runs: the torch.cuda.Stream-object path)
+
+
+def stream(device=None):
+    """hipStream_t of torch's current stream on `device` (default: the current device) as an integer.  Called ~900 times per
+    train step: torch.cuda.current_stream() cost 4.4 ms of host time per step (tools/exp/host_profile.py)."""
+    if _SLOW_STREAM:
+        return torch.cuda.current_stream(device).cuda_stream
+    return _raw_stream(_cur_device() if device is None or device.index is None else device.index)
 
 
 # Generation counter of raw-pointer parameter / buffer writes.  The library's own writers (FusedAdam.step, the EMA
@@ -125,7 +136,7 @@ def bn_finalize_ws(device):
     stream are serial.  (Inside a capture it comes from the capture's pool, see begin_capture.)"""
     if not _FINALIZE_SPLIT:
         return None
-    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    key = (device, stream(device))
     cache = _finalize_ws_capture if torch.cuda.is_current_stream_capturing() else _finalize_ws
     ws = cache.get(key)
     if ws is None:
@@ -138,7 +149,7 @@ def amax_slot(device):
     """A zero-initialised device scalar (1-element view) for a kernel's `amax` side output.  Slots come from a
     zero-filled pool per (device, stream) and are written once, so there is no per-call memset; the view keeps its
     pool buffer alive."""
-    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    key = (device, stream(device))
     pools = _amax_pool_capture if torch.cuda.is_current_stream_capturing() else _amax_pool
     ent = pools.get(key)
     if ent is None or ent[1] >= ent[0].numel():
@@ -968,7 +979,7 @@ _ws_cache = {}
 
 def _bn_ws(C, like):
     # one workspace per (channels, device, STREAM): two backward passes on different streams must not share it
-    key = (C, like.device, torch.cuda.current_stream(like.device).cuda_stream)
+    key = (C, like.device, stream(like.device))
     ws = _ws_cache.get(key)
     if ws is None:
         ws = empty((L.load().trid_bn_bwd_ws_floats(C),), like)
