@@ -569,10 +569,13 @@ int trid_sim_topk_f32(const float* q, const float* g, float* out_val, int64_t* o
  * panel: split once instead of once per panel, and the admission-filter pass runs on the streaming kernel with 256 queries
  * resident in a workgroup's registers (csrc/gemm_stream.hip) - the gallery crosses LDS once per 256 queries, nothing is
  * stored but candidates.  Results as trid_sim_topk_f32 with precision 16 (same arithmetic; values agree to the last bits).
+ * The rows beyond the first panel are filtered in SEGMENTS of growing length (x 8: 8192 | 65536 | 524288 | ...), each merged into the
+ * running top-k before the next starts, so a query's threshold is the k-th best of everything before the segment (~7 k
+ * candidates per query and segment); ws also keeps the top-k as it stood after the first panel, which the fall-back restores.
  * mode 0: as trid_sim_topk_f32 (the overflow fall-back passes are enqueued behind the fused pass, gated on a device flag).
  * mode 1: without them - the caller reads the int at ws[trid_topk_ws_flag_offset(Q, G)] afterwards and, when it is non-zero (a
- * candidate list overflowed: an adversarially ordered gallery), calls mode 2 (q16 / g16 unused), which redoes the columns
- * beyond the first panel densely.  One 4-byte read instead of ~2 G / 8192 gated no-op launches (1.4 of 17 ms at G = 1e6). */
+ * candidate list overflowed: an adversarially ordered gallery), calls mode 2 with the same arguments and ws, which redoes the
+ * columns beyond the first panel densely.  One 4-byte read instead of ~2 G / 8192 gated no-op launches (1.4 of 17 ms at G = 1e6). */
 int trid_sim_topk_p16(const float* q, const float* g, const void* q16, const void* g16, float* out_val, int64_t* out_idx, int Q, int G,
                       int k, long long idx_offset, const float* q_amax, const float* g_amax, float* ws, int mode, void* stream);
 long long trid_topk_ws_flag_offset(int Q, int G);

@@ -166,6 +166,37 @@ def test_fused_similarity_topk_presplit_overflow_and_negative_thresholds(gpu):
     assert torch.allclose(vals.cpu(), order.values[:, :10], rtol=1e-6, atol=0)
 
 
+@pytest.mark.parametrize("device_gated", [False, True])
+def test_fused_similarity_topk_presplit_segments_and_late_overflow(gpu, device_gated):
+    """A gallery long enough for the filter pass to run in SEGMENTS (8192 | 57344 | the rest, each merged before the next
+    starts): random queries (thresholds tighten from segment to segment), and queries whose similarity ascends with the
+    index only in the LAST segment - its lists overflow after the earlier segments were merged, so the fall-back must
+    restart from the top-k of the first chunk (no row twice).  Both fall-back forms: host-read flag, device-gated."""
+    import textreid_amd.evaluation as E
+
+    G, Q, C = 8192 * 8 + 40000, 70, 256
+    gen = torch.Generator().manual_seed(5)
+    gal = torch.randn(G, C, generator=gen) * 0.05
+    gal[:, 0] = torch.randn(G, generator=gen)
+    gal[8192 * 8:, 0] = 4.0 + torch.arange(G - 8192 * 8, dtype=torch.float32) * 1e-4   # ascending: 40000 admissions per list
+    q = torch.randn(Q, C, generator=gen) * 0.05
+    q[:32, 0] = 1.0
+    q[32:, 0] = 0.0            # these never see the ascending column: ordinary lists
+    try:
+        E.DEVICE_GATED_FALLBACK = device_gated
+        vals, idx = E.similarity_topk(q.to(gpu), gal.to(gpu), 10, normalize=False)
+    finally:
+        E.DEVICE_GATED_FALLBACK = False
+    order = torch.sort(q.double() @ gal.double().t(), dim=1, descending=True, stable=True)
+    assert all(len(set(r)) == 10 for r in idx.cpu().tolist())
+    assert torch.allclose(vals.cpu().double(), order.values[:, :10], rtol=2e-6, atol=2e-6)
+    clear = torch.ones(Q, 10, dtype=torch.bool)
+    gap = order.values[:, :10] - order.values[:, 1:11]
+    clear &= gap > 1e-5
+    clear[:, 1:] &= gap[:, :-1] > 1e-5
+    assert torch.equal(idx.cpu()[clear], order.indices[:, :10][clear]) and float(clear.float().mean()) > 0.8
+
+
 def test_rank_full_argsort_beyond_the_lds_sort(gpu):
     """rank(get_mAP=True) on a gallery wider than the in-LDS bitonic sort (G > 16384: ICFG-PEDES i2t has 19 848
     captions): packed keys + segmented radix sort (argsort_large.hip).  Index-exact against a stable descending sort,

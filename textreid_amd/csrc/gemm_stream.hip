@@ -89,10 +89,30 @@ struct StreamParams {
     // (columns = queries, rows = gallery rows): appended to the column's candidate list through an atomic counter
     GemmFilter filt;
     int n_real;              // columns that exist (N is padded to a multiple of 32)
+    int flags;               // FUSE == 4: 1 = DMA pieces spread over the k loop, 2 = the upper waves scan one step late
 };
 
 __device__ __forceinline__ void lds_store1(const void* p, float v) {
     asm volatile("ds_write_b32 %0, %1" ::"v"((unsigned)(uintptr_t)p), "v"(v) : "memory");
+}
+// (inline asm for the same reason: beside an LDS-DMA in flight hipcc puts s_waitcnt vmcnt(0) before a visible LDS access)
+__device__ __forceinline__ unsigned lds_add_rtn(unsigned addr, unsigned v) {
+    unsigned r;
+    asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(r) : "v"(addr), "v"(v) : "memory");
+    return r;
+}
+__device__ __forceinline__ unsigned lds_load1(unsigned addr) {
+    unsigned r;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(r) : "v"(addr) : "memory");
+    return r;
+}
+__device__ __forceinline__ void lds_store1u(unsigned addr, unsigned v) {
+    asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+__device__ __forceinline__ void filter_append(const GemmFilter& f, int col, float v, int row) {
+    const int slot = atomicAdd(f.cnt + col, 1);
+    if (slot < f.cap) reinterpret_cast<float2*>(f.cand)[(long long)col * f.cap + slot] = make_float2(v, __int_as_float(row));
+    else *f.overflow = 1;
 }
 
 }  // namespace
@@ -192,6 +212,25 @@ __global__ __launch_bounds__(512, 2) void gemm_p16_stream_kernel(StreamParams p)
         const int col = n0 + (lane & 31);
         if (col_live && col < p.n_real) f_thr = p.filt.thr[(long long)col * p.filt.thr_stride];
     }
+    // FUSE == 4: this wave's staging list of candidates, [FCAP] x (value, gallery row, query), and its counter
+    constexpr int FCAP = 128;
+    // (LDS byte addresses held in ONE vector register each: handed to the inline asm as wave-uniform values the compiler makes
+    // a copy per use and hoists all of them out of the loop - 33 spilled registers)
+    unsigned f_wbuf = (unsigned)(uintptr_t)(tbuf + wave * (3 * FCAP));
+    unsigned f_wcnt = (unsigned)(uintptr_t)(reinterpret_cast<unsigned*>(sstat) + wave);
+    if constexpr (FUSE == 4) {
+        asm volatile("" : "+v"(f_wbuf), "+v"(f_wcnt));
+        if (lane == 0) lds_store1u(f_wcnt, 0u);
+    }
+    auto flush_staged = [&](unsigned staged) {  // wave-uniform: the whole wave empties its list, one candidate per lane and round
+        const unsigned n = staged < (unsigned)FCAP ? staged : (unsigned)FCAP;
+        for (unsigned e = lane; e < n; e += 64) {
+            const float v = __uint_as_float(lds_load1(f_wbuf + 12u * e));
+            const int row = (int)lds_load1(f_wbuf + 12u * e + 4u), col = (int)lds_load1(f_wbuf + 12u * e + 8u);
+            filter_append(p.filt, col, v, row);
+        }
+        if (lane == 0) lds_store1u(f_wcnt, 0u);  // (the wave's LDS operations execute in order: behind the reads above)
+    };
 
     // loader: chunk c (1 KB = RPC rows) of a stage; lane -> (row, stored unit j); source unit = j ^ (row & 15).  The per-chunk
     // offsets are re-derived from the lane index in every step (`zero` is opaque to the compiler): kept across the loop
@@ -209,12 +248,96 @@ __global__ __launch_bounds__(512, 2) void gemm_p16_stream_kernel(StreamParams p)
         }
     };
 
+    auto issue_piece = [&](int tile, int stage, int zero, int d) {
+        const size_t base = (size_t)tile * RB * ROWB;
+        char* dst = ring + stage * STAGE;
+        const int ln = lane + zero;
+        const int lr = ln / UPR, j = ln % UPR;
+        const int r = (d * NW + wave) * RPC + lr;
+        const bool ok = (long long)tile * RB + r < p.M;
+        dma16(rsA, dst + (d * NW + wave) * 1024, ok ? (unsigned)(base + r * ROWB + ((j ^ (r & 15)) << 4)) : OOB, p.nt_a != 0);
+    };
+
     // fragment reads: row block i of this wave = rows (rw * TM + i) * 32 + (lane & 31) of the step tile
     int a_off[TM];
 #pragma unroll
     for (int i = 0; i < TM; ++i) a_off[i] = ((rw * TM + i) * 32 + (lane & 31)) * ROWB;
     const int rsw = lane & 15;  // (row & 15) of this lane's rows: the tile's row blocks start at multiples of 32
 
+    v16f acc[TM];
+    // FUSE == 4: the waves of one SIMD (w and w + 4) leave every barrier together and would issue their DMA, run their MFMAs and
+    // scan their accumulators in phase - the matrix pipe idle while both do something else.  The upper four waves therefore
+    // scan the accumulators of step t AFTER the barrier of step t + 1, under the MFMAs of the lower four
+    const bool late = FUSE == 4 && (p.flags & 2) != 0 && wave >= 4;
+    auto filter_epi = [&](int tt) {
+        if constexpr (FUSE == 4) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][r] *= unscale;
+            const long long row0 = (long long)tt * RB + rw * TM * 32;
+            // top-k admission filter: rows beyond M (a ragged last tile read zeros) are taken out first; then ONE comparison
+            // of the lane's maximum tells whether any of its TM * 16 elements is a candidate (~k / Gc of them are)
+            const long long rb = row0 + 4 * khalf;
+            if ((long long)(tt + 1) * RB > p.M) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (rb + i * 32 + (r & 3) + 8 * (r >> 2) >= p.M) acc[i][r] = -INFINITY;
+            }
+            float mx = -INFINITY;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, acc[i][r]);
+            // Candidates are STAGED in a wave-private LDS list (an LDS atomic answers in ~100 cycles) and leave for the
+            // queries' lists 64 at a time.  Appending each one through its query's global counter made the wave wait ~1 us
+            // for every returning atomic, ~5 times per step of 6.6 us at two waves per SIMD: 46 % of the wave cycles parked
+            // (profiles/r05e_pmc_sq_retrieval_before_staging.txt)
+            if (__ballot(mx >= f_thr) != 0ull) {
+                if (mx >= f_thr) {
+                    const int col = n0 + (lane & 31);
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const float v = acc[i][r];
+                            if (v >= f_thr) {
+                                const int row = (int)(rb + i * 32 + (r & 3) + 8 * (r >> 2)) + p.filt.col0;
+                                const unsigned pos = lds_add_rtn(f_wcnt, 1u);
+                                if (pos < (unsigned)FCAP) {
+                                    lds_store1u(f_wbuf + 12u * pos, __float_as_uint(v));
+                                    lds_store1u(f_wbuf + 12u * pos + 4u, (unsigned)row);
+                                    lds_store1u(f_wbuf + 12u * pos + 8u, (unsigned)col);
+                                } else {  // (staging list full - more than FCAP - 64 candidates in one step: straight to the list)
+                                    filter_append(p.filt, col, v, row);
+                                }
+                            }
+                        }
+                }
+                const unsigned staged = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_load1(f_wcnt));
+                if (staged >= 64u) flush_staged(staged);
+            }
+        }
+    };
+    // Everything fetched so far (the filter panel, the epilogue coefficients) is waited for HERE, by an instruction the compiler
+    // accounts for.  The waits of the loop are inline asm it does not see: left to itself it keeps the panel's K / 8 loads
+    // "possibly in flight" around the back edge and guards the MFMAs with a ladder s_waitcnt vmcnt(K / 8 - 3) ... vmcnt(0) -
+    // which in steady state waits for the NEXT tile's DMA (and this step's stores) before the step's last MFMAs
+    // (the empty asm statements pin the loads above the wait: the scheduler otherwise sinks them below it)
+#pragma unroll
+    for (int g = 0; g < KG; ++g)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) asm volatile("" : "+v"(bf[g][ks][pl]));
+    if constexpr (FUSE == 1 || FUSE == 2) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(fsc[j]), "+v"(fsh[j]));
+    }
+    if constexpr (FUSE == 4) asm volatile("" : "+v"(f_thr));
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt and lgkmcnt untouched
     int t = worker;
     if (t < p.tiles) issue(t, 0, 0);
     if (NS == 3 && t + p.workers < p.tiles) issue(t + p.workers, 1, 0);
@@ -244,6 +367,9 @@ __global__ __launch_bounds__(512, 2) void gemm_p16_stream_kernel(StreamParams p)
             else wait_vm<NSC>();
         }
         lds_barrier();
+        if constexpr (FUSE == 4) {
+            if (late && !first) filter_epi(t - p.workers);
+        }
         const int tn = t + (NS - 1) * p.workers;
         // RW > 1: the previous step's BatchNorm partials, merged by the first lanes of the workgroup (one column each)
         if (RW > 1 && p.stats != nullptr && !first && tid < CW * 32) {
@@ -316,10 +442,10 @@ __global__ __launch_bounds__(512, 2) void gemm_p16_stream_kernel(StreamParams p)
         }
         int zero = 0;
         asm volatile("" : "+v"(zero));
-        if (tn < p.tiles) issue(tn, NS == 2 ? (stage ^ 1) : (stage == 0 ? NS - 1 : stage - 1), zero);
+        const bool dma_spread = FUSE == 4 && (p.flags & 1) != 0;  // the DMA pieces among the MFMAs instead of ahead of them
+        if (tn < p.tiles && !dma_spread) issue(tn, NS == 2 ? (stage ^ 1) : (stage == 0 ? NS - 1 : stage - 1), zero);
 
         // ---- MFMAs of this tile: per 16-deep k step 2 fragment reads per row block, 3 products
-        v16f acc[TM];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -343,6 +469,9 @@ __global__ __launch_bounds__(512, 2) void gemm_p16_stream_kernel(StreamParams p)
 #pragma unroll
         for (int q = 0; q < 2 * KG; ++q) {
             if (q + PF < 2 * KG) fetch(q + PF, af[(q + PF) % (PF + 1)]);
+            if constexpr (FUSE == 4) {
+                if (dma_spread && tn < p.tiles && (q & 1) == 0 && (q >> 1) < DPW) issue_piece(tn, stage ^ 1, zero, q >> 1);
+            }
             const int g = q >> 1, ks = q & 1;
             constexpr int NB = PF + 1;
 #pragma unroll
@@ -354,10 +483,12 @@ __global__ __launch_bounds__(512, 2) void gemm_p16_stream_kernel(StreamParams p)
         }
 
         // ---- epilogue
+        if constexpr (FUSE != 4) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][r] *= unscale;
+                for (int r = 0; r < 16; ++r) acc[i][r] *= unscale;
+        }
         if constexpr (ACC) {
             wait_vm<DPW>();  // the old C values (older than this step's DMA)
             if (p.cmask != nullptr) {
@@ -448,39 +579,7 @@ __global__ __launch_bounds__(512, 2) void gemm_p16_stream_kernel(StreamParams p)
             }
         }
         if constexpr (FUSE == 4) {
-            // top-k admission filter: rows beyond M (a ragged last tile read zeros) are taken out first; then ONE comparison
-            // of the lane's maximum tells whether any of its TM * 16 elements is a candidate (~k / Gc of them are)
-            const long long rb = row0 + 4 * khalf;
-            if ((long long)(t + 1) * RB > p.M) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        if (rb + i * 32 + (r & 3) + 8 * (r >> 2) >= p.M) acc[i][r] = -INFINITY;
-            }
-            float mx = -INFINITY;
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, acc[i][r]);
-            if (mx >= f_thr) {
-                const int col = n0 + (lane & 31);
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float v = acc[i][r];
-                        if (v >= f_thr) {
-                            const int slot = atomicAdd(p.filt.cnt + col, 1);
-                            if (slot < p.filt.cap) {
-                                float2* dst = reinterpret_cast<float2*>(p.filt.cand) + (long long)col * p.filt.cap + slot;
-                                *dst = make_float2(v, __int_as_float((int)(rb + i * 32 + (r & 3) + 8 * (r >> 2)) + p.filt.col0));
-                            } else {
-                                *p.filt.overflow = 1;
-                            }
-                        }
-                    }
-            }
+            if (!late) filter_epi(t);
         }
         if constexpr (FUSE == 1 || FUSE == 2) {
             // out = relu(y * scale + shift + identity) as a P16 tensor, the arithmetic of bn_apply_kernel<1, 1> (bn_pool.hip).
@@ -570,6 +669,11 @@ __global__ __launch_bounds__(512, 2) void gemm_p16_stream_kernel(StreamParams p)
             }
         }
         first = false;
+    }
+    if constexpr (FUSE == 4) {
+        if (late && !first) filter_epi(t - p.workers);
+        const unsigned staged = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_load1(f_wcnt));
+        if (staged != 0u) flush_staged(staged);
     }
     if constexpr (FUSE == 1 || FUSE == 2) {
         if (p.ev.out_tmax != nullptr) {  // one atomic per workgroup
@@ -724,8 +828,10 @@ int trid::stream_topk_filter(const void* g16, const float* g_amax, const void* q
     p.a_amax = g_amax; p.b_amax = q_amax;
     p.M = G; p.N = Qp; p.ldc = Qp;
     p.filt = filt; p.n_real = Q;
+    static const int f_env = getenv("TRID_TOPK_FLAGS") ? atoi(getenv("TRID_TOPK_FLAGS")) : 3;  // (A/B runs: tools/exp/r05_run9.sh)
+    p.flags = f_env;
     constexpr int K = 256, CW = 8, TM = 2, RB = TM * 32;
-    const size_t lds = (size_t)2 * RB * K * 4 + 2 * 8 * 32 * sizeof(float4);
+    const size_t lds = (size_t)2 * RB * K * 4 + 2 * 8 * 32 * sizeof(float4) + (size_t)8 * 3 * 128 * 4;  // ring, counters, staging lists
     static std::once_flag once;
     static hipError_t attr_err = hipSuccess;
     std::call_once(once, [] {
@@ -737,10 +843,17 @@ int trid::stream_topk_filter(const void* g16, const float* g_amax, const void* q
     }
     p.panels = (Qp + CW * 32 - 1) / (CW * 32);
     p.tiles = (G + RB - 1) / RB;
-    // workers per panel: whole rounds of the chip's 256 CUs, >= 64 tiles per worker
+    // workers per panel (a multiple of 8: one per XCD and round): the count that minimises rounds of the chip x (steps per
+    // worker + the panel fetch), e.g. 32 for 40 panels (1280 workgroups = 5 full rounds) whatever the segment's length
     int workers = 8;
-    while (workers < 256 && (long long)p.panels * workers < 1024 && p.tiles / (workers * 2) >= 64) workers *= 2;
-    while ((long long)p.panels * workers % 256 != 0 && workers < 256 && p.tiles / (workers + 8) >= 64) workers += 8;
+    {
+        double best = 1e300;
+        for (int w = 8; w <= 256; w += 8) {
+            const long long rounds = ((long long)p.panels * w + 255) / 256;
+            const double cost = (double)rounds * ((double)((p.tiles + w - 1) / w) * 5.0 + 3.0);
+            if (cost < best * 0.999) { best = cost; workers = w; }
+        }
+    }
     static const int w_env = getenv("TRID_TOPK_WORKERS") ? atoi(getenv("TRID_TOPK_WORKERS")) : 0;  // (experiments)
     if (w_env > 0) workers = w_env;
     p.workers = std::min(workers, (p.tiles + 7) / 8 * 8);

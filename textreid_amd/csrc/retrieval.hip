@@ -107,8 +107,9 @@ __global__ __launch_bounds__(256) void topk_merge_rows_kernel(const float* __res
 
 // Candidate lists written by the GEMM's admission-filter epilogue (value, column) -> running top-k.
 // A no-op when any list overflowed (*overflow != 0): the caller's gated dense passes redo the work.
+// The row's counter is zeroed behind the merge: the next gallery segment's filter pass appends to an empty list.
 template <int KK>
-__global__ __launch_bounds__(256) void topk_merge_cands_kernel(const float2* __restrict__ cand, const int* __restrict__ cnt,
+__global__ __launch_bounds__(256) void topk_merge_cands_kernel(const float2* __restrict__ cand, int* __restrict__ cnt,
                                                                int cap, int Q, long long idx_offset,
                                                                float* __restrict__ best_val, long long* __restrict__ best_idx,
                                                                const int* __restrict__ overflow) {
@@ -127,6 +128,20 @@ __global__ __launch_bounds__(256) void topk_merge_cands_kernel(const float2* __r
         L.offer_lanes(ok, pr.x, idx_offset + __float_as_int(pr.y));
     }
     L.store(best_val + (long long)row * KK, best_idx + (long long)row * KK);
+    if (lane == 0) cnt[row] = 0;
+}
+
+// The running top-k as it stood after step 1, put back before the dense passes redo every column >= Gc (gate: only when a
+// candidate list overflowed; null: unconditionally).
+__global__ __launch_bounds__(256) void topk_restore_kernel(float* __restrict__ val, long long* __restrict__ idx,
+                                                           const float* __restrict__ sval, const long long* __restrict__ sidx,
+                                                           long long n, const int* __restrict__ gate) {
+    if (gate != nullptr && *gate == 0) return;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) {
+        val[i] = sval[i];
+        idx[i] = sidx[i];
+    }
 }
 
 // Full descending argsort of each row (evaluation.py:14): one workgroup per row,
@@ -240,10 +255,10 @@ using namespace trid;
 static int topk_chunk_cols(int G) { return G < 8192 ? ((G + 3) / 4 * 4) : 8192; }
 
 // workspace: [Q x Gc similarity panel | later reused as Q candidate lists of Gc/2 (value, column) pairs]
-//            [Q list counters][1 overflow flag]
+//            [Q list counters][1 overflow flag][copy of the running top-k after step 1: Q x k indices, Q x k values]
+static long long topk_ws_snap_offset(int Q, int G) { return ((long long)Q * topk_chunk_cols(G) + Q + 4 + 1) / 2 * 2; }
 extern "C" long long trid_topk_ws_floats(int Q, int G, int k) {
-    (void)k;
-    return (long long)Q * topk_chunk_cols(G) + Q + 4;
+    return topk_ws_snap_offset(Q, G) + 3ll * Q * k + 2;
 }
 
 template <int KK>
@@ -253,7 +268,7 @@ static void launch_scan(const float* ws, int ld, int Q, int n, long long off, fl
                        (long long*)out_idx, first, gate);
 }
 template <int KK>
-static void launch_cands(const float* cand, const int* cnt, int cap, int Q, long long off, float* out_val, int64_t* out_idx,
+static void launch_cands(const float* cand, int* cnt, int cap, int Q, long long off, float* out_val, int64_t* out_idx,
                          const int* overflow, hipStream_t stream) {
     hipLaunchKernelGGL(topk_merge_cands_kernel<KK>, dim3((Q + 3) / 4), dim3(256), 0, stream, (const float2*)cand, cnt, cap, Q,
                        off, out_val, (long long*)out_idx, overflow);
@@ -321,35 +336,68 @@ static int sim_topk(const float* q, const float* g, const void* q16, const void*
     if (mode != 2) rc = dense_pass(0, nullptr);
     if (rc || G <= Gc) return rc;
 
+    // pre-split operands: the columns >= Gc go through the streaming filter in SEGMENTS of growing length (x 8), each merged
+    // before the next starts - a query's threshold is then the k-th best of everything before the segment, and it admits
+    // ~k (s1 - s0) / s0 <= 7 k candidates per segment instead of ~k (G - Gc) / Gc in all (G = 1e6, k = 10: 150 per query
+    // instead of 1210; the appends and their merge were 15 % of the pass)
+    const bool presplit = q16 != nullptr && g16 != nullptr;
+    long long* snap_idx = reinterpret_cast<long long*>(ws + topk_ws_snap_offset(Q, G));
+    float* snap_val = reinterpret_cast<float*>(snap_idx + (long long)Q * k);
+    const long long nk = (long long)Q * k;
+    auto restore = [&](const int* gate) {
+        hipLaunchKernelGGL(topk_restore_kernel, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, stream, out_val, (long long*)out_idx,
+                           (const float*)snap_val, (const long long*)snap_idx, nk, gate);
+        return check_launch("trid_sim_topk: restore");
+    };
+
     bool fused = false;
     if (mode != 2) {
         hipError_t e = hipMemsetAsync(cnt, 0, (size_t)(Q + 1) * sizeof(int), stream);
         if (e != hipSuccess) { set_error("trid_sim_topk_f32: memset failed: %s", hipGetErrorString(e)); return (int)e; }
-        trid_gemm_desc d;
-        memset(&d, 0, sizeof(d));
-        d.A = q; d.B = g + (long long)Gc * C; d.C = nullptr;
-        d.M = Q; d.N = G - Gc; d.K = C;
-        d.lda = C; d.ldb = C; d.ldc = 0;
-        d.batch = 1; d.splits = 1; d.alpha = 1.f;
-        d.a_mode = TRID_A_KC; d.b_mode = TRID_B_KC;
-        d.precision = precision;
-        d.a_amax = q_amax; d.b_amax = g_amax;
         GemmFilter f;
         f.thr = out_val + (k - 1); f.thr_stride = k;
         f.cnt = cnt; f.cand = ws; f.cap = cap; f.col0 = Gc; f.overflow = overflow;
-        if (q16 != nullptr && g16 != nullptr)
-            rc = stream_topk_filter(reinterpret_cast<const char*>(g16) + (size_t)Gc * 1024, g_amax, q16, q_amax, G - Gc, Q, f, stream);
-        else
-            rc = trid_gemm_launch(&d, &f, nullptr, stream);
-        if (rc == TRID_OK) {
-            fused = true;
+        if (presplit) {
+            // (the dense passes that redo the columns >= Gc after an overflow must start from the top-k of step 1)
+            e = hipMemcpyAsync(snap_val, out_val, (size_t)nk * sizeof(float), hipMemcpyDeviceToDevice, stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(snap_idx, out_idx, (size_t)nk * sizeof(long long), hipMemcpyDeviceToDevice, stream);
+            if (e != hipSuccess) { set_error("trid_sim_topk: copy failed: %s", hipGetErrorString(e)); return (int)e; }
+            static const int seg_env = getenv("TRID_TOPK_SEGMENTS") ? atoi(getenv("TRID_TOPK_SEGMENTS")) : 1;  // (0: one segment)
+            for (long long s0 = Gc; s0 < G && rc == TRID_OK;) {
+                long long s1 = seg_env ? s0 * 8 : G;
+                if (s1 >= G || G - s1 < s1 / 4) s1 = G;  // (no short last segment)
+                f.col0 = (int)s0;
+                rc = stream_topk_filter(reinterpret_cast<const char*>(g16) + (size_t)s0 * 1024, g_amax, q16, q_amax, (int)(s1 - s0), Q, f, stream);
+                if (rc) break;
 #define TRID_CALL(KK) launch_cands<KK>(ws, cnt, cap, Q, idx_offset, out_val, out_idx, overflow, stream)
-            TRID_TOPK_SWITCH(k, TRID_CALL)
+                TRID_TOPK_SWITCH(k, TRID_CALL)
 #undef TRID_CALL
-            rc = check_launch("trid_sim_topk_f32");
+                rc = check_launch("trid_sim_topk_f32");
+                s0 = s1;
+            }
             if (rc) return rc;
-        } else if (rc != TRID_E_UNSUPPORTED) {
-            return rc;
+            fused = true;
+        } else {
+            trid_gemm_desc d;
+            memset(&d, 0, sizeof(d));
+            d.A = q; d.B = g + (long long)Gc * C; d.C = nullptr;
+            d.M = Q; d.N = G - Gc; d.K = C;
+            d.lda = C; d.ldb = C; d.ldc = 0;
+            d.batch = 1; d.splits = 1; d.alpha = 1.f;
+            d.a_mode = TRID_A_KC; d.b_mode = TRID_B_KC;
+            d.precision = precision;
+            d.a_amax = q_amax; d.b_amax = g_amax;
+            rc = trid_gemm_launch(&d, &f, nullptr, stream);
+            if (rc == TRID_OK) {
+                fused = true;
+#define TRID_CALL(KK) launch_cands<KK>(ws, cnt, cap, Q, idx_offset, out_val, out_idx, overflow, stream)
+                TRID_TOPK_SWITCH(k, TRID_CALL)
+#undef TRID_CALL
+                rc = check_launch("trid_sim_topk_f32");
+                if (rc) return rc;
+            } else if (rc != TRID_E_UNSUPPORTED) {
+                return rc;
+            }
         }
     }
     // dense passes over the remaining chunks: unconditional without the fused path, gated on overflow with it
@@ -357,6 +405,10 @@ static int sim_topk(const float* q, const float* g, const void* q16, const void*
     if (mode == 1) {  // (the fused pass did not apply: the dense passes are the result - tell the caller not to redo them)
         hipError_t e = hipMemsetAsync(overflow, 0, sizeof(int), stream);
         if (e != hipSuccess) { set_error("trid_sim_topk: memset failed: %s", hipGetErrorString(e)); return (int)e; }
+    }
+    if (presplit && (mode == 2 || fused)) {  // (merged segments before the one that overflowed are in the running top-k: back to step 1)
+        rc = restore(mode == 2 ? nullptr : overflow);
+        if (rc) return rc;
     }
     for (int c0 = Gc; c0 < G; c0 += Gc) {
         rc = dense_pass(c0, (fused && mode == 0) ? overflow : nullptr);
@@ -376,7 +428,8 @@ extern "C" int trid_sim_topk_f32(const float* q, const float* g, float* out_val,
 extern "C" int trid_sim_topk_p16(const float* q, const float* g, const void* q16, const void* g16, float* out_val, int64_t* out_idx, int Q, int G,
                                  int k, long long idx_offset, const float* q_amax, const float* g_amax, float* ws, int mode, void* stream_) {
     TRID_REQUIRE(mode >= 0 && mode <= 2, "trid_sim_topk_p16: mode must be 0, 1 or 2");
-    if (mode == 2) return sim_topk(q, g, nullptr, nullptr, out_val, out_idx, Q, G, 256, k, idx_offset, 16, q_amax, g_amax, ws, 2, (hipStream_t)stream_);
+    // (mode 2 reads neither pre-split operand, but the call must say that the mode-1 pass before it ran on them: the segments it
+    // merged before a list overflowed are undone from the copy in ws)
     TRID_REQUIRE(q16 && g16 && q_amax && g_amax && aligned16(q16) && aligned16(g16), "trid_sim_topk_p16: the pre-split operands and their amax scalars are needed");
     TRID_REQUIRE((long long)G * 1024 < (1ll << 31), "trid_sim_topk_p16: the gallery shard must stay below 2 GB (G <= 2097151 rows of 256)");
     return sim_topk(q, g, q16, g16, out_val, out_idx, Q, G, 256, k, idx_offset, 16, q_amax, g_amax, ws, mode, (hipStream_t)stream_);

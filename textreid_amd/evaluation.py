@@ -83,6 +83,7 @@ def _sim_precision(q, g):
 
 
 USE_SIM_P16 = os.environ.get("TRID_SIM_P16", "1") != "0"  # retrieval match on pre-split operands (0: the on-the-fly split GEMM, A/B runs)
+DEVICE_GATED_FALLBACK = False  # True: the capture-safe form (fall-back passes gated on the device) outside a capture too (tests)
 
 
 def _sim_topk_call(q, g, vals, idx, k, offset, ws):
@@ -97,14 +98,14 @@ def _sim_topk_call(q, g, vals, idx, k, offset, ws):
         call("trid_p16_pack_f32", _p(q), Q, C, C, _p(qa), _p(q16), 1, stream())
         g16 = torch.empty_like(g)
         call("trid_p16_pack_f32", _p(g), G, C, C, _p(ga), _p(g16), 1, stream())
-        if torch.cuda.is_current_stream_capturing():  # (no host read inside a capture: the device-gated fall-back passes)
+        if DEVICE_GATED_FALLBACK or torch.cuda.is_current_stream_capturing():  # (no host read inside a capture: the device-gated fall-back passes)
             call("trid_sim_topk_p16", _p(q), _p(g), _p(q16), _p(g16), _p(vals), _p(idx), Q, G, k, offset, _p(qa), _p(ga), _p(ws), 0, stream())
             return
         call("trid_sim_topk_p16", _p(q), _p(g), _p(q16), _p(g16), _p(vals), _p(idx), Q, G, k, offset, _p(qa), _p(ga), _p(ws), 1, stream())
         # a candidate list overflowed (adversarially ordered gallery)?  One 4-byte read; the dense passes only then
         flag = ws[ops.L.load().trid_topk_ws_flag_offset(Q, G):][:1].view(torch.int32)
         if int(flag.item()) != 0:
-            call("trid_sim_topk_p16", _p(q), _p(g), None, None, _p(vals), _p(idx), Q, G, k, offset, _p(qa), _p(ga), _p(ws), 2, stream())
+            call("trid_sim_topk_p16", _p(q), _p(g), _p(q16), _p(g16), _p(vals), _p(idx), Q, G, k, offset, _p(qa), _p(ga), _p(ws), 2, stream())
         return
     call("trid_sim_topk_f32", _p(q), _p(g), _p(vals), _p(idx), Q, G, C, k, offset, prec, _p(qa), _p(ga), _p(ws), stream())
 
