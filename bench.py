@@ -352,6 +352,15 @@ def retrieval_bench(device, world, rank, G_total=1000000, Q=10000, k=10, shard_r
     scored = shard * world
     tfl = 2.0 * Q * scored * 256 / dt / 1e12
     k_ms, k_src = stored_kernel_avg_ms("gemm_p16_stream_kernel<256, 8, 2, false, 4>", "_retrieval_kernel_stats.csv")
+    # launches of the filter kernel per match: the rows beyond the first 8192 go in segments of growing length (x 8, no short last
+    # one: csrc/retrieval.hip sim_topk), each merged before the next starts
+    nseg, s0 = 0, 8192
+    while s0 < shard:
+        s1 = s0 * 8
+        if s1 >= shard or shard - s1 < s1 // 4:
+            s1 = shard
+        nseg, s0 = nseg + 1, s1
+    tr, tr_src = stored_traffic("gemm_p16_stream_kernel<256, 8, 2, false, 4>", infer="rt")
     roof = {
         "bound": "mfma",
         "kernel": "trid::gemm_p16_stream_kernel<256, 8, 2, false, 4> (similarity of pre-split operands with the top-k admission filter as epilogue: 256 queries resident in a workgroup's registers, the gallery streamed through LDS once per query panel; fp16 two-plane arithmetic, 3 MFMA products per multiply-add)",
@@ -359,14 +368,14 @@ def retrieval_bench(device, world, rank, G_total=1000000, Q=10000, k=10, shard_r
         "peak": F16_SPLIT_PEAK_TFLOPS,
         "unit": "TFLOP/s",
         "frac": tfl / world / F16_SPLIT_PEAK_TFLOPS,
-        "traffic": stored_traffic("gemm_p16_stream_kernel<256, 8, 2, false, 4>")[0] if (shard_rows is None and world == 1) else None,
-        "traffic_source": stored_traffic("gemm_p16_stream_kernel<256, 8, 2, false, 4>")[1] if (shard_rows is None and world == 1) else None,
-        "traffic_note": "HBM-side bytes of the filter kernel per launch (stored PMC passes of tools/retrieval_time.py, same Q and G): the 1 GB gallery crosses the fabric about once per XCD (7.7 GB read) although 40 query panels stream it - the panels of one worker share an L2; the writes are the candidate appends and their atomics",
-        "note": "achieved = algorithmic FLOPs of the WHOLE match (2 Q G C, per GPU) / wall time of the whole call (amax + split of both operands, first-panel GEMM + row scan, filter pass, list merge, one 4-byte host read): the kernel itself is ~98 % of it",
+        "traffic": tr * nseg if (tr and shard_rows is None and world == 1) else None,
+        "traffic_source": tr_src if (shard_rows is None and world == 1) else None,
+        "traffic_note": "HBM-side bytes of the filter kernel per MATCH = per-launch average of the stored PMC passes (tools/retrieval_time.py, same Q and G) x its %d launches (gallery segments): the 1 GB gallery crosses the fabric about three times although 40 query panels stream it - the panels of one worker share an L2; the writes are the candidate appends" % nseg,
+        "note": "achieved = algorithmic FLOPs of the WHOLE match (2 Q G C, per GPU) / wall time of the whole call (amax + split of both operands, first-panel GEMM + row scan, the filter pass in %d segments, list merges, one 4-byte host read): the filter kernel is ~93 %% of it" % nseg,
     }
     if k_ms and shard_rows is None and world == 1:
         gf = 2.0 * Q * (shard - 8192) * 256 / 1e9
-        roof["rocprof_kernel"] = {"avg_launch_ms": k_ms, "achieved": gf / k_ms, "frac": gf / k_ms / F16_SPLIT_PEAK_TFLOPS, "source": k_src + ": average duration of this kernel in rocprofv3 --kernel-trace --stats of tools/retrieval_time.py (same Q, G)"}
+        roof["rocprof_kernel"] = {"launches_per_match": nseg, "avg_launch_ms": k_ms, "kernel_ms_per_match": k_ms * nseg, "achieved": gf / (k_ms * nseg), "frac": gf / (k_ms * nseg) / F16_SPLIT_PEAK_TFLOPS, "source": k_src + ": average duration of this kernel in rocprofv3 --kernel-trace --stats of tools/retrieval_time.py (same Q, G) x launches per match"}
     return {
         "roofline": roof,
         "metric": "gallery imgs/sec (retrieval: similarity + top-10, Q=1e4 queries)",
@@ -379,15 +388,19 @@ def retrieval_bench(device, world, rank, G_total=1000000, Q=10000, k=10, shard_r
         "seconds": dt,
         "tflops": tfl,
         "algorithmic_bytes_per_gpu": shard * 256 * 4 + Q * 256 * 4 + Q * k * 12,
-        "note": "fp32 embeddings in, split ONCE into fp16 planes (fp32-class two-plane arithmetic), exact top-10: first 8192 gallery rows via a [Q,8192] panel + streaming scan, the rest via the admission-filter epilogue of the streaming kernel (no similarity matrix in HBM)",
+        "note": "fp32 embeddings in, split ONCE into fp16 planes (fp32-class two-plane arithmetic), exact top-10: first 8192 gallery rows via a [Q,8192] panel + streaming scan, the rest via the admission-filter epilogue of the streaming kernel in segments of growing length, thresholds tightened in between (no similarity matrix in HBM)",
     }
 
 
-def newest_profiles(suffix):
-    """File names under profiles/ that end in `suffix`, newest round first (names are r<round><letter>_...: descending name order)."""
+def newest_profiles(suffix, infer=None):
+    """File names under profiles/ that end in `suffix`, newest round first (names are r<round><letter>_...: descending name order).
+    infer: None = the summaries of THIS command's train step only (names without "_infer_"); "rt" / "ev" = those of the
+    inference-side tools (r*_infer_rt_* : tools/retrieval_time.py, r*_infer_ev_* : tools/eval_time.py) - the eval pass launches
+    the same kernel templates as the train step, and its numbers must not stand in for the step's."""
     here = os.path.dirname(os.path.abspath(__file__))
     try:
-        return sorted((f for f in os.listdir(os.path.join(here, "profiles")) if f.endswith(suffix) and f.startswith("r")), reverse=True)
+        names = (f for f in os.listdir(os.path.join(here, "profiles")) if f.endswith(suffix) and f.startswith("r"))
+        return sorted((f for f in names if (("_infer_%s_" % infer) in f if infer else "_infer_" not in f)), reverse=True)
     except OSError:
         return []
 
@@ -412,12 +425,12 @@ def stored_kernel_avg_ms(pattern, suffix):
     return None, None
 
 
-def stored_traffic(pattern):
+def stored_traffic(pattern, infer=None):
     """(HBM-side bytes per launch, file) of the kernels whose name contains `pattern` in the NEWEST committed PMC summary that
     lists them (profiles/r*_pmc_hbm_traffic.txt, newest first by name; calls-weighted over the matching lines; separate
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes with the gfx950 2x FETCH_SIZE correction, tools/pmc_summary.py), or (None, None)."""
     here = os.path.dirname(os.path.abspath(__file__))
-    for fn in newest_profiles("_pmc_hbm_traffic.txt"):
+    for fn in newest_profiles("_pmc_hbm_traffic.txt", infer):
         try:
             tot, calls = 0.0, 0
             for ln in open(os.path.join(here, "profiles", fn)):
