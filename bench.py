@@ -621,17 +621,37 @@ def main():
 
         base = n_prep + args.warmup
         probe(lambda j: runner._eager(*batch(base + j)), 2)  # (the eager path's own warm-up after the recording)
-        ms_graph = probe(lambda j: step(base + 2 + j))
-        ms_eager = probe(lambda j: runner._eager(*batch(base + 6 + j)))
+        ms_streams = probe(lambda j: step(base + 2 + j)) if runner.replayer is not None else None
+        ms_graph = None
+        try:  # hipGraphLaunch of the same recording
+            runner.force_graph_launch = True
+            step(base + 6)
+            ms_graph = probe(lambda j: step(base + 7 + j))
+        except RuntimeError as e:
+            log("launch probe: hipGraphLaunch failed (%s)" % (str(e).splitlines()[0] if str(e) else type(e).__name__))
+        finally:
+            runner.force_graph_launch = False
+        ms_eager = probe(lambda j: runner._eager(*batch(base + 11 + j)))
         forced = os.environ.get("TRID_BENCH_LAUNCH", "")
-        use_eager = forced == "eager" or (forced != "graph" and ms_eager < 0.995 * ms_graph)
-        launch_probe = {"hipgraph_replay_ms_per_step": ms_graph, "eager_ms_per_step": ms_eager, "chosen": "eager" if use_eager else "hipgraph replay"}
+        cands = {"stream replay": ms_streams, "hipgraph replay": ms_graph, "eager": ms_eager}
+        if forced in ("eager", "graph", "streams"):
+            chosen = {"eager": "eager", "graph": "hipgraph replay", "streams": "stream replay"}[forced]
+        else:
+            chosen = min((k for k in cands if cands[k] is not None), key=lambda k: cands[k] * (0.995 if k == "eager" else 1.0))
+        if cands[chosen] is None:
+            chosen = "eager"
+        launch_probe = {"stream_replay_ms_per_step": ms_streams, "hipgraph_replay_ms_per_step": ms_graph, "eager_ms_per_step": ms_eager,
+                        "chosen": chosen, "stream_replay_plan": runner.replay_info}
         if world > 1:  # every rank must take the same path: rank 0 decides
-            flag = torch.tensor([1 if use_eager else 0], device=device)
+            names = ["stream replay", "hipgraph replay", "eager"]
+            flag = torch.tensor([names.index(chosen)], device=device)
             dist.broadcast(flag, 0)
-            use_eager = bool(flag.item())
-        log("launch probe: replay %.2f ms, eager %.2f ms per step -> %s" % (ms_graph, ms_eager, "eager" if use_eager else "replay"))
-        n_prep += 10
+            chosen = names[int(flag.item())]
+        use_eager = chosen == "eager"
+        runner.force_graph_launch = chosen == "hipgraph replay"
+        log("launch probe: stream replay %s, hipGraphLaunch %s, eager %.2f ms per step -> %s" % (
+            "%.2f" % ms_streams if ms_streams else "-", "%.2f" % ms_graph if ms_graph else "-", ms_eager, chosen))
+        n_prep += 17
     timed_step = (lambda i: runner._eager(*batch(i))) if use_eager else step
     # live roofline of the dominant kernel: 3x3 implicit-GEMM conv, 128x128 tiles
     split = ops.GEMM_PRECISION in (1, 3, 6)
@@ -863,7 +883,9 @@ def main():
         log("retrieval: %.1f M gallery imgs/s" % (retr["value"] / 1e6))
     qsim = [queue_similarity_bench(device, B=B, K=k) for k in sorted({args.queue, 65536})]
     qsim.append(queue_similarity_bench(device, B=B, K=65536, bf16=True))
-    step_launch = ("eager launches, four streams (chosen by the probe over the recorded step)" if use_eager else "hipGraph replay (one launch per step)") if runner is not None else "eager (%d rank(s)%s)" % (world, ": RCCL collectives inside backward" if world > 1 else "")
+    step_launch = ("eager launches, four streams (chosen by the probe over the recorded step)" if use_eager else
+                   ("hipGraph replay (one launch per step)" if (runner.force_graph_launch or runner.replayer is None) else
+                    "stream replay: the recorded step re-issued as stream launches by one library call per step (csrc/step_replay.hip; chosen by the probe)")) if runner is not None else "eager (%d rank(s)%s)" % (world, ": RCCL collectives inside backward" if world > 1 else "")
     c3 = None
     if world == 1 and not args.no_configs3 and ops.conv_precision() == 16 and args.model == "m_resnet50":
         del model, opt, runner

@@ -601,6 +601,22 @@ int trid_rank_metrics(const int64_t* indices, const int64_t* q_pids, const int64
 int trid_jaccard_add_f32(const int64_t* qnn, const int64_t* gnn, const float* base, long long ldb, float* out, int Q,
                          int G, int k, float alpha, void* stream);
 
+/* ------------------------------------------------------------------------- *
+ * The train step as one host call (lib/engine/trainer.py:72-91: model(images, captions) -> sum of the losses ->
+ * zero_grad -> backward -> optimizer.step, ~1100 launches on four streams).
+ * ------------------------------------------------------------------------- */
+/* graph: the hipGraph_t a stream capture of one step produced (kept alive by the caller for as long as the handle lives: the
+ * launches point at the graph's own argument copies).  build reads its kernel / memcpy / memset nodes and edges back and lays
+ * them out on at most max_lanes streams: a node continues the stream of a predecessor it directly follows, every other edge
+ * becomes an event.  run re-issues the step as ordinary stream launches - what the eager step does, without its 35-39 ms of
+ * Python / ctypes time per step and with every stream fed at once; work enqueued on `origin_stream` before the call happens
+ * before the step, work enqueued after it happens after.  Graphs with other node types (host callbacks, child graphs) are
+ * refused with TRID_E_UNSUPPORTED.  info: counts[8] = nodes, kernels, copies, memsets, lanes, events, waits, empty nodes. */
+int trid_step_replay_build(void* graph, int max_lanes, void** out_handle);
+int trid_step_replay_info(void* handle, int* counts);
+int trid_step_replay_run(void* handle, void* origin_stream);
+int trid_step_replay_destroy(void* handle);
+
 #ifdef __cplusplus
 }
 #endif

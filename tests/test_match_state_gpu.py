@@ -513,11 +513,11 @@ def test_captured_train_step_equals_eager_bitwise(gpu):
     batches = [bench.synth_batch(B, s, gpu, 5, vocab=3000) for s in range(steps)]
     small = bench.synth_batch(4, 99, gpu, 5, vocab=3000)
     runs = {}
-    for mode in ("eager", "graph"):
+    for mode in ("eager", "graph", "streams"):
         torch.manual_seed(0)
         model = build_model(cfg, vocab_dict=table).to(gpu).train()
         opt = make_optimizer(cfg, model)
-        runner = CapturedTrainStep(model, opt, warmup=2, caption_bound=64)
+        runner = CapturedTrainStep(model, opt, warmup=2, caption_bound=64, launch="graph" if mode == "eager" else mode)
         losses = []
         for i in range(steps):
             images, tokens, lengths, ids = batches[i]
@@ -537,18 +537,76 @@ def test_captured_train_step_equals_eager_bitwise(gpu):
             ld = runner._eager(images, cb) if mode == "eager" else runner(images, cb)
             losses.append(torch.stack([v.detach().clone() for v in ld.values()]))
         torch.cuda.synchronize()
-        if mode == "graph":
+        if mode != "eager":
             assert runner.graph is not None and runner.recaptures == 1 and runner.plan is opt._plan
+        if mode == "streams":  # the recording read back and re-issued as stream launches by the library (csrc/step_replay.hip)
+            info = runner.replay_info
+            assert runner.replayer is not None and info["kernels"] == info["nodes"] > 500 and info["copies"] == 0
+            assert 2 <= info["lanes"] <= 8 and info["events"] >= info["lanes"] - 1
         runs[mode] = (torch.stack(losses), {k: v.detach().clone() for k, v in model.state_dict().items()},
                       [opt.state[p]["exp_avg_sq"].clone() for g_ in opt.param_groups for p in g_["params"]],
                       [int(opt.state[p]["step"]) for g_ in opt.param_groups for p in g_["params"]])
         del model, opt, runner
-    assert torch.equal(runs["eager"][0], runs["graph"][0]), (runs["eager"][0] - runs["graph"][0]).abs().max()
-    for k, v in runs["eager"][1].items():
-        assert torch.equal(v, runs["graph"][1][k]), k
-    for a, b in zip(runs["eager"][2], runs["graph"][2]):
-        assert torch.equal(a, b)
-    assert runs["eager"][3] == runs["graph"][3] and set(runs["graph"][3]) == {steps + 1}
+    for other in ("graph", "streams"):
+        assert torch.equal(runs["eager"][0], runs[other][0]), (other, (runs["eager"][0] - runs[other][0]).abs().max())
+        for k, v in runs["eager"][1].items():
+            assert torch.equal(v, runs[other][1][k]), (other, k)
+        for a, b in zip(runs["eager"][2], runs[other][2]):
+            assert torch.equal(a, b), other
+        assert runs["eager"][3] == runs[other][3] and set(runs[other][3]) == {steps + 1}
+
+
+def test_step_replay_of_a_small_forked_recording(gpu):
+    """csrc/step_replay.hip on a recording small enough to check by hand: a chain on the capturing stream, a fork to a side
+    stream, a join - the plan must keep two lanes and one event per cross-lane edge, re-running it must recompute the outputs
+    from the CURRENT contents of the static inputs, and work enqueued on the caller's stream before / after the call must be
+    ordered before / after the step.  A recording that holds a host-to-device copy (the one node type this runtime does not
+    let the library read back) is refused, not guessed at."""
+    import ctypes
+
+    from textreid_amd import ops
+
+    x = torch.zeros(1 << 16, device=gpu)
+    y = torch.zeros_like(x)
+    side = torch.cuda.Stream(device=gpu)
+    g = torch.cuda.CUDAGraph(keep_graph=True)
+    with torch.cuda.graph(g):
+        a = x * 2.0
+        main = torch.cuda.current_stream()
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            b = a + 1.0
+            b2 = b * b
+        c = a - 3.0
+        main.wait_stream(side)
+        out = b2 + c + y
+    h = ctypes.c_void_p()
+    ops.call("trid_step_replay_build", int(g.raw_cuda_graph()), 8, ctypes.byref(h))
+    counts = (ctypes.c_int * 8)()
+    ops.call("trid_step_replay_info", h, counts)
+    nodes, kernels, copies, memsets, lanes, events, waits, empty = [int(c) for c in counts]
+    assert nodes == kernels == 6 and copies == 0 and lanes == 2 and events == 2 and waits == 2
+    for step in range(3):
+        x.fill_(float(step + 1))          # enqueued before the call: the step must see it
+        y.fill_(10.0 * step)
+        ops.call("trid_step_replay_run", h, ops.stream())
+        got = out.clone()                  # enqueued after the call: must see the step's result
+        xv = float(step + 1)
+        want = (2 * xv + 1) ** 2 + (2 * xv - 3) + 10.0 * step
+        assert torch.equal(got, torch.full_like(got, want)), (step, float(got[0]), want)
+    torch.cuda.synchronize()
+    ops.call("trid_step_replay_destroy", h)
+
+    pinned = torch.arange(1024, dtype=torch.float32).pin_memory()
+    dev = torch.zeros(1024, device=gpu)
+    g2 = torch.cuda.CUDAGraph(keep_graph=True)
+    with torch.cuda.graph(g2):
+        dev.copy_(pinned, non_blocking=True)
+        z = dev + 1.0
+    h2 = ctypes.c_void_p()
+    with pytest.raises(RuntimeError, match="cannot be read back|cannot be replayed"):
+        ops.call("trid_step_replay_build", int(g2.raw_cuda_graph()), 8, ctypes.byref(h2))
+    assert not h2.value
 
 
 def test_failed_capture_falls_back_to_eager(gpu):

@@ -13,9 +13,17 @@ What varies between steps lives in device memory that the replay reads:
 
 Shapes are part of the recording: a batch of another shape (or another caption length bound) runs EAGERLY, with a
 warning - never silently through a graph recorded for different sizes.
+
+Two ways to run the recording (``launch=``): "graph" = hipGraphLaunch; "streams" (default) = the recorded nodes re-issued as
+ordinary stream launches by ONE call into the library (csrc/step_replay.hip: the graph is read back - launch parameters,
+edges - and laid out on a few streams, chains in stream order, an event per cross-chain edge).  On this runtime
+hipGraphLaunch of the step is slower than the eager step (45.2 vs 44.0 ms); the stream form is the eager step without its
+35-39 ms of Python / ctypes time, with every stream fed at once.
 """
 
+import ctypes
 import logging
+import os
 
 import torch
 
@@ -24,7 +32,7 @@ from ..parallel import dp_active
 
 
 class CapturedTrainStep:
-    def __init__(self, model, optimizer, warmup=2, caption_bound=None, reducer=None, pre_gather=None):
+    def __init__(self, model, optimizer, warmup=2, caption_bound=None, reducer=None, pre_gather=None, launch=None, lanes=8):
         """warmup: eager steps before the capture (they build every cached pointer table / workspace / side stream the
         step uses; they are REAL training steps).  optimizer=None: forward + backward only (parity tests).
         caption_bound: number of recurrence steps the recorded text encoder runs (None: the token tensor's width, i.e.
@@ -35,6 +43,14 @@ class CapturedTrainStep:
         (probed: tools/exp/rccl_capture_probe.py).  Every rank records the same sequence; a transport that stages
         through the host (gloo) fails the recording and the step stays eager."""
         self.model, self.optimizer = model, optimizer
+        # launch: "streams" | "graph" (None: TRID_STEP_LAUNCH, else "streams"); lanes: streams the recorded nodes are laid out on
+        self.launch = launch or os.environ.get("TRID_STEP_LAUNCH", "streams")
+        if self.launch not in ("streams", "graph"):
+            raise ValueError("CapturedTrainStep: launch must be 'streams' or 'graph', not %r" % (self.launch,))
+        self.lanes = int(os.environ.get("TRID_STEP_LANES", lanes))
+        self.replayer = None     # handle of csrc/step_replay.hip (launch == "streams")
+        self.force_graph_launch = False  # (A/B runs: hipGraphLaunch although a stream plan exists)
+        self.replay_info = None
         self.reducer, self.pre_gather = reducer, pre_gather
         self.caption_bound = caption_bound
         self.warmup = max(int(warmup), 1)
@@ -90,7 +106,7 @@ class CapturedTrainStep:
         self.bound = int(self.caption_bound) if self.caption_bound is not None else int(cb.tokens.shape[1])
         scb = CaptionBatch(self.static["tokens"], self.static["lengths"], self.static["ids"], max_len=self.bound, bound_only=True)
         if isinstance(self.optimizer, FusedAdam):
-            self.optimizer.prepare_capture()
+            self.optimizer.prepare_capture(defer_table_copy=True)
         elif self.optimizer is not None:
             raise RuntimeError("CapturedTrainStep needs textreid_amd.solver.FusedAdam (or optimizer=None)")
         for p in self.model.parameters():
@@ -99,7 +115,7 @@ class CapturedTrainStep:
 
         ops.begin_capture()
         torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
+        g = torch.cuda.CUDAGraph(keep_graph=True) if self.launch == "streams" else torch.cuda.CUDAGraph()
         # thread_local: every launch of the step is issued from this thread (the backward runs on the autograd engine's
         # thread for this device, which torch's capture tracks); a HIP call from an UNRELATED thread - a DataLoader's
         # pin_memory thread allocating or polling events - must not invalidate the ~1100-launch recording
@@ -112,15 +128,52 @@ class CapturedTrainStep:
                 self.optimizer.step()
         self.graph, self.out = g, {k: v.detach() for k, v in loss_dict.items()}
         del loss_dict, losses
+        if isinstance(self.optimizer, FusedAdam):
+            self.optimizer.finish_capture()  # the gradient address table of the recorded Adam launch: copied once, here
         self.grads = [(p, p.grad) for p in self.model.parameters() if p.grad is not None]  # live in the graph's pool
         self.signature = self._sig(images, cb)
         # the recorded Adam launch has the ADDRESSES of this plan's tables baked in: hold it (so the allocator cannot
         # recycle them under the graph) and replay only while the optimizer still uses this very object
         self.plan = getattr(self.optimizer, "_plan", None)
-        self.log.info("train step captured: one graph launch per step from here on")
+        if self.launch == "streams":
+            self._build_replayer(g)
+        self.log.info("train step captured: one %s per step from here on", "call into the library (stream replay)" if self.replayer else "graph launch")
+
+    def _build_replayer(self, g):
+        """The recorded graph read back into a stream-launch plan.  Under data parallelism the RCCL nodes of the recording are
+        kernels on RCCL's stream like any other; a graph holding a node type the replayer refuses (host callback, child graph)
+        stays on hipGraphLaunch."""
+        from .. import ops
+
+        self._drop_replayer()
+        h = ctypes.c_void_p()
+        try:
+            ops.call("trid_step_replay_build", int(g.raw_cuda_graph()), self.lanes, ctypes.byref(h))
+        except RuntimeError as e:
+            self.log.warning("train step: the recorded graph cannot be replayed as stream launches (%s) - using hipGraphLaunch", str(e).splitlines()[0])
+            return
+        counts = (ctypes.c_int * 8)()
+        ops.call("trid_step_replay_info", h, counts)
+        self.replayer = h
+        self.replay_info = dict(zip(("nodes", "kernels", "copies", "memsets", "lanes", "events", "waits", "empty"), [int(c) for c in counts]))
+
+    def _drop_replayer(self):
+        if self.replayer is not None:
+            from .. import ops
+
+            torch.cuda.synchronize()
+            ops.call("trid_step_replay_destroy", self.replayer)
+        self.replayer = self.replay_info = None
+
+    def __del__(self):
+        try:
+            self._drop_replayer()
+        except Exception:  # (interpreter shutdown)
+            pass
 
     def _drop_graph(self, why):
         self.log.warning("train step: %s - dropping the recorded graph", why)
+        self._drop_replayer()
         self.graph = self.static = self.out = self.signature = None
         self.grads = []
 
@@ -180,6 +233,7 @@ class CapturedTrainStep:
         if self.reducer is not None:
             self.reducer.abort()
         ops.begin_capture()  # (clears the capture-private pools)
+        self._drop_replayer()
         self.graph = self.static = self.out = self.signature = None
         self.grads = []
 
@@ -216,5 +270,10 @@ class CapturedTrainStep:
                 p.grad = g
         if self.optimizer is not None:
             self.optimizer.advance_for_replay()
-        self.graph.replay()
+        if self.replayer is not None and not self.force_graph_launch:
+            from .. import ops
+
+            ops.call("trid_step_replay_run", self.replayer, ops.stream())
+        else:
+            self.graph.replay()
         return self.out

@@ -64,7 +64,10 @@ def do_train(model, data_loader, data_loader_val, optimizer, scheduler, checkpoi
         from .graph import CapturedTrainStep
 
         if isinstance(optimizer, FusedAdam):
-            runner = CapturedTrainStep(model, optimizer, warmup=2, reducer=reducer if dp_active() else None, pre_gather=pre_gather)
+            # (a recording that holds RCCL's kernels is launched as a graph: re-issuing a collective's kernels outside the
+            # library's own launch path is not something RCCL promises to survive)
+            runner = CapturedTrainStep(model, optimizer, warmup=2, reducer=reducer if dp_active() else None, pre_gather=pre_gather,
+                                       launch="graph" if dp_active() else None)
     best_top1 = 0.0
     pending, keys = [], None  # per-step loss vectors still on the device
 

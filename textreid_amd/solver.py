@@ -112,9 +112,12 @@ class FusedAdam(torch.optim.Optimizer):
     # schedulers), the per-parameter bias corrections - lives in the tail of the same device table and is refreshed by
     # `advance_for_replay()` with a stream-ordered copy from a small ring of pinned buffers right before each replay
     # (no host sync, no captured host memory that changes).
-    def prepare_capture(self):
+    def prepare_capture(self, defer_table_copy=False):
         """OUTSIDE capture (pinned allocations are not capturable), after at least one eager step built the static
-        pointer tables: the device / pinned tables of the captured step."""
+        pointer tables: the device / pinned tables of the captured step.
+        defer_table_copy: the copy of the captured gradients' addresses to the device is NOT recorded; the caller runs it once,
+        right after the recording ended, with finish_capture() (the addresses never change afterwards; a recorded host-to-device
+        copy is the one node of the step that csrc/step_replay.hip cannot read back from the graph)."""
         if self._plan is None:
             raise RuntimeError("FusedAdam.prepare_capture(): run one eager step first (static pointer tables)")
         pl = self._plan
@@ -125,6 +128,16 @@ class FusedAdam(torch.optim.Optimizer):
         pl["graph_ring"] = [torch.empty(2 * n + 1, dtype=torch.int64).pin_memory() for _ in range(4)]
         pl["graph_ring_ev"] = [None] * 4
         pl["graph_turn"] = 0
+        pl["graph_defer"] = bool(defer_table_copy)
+        pl["graph_pending"] = False
+
+    def finish_capture(self):
+        """After the recording ended (prepare_capture(defer_table_copy=True)): the gradient address table -> device, once."""
+        pl = self._plan
+        if pl is not None and pl.get("graph_pending"):
+            n = pl["graph_n"]
+            pl["graph_dyn"][:n].copy_(pl["graph_gptr_host"], non_blocking=True)
+            pl["graph_pending"] = False
 
     def _capture_tables(self, items):
         """INSIDE the capture: the captured gradients' addresses -> the static table (a captured copy node)."""
@@ -134,7 +147,10 @@ class FusedAdam(torch.optim.Optimizer):
             raise RuntimeError("FusedAdam.step() inside a stream capture needs prepare_capture() first (engine.graph.CapturedTrainStep "
                                "does it) and the same set of parameters with gradients as the eager steps")
         pl["graph_gptr_host"].numpy()[:] = np.array([g.data_ptr() for _, g, _ in items], dtype=np.uint64).view(np.int64)
-        pl["graph_dyn"][:n].copy_(pl["graph_gptr_host"], non_blocking=True)
+        if pl.get("graph_defer"):
+            pl["graph_pending"] = True  # (finish_capture() copies it once the recording has ended)
+        else:
+            pl["graph_dyn"][:n].copy_(pl["graph_gptr_host"], non_blocking=True)
         return pl["graph_dyn"]
 
     def advance_for_replay(self):
