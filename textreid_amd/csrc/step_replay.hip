@@ -198,6 +198,8 @@ extern "C" int trid_step_replay_build(void* graph_, int max_lanes, void** out) {
         r->nodes.push_back(std::move(nd));
     }
     hipError_t e = hipSuccess;
+    // (stream priorities were tried - the recording stream's chain, the step's critical path, on the most urgent priority and
+    // the side lanes on the least: 48.8 ms per step against 43.6, the reverse 52.6: tools/exp/r05_run15.sh - and dropped)
     for (size_t l = 0; l < tail.size() && e == hipSuccess; ++l) {
         hipStream_t s = nullptr;
         e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);

@@ -27,3 +27,16 @@ for i in range(5):
     except RuntimeError as e:
         print(i, "FAILED", str(e)[:400], runner.replay_info)
         break
+
+# host time of one replay call with the GPU idle at the start (is the call slow, or does it wait for queue space?)
+import time
+if runner.replayer is not None:
+    from textreid_amd import ops
+    for rep in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ops.call("trid_step_replay_run", runner.replayer, ops.stream())
+        t1 = time.perf_counter()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        print("replay call: host %.2f ms, until the GPU is done %.2f ms" % ((t1 - t0) * 1e3, (t2 - t0) * 1e3))
