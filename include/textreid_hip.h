@@ -109,6 +109,20 @@ typedef struct trid_gemm_desc {
     int32_t eval_pool_w;     /* c_format 1, a_mode TRID_A_CONV, no residual: != 0 (= W) writes AvgPool2d(2) of act(.) instead: C = P16 [M / 4][N]
                               * (a stride-2 block's conv2 + bn2 + ReLU + avgpool, m_resnet.py:59-61); needs W | 128 with an even
                               * number of image rows per 128-row tile, H * W % 128 == 0, N > 64 */
+    /* trid_gemm_p16, c_format 0, batch == splits == 1, ldc == N, N % 128 == 0 - a DATA GRADIENT that feeds a BatchNorm
+     * backward (m_resnet.py:54-67): with bnb_y = the saved fp32 output y [M][N] of the convolution that BatchNorm layer
+     * normalised (and its batch mean / invstd / scale / shift vectors [N]), every 128-row tile also writes the sums
+     * sum g m, sum g m xhat and the maxima max|g m|, max|xhat| of its rows of C = g (m = [scale y + shift > 0] when bnb_relu,
+     * else 1) to bnb_ws / bnb_ws2 (trid_bn_bwd_fused_ws_floats floats each), in the layout trid_bn_bwd_final_f32 folds:
+     * the BatchNorm-backward reduce pass over g and y is then not needed.  NULL: off. */
+    const float* bnb_y;
+    const float* bnb_mean;
+    const float* bnb_invstd;
+    const float* bnb_scale;
+    const float* bnb_shift;
+    float* bnb_ws;
+    float* bnb_ws2;
+    int32_t bnb_relu;
 } trid_gemm_desc;
 
 int trid_gemm_f32(const trid_gemm_desc* d, void* stream);
@@ -322,6 +336,12 @@ int trid_avgpool2_bwd_f32(const void* g, void* dx, int B, int H, int W, int C, i
  * (workspace: ws floats >= trid_bn_bwd_ws_floats(C)); step 2 writes
  * dy = scale*(gm - dbeta/M - xhat*dgamma/M) and optionally dres = gm. */
 long long trid_bn_bwd_ws_floats(int C);
+/* BatchNorm-backward sums written by the producing data-gradient GEMM (trid_gemm_desc.bnb_*): floats of EACH of its two
+ * workspaces for M rows of C channels, and the fold that replaces trid_bn_bwd_reduce_bound_f32's: dgamma / dbeta [C] and
+ * the bound of max|dy| (atomicMax'ed into *bound, zeroed by the caller) from the per-tile partials. */
+long long trid_bn_bwd_fused_ws_floats(long long M, int C);
+int trid_bn_bwd_final_f32(const float* ws, const float* ws2, long long M, int C, const float* scale, float* dgamma, float* dbeta,
+                          float* bound, void* stream);
 int trid_bn_bwd_reduce_f32(const float* g, const float* y, const float* act, const float* mean,
                            const float* invstd, const float* scale, const float* shift, int mask_mode,
                            int pooled, int B, int H, int W, int C, float* dgamma, float* dbeta, float* ws,

@@ -938,6 +938,61 @@ def test_bn_backward_bound_with_a_tiny_variance_channel(ops, mask_mode):
     assert err < 1e-3, err
 
 
+@pytest.mark.parametrize("M_,N,K,conv,relu,acc", [(128 * 3 + 40, 128, 512, None, True, False), (2 * 24 * 8, 256, 9 * 64, (24, 8, 64), True, False),
+                                                   (128 * 2, 512, 1024, None, False, True), (128 * 5 + 7, 2048, 64 * 4, None, True, True)])
+def test_gemm_p16_bn_backward_sums_from_the_epilogue(ops, M_, N, K, conv, relu, acc):
+    """csrc/gemm_p16.hip BnBwdFuse: the data-gradient GEMM that PRODUCES a BatchNorm layer's incoming gradient also forms that
+    layer's backward sums (sum g m, sum g m xhat, max|g m|, max|xhat| per channel and 128-row tile) from its final tile values
+    and the saved conv output y - 1x1 and 3x3 forms, a ragged last tile, 128 ... 2048 channels (one / two channel-quad slices
+    per partial), with and without ReLU, on top of an accumulate.  (1) C is bit for bit what the plain launch writes;
+    (2) dgamma / dbeta / the bound / dy of bn_bwd_p16(presummed=) agree with the reduce pass they replace (other summation
+    order: 1e-5 of each vector's largest entry), and with float64."""
+    import torch as T
+
+    if conv is None:
+        x = R("bnbx%d" % K, M_, K)
+    else:
+        H, W, C = conv
+        x = R("bnbc%d" % C, M_ // (H * W), H, W, C)
+    xp = ops.p16_pack(dev(x))
+    wp = ops.p16_pack(dev(R("bnbw%d" % N, N, K, scale=0.2)))
+    y = dev(R("bnby%d" % N, 1, 1, M_, N) * 1.3 + 0.1)   # the saved conv output of the layer the gradient belongs to ([B,H,W,C]-shaped)
+    gamma, beta = dev(R("bnbg", N).abs() + 0.5), dev(R("bnbb", N) * 0.3)
+    yd = y.double().reshape(M_, N)
+    mean, var = yd.mean(0), yd.var(0, unbiased=False)
+    invstd = 1.0 / T.sqrt(var + 1e-5)
+
+    class St:
+        pass
+
+    st = St()
+    st.mean, st.invstd = mean.float().contiguous(), invstd.float().contiguous()
+    st.scale = (gamma.double() * invstd).float().contiguous()
+    st.shift = (beta.double() - gamma.double() * invstd * mean).float().contiguous()
+    c0 = dev(R("bnbacc", M_, N))
+    plain, fused = c0.clone(), c0.clone()
+    ops.gemm_p16(xp, wp, plain, M_, N, K, N, conv=conv, accumulate=acc)
+    assert ops.bn_bwd_fusable(y, M_, N)
+    sums = ops.BnBwdSums(y, st, relu=relu)
+    ops.gemm_p16(xp, wp, fused, M_, N, K, N, conv=conv, accumulate=acc, bn_bwd=sums)
+    assert T.equal(plain, fused)
+    g4 = fused.reshape(1, 1, M_, N)
+    a = ops.bn_bwd_p16(g4, y, st, 1 if relu else 0)
+    b = ops.bn_bwd_p16(g4, y, st, 1 if relu else 0, presummed=sums)
+    for u, v, name in ((a[1], b[1], "dgamma"), (a[2], b[2], "dbeta")):
+        assert float((u - v).abs().max()) <= 1e-5 * float(u.abs().max()), name
+    assert abs(float(a[0].amax) - float(b[0].amax)) <= 1e-5 * float(a[0].amax)
+    assert float((a[0].unpack() - b[0].unpack()).abs().max()) <= 2e-5 * float(a[0].unpack().abs().max())
+    # float64: dgamma = sum g m xhat, dbeta = sum g m
+    gd = fused.double().reshape(M_, N)
+    xh = (yd - mean) * invstd
+    m = ((yd * st.scale.double() + st.shift.double()) > 0).double() if relu else T.ones_like(yd)
+    assert rel(b[1], (gd * m * xh).sum(0)) < 1e-4 and rel(b[2], (gd * m).sum(0)) < 1e-4
+    with pytest.raises(RuntimeError, match="bnb_y"):  # whole 128-column tiles only
+        bad = ops.BnBwdSums(y[..., :64].contiguous(), st, relu=relu)
+        ops.gemm_p16(xp, ops.p16_pack(dev(R("bnbw64", 64, K))), ops.empty((M_, 64), xp.data), M_, 64, K, 64, conv=conv, bn_bwd=bad)
+
+
 def test_abi_argument_errors_are_reported_not_fatal(ops):
     """C-ABI contract: bad arguments return a negative TRID_E_* code with a thread-local message
     (surfaced as RuntimeError by the binding) and leave the device usable - no abort, no sticky HIP error."""

@@ -546,19 +546,24 @@ def block_backward_p16(blk, rec, g, WPT, ws, G):
     planes = blk.conv2.out_channels
     Mc = dyc.data.numel() // dyc.shape[-1]
     dab = ops.empty(tuple(ab.shape), g, dtype=g.dtype)  # (bf16 mode: data gradients are bf16 tensors, like g)
-    ops.gemm_p16(dyc, WPT[id(blk.conv3.weight)], dab, Mc, planes, dyc.shape[-1], planes)
+    # bn2's / bn1's backward sums come out of the epilogue of the data-gradient GEMM that produces their gradient (the tile
+    # kernel: planes >= 128, no pool in between) - the reduce pass over (gradient, saved conv output) is then not run
+    sums_b = ops.BnBwdSums(yb, stb) if (stride == 1 and g.dtype == torch.float32 and ops.bn_bwd_fusable(yb, Mc, planes, fmt)) else None
+    ops.gemm_p16(dyc, WPT[id(blk.conv3.weight)], dab, Mc, planes, dyc.shape[-1], planes, bn_bwd=sums_b)
     G[id(blk.conv3.weight)] = wgrad(dyc, ab).view_as(blk.conv3.weight)
-    dyb, dg, db, _ = ops.bn_bwd_p16(dab, yb, stb, 1, pooled=stride > 1, fmt=fmt)
+    dyb, dg, db, _ = ops.bn_bwd_p16(dab, yb, stb, 1, pooled=stride > 1, fmt=fmt, presummed=sums_b)
     G[id(blk.bn2.weight)], G[id(blk.bn2.bias)] = dg, db
     Bi, H, W, _ = yb.shape
     Ma = Bi * H * W
+    sums_a = None
     if fmt == 1 and ops.USE_HALO_BLOCKS and ops.conv3x3_halo_rows(H, W, planes, planes):
         daa = ops.conv3x3_halo_p16(dyb, WPT[id(blk.conv2.weight)], stats=False)  # (layer1: 64 channels, the stem's ring-of-rows kernel)
     else:
         daa = ops.empty(tuple(aa.shape), g, dtype=g.dtype)
-        ops.gemm_p16(dyb, WPT[id(blk.conv2.weight)], daa, Ma, planes, 9 * planes, planes, conv=(H, W, planes))
+        sums_a = ops.BnBwdSums(ya, sta) if (g.dtype == torch.float32 and ops.bn_bwd_fusable(ya, Ma, planes, fmt)) else None
+        ops.gemm_p16(dyb, WPT[id(blk.conv2.weight)], daa, Ma, planes, 9 * planes, planes, conv=(H, W, planes), bn_bwd=sums_a)
     G[id(blk.conv2.weight)] = _g3x3(wgrad(dyb, aa, conv=(H, W, planes)), planes, planes)
-    dya, dg, db, _ = ops.bn_bwd_p16(daa, ya, sta, 1, fmt=fmt)
+    dya, dg, db, _ = ops.bn_bwd_p16(daa, ya, sta, 1, fmt=fmt, presummed=sums_a)
     G[id(blk.bn1.weight)], G[id(blk.bn1.bias)] = dg, db
     cin = blk.conv1.in_channels
     if has_down:

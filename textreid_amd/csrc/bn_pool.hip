@@ -824,6 +824,26 @@ extern "C" long long trid_bn_bwd_ws_floats(int C) {
     return 2 * (long long)(1024 + 8) * CW * 8;  // sums + (trid_bn_bwd_reduce_bound_f32) maxima
 }
 
+// partials of the fused form (gemm_p16.hip, BnBwdFuse): one per 128-row tile and channel-quad slice
+extern "C" long long trid_bn_bwd_fused_ws_floats(long long M, int C) {
+    const int CQ = C / 4;
+    const int CW = CQ < 256 ? CQ : 256;
+    const long long S = CQ / CW;
+    return ((M + 127) / 128 * S + 8) * CW * 8;
+}
+
+extern "C" int trid_bn_bwd_final_f32(const float* ws, const float* ws2, long long M, int C, const float* scale, float* dgamma,
+                                     float* dbeta, float* bound, void* stream) {
+    TRID_REQUIRE(ws && ws2 && scale && dgamma && dbeta && bound && M > 0 && C > 0 && C % 4 == 0, "trid_bn_bwd_final_f32: bad arguments");
+    const int CQ = C / 4;
+    TRID_REQUIRE(256 % CQ == 0 || CQ % 256 == 0, "trid_bn_bwd_final_f32: C/4 must divide 256 or be a multiple of 256 (C=%d)", C);
+    const int CW = CQ < 256 ? CQ : 256;
+    const int nblk = (int)((M + 127) / 128) * (CQ / CW);
+    hipLaunchKernelGGL(bn_bwd_reduce_final_kernel, dim3(CQ), dim3(256), 0, (hipStream_t)stream, ws, nblk, CQ, dgamma, dbeta, C, ws2,
+                       scale, 1.f / (float)M, bound);
+    return check_launch("trid_bn_bwd_final_f32");
+}
+
 static int bn_bwd_fill(BnBwdArgs& a, const float* g, const float* y, const float* act, const float* mean,
                        const float* invstd, const float* scale, const float* shift, int mask_mode, int pooled, int B,
                        int H, int W, int C, int g_fmt = 0, int y_fmt = 0) {

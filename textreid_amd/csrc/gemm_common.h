@@ -39,6 +39,23 @@ struct EvalBound {
     float* out_tmax;     // atomicMax (bits of a non-negative float; zeroed by the caller): true max|out|
 };
 
+// BatchNorm-backward sums from the epilogue of the data-gradient GEMM that PRODUCES the gradient g (gemm_p16.hip, the
+// staged-through-LDS store path): with y the saved conv output of the BatchNorm layer g belongs to, every 128-row tile adds
+//   s1_c = sum g m,  s2_c = sum g m xhat,  max |g m|,  max |xhat|     (xhat = (y - mean_c) invstd_c, m = [scale_c y + shift_c > 0])
+// over its rows and writes them in the layout bn_bwd_reduce_kernel leaves for bn_bwd_reduce_final_kernel (bn_pool.hip:
+// [partial b][CW quads][8] sums, the same for the maxima; partial b = tile row * S + slice) - the reduce pass, which re-reads g
+// and y from HBM only to form these sums, is then not run (m_resnet.py:54-67 backward).
+struct BnBwdFuse {
+    const float* y;        // [M][N] fp32, row pitch N; null: off
+    const float* mean;     // [N]
+    const float* invstd;
+    const float* scale;
+    const float* shift;
+    float* ws;             // sums
+    float* ws2;            // maxima
+    int relu;              // 1: the layer's output went through ReLU (the mask is recomputed from y); 0: m = 1
+};
+
 struct GemmParams {
     const float* A;
     const float* B;
@@ -77,6 +94,7 @@ struct GemmParams {
     const float* res16_amax;
     EvalBound ev;
     int pool_w;             // > 0: the epilogue output is the 2x2 average pool of act(.) over images of this width ([M / 4][N])
+    BnBwdFuse bb;
 };
 
 constexpr int BK = 32;

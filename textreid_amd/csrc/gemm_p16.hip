@@ -542,12 +542,30 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 && STAGES == 2) ? 2 : (W
                 }
                 return;
             }
+            // BatchNorm-backward sums of this tile's rows (gemm_common.h BnBwdFuse): this lane's 4 channels over its BM / RG rows.
+            // Its eight arguments are read from the kernel-argument segment HERE, through a pointer the compiler cannot see
+            // through: fetched at kernel entry like the others they stay live across the main loop, and the SGPRs this kernel
+            // already spills into VGPR lanes cost it one more VGPR than its 128 (two waves per SIMD x 2 workgroups) hold
+            unsigned long long kargs = (unsigned long long)(uintptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+            asm volatile("" : "+s"(kargs));
+            const BnBwdFuse bb = reinterpret_cast<const GemmParams*>(kargs)->bb;
+            const bool bnb = bb.y != nullptr && col < p.N;
+            float4 b_mu = make_float4(0.f, 0.f, 0.f, 0.f), b_is = b_mu, b_sc = b_mu, b_sh = b_mu;
+            float4 b_s1 = b_mu, b_s2 = b_mu, b_mg = b_mu, b_mx = b_mu;
+            if (bnb) {
+                b_mu = *reinterpret_cast<const float4*>(bb.mean + col);
+                b_is = *reinterpret_cast<const float4*>(bb.invstd + col);
+                b_sc = *reinterpret_cast<const float4*>(bb.scale + col);
+                b_sh = *reinterpret_cast<const float4*>(bb.shift + col);
+            }
 #pragma unroll
             for (int ps = 0; ps < BM / RG; ++ps) {
                 const int rl = ps * RG + rg, row = m0 + rl;
                 if (row >= p.M || col >= p.N) continue;
                 float4 v = *reinterpret_cast<const float4*>(Ct + rl * BN + 4 * c4);
                 const long long at = (long long)row * p.ldc + col;
+                float4 yv = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (bnb) yv = *reinterpret_cast<const float4*>(bb.y + (long long)row * p.N + col);  // (issued ahead of the stores)
                 if (!pre) {
                     v.x += bv4.x; v.y += bv4.y; v.z += bv4.z; v.w += bv4.w;
                     if (p.accumulate) {
@@ -577,6 +595,49 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 && STAGES == 2) ? 2 : (W
                 }
                 if (p.c_fmt == 2) *reinterpret_cast<uint2*>(Cb + at) = make_uint2(cvt_pk_bf16(v.x, v.y), cvt_pk_bf16(v.z, v.w));
                 else *reinterpret_cast<float4*>(C + at) = v;
+                if (bnb) {  // the arithmetic of bn_bwd_elem / bn_bwd_reduce_kernel (bn_pool.hip)
+                    const float4 xh = make_float4((yv.x - b_mu.x) * b_is.x, (yv.y - b_mu.y) * b_is.y, (yv.z - b_mu.z) * b_is.z, (yv.w - b_mu.w) * b_is.w);
+                    float4 g = v;
+                    if (bb.relu) {
+                        g.x = fmaf(yv.x, b_sc.x, b_sh.x) > 0.f ? g.x : 0.f; g.y = fmaf(yv.y, b_sc.y, b_sh.y) > 0.f ? g.y : 0.f;
+                        g.z = fmaf(yv.z, b_sc.z, b_sh.z) > 0.f ? g.z : 0.f; g.w = fmaf(yv.w, b_sc.w, b_sh.w) > 0.f ? g.w : 0.f;
+                    }
+                    b_s1.x += g.x; b_s1.y += g.y; b_s1.z += g.z; b_s1.w += g.w;
+                    b_s2.x = fmaf(g.x, xh.x, b_s2.x); b_s2.y = fmaf(g.y, xh.y, b_s2.y); b_s2.z = fmaf(g.z, xh.z, b_s2.z); b_s2.w = fmaf(g.w, xh.w, b_s2.w);
+                    b_mg.x = fmaxf(b_mg.x, fabsf(g.x)); b_mg.y = fmaxf(b_mg.y, fabsf(g.y)); b_mg.z = fmaxf(b_mg.z, fabsf(g.z)); b_mg.w = fmaxf(b_mg.w, fabsf(g.w));
+                    b_mx.x = fmaxf(b_mx.x, fabsf(xh.x)); b_mx.y = fmaxf(b_mx.y, fabsf(xh.y)); b_mx.z = fmaxf(b_mx.z, fabsf(xh.z)); b_mx.w = fmaxf(b_mx.w, fabsf(xh.w));
+                }
+            }
+            if (bb.y != nullptr) {
+                // the RG row groups of a channel quad meet in LDS; the first C4 lanes fold them in row-group order (fixed order:
+                // the partial is a function of the tile alone) and write the quad's entry of this tile's partial
+                __syncthreads();  // every wave is done reading Ct
+                float* redf = reinterpret_cast<float*>(smem);  // [RG][C4][16]
+                float* mine = redf + (rg * C4 + c4) * 16;
+                *reinterpret_cast<float4*>(mine) = b_s1;
+                *reinterpret_cast<float4*>(mine + 4) = b_s2;
+                *reinterpret_cast<float4*>(mine + 8) = b_mg;
+                *reinterpret_cast<float4*>(mine + 12) = b_mx;
+                __syncthreads();
+                if (tid < C4 && n0 + 4 * tid < p.N) {
+                    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1, mg = s1, mx = s1;
+                    for (int r = 0; r < RG; ++r) {
+                        const float* src = redf + (r * C4 + tid) * 16;
+                        const float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 4);
+                        const float4 c = *reinterpret_cast<const float4*>(src + 8), d = *reinterpret_cast<const float4*>(src + 12);
+                        s1.x += a.x; s1.y += a.y; s1.z += a.z; s1.w += a.w;
+                        s2.x += b.x; s2.y += b.y; s2.z += b.z; s2.w += b.w;
+                        mg.x = fmaxf(mg.x, c.x); mg.y = fmaxf(mg.y, c.y); mg.z = fmaxf(mg.z, c.z); mg.w = fmaxf(mg.w, c.w);
+                        mx.x = fmaxf(mx.x, d.x); mx.y = fmaxf(mx.y, d.y); mx.z = fmaxf(mx.z, d.z); mx.w = fmaxf(mx.w, d.w);
+                    }
+                    const int CQ = p.N >> 2, CW = CQ < 256 ? CQ : 256, S = CQ / CW;
+                    const int q = (n0 >> 2) + tid;
+                    const long long e = (((long long)mb * S + q / CW) * CW + q % CW) * 8;
+                    *reinterpret_cast<float4*>(bb.ws + e) = s1;
+                    *reinterpret_cast<float4*>(bb.ws + e + 4) = s2;
+                    *reinterpret_cast<float4*>(bb.ws2 + e) = mg;
+                    *reinterpret_cast<float4*>(bb.ws2 + e + 4) = mx;
+                }
             }
             return;
         }
@@ -999,7 +1060,7 @@ static int pick_p16(GemmParams& p, int variant, int planes, hipStream_t stream) 
     }
     if (p.N <= 32) return launch_p16<AMODE, 256, 32, 4, 1, 3>(p, stream);
     if (p.N <= 64) return launch_p16<AMODE, 128, 64, 2, 2, 3>(p, stream);
-    if (variant < 0 || p.c_fmt == 1) variant = 3;  // (the eval epilogue lives in the staged-through-LDS store path of the default tile)
+    if (variant < 0 || p.c_fmt == 1 || p.bb.y != nullptr) variant = 3;  // (the eval epilogue and the BatchNorm-backward sums live in the staged-through-LDS store path of the default tile)
     switch (variant) {
         case 1: return launch_p16<AMODE, 128, 128, 2, 2, 3>(p, stream);   // 4 waves of 64x64, 3 stages (96 KB): 1 WG / CU
         case 2: return launch_p16<AMODE, 256, 128, 4, 2, 3>(p, stream);   // 8 waves of 64x64, 3 stages (144 KB)
@@ -1125,6 +1186,11 @@ extern "C" int trid_gemm_p16_rows(int M, int N, int precision, int variant) {
     return variant == 9 ? 96 : 128;
 }
 
+static int wide_env_ok() {
+    static const int wide_env = getenv("TRID_GEMM_WIDE_EPILOGUE") ? atoi(getenv("TRID_GEMM_WIDE_EPILOGUE")) : 1;  // (0: A/B runs)
+    return wide_env;
+}
+
 extern "C" int trid_gemm_p16(const trid_gemm_desc* d, int variant, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     TRID_REQUIRE(d != nullptr && d->A && d->B && d->C, "trid_gemm_p16: null operand");
@@ -1155,10 +1221,20 @@ extern "C" int trid_gemm_p16(const trid_gemm_desc* d, int variant, void* stream_
     p.ev.coef = d->eval_coef; p.ev.tin = d->eval_tin; p.ev.tres = d->eval_tres;
     p.ev.out_bound = d->out_bound; p.ev.out_tmax = d->out_tmax;
     p.pool_w = d->eval_pool_w;
+    p.bb.y = d->bnb_y; p.bb.mean = d->bnb_mean; p.bb.invstd = d->bnb_invstd; p.bb.scale = d->bnb_scale; p.bb.shift = d->bnb_shift;
+    p.bb.ws = d->bnb_ws; p.bb.ws2 = d->bnb_ws2; p.bb.relu = d->bnb_relu;
+    if (d->bnb_y != nullptr) {
+        const int CQ = d->N / 4;
+        TRID_REQUIRE(planes == 2 && d->c_format == 0 && d->batch == 1 && d->splits == 1 && d->ldc == d->N && d->N % 128 == 0 && !d->stats &&
+                     (256 % CQ == 0 || CQ % 256 == 0) && wide_env_ok(),
+                     "trid_gemm_p16: the BatchNorm-backward sums (bnb_y) need P16 operands, fp32 C with ldc == N, N %% 128 == 0, batch == splits == 1, no stats (N=%d)", d->N);
+        TRID_REQUIRE(d->bnb_mean && d->bnb_invstd && d->bnb_scale && d->bnb_shift && d->bnb_ws && d->bnb_ws2 && aligned16(d->bnb_y) && aligned16(d->bnb_mean) &&
+                     aligned16(d->bnb_invstd) && aligned16(d->bnb_scale) && aligned16(d->bnb_shift) && aligned16(d->bnb_ws) && aligned16(d->bnb_ws2),
+                     "trid_gemm_p16: the BatchNorm-backward sums need all of bnb_mean / invstd / scale / shift / ws / ws2, 16-byte aligned");
+    }
     TRID_REQUIRE(p.cmask == nullptr || (d->accumulate && d->batch == 1 && d->splits == 1 && d->ldc == d->N && d->N % 4 == 0 && !d->stats),
                  "trid_gemm_p16: c_mask needs accumulate, batch == splits == 1, ldc == N, N %% 4 == 0");
-    static const int wide_env = getenv("TRID_GEMM_WIDE_EPILOGUE") ? atoi(getenv("TRID_GEMM_WIDE_EPILOGUE")) : 1;  // (0: A/B runs)
-    p.wide_epilogue = wide_env;
+    p.wide_epilogue = wide_env_ok();
     TRID_REQUIRE(p.c_fmt == 0 || ((p.c_fmt == 2 || p.c_fmt == 1) && d->batch == 1 && d->splits == 1),
                  "trid_gemm_p16: c_format must be 0, or 1 / 2 with batch == splits == 1");
     if (p.c_fmt == 1) {

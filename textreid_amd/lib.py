@@ -61,6 +61,14 @@ class GemmDesc(ctypes.Structure):
         ("out_bound", ctypes.c_void_p),
         ("out_tmax", ctypes.c_void_p),
         ("eval_pool_w", ctypes.c_int32),
+        ("bnb_y", ctypes.c_void_p),
+        ("bnb_mean", ctypes.c_void_p),
+        ("bnb_invstd", ctypes.c_void_p),
+        ("bnb_scale", ctypes.c_void_p),
+        ("bnb_shift", ctypes.c_void_p),
+        ("bnb_ws", ctypes.c_void_p),
+        ("bnb_ws2", ctypes.c_void_p),
+        ("bnb_relu", ctypes.c_int32),
     ]
 
 

@@ -293,13 +293,41 @@ def p16_pack_wt(w, N, T, C, flip, amax_):
     return P16(out, amax_)
 
 
+class BnBwdSums:
+    """The BatchNorm-backward sums of a gradient tensor, written by the data-gradient GEMM that produces it (gemm_p16(bn_bwd=...),
+    csrc/gemm_p16.hip BnBwdFuse) and consumed by bn_bwd_p16(presummed=...) instead of its reduce pass over g and y."""
+
+    __slots__ = ("y", "st", "relu", "ws", "ws2", "M")
+
+    def __init__(self, y, st, relu=True):
+        C = y.shape[-1]
+        self.y, self.st, self.relu = y, st, relu
+        self.M = y.numel() // C
+        n = _query("trid_bn_bwd_fused_ws_floats", int(self.M), int(C))
+        both = empty((2 * n,), y)
+        self.ws, self.ws2 = both[:n], both[n:]
+
+
+USE_BNB_FUSE = os.environ.get("TRID_BNB_FUSE", "1") != "0"  # BatchNorm-backward sums from the producing GEMM's epilogue (0: A/B runs)
+
+
+def bn_bwd_fusable(y, M, N, fmt=1):
+    """Can the data-gradient GEMM that writes g [M, N] also form the BatchNorm-backward sums against the saved conv output y?
+    (the tile kernel's staged store path: P16 operands, fp32 g and y, whole 128-column tiles; the streaming short-K kernel
+    and the ring-of-rows kernel do not carry the epilogue)"""
+    CQ = N // 4
+    return (USE_BNB_FUSE and fmt == 1 and y.dtype == torch.float32 and N % 128 == 0 and (256 % CQ == 0 or CQ % 256 == 0)
+            and y.numel() == M * N and M * N * 4 < (1 << 31))
+
+
 def gemm_p16(A, B, C, M, N, K, ldc, conv=None, alpha=1.0, accumulate=False, bias=None, stats=None, residual=None, ldres=0,
-             relu=False, splits=1, strideSplit=0, variant=None, minmax=False, cmask=None):
+             relu=False, splits=1, strideSplit=0, variant=None, minmax=False, cmask=None, bn_bwd=None):
     """C[M,N] = alpha * A . B^T with both operands P16: A [M][K] (or an NHWC image [B,H,W,Cin] with conv=(H,W,Cin),
     K = 9*Cin), B [N][K].  minmax: the BatchNorm partials `stats` are [tiles][N][4] = (mean, M2, min, max).
-    cmask (with accumulate, ldc == N): a relu_mask of bn_apply_p16 over C; C = A . B^T + (bit ? C : 0)."""
+    cmask (with accumulate, ldc == N): a relu_mask of bn_apply_p16 over C; C = A . B^T + (bit ? C : 0).
+    bn_bwd: a BnBwdSums - C is a gradient that feeds that BatchNorm layer's backward; its sums come out of the epilogue."""
     if (USE_STREAM and conv is None and A.fmt == 1 and B.fmt == 1 and C.dtype == torch.float32 and stats is None and alpha == 1.0
-            and bias is None and residual is None and not relu and splits == 1 and gemm_p16_stream_rows(M, N, K, accumulate)
+            and bias is None and residual is None and not relu and splits == 1 and bn_bwd is None and gemm_p16_stream_rows(M, N, K, accumulate)
             and (cmask is None or N % 256 == 0)):
         return gemm_p16_stream(A, B, C, M, N, K, ldc, accumulate=accumulate, cmask=cmask)  # short-K data gradients (conv1 of a block)
     d = GemmDesc()
@@ -324,6 +352,10 @@ def gemm_p16(A, B, C, M, N, K, ldc, conv=None, alpha=1.0, accumulate=False, bias
     d.c_mask = _p(cmask)
     d.stats_minmax = 1 if minmax else 0
     d.c_format = 2 if C.dtype == torch.bfloat16 else 0  # (data gradients of the bf16 mode are bf16 tensors)
+    if bn_bwd is not None:
+        st = bn_bwd.st
+        d.bnb_y, d.bnb_mean, d.bnb_invstd, d.bnb_scale, d.bnb_shift = _p(bn_bwd.y), _p(st.mean), _p(st.invstd), _p(st.scale), _p(st.shift)
+        d.bnb_ws, d.bnb_ws2, d.bnb_relu = _p(bn_bwd.ws), _p(bn_bwd.ws2), 1 if bn_bwd.relu else 0
     v = P16_VARIANT if variant is None else variant
     if stats is not None:
         rows = gemm_p16_rows(M, N, A.fmt, v)
@@ -669,23 +701,29 @@ def bn_apply_pool2_p16(y, st, bound, relu=True, fmt=1):
     return P16(out, bound if fmt == 1 else None, fmt, y.tmax if (isinstance(y, P16) and st is None and fmt == 1) else None)
 
 
-def bn_bwd_p16(g, y, st, mask_mode, act=None, pooled=False, want_dres=False, fmt=1):
+def bn_bwd_p16(g, y, st, mask_mode, act=None, pooled=False, want_dres=False, fmt=1, presummed=None):
     """BatchNorm backward with dy written as a P16 tensor: the reduce pass also bounds max|dy| (triangle inequality
     over per-channel maxima), the apply pass scales by that bound.  Returns (dy P16, dgamma, dbeta, dres).
-    g: fp32, or (fmt 2) a bf16 tensor - dres, its masked copy, has g's dtype."""
+    g: fp32, or (fmt 2) a bf16 tensor - dres, its masked copy, has g's dtype.
+    presummed: the BnBwdSums the GEMM that produced g filled - the reduce pass over g and y is skipped, only its fold runs."""
     Bi, H, W, C = y.shape
     dg = empty((2, C), y)
     dgamma, dbeta = dg[0], dg[1]
-    ws = _bn_ws(C, y)
     bound = None
     g_fmt = 2 if g.dtype == torch.bfloat16 else 0
     y_fmt = 2 if y.dtype == torch.bfloat16 else 0
-    if fmt == 1:
+    if presummed is not None:
+        assert fmt == 1 and g_fmt == 0 and y_fmt == 0 and not pooled and presummed.y is y and mask_mode == (1 if presummed.relu else 0)
+        bound = amax_slot(y.device)
+        call("trid_bn_bwd_final_f32", _p(presummed.ws), _p(presummed.ws2), presummed.M, C, _p(st.scale), _p(dgamma), _p(dbeta), _p(bound), stream())
+    elif fmt == 1:
+        ws = _bn_ws(C, y)
         assert g_fmt == 0 and y_fmt == 0
         bound = amax_slot(y.device)
         call("trid_bn_bwd_reduce_bound_f32", _p(g), _p(y), _p(act), _p(st.mean), _p(st.invstd), _p(st.scale), _p(st.shift),
              mask_mode, 1 if pooled else 0, Bi, H, W, C, _p(dgamma), _p(dbeta), _p(ws), _p(bound), stream())
     else:
+        ws = _bn_ws(C, y)
         call("trid_bn_bwd_reduce_g_f32", _p(g), g_fmt, _p(y), y_fmt, _p(act), _p(st.mean), _p(st.invstd), _p(st.scale), _p(st.shift),
              mask_mode, 1 if pooled else 0, Bi, H, W, C, _p(dgamma), _p(dbeta), _p(ws), stream())
     dy = p16_empty(y.shape, y, fmt)
