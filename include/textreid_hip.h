@@ -109,7 +109,7 @@ typedef struct trid_gemm_desc {
     int32_t eval_pool_w;     /* c_format 1, a_mode TRID_A_CONV, no residual: != 0 (= W) writes AvgPool2d(2) of act(.) instead: C = P16 [M / 4][N]
                               * (a stride-2 block's conv2 + bn2 + ReLU + avgpool, m_resnet.py:59-61); needs W | 128 with an even
                               * number of image rows per 128-row tile, H * W % 128 == 0, N > 64 */
-    /* trid_gemm_p16, c_format 0, batch == splits == 1, ldc == N, N % 128 == 0 - a DATA GRADIENT that feeds a BatchNorm
+    /* trid_gemm_p16, c_format 0, batch == splits == 1, ldc == N, N == 64 or N % 128 == 0 - a DATA GRADIENT that feeds a BatchNorm
      * backward (m_resnet.py:54-67): with bnb_y = the saved fp32 output y [M][N] of the convolution that BatchNorm layer
      * normalised (and its batch mean / invstd / scale / shift vectors [N]), every 128-row tile also writes the sums
      * sum g m, sum g m xhat and the maxima max|g m|, max|xhat| of its rows of C = g (m = [scale y + shift > 0] when bnb_relu,

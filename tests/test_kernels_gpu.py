@@ -939,7 +939,8 @@ def test_bn_backward_bound_with_a_tiny_variance_channel(ops, mask_mode):
 
 
 @pytest.mark.parametrize("M_,N,K,conv,relu,acc", [(128 * 3 + 40, 128, 512, None, True, False), (2 * 24 * 8, 256, 9 * 64, (24, 8, 64), True, False),
-                                                   (128 * 2, 512, 1024, None, False, True), (128 * 5 + 7, 2048, 64 * 4, None, True, True)])
+                                                   (128 * 2, 512, 1024, None, False, True), (128 * 5 + 7, 2048, 64 * 4, None, True, True),
+                                                   (128 * 4 + 90, 64, 512, None, True, False)])
 def test_gemm_p16_bn_backward_sums_from_the_epilogue(ops, M_, N, K, conv, relu, acc):
     """csrc/gemm_p16.hip BnBwdFuse: the data-gradient GEMM that PRODUCES a BatchNorm layer's incoming gradient also forms that
     layer's backward sums (sum g m, sum g m xhat, max|g m|, max|xhat| per channel and 128-row tile) from its final tile values
@@ -988,9 +989,9 @@ def test_gemm_p16_bn_backward_sums_from_the_epilogue(ops, M_, N, K, conv, relu, 
     xh = (yd - mean) * invstd
     m = ((yd * st.scale.double() + st.shift.double()) > 0).double() if relu else T.ones_like(yd)
     assert rel(b[1], (gd * m * xh).sum(0)) < 1e-4 and rel(b[2], (gd * m).sum(0)) < 1e-4
-    with pytest.raises(RuntimeError, match="bnb_y"):  # whole 128-column tiles only
-        bad = ops.BnBwdSums(y[..., :64].contiguous(), st, relu=relu)
-        ops.gemm_p16(xp, ops.p16_pack(dev(R("bnbw64", 64, K))), ops.empty((M_, 64), xp.data), M_, 64, K, 64, conv=conv, bn_bwd=bad)
+    with pytest.raises(RuntimeError, match="bnb_y"):  # whole 64- / 128-column tiles only
+        bad = ops.BnBwdSums(dev(R("bnby96", 1, 1, M_, 96)), st, relu=relu)
+        ops.gemm_p16(xp, ops.p16_pack(dev(R("bnbw96", 96, K))), ops.empty((M_, 96), xp.data), M_, 96, K, 96, conv=conv, bn_bwd=bad)
 
 
 def test_abi_argument_errors_are_reported_not_fatal(ops):

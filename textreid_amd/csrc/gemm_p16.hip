@@ -1225,9 +1225,9 @@ extern "C" int trid_gemm_p16(const trid_gemm_desc* d, int variant, void* stream_
     p.bb.ws = d->bnb_ws; p.bb.ws2 = d->bnb_ws2; p.bb.relu = d->bnb_relu;
     if (d->bnb_y != nullptr) {
         const int CQ = d->N / 4;
-        TRID_REQUIRE(planes == 2 && d->c_format == 0 && d->batch == 1 && d->splits == 1 && d->ldc == d->N && d->N % 128 == 0 && !d->stats &&
+        TRID_REQUIRE(planes == 2 && d->c_format == 0 && d->batch == 1 && d->splits == 1 && d->ldc == d->N && (d->N == 64 || d->N % 128 == 0) && !d->stats &&
                      (256 % CQ == 0 || CQ % 256 == 0) && wide_env_ok(),
-                     "trid_gemm_p16: the BatchNorm-backward sums (bnb_y) need P16 operands, fp32 C with ldc == N, N %% 128 == 0, batch == splits == 1, no stats (N=%d)", d->N);
+                     "trid_gemm_p16: the BatchNorm-backward sums (bnb_y) need P16 operands, fp32 C with ldc == N, N == 64 or N %% 128 == 0, batch == splits == 1, no stats (N=%d)", d->N);
         TRID_REQUIRE(d->bnb_mean && d->bnb_invstd && d->bnb_scale && d->bnb_shift && d->bnb_ws && d->bnb_ws2 && aligned16(d->bnb_y) && aligned16(d->bnb_mean) &&
                      aligned16(d->bnb_invstd) && aligned16(d->bnb_scale) && aligned16(d->bnb_shift) && aligned16(d->bnb_ws) && aligned16(d->bnb_ws2),
                      "trid_gemm_p16: the BatchNorm-backward sums need all of bnb_mean / invstd / scale / shift / ws / ws2, 16-byte aligned");
