@@ -851,7 +851,13 @@ def main():
             if ms_r and obj["launches"]:
                 gf = obj["algorithmic_gflop_per_launch"]
                 obj["rocprof_in_graph"] = {"avg_launch_ms": ms_r, "achieved": gf / ms_r, "frac": gf / ms_r / peak,
-                                           "source": "%s: average duration of this template inside the timed step x the algorithmic GFLOP per launch of the live events" % src_r}
+                                           "source": "%s: average duration of this template inside the timed step x the algorithmic GFLOP per launch of the live events" % src_r,
+                                           "note": "begin-to-end durations with the step's four streams co-running (under the stream replay all of them are fed at once): a kernel's duration includes the time it shares the CUs with the other streams' kernels - the step got faster while these got longer; rocprof_one_lane is the kernel on its own"}
+            ms_1, src_1 = stored_kernel_avg_ms(pat, "_bench_kernel_stats_one_lane.csv")
+            if ms_1 and obj["launches"]:
+                gf = obj["algorithmic_gflop_per_launch"]
+                obj["rocprof_one_lane"] = {"avg_launch_ms": ms_1, "achieved": gf / ms_1, "frac": gf / ms_1 / peak,
+                                           "source": "%s: the same command with the recorded step laid out on ONE stream (TRID_STEP_LANES=1, tools/exp/r05_prof_one_lane.sh): every kernel has the chip to itself, as in the live one-stream events above" % src_1}
     # the two MFMA-bound tile kernels as equals, the one with the larger total per step first; and the HBM-bound streaming kernel
     nrun = max(profiled_eager, 1) if runner is not None else args.steps
     roofline["total_ms_per_step"] = ms / nrun
