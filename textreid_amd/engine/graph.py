@@ -115,7 +115,15 @@ class CapturedTrainStep:
 
         ops.begin_capture()
         torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph(keep_graph=True) if self.launch == "streams" else torch.cuda.CUDAGraph()
+        g = None
+        if self.launch == "streams":
+            try:
+                g = torch.cuda.CUDAGraph(keep_graph=True)  # the hipGraph_t must outlive the recording: the stream plan reads it back
+            except TypeError:  # (a PyTorch without keep_graph / raw_cuda_graph)
+                self.log.warning("train step: this PyTorch cannot hand out the recorded hipGraph - using hipGraphLaunch")
+                self.launch = "graph"
+        if g is None:
+            g = torch.cuda.CUDAGraph()
         # thread_local: every launch of the step is issued from this thread (the backward runs on the autograd engine's
         # thread for this device, which torch's capture tracks); a HIP call from an UNRELATED thread - a DataLoader's
         # pin_memory thread allocating or polling events - must not invalidate the ~1100-launch recording
