@@ -370,6 +370,21 @@ int trid_bn_bwd_apply_p16_f32(const void* g, int g_fmt, const void* y, int y_fmt
                               int mask_mode, int pooled, int B, int H, int W, int C, void* dy, int fmt, void* dres,
                               const float* bound, void* stream);
 
+/* The two BatchNorm layers of a downsample block that share one incoming gradient (m_resnet.py:62-66: out = relu(bn3(.) +
+ * downsample(x)): bn3 and the downsample branch's BatchNorm both see g masked by the block's ReLU bits) in ONE reduce pass
+ * and ONE apply pass: g [M][C] fp32, relu_bits = the block output's relu_mask (trid_bn_apply_p16_f32), y1 / y2 the two saved
+ * conv outputs with their batch (mean, invstd, scale) vectors.  dbeta (= sum g m) is the same for both layers and written to
+ * dbeta and dbeta2; ws: 2 x trid_bn_bwd_ws_floats(C) floats; bound1 / bound2: zeroed device scalars that receive the bounds
+ * of max|dy1| / max|dy2|, which the apply pass scales its P16 outputs by. */
+int trid_bn_bwd_dual_reduce_bound_f32(const float* g, const uint64_t* relu_bits, const float* y1, const float* y2, const float* mean1,
+                                      const float* invstd1, const float* scale1, const float* mean2, const float* invstd2,
+                                      const float* scale2, long long M, int C, float* dgamma1, float* dgamma2, float* dbeta,
+                                      float* dbeta2, float* ws, float* bound1, float* bound2, void* stream);
+int trid_bn_bwd_dual_apply_p16_f32(const float* g, const uint64_t* relu_bits, const float* y1, const float* y2, const float* mean1,
+                                   const float* invstd1, const float* scale1, const float* mean2, const float* invstd2,
+                                   const float* scale2, const float* dgamma1, const float* dgamma2, const float* dbeta, long long M,
+                                   int C, void* dy1, void* dy2, const float* bound1, const float* bound2, void* stream);
+
 /* ------------------------------------------------------------------------- *
  * Attention pool (m_resnet.py:103-135), token-0 query only.
  * ------------------------------------------------------------------------- */

@@ -994,6 +994,43 @@ def test_gemm_p16_bn_backward_sums_from_the_epilogue(ops, M_, N, K, conv, relu, 
         ops.gemm_p16(xp, ops.p16_pack(dev(R("bnbw96", 96, K))), ops.empty((M_, 96), xp.data), M_, 96, K, 96, conv=conv, bn_bwd=bad)
 
 
+@pytest.mark.parametrize("M_,C", [(128 * 24 * 8, 1024), (4 * 96 * 32 + 37, 256), (3000, 2048)])
+def test_bn_backward_of_two_layers_sharing_a_gradient(ops, M_, C):
+    """bn_pool.hip bn_bwd_dual_*: a downsample block's bn3 and the BatchNorm of its downsample branch receive the same gradient
+    behind the same ReLU bits - one reduce pass and one apply pass for both must return what two separate backward calls
+    return (same per-element arithmetic; the sums in another blocking: 1e-5 of each vector's largest entry; dy to the last
+    bits of its P16 scale)."""
+    import torch as T
+
+    g4 = dev(R("dualg%d" % C, 1, 1, M_, C))
+    ys = [dev(R("dualy%d%d" % (k, C), 1, 1, M_, C) * (1.0 + k) + 0.3 * k) for k in range(2)]
+    sts = []
+    for k, y in enumerate(ys):
+        yd = y.double().reshape(M_, C)
+        mean, var = yd.mean(0), yd.var(0, unbiased=False)
+        invstd = 1.0 / T.sqrt(var + 1e-5)
+        gamma, beta = dev(R("dualga%d" % k, C).abs() + 0.5).double(), dev(R("dualbe%d" % k, C) * 0.3).double()
+
+        class St:
+            pass
+
+        st = St()
+        st.mean, st.invstd = mean.float().contiguous(), invstd.float().contiguous()
+        st.scale, st.shift = (gamma * invstd).float().contiguous(), (beta - gamma * invstd * mean).float().contiguous()
+        sts.append(st)
+    n4 = M_ * C // 4
+    bits = dev(T.randint(-2 ** 62, 2 ** 62, (((n4 + 63) // 64) * 4,), generator=T.Generator().manual_seed(C)))
+    assert ops.bn_bwd_dual_ok(g4, ys[0], ys[1])
+    a1 = ops.bn_bwd_p16(g4, ys[0], sts[0], 3, act=bits)
+    a2 = ops.bn_bwd_p16(g4, ys[1], sts[1], 3, act=bits)
+    dy1, dg1, db1, dy2, dg2, db2 = ops.bn_bwd_dual_p16(g4, bits, ys[0], sts[0], ys[1], sts[1])
+    for u, v, name in ((a1[1], dg1, "dgamma1"), (a1[2], db1, "dbeta1"), (a2[1], dg2, "dgamma2"), (a2[2], db2, "dbeta2")):
+        assert float((u - v).abs().max()) <= 1e-5 * float(u.abs().max()), name
+    for ref, got in ((a1[0], dy1), (a2[0], dy2)):
+        assert abs(float(ref.amax) - float(got.amax)) <= 1e-5 * float(ref.amax)
+        assert float((ref.unpack() - got.unpack()).abs().max()) <= 2e-5 * float(ref.unpack().abs().max())
+
+
 def test_abi_argument_errors_are_reported_not_fatal(ops):
     """C-ABI contract: bad arguments return a negative TRID_E_* code with a thread-local message
     (surfaced as RuntimeError by the binding) and leave the device usable - no abort, no sticky HIP error."""

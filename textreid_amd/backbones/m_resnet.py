@@ -538,11 +538,18 @@ def block_backward_p16(blk, rec, g, WPT, ws, G):
     # gradient lands on g itself with the mask applied to the old values in its epilogue (gemm_p16 cmask) - g is dead after
     # bn3's backward passes.  (TRID_MASKED_ACC=0: bn_bwd writes the masked copy, for A/B runs)
     masked_acc = _MASKED_ACC and not has_down and g.is_contiguous()
-    dyc, dg, db, dres = ops.bn_bwd_p16(g, yc, stc, 3, act=rmask, want_dres=not has_down and not masked_acc, fmt=fmt)
-    G[id(blk.bn3.weight)], G[id(blk.bn3.bias)] = dg, db
-    if has_down:
-        dyd, dg, db, _ = ops.bn_bwd_p16(g, yd, std, 3, act=rmask, fmt=fmt)
-        G[id(blk.downsample[2].weight)], G[id(blk.downsample[2].bias)] = dg, db
+    if has_down and ops.bn_bwd_dual_ok(g, yc, yd, fmt):
+        # bn3 and the downsample branch's BatchNorm share g and the mask: one reduce pass and one apply pass for both
+        dyc, dg, db, dyd, dg2, db2 = ops.bn_bwd_dual_p16(g, rmask, yc, stc, yd, std)
+        G[id(blk.bn3.weight)], G[id(blk.bn3.bias)] = dg, db
+        G[id(blk.downsample[2].weight)], G[id(blk.downsample[2].bias)] = dg2, db2
+        dres = None
+    else:
+        dyc, dg, db, dres = ops.bn_bwd_p16(g, yc, stc, 3, act=rmask, want_dres=not has_down and not masked_acc, fmt=fmt)
+        G[id(blk.bn3.weight)], G[id(blk.bn3.bias)] = dg, db
+        if has_down:
+            dyd, dg, db, _ = ops.bn_bwd_p16(g, yd, std, 3, act=rmask, fmt=fmt)
+            G[id(blk.downsample[2].weight)], G[id(blk.downsample[2].bias)] = dg, db
     planes = blk.conv2.out_channels
     Mc = dyc.data.numel() // dyc.shape[-1]
     dab = ops.empty(tuple(ab.shape), g, dtype=g.dtype)  # (bf16 mode: data gradients are bf16 tensors, like g)

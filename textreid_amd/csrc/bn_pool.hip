@@ -642,6 +642,134 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a, const fl
     if (OFMT == 0 && amax != nullptr) amax_commit(am, amax);
 }
 
+// ---- the two BatchNorm layers that share a gradient: a downsample block's bn3 and the BatchNorm of its downsample branch
+// (m_resnet.py:62-66: out = relu(bn3(conv3(.)) + downsample(x))) both receive g masked by the block's ReLU bits.  One pass
+// reads g, the bits and BOTH saved conv outputs: sum g m is shared, sum g m xhat and the maxima are kept per layer, in the
+// workspaces bn_bwd_reduce_final_kernel folds (one call per layer).  12 instead of 16 bytes per element for the sums,
+// 20 instead of 24 for the apply pass, two launches instead of four.
+struct BnBwdDual {
+    const float4* g;
+    const unsigned long long* bits;  // relu_mask of the block output
+    const float4* y1;
+    const float4* y2;
+    const float4* mean1;
+    const float4* invstd1;
+    const float4* scale1;
+    const float4* mean2;
+    const float4* invstd2;
+    const float4* scale2;
+    int CQ;
+    long long total4;
+    int nt;
+};
+
+__device__ __forceinline__ void bn_bwd_dual_elem(const BnBwdDual& a, long long i, int cq, float4& gm, float4& xh1, float4& xh2) {
+    float4 g = ld_stream4(a.g + i, a.nt);
+    const float4 ya = ld_stream4(a.y1 + i, a.nt), yb = ld_stream4(a.y2 + i, a.nt);
+    const unsigned long long* m = a.bits + (i >> 6) * 4;
+    const int bit = (int)(i & 63);
+    g.x = ((m[0] >> bit) & 1ull) ? g.x : 0.f; g.y = ((m[1] >> bit) & 1ull) ? g.y : 0.f;
+    g.z = ((m[2] >> bit) & 1ull) ? g.z : 0.f; g.w = ((m[3] >> bit) & 1ull) ? g.w : 0.f;
+    const float4 mu1 = a.mean1[cq], is1 = a.invstd1[cq], mu2 = a.mean2[cq], is2 = a.invstd2[cq];
+    xh1 = make_float4((ya.x - mu1.x) * is1.x, (ya.y - mu1.y) * is1.y, (ya.z - mu1.z) * is1.z, (ya.w - mu1.w) * is1.w);
+    xh2 = make_float4((yb.x - mu2.x) * is2.x, (yb.y - mu2.y) * is2.y, (yb.z - mu2.z) * is2.z, (yb.w - mu2.w) * is2.w);
+    gm = g;
+}
+
+// ws layout per layer as bn_bwd_reduce_kernel<true>: wsA / wsB = [grid][CW][8] sums (s1 | s2), ws2A / ws2B = maxima (|g m| | |xhat|)
+__global__ __launch_bounds__(256) void bn_bwd_dual_reduce_kernel(BnBwdDual a, float* __restrict__ wsA, float* __restrict__ ws2A,
+                                                                 float* __restrict__ wsB, float* __restrict__ ws2B) {
+    const int tid = threadIdx.x;
+    const long long T = (long long)gridDim.x * 256;
+    const long long t0 = (long long)blockIdx.x * 256 + tid;
+    const int cq = (int)(t0 % a.CQ);
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), sa = s1, sb = s1, mg = s1, ma = s1, mb = s1;
+    for (long long i = t0; i < a.total4; i += T) {
+        float4 gm, x1, x2;
+        bn_bwd_dual_elem(a, i, cq, gm, x1, x2);
+        s1.x += gm.x; s1.y += gm.y; s1.z += gm.z; s1.w += gm.w;
+        sa.x = fmaf(gm.x, x1.x, sa.x); sa.y = fmaf(gm.y, x1.y, sa.y); sa.z = fmaf(gm.z, x1.z, sa.z); sa.w = fmaf(gm.w, x1.w, sa.w);
+        sb.x = fmaf(gm.x, x2.x, sb.x); sb.y = fmaf(gm.y, x2.y, sb.y); sb.z = fmaf(gm.z, x2.z, sb.z); sb.w = fmaf(gm.w, x2.w, sb.w);
+        mg.x = fmaxf(mg.x, fabsf(gm.x)); mg.y = fmaxf(mg.y, fabsf(gm.y)); mg.z = fmaxf(mg.z, fabsf(gm.z)); mg.w = fmaxf(mg.w, fabsf(gm.w));
+        ma.x = fmaxf(ma.x, fabsf(x1.x)); ma.y = fmaxf(ma.y, fabsf(x1.y)); ma.z = fmaxf(ma.z, fabsf(x1.z)); ma.w = fmaxf(ma.w, fabsf(x1.w));
+        mb.x = fmaxf(mb.x, fabsf(x2.x)); mb.y = fmaxf(mb.y, fabsf(x2.y)); mb.z = fmaxf(mb.z, fabsf(x2.z)); mb.w = fmaxf(mb.w, fabsf(x2.w));
+    }
+    __shared__ float red[256][13];
+    const int CW = a.CQ < 256 ? a.CQ : 256;
+    // sums: s1 (shared), sa, sb
+    red[tid][0] = s1.x; red[tid][1] = s1.y; red[tid][2] = s1.z; red[tid][3] = s1.w;
+    red[tid][4] = sa.x; red[tid][5] = sa.y; red[tid][6] = sa.z; red[tid][7] = sa.w;
+    red[tid][8] = sb.x; red[tid][9] = sb.y; red[tid][10] = sb.z; red[tid][11] = sb.w;
+    __syncthreads();
+    if (tid < CW) {
+        float acc[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) acc[k] = 0.f;
+        for (int r = tid; r < 256; r += CW)
+#pragma unroll
+            for (int k = 0; k < 12; ++k) acc[k] += red[r][k];
+        float* da = wsA + ((long long)blockIdx.x * CW + tid) * 8;
+        float* db = wsB + ((long long)blockIdx.x * CW + tid) * 8;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            da[k] = acc[k]; db[k] = acc[k];
+            da[4 + k] = acc[4 + k]; db[4 + k] = acc[8 + k];
+        }
+    }
+    __syncthreads();
+    red[tid][0] = mg.x; red[tid][1] = mg.y; red[tid][2] = mg.z; red[tid][3] = mg.w;
+    red[tid][4] = ma.x; red[tid][5] = ma.y; red[tid][6] = ma.z; red[tid][7] = ma.w;
+    red[tid][8] = mb.x; red[tid][9] = mb.y; red[tid][10] = mb.z; red[tid][11] = mb.w;
+    __syncthreads();
+    if (tid < CW) {
+        float acc[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) acc[k] = 0.f;
+        for (int r = tid; r < 256; r += CW)
+#pragma unroll
+            for (int k = 0; k < 12; ++k) acc[k] = fmaxf(acc[k], red[r][k]);
+        float* da = ws2A + ((long long)blockIdx.x * CW + tid) * 8;
+        float* db = ws2B + ((long long)blockIdx.x * CW + tid) * 8;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            da[k] = acc[k]; db[k] = acc[k];
+            da[4 + k] = acc[4 + k]; db[4 + k] = acc[8 + k];
+        }
+    }
+}
+
+// dy1 / dy2: P16 tensors scaled for *bound1 / *bound2 (the folds of the two layers)
+__global__ __launch_bounds__(256) void bn_bwd_dual_apply_kernel(BnBwdDual a, const float4* __restrict__ dgamma1, const float4* __restrict__ dgamma2,
+                                                                const float4* __restrict__ dbeta, float invM, float4* __restrict__ dy1,
+                                                                float4* __restrict__ dy2, const float* __restrict__ bound1,
+                                                                const float* __restrict__ bound2) {
+    const float os1 = f16_scale_of(*bound1), os2 = f16_scale_of(*bound2);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < a.total4; i += (long long)gridDim.x * 256) {
+        const int cq = (int)(i % a.CQ);
+        float4 gm, x1, x2;
+        bn_bwd_dual_elem(a, i, cq, gm, x1, x2);
+        const float4 db = dbeta[cq];
+        {
+            const float4 sc = a.scale1[cq], dg = dgamma1[cq];
+            float4 o;
+            o.x = sc.x * (gm.x - db.x * invM - x1.x * dg.x * invM);
+            o.y = sc.y * (gm.y - db.y * invM - x1.y * dg.y * invM);
+            o.z = sc.z * (gm.z - db.z * invM - x1.z * dg.z * invM);
+            o.w = sc.w * (gm.w - db.w * invM - x1.w * dg.w * invM);
+            p16_store4(reinterpret_cast<uint2*>(dy1), i, a.CQ, o, os1, a.nt);
+        }
+        {
+            const float4 sc = a.scale2[cq], dg = dgamma2[cq];
+            float4 o;
+            o.x = sc.x * (gm.x - db.x * invM - x2.x * dg.x * invM);
+            o.y = sc.y * (gm.y - db.y * invM - x2.y * dg.y * invM);
+            o.z = sc.z * (gm.z - db.z * invM - x2.z * dg.z * invM);
+            o.w = sc.w * (gm.w - db.w * invM - x2.w * dg.w * invM);
+            p16_store4(reinterpret_cast<uint2*>(dy2), i, a.CQ, o, os2, a.nt);
+        }
+    }
+}
+
 // non-temporal accesses for this launch?  (bytes of ONE fp32-sized tensor of the pass; TRID_BN_NT=0 / 1 forces it off / on)
 static int stream_nt(long long tensor_bytes) {
     static const int env = getenv("TRID_BN_NT") ? atoi(getenv("TRID_BN_NT")) : -1;
@@ -907,6 +1035,57 @@ extern "C" int trid_bn_bwd_reduce_bound_f32(const float* g, const float* y, cons
     hipLaunchKernelGGL(bn_bwd_reduce_final_kernel, dim3(a.CQ), dim3(256), 0, (hipStream_t)stream, ws, grid, a.CQ, dgamma,
                        dbeta, C, (const float*)ws2, scale, invM, bound);
     return check_launch("trid_bn_bwd_reduce_bound_f32");
+}
+
+static int bn_bwd_dual_fill(BnBwdDual& a, const float* g, const uint64_t* bits, const float* y1, const float* y2, const float* mean1,
+                            const float* invstd1, const float* scale1, const float* mean2, const float* invstd2, const float* scale2,
+                            long long M, int C) {
+    TRID_REQUIRE(g && bits && y1 && y2 && mean1 && invstd1 && scale1 && mean2 && invstd2 && scale2, "bn_bwd_dual: null pointer");
+    TRID_REQUIRE(M > 0 && M < (1ll << 31) && C > 0 && C % 32 == 0, "bn_bwd_dual: bad shape (C %% 32)");
+    const int CQ = C / 4;
+    TRID_REQUIRE(256 % CQ == 0 || CQ % 256 == 0, "bn_bwd_dual: C/4 must divide 256 or be a multiple of 256 (C=%d)", C);
+    a.g = (const float4*)g; a.bits = (const unsigned long long*)bits; a.y1 = (const float4*)y1; a.y2 = (const float4*)y2;
+    a.mean1 = (const float4*)mean1; a.invstd1 = (const float4*)invstd1; a.scale1 = (const float4*)scale1;
+    a.mean2 = (const float4*)mean2; a.invstd2 = (const float4*)invstd2; a.scale2 = (const float4*)scale2;
+    a.CQ = CQ;
+    a.total4 = M * CQ;
+    a.nt = stream_nt(a.total4 * 16);
+    return TRID_OK;
+}
+
+// ws: 2 x trid_bn_bwd_ws_floats(C) floats (one workspace per layer)
+extern "C" int trid_bn_bwd_dual_reduce_bound_f32(const float* g, const uint64_t* relu_bits, const float* y1, const float* y2, const float* mean1,
+                                                 const float* invstd1, const float* scale1, const float* mean2, const float* invstd2,
+                                                 const float* scale2, long long M, int C, float* dgamma1, float* dgamma2, float* dbeta,
+                                                 float* dbeta2, float* ws, float* bound1, float* bound2, void* stream) {
+    BnBwdDual a;
+    int rc = bn_bwd_dual_fill(a, g, relu_bits, y1, y2, mean1, invstd1, scale1, mean2, invstd2, scale2, M, C);
+    if (rc) return rc;
+    TRID_REQUIRE(dgamma1 && dgamma2 && dbeta && dbeta2 && ws && bound1 && bound2, "trid_bn_bwd_dual_reduce_bound_f32: null output");
+    const int grid = bn_bwd_grid(a.total4, a.CQ);
+    const int CW = a.CQ < 256 ? a.CQ : 256;
+    const long long half = (long long)(1024 + 8) * CW * 8;
+    float* wsA = ws; float* ws2A = ws + half; float* wsB = ws + 2 * half; float* ws2B = ws + 3 * half;
+    const float invM = 1.f / (float)M;
+    hipLaunchKernelGGL(bn_bwd_dual_reduce_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, wsA, ws2A, wsB, ws2B);
+    hipLaunchKernelGGL(bn_bwd_reduce_final_kernel, dim3(a.CQ), dim3(256), 0, (hipStream_t)stream, (const float*)wsA, grid, a.CQ, dgamma1, dbeta, C,
+                       (const float*)ws2A, scale1, invM, bound1);
+    hipLaunchKernelGGL(bn_bwd_reduce_final_kernel, dim3(a.CQ), dim3(256), 0, (hipStream_t)stream, (const float*)wsB, grid, a.CQ, dgamma2, dbeta2, C,
+                       (const float*)ws2B, scale2, invM, bound2);
+    return check_launch("trid_bn_bwd_dual_reduce_bound_f32");
+}
+
+extern "C" int trid_bn_bwd_dual_apply_p16_f32(const float* g, const uint64_t* relu_bits, const float* y1, const float* y2, const float* mean1,
+                                              const float* invstd1, const float* scale1, const float* mean2, const float* invstd2,
+                                              const float* scale2, const float* dgamma1, const float* dgamma2, const float* dbeta, long long M,
+                                              int C, void* dy1, void* dy2, const float* bound1, const float* bound2, void* stream) {
+    BnBwdDual a;
+    int rc = bn_bwd_dual_fill(a, g, relu_bits, y1, y2, mean1, invstd1, scale1, mean2, invstd2, scale2, M, C);
+    if (rc) return rc;
+    TRID_REQUIRE(dgamma1 && dgamma2 && dbeta && dy1 && dy2 && bound1 && bound2, "trid_bn_bwd_dual_apply_p16_f32: null pointer");
+    hipLaunchKernelGGL(bn_bwd_dual_apply_kernel, dim3(grid_for(a.total4, 256 * 4)), dim3(256), 0, (hipStream_t)stream, a, (const float4*)dgamma1,
+                       (const float4*)dgamma2, (const float4*)dbeta, 1.f / (float)M, (float4*)dy1, (float4*)dy2, bound1, bound2);
+    return check_launch("trid_bn_bwd_dual_apply_p16_f32");
 }
 
 extern "C" int trid_bn_bwd_apply_f32(const float* g, const float* y, const float* act, const float* mean,

@@ -733,6 +733,37 @@ def bn_bwd_p16(g, y, st, mask_mode, act=None, pooled=False, want_dres=False, fmt
     return P16(dy, bound, fmt), dgamma, dbeta, dres
 
 
+USE_BN_DUAL = os.environ.get("TRID_BN_DUAL", "1") != "0"  # bn3 + downsample BatchNorm backward in one reduce / one apply pass (0: A/B runs)
+
+
+def bn_bwd_dual_ok(g, y1, y2, fmt=1):
+    C = y1.shape[-1]
+    CQ = C // 4
+    return (USE_BN_DUAL and fmt == 1 and g.dtype == torch.float32 and y1.dtype == torch.float32 and y2.dtype == torch.float32 and g.is_contiguous()
+            and tuple(y1.shape) == tuple(y2.shape) == tuple(g.shape) and C % 32 == 0 and (256 % CQ == 0 or CQ % 256 == 0))
+
+
+def bn_bwd_dual_p16(g, bits, y1, st1, y2, st2):
+    """The backward of the two BatchNorm layers a downsample block's output gradient feeds (bn3 and the downsample branch's), both
+    behind the block's ReLU mask `bits`: one reduce pass and one apply pass over (g, y1, y2).  Returns
+    (dy1 P16, dgamma1, dbeta, dy2 P16, dgamma2, dbeta2) - what two bn_bwd_p16(..., 3, act=bits) calls return."""
+    C = y1.shape[-1]
+    M = y1.numel() // C
+    dg = empty((4, C), y1)
+    key = ("dual", C, y1.device, stream(y1.device))
+    ws = _ws_cache.get(key)
+    if ws is None:
+        ws = empty((2 * L.load().trid_bn_bwd_ws_floats(C),), y1)
+        _ws_cache[key] = ws
+    b1, b2 = amax_slot(y1.device), amax_slot(y1.device)
+    call("trid_bn_bwd_dual_reduce_bound_f32", _p(g), _p(bits), _p(y1), _p(y2), _p(st1.mean), _p(st1.invstd), _p(st1.scale), _p(st2.mean),
+         _p(st2.invstd), _p(st2.scale), M, C, _p(dg[0]), _p(dg[1]), _p(dg[2]), _p(dg[3]), _p(ws), _p(b1), _p(b2), stream())
+    dy1, dy2 = p16_empty(y1.shape, y1, 1), p16_empty(y2.shape, y2, 1)
+    call("trid_bn_bwd_dual_apply_p16_f32", _p(g), _p(bits), _p(y1), _p(y2), _p(st1.mean), _p(st1.invstd), _p(st1.scale), _p(st2.mean),
+         _p(st2.invstd), _p(st2.scale), _p(dg[0]), _p(dg[1]), _p(dg[2]), M, C, _p(dy1), _p(dy2), _p(b1), _p(b2), stream())
+    return P16(dy1, b1, 1), dg[0], dg[2], P16(dy2, b2, 1), dg[1], dg[3]
+
+
 def wgrad_p16(dy, x, conv=None, alpha=1.0):
     """Weight gradient on P16 operands: dW [N, J] = dy[M,N]^T @ X[M,J] with X = x [M, C] (1x1) or the 3x3 gather of the
     NHWC image x [B,H,W,C] (conv=(H,W,C), J = 9*C).  Split over the pixels, slabs folded by trid_slab_reduce_f32."""
