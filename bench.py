@@ -570,7 +570,8 @@ def main():
         from textreid_amd.engine.graph import CapturedTrainStep
 
         runner = CapturedTrainStep(model, opt, warmup=2, caption_bound=64,  # 64-token captions (padded to 105)
-                                   reducer=reducer if world > 1 else None, pre_gather=pre_gather)
+                                   reducer=reducer if world > 1 else None, pre_gather=pre_gather,
+                                   launch="graph" if world > 1 else None)  # (a recording with RCCL's kernels is launched as a graph)
 
     def batch(i):
         images, tokens, lengths, ids = batches[i % len(batches)]
