@@ -7,9 +7,10 @@ cd /tmp && export TMPDIR=/tmp
 TRID_BENCH_LAUNCH=streams rocprofv3 --kernel-trace --output-format csv -d $OUT/kt -- python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-retrieval --no-configs3 > $OUT/line.json 2> $OUT/kt.err
 cd $GRAFT_REPO_ROOT
 f=$(find "$OUT/kt" -name "*kernel_trace.csv" | head -1)
-python tools/trace_gaps.py $f 26 32 > $OUT/gaps.txt 2>&1
+python tools/trace_gaps.py $f 27 31 > $OUT/gaps.txt 2>&1
 python tools/trace_streams.py $f adam 28 30 > $OUT/streams.txt 2>&1 || true
 python tools/trace_busy.py $f 0.3 > $OUT/busy.txt 2>&1 || true
 python tools/trace_region.py $f 28 -2.5 5.0 > $OUT/region.txt 2>&1 || true
+python tools/trace_region.py $f 28 9.0 16.0 > $OUT/region_head.txt 2>&1 || true
 rm -rf $OUT/kt
-cat $OUT/region.txt | cut -c1-150
+head -20 $OUT/gaps.txt
