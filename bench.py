@@ -612,7 +612,7 @@ def main():
     launch_probe = None
     use_eager = False
     if runner is not None and runner.graph is not None:
-        def probe(fn, n=4):
+        def probe(fn, n=6):
             torch.cuda.synchronize()
             t0p = time.perf_counter()
             for j in range(n):
@@ -626,13 +626,13 @@ def main():
         ms_graph = None
         try:  # hipGraphLaunch of the same recording
             runner.force_graph_launch = True
-            step(base + 6)
-            ms_graph = probe(lambda j: step(base + 7 + j))
+            step(base + 8)
+            ms_graph = probe(lambda j: step(base + 9 + j))
         except RuntimeError as e:
             log("launch probe: hipGraphLaunch failed (%s)" % (str(e).splitlines()[0] if str(e) else type(e).__name__))
         finally:
             runner.force_graph_launch = False
-        ms_eager = probe(lambda j: runner._eager(*batch(base + 11 + j)))
+        ms_eager = probe(lambda j: runner._eager(*batch(base + 15 + j)))
         forced = os.environ.get("TRID_BENCH_LAUNCH", "")
         cands = {"stream replay": ms_streams, "hipgraph replay": ms_graph, "eager": ms_eager}
         if forced in ("eager", "graph", "streams"):
@@ -652,7 +652,7 @@ def main():
         runner.force_graph_launch = chosen == "hipgraph replay"
         log("launch probe: stream replay %s, hipGraphLaunch %s, eager %.2f ms per step -> %s" % (
             "%.2f" % ms_streams if ms_streams else "-", "%.2f" % ms_graph if ms_graph else "-", ms_eager, chosen))
-        n_prep += 17
+        n_prep += 23
     timed_step = (lambda i: runner._eager(*batch(i))) if use_eager else step
     # live roofline of the dominant kernel: 3x3 implicit-GEMM conv, 128x128 tiles
     split = ops.GEMM_PRECISION in (1, 3, 6)
