@@ -354,7 +354,7 @@ __global__ __attribute__((amdgpu_num_vgpr(32))) void bn_apply_kernel(const float
         }
         if (relu) v = relu4(v);
         if (OFMT == 1) {
-            p16_store4(reinterpret_cast<uint2*>(out), i, CQ, v, oscale, nt);
+            p16_store4_pair(reinterpret_cast<uint2*>(out), i, CQ, v, oscale, nt);  // (total4 is even and the stride a multiple of 256: lane pairs hold quad pairs)
         } else if (OFMT == 2) {
             bf16_store4(reinterpret_cast<uint2*>(out), i, v);
         } else {
@@ -400,7 +400,7 @@ __global__ void bn_apply_pool2_kernel(const float4* __restrict__ y, const float4
             }
         const float4 o = make_float4(acc.x * 0.25f, acc.y * 0.25f, acc.z * 0.25f, acc.w * 0.25f);
         if (OFMT == 1) {
-            p16_store4(reinterpret_cast<uint2*>(out), i, CQ, o, oscale);
+            p16_store4_pair(reinterpret_cast<uint2*>(out), i, CQ, o, oscale);
         } else if (OFMT == 2) {
             bf16_store4(reinterpret_cast<uint2*>(out), i, o);
         } else {
@@ -627,7 +627,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a, const fl
         o.z = sc.z * (gm.z - db.z * invM - xh.z * dg.z * invM);
         o.w = sc.w * (gm.w - db.w * invM - xh.w * dg.w * invM);
         if (OFMT == 1) {
-            p16_store4(reinterpret_cast<uint2*>(dy), i, a.CQ, o, oscale, a.nt);
+            p16_store4_pair(reinterpret_cast<uint2*>(dy), i, a.CQ, o, oscale, a.nt);
         } else if (OFMT == 2) {
             bf16_store4(reinterpret_cast<uint2*>(dy), i, o);
         } else {
@@ -756,7 +756,7 @@ __global__ __launch_bounds__(256) void bn_bwd_dual_apply_kernel(BnBwdDual a, con
             o.y = sc.y * (gm.y - db.y * invM - x1.y * dg.y * invM);
             o.z = sc.z * (gm.z - db.z * invM - x1.z * dg.z * invM);
             o.w = sc.w * (gm.w - db.w * invM - x1.w * dg.w * invM);
-            p16_store4(reinterpret_cast<uint2*>(dy1), i, a.CQ, o, os1, a.nt);
+            p16_store4_pair(reinterpret_cast<uint2*>(dy1), i, a.CQ, o, os1, a.nt);
         }
         {
             const float4 sc = a.scale2[cq], dg = dgamma2[cq];
@@ -765,7 +765,7 @@ __global__ __launch_bounds__(256) void bn_bwd_dual_apply_kernel(BnBwdDual a, con
             o.y = sc.y * (gm.y - db.y * invM - x2.y * dg.y * invM);
             o.z = sc.z * (gm.z - db.z * invM - x2.z * dg.z * invM);
             o.w = sc.w * (gm.w - db.w * invM - x2.w * dg.w * invM);
-            p16_store4(reinterpret_cast<uint2*>(dy2), i, a.CQ, o, os2, a.nt);
+            p16_store4_pair(reinterpret_cast<uint2*>(dy2), i, a.CQ, o, os2, a.nt);
         }
     }
 }

@@ -210,6 +210,24 @@ __device__ __forceinline__ void p16_store4(uint2* __restrict__ base, long long i
     st_stream2(dst, make_uint2(h0, h1), nt);
     st_stream2(dst + 8, make_uint2(l0, l1), nt);
 }
+// The same store from a wave whose lanes 2k, 2k + 1 hold quads i, i + 1 (i even) of one row - the elementwise passes, whose
+// quad index runs with the thread index: the pair swaps plane halves (the even lane takes both quads' high parts, the odd lane
+// both low parts) and every lane writes ONE 16-byte piece, so a wave's store instruction covers whole 128-byte lines.  With
+// two 8-byte stores per lane each instruction wrote every other 64-byte half line: bn_apply ran at 4.6-4.75 TB/s writing P16
+// against 5.5-6.9 writing fp32 (profiles/r05g_bn_bandwidth_probe.txt).  Every lane of the wave must make the call (shuffle).
+__device__ __forceinline__ void p16_store4_pair(uint2* __restrict__ base, long long i, int CQ, float4 v, float scale, bool nt = false) {
+    const long long row = i / CQ;
+    const int cq = (int)(i - row * CQ);
+    unsigned h0, l0, h1, l1;
+    f16_split2(v.x * scale, v.y * scale, h0, l0);
+    f16_split2(v.z * scale, v.w * scale, h1, l1);
+    const bool odd = (cq & 1) != 0;
+    const unsigned rx = __shfl_xor(odd ? h0 : l0, 1, 64), ry = __shfl_xor(odd ? h1 : l1, 1, 64);
+    const float4 piece = odd ? make_float4(__uint_as_float(rx), __uint_as_float(ry), __uint_as_float(l0), __uint_as_float(l1))
+                             : make_float4(__uint_as_float(h0), __uint_as_float(h1), __uint_as_float(rx), __uint_as_float(ry));
+    uint2* dst = base + row * (2 * CQ) + (cq >> 3) * 16 + (odd ? 8 + (cq & 7) - 1 : (cq & 7));
+    st_stream4(reinterpret_cast<float4*>(dst), piece, nt);
+}
 __device__ __forceinline__ float4 p16_load4(const uint2* __restrict__ base, long long i, int CQ, float inv) {
     const long long row = i / CQ;
     const int cq = (int)(i - row * CQ);

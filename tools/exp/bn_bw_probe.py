@@ -48,5 +48,7 @@ for (B, H, W, C) in ((128, 96, 32, 256), (128, 48, 16, 512), (128, 24, 8, 1024),
     t_bwd = timeit(lambda: ops.bn_bwd_p16(g, y2, st, 1))
     bound = ops.amax(y2)
     t_fwd = timeit(lambda: ops.bn_apply_p16(y2, st, bound, relu=True))
-    print("[%d,%d,%d,%d] %6.1f MB/tensor | add %6.1f us %5.2f TB/s | copy %6.1f us %5.2f TB/s | bn_bwd (reduce+final+apply, 20 B/el) %6.1f us %5.2f TB/s | bn_apply (8 B/el) %6.1f us %5.2f TB/s"
-          % (B, H, W, C, n * 4 / 1e6, t_add, 12 * n / t_add / 1e6, t_cpy, 8 * n / t_cpy / 1e6, t_bwd, 20 * n / t_bwd / 1e6, t_fwd, 8 * n / t_fwd / 1e6))
+    t_f32 = timeit(lambda: ops.bn_apply(y2, st, relu=True))
+    print("[%d,%d,%d,%d] %6.1f MB/tensor | add %6.1f us %5.2f TB/s | copy %6.1f us %5.2f TB/s | bn_bwd (reduce+final+apply, 20 B/el) %6.1f us %5.2f TB/s | bn_apply (8 B/el) P16 out %6.1f us %5.2f TB/s, fp32 out %6.1f us %5.2f TB/s"
+          % (B, H, W, C, n * 4 / 1e6, t_add, 12 * n / t_add / 1e6, t_cpy, 8 * n / t_cpy / 1e6, t_bwd, 20 * n / t_bwd / 1e6, t_fwd, 8 * n / t_fwd / 1e6,
+             t_f32, 8 * n / t_f32 / 1e6))
