@@ -498,8 +498,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 && STAGES == 2) ? 2 : (W
                         unsigned q0h, q0l, q1h, q1l;
                         f16_split2(a.x * oscale, a.y * oscale, q0h, q0l);
                         f16_split2(a.z * oscale, a.w * oscale, q1h, q1l);
-                        *reinterpret_cast<uint2*>(outb + at) = make_uint2(q0h, q1h);
-                        *reinterpret_cast<uint2*>(outb + at + 64) = make_uint2(q0l, q1l);
+                        p16_pair_store(outb + at, c4, q0h, q0l, q1h, q1l);
                     }
                 } else
 #pragma unroll
@@ -522,8 +521,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 && STAGES == 2) ? 2 : (W
                     unsigned q0h, q0l, q1h, q1l;
                     f16_split2(v.x * oscale, v.y * oscale, q0h, q0l);
                     f16_split2(v.z * oscale, v.w * oscale, q1h, q1l);
-                    *reinterpret_cast<uint2*>(outb + at) = make_uint2(q0h, q1h);
-                    *reinterpret_cast<uint2*>(outb + at + 64) = make_uint2(q0l, q1l);
+                    p16_pair_store(outb + at, c4, q0h, q0l, q1h, q1l);
                 }
                 // ONE atomic per workgroup, and only when it saw something above what the scalar held when it started (after the
                 // first round of resident workgroups nearly none does).  Same-address device-scope atomics retire one by one,

@@ -637,12 +637,23 @@ __global__ __launch_bounds__(512, 2) void gemm_p16_stream_kernel(StreamParams p)
                             tmax_bits = a > tmax_bits ? a : tmax_bits;
                         }
                     }
+                    // Whole 128-byte lines per store instruction: the four lanes of row r (even) and the four of row r + 1 swap
+                    // low planes - the first store writes row r (high parts from its own lanes, low parts through the lanes of
+                    // row r + 1), the second row r + 1.  (With one row's 64-byte plane half per lane quad and instruction every
+                    // store covered half lines: split_common.h p16_store4_pair.)
+                    v4u pol;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) pol[q] = (unsigned)__shfl_xor((int)ol[q], 4, 64);
+                    const bool odd_row = (rl & 1) != 0;
+                    const unsigned off_e = col_live ? (row & ~1u) * rowb + (unsigned)(n0 >> 5) * 128u + (unsigned)oc * 16u + (odd_row ? 64u : 0u) : OOB;
+                    const unsigned off_o = col_live ? (row | 1u) * rowb + (unsigned)(n0 >> 5) * 128u + (unsigned)oc * 16u + (odd_row ? 0u : 64u) : OOB;
+                    const v4u d_e = odd_row ? pol : oh, d_o = odd_row ? oh : pol;
                     if (p.nt_o) {
-                        __builtin_amdgcn_raw_buffer_store_b128(oh, rsO, off, 0, 2);
-                        __builtin_amdgcn_raw_buffer_store_b128(ol, rsO, col_live ? off + 64u : OOB, 0, 2);
+                        __builtin_amdgcn_raw_buffer_store_b128(d_e, rsO, off_e, 0, 2);
+                        __builtin_amdgcn_raw_buffer_store_b128(d_o, rsO, off_o, 0, 2);
                     } else {
-                        __builtin_amdgcn_raw_buffer_store_b128(oh, rsO, off, 0, 0);
-                        __builtin_amdgcn_raw_buffer_store_b128(ol, rsO, col_live ? off + 64u : OOB, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(d_e, rsO, off_e, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(d_o, rsO, off_o, 0, 0);
                     }
                 }
                 if (p.mask != nullptr) {

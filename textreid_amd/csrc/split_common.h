@@ -228,6 +228,14 @@ __device__ __forceinline__ void p16_store4_pair(uint2* __restrict__ base, long l
     uint2* dst = base + row * (2 * CQ) + (cq >> 3) * 16 + (odd ? 8 + (cq & 7) - 1 : (cq & 7));
     st_stream4(reinterpret_cast<float4*>(dst), piece, nt);
 }
+// ... for a lane that already holds the planes of its channel quad (dwords q0 = channels 0, 1; q1 = channels 2, 3) and the
+// byte address `hi` of the quad's high part: lanes with quad numbers c4, c4 ^ 1 (same row) are neighbours in the wave
+__device__ __forceinline__ void p16_pair_store(char* hi, int c4, unsigned q0h, unsigned q0l, unsigned q1h, unsigned q1l) {
+    const bool odd = (c4 & 1) != 0;
+    const unsigned rx = __shfl_xor(odd ? q0h : q0l, 1, 64), ry = __shfl_xor(odd ? q1h : q1l, 1, 64);
+    const uint4 piece = odd ? make_uint4(rx, ry, q0l, q1l) : make_uint4(q0h, q1h, rx, ry);
+    *reinterpret_cast<uint4*>(odd ? hi + 56 : hi) = piece;  // (odd: the low plane's 16 bytes of quads c4 - 1, c4 = 64 bytes on, 8 back)
+}
 __device__ __forceinline__ float4 p16_load4(const uint2* __restrict__ base, long long i, int CQ, float inv) {
     const long long row = i / CQ;
     const int cq = (int)(i - row * CQ);
