@@ -10,7 +10,6 @@ f=$(find "$OUT/kt" -name "*kernel_trace.csv" | head -1)
 python tools/trace_gaps.py $f 27 31 > $OUT/gaps.txt 2>&1
 python tools/trace_streams.py $f adam 28 30 > $OUT/streams.txt 2>&1 || true
 python tools/trace_busy.py $f 0.3 > $OUT/busy.txt 2>&1 || true
-python tools/trace_region.py $f 28 -2.5 5.0 > $OUT/region.txt 2>&1 || true
-python tools/trace_region.py $f 28 9.0 16.0 > $OUT/region_head.txt 2>&1 || true
+python tools/trace_lane_gaps.py $f 27 30 > $OUT/lane_gaps.txt 2>&1 || true
 rm -rf $OUT/kt
-head -20 $OUT/gaps.txt
+cat $OUT/lane_gaps.txt
