@@ -175,6 +175,23 @@ extern "C" int trid_step_replay_build(void* graph_, int max_lanes, void** out) {
         tail[pick] = v;
         load[pick]++;
     }
+    if (getenv("TRID_REPLAY_DEBUG")) {  // what each lane starts with
+        for (size_t l = 0; l < tail.size(); ++l) {
+            int shown = 0;
+            fprintf(stderr, "[step_replay] lane %d: %d nodes:", (int)l, load[l]);
+            for (int v : order)
+                if (lane[v] == (int)l && raw[v].type == hipGraphNodeTypeKernel && shown < 6) {
+                    const char* nm = hipKernelNameRefByPtr(raw[v].k.func, nullptr);
+                    fprintf(stderr, " %.28s", nm ? nm : "?");
+                    ++shown;
+                }
+            fprintf(stderr, "\n");
+        }
+    }
+    // (Holding the key encoder a fixed number of kernels behind the query encoder - extra edges b_j after a_{j + d1}, a_{j + d2}
+    // after b_j, so that one encoder's BatchNorm passes meet the other's convolutions instead of both running the same kind of
+    // kernel at the same time - was tried on this plan: 44.3-45.7 ms per step against 41.85, the ~380 extra event waits cost
+    // more than the pairing buys: profiles/r05g_replay_pingpong.txt, tools/exp/r05_run27.sh)
     std::vector<int> ev_of(n, -1);
     int n_events = 0;
     for (int v : order)
