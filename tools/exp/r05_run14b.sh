@@ -1,2 +1,2 @@
 #!/bin/bash
-python tools/exp/replay_probe.py 128 2>&1 | grep -v amdgpu.ids | tail -5
+python -m pytest tests/test_match_state_gpu.py -x -q -m gpu -k "replay or captur" 2>&1 | tail -3
