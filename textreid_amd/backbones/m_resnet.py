@@ -100,6 +100,7 @@ def _bn_coeffs(bn, partials, M, training, counters=None):
 
 import os as _os
 _SERIAL_WGRAD = "1" in (_os.environ.get("TRID_SERIAL_WGRAD", "0"), _os.environ.get("TRID_SERIAL", "0"))  # experiment: weight gradients on the main stream
+_BATCH_WGRAD = _os.environ.get("TRID_WGRAD_BATCH", "1") != "0"  # a block's weight gradients behind one event (0: one event each, A/B runs)
 
 
 class _WgradStream:
@@ -111,6 +112,7 @@ class _WgradStream:
         self.main = torch.cuda.current_stream(device)
         self.side = _WgradStream._streams.setdefault(device, torch.cuda.Stream(device=device))
         self.side.wait_stream(self.main)
+        self.pending = []
 
     _streams = {}
 
@@ -130,7 +132,34 @@ class _WgradStream:
         out.record_stream(self.main)
         return out
 
+    def defer(self, G, key, fn, tensors, keep=(), post=None):
+        """G[key] = post(fn(*tensors)), run on the side stream at the next flush().  Every run() costs the main stream an event
+        record (a marker packet: ~7 us of bubble on the stream that carries the step's critical path - 50 per backward pass in the
+        recorded step's timeline); a residual block's three or four weight gradients share ONE by waiting until the block's
+        last data gradient is enqueued (they start a few hundred microseconds later, on a stream that is never the long one)."""
+        if _SERIAL_WGRAD or not _BATCH_WGRAD:
+            out = self.run(fn, *tensors, keep=keep)
+            G[key] = post(out) if post is not None else out
+            return
+        self.pending.append((G, key, fn, tensors, keep, post))
+
+    def flush(self):
+        if not self.pending:
+            return
+        ev = torch.cuda.Event()
+        ev.record(self.main)
+        self.side.wait_event(ev)
+        for G, key, fn, tensors, keep, post in self.pending:
+            for t in tensors + tuple(k for k in keep if k is not None):
+                t.record_stream(self.side)
+            with torch.cuda.stream(self.side):
+                out = fn(*tensors)
+            out.record_stream(self.main)
+            G[key] = post(out) if post is not None else out
+        self.pending = []
+
     def join(self):
+        self.flush()
         self.main.wait_stream(self.side)
 
 
@@ -527,12 +556,13 @@ def block_backward_p16(blk, rec, g, WPT, ws, G):
 
     fmt = x.fmt
 
-    def wgrad(dy, act, conv=None):
+    def wgrad(weight, dy, act, conv=None, post=None):
+        """G[weight] = the weight gradient, computed on the side stream at the end of the block (ws.flush below)."""
         if conv is not None and fmt == 1 and ops.conv3x3_wgrad_halo_rows(conv[0], conv[1], conv[2], dy.shape[-1]):  # layer1's conv2
-            return ws.run(lambda d_, x_: ops.conv3x3_wgrad_halo_p16(ops.P16(d_, dy.amax), ops.P16(x_, act.amax)), dy.data, act.data,
-                          keep=(dy.amax, act.amax))
-        return ws.run(lambda d_, x_: ops.wgrad_p16(ops.P16(d_, dy.amax, fmt), ops.P16(x_, act.amax, fmt), conv=conv), dy.data, act.data,
-                      keep=(dy.amax, act.amax))
+            fn = lambda d_, x_: ops.conv3x3_wgrad_halo_p16(ops.P16(d_, dy.amax), ops.P16(x_, act.amax))
+        else:
+            fn = lambda d_, x_: ops.wgrad_p16(ops.P16(d_, dy.amax, fmt), ops.P16(x_, act.amax, fmt), conv=conv)
+        ws.defer(G, id(weight), fn, (dy.data, act.data), keep=(dy.amax, act.amax), post=post if post is not None else (lambda o: o.view_as(weight)))
 
     # identity blocks: dL/dx = relu_mask * g + conv1's data gradient.  The masked copy of g is never written: conv1's data
     # gradient lands on g itself with the mask applied to the old values in its epilogue (gemm_p16 cmask) - g is dead after
@@ -557,7 +587,7 @@ def block_backward_p16(blk, rec, g, WPT, ws, G):
     # kernel: planes >= 128, no pool in between) - the reduce pass over (gradient, saved conv output) is then not run
     sums_b = ops.BnBwdSums(yb, stb) if (stride == 1 and g.dtype == torch.float32 and ops.bn_bwd_fusable(yb, Mc, planes, fmt)) else None
     ops.gemm_p16(dyc, WPT[id(blk.conv3.weight)], dab, Mc, planes, dyc.shape[-1], planes, bn_bwd=sums_b)
-    G[id(blk.conv3.weight)] = wgrad(dyc, ab).view_as(blk.conv3.weight)
+    wgrad(blk.conv3.weight, dyc, ab)
     dyb, dg, db, _ = ops.bn_bwd_p16(dab, yb, stb, 1, pooled=stride > 1, fmt=fmt, presummed=sums_b)
     G[id(blk.bn2.weight)], G[id(blk.bn2.bias)] = dg, db
     Bi, H, W, _ = yb.shape
@@ -569,19 +599,20 @@ def block_backward_p16(blk, rec, g, WPT, ws, G):
         daa = ops.empty(tuple(aa.shape), g, dtype=g.dtype)
         sums_a = ops.BnBwdSums(ya, sta) if (g.dtype == torch.float32 and ops.bn_bwd_fusable(ya, Ma, planes, fmt)) else None
         ops.gemm_p16(dyb, WPT[id(blk.conv2.weight)], daa, Ma, planes, 9 * planes, planes, conv=(H, W, planes), bn_bwd=sums_a)
-    G[id(blk.conv2.weight)] = _g3x3(wgrad(dyb, aa, conv=(H, W, planes)), planes, planes)
+    wgrad(blk.conv2.weight, dyb, aa, conv=(H, W, planes), post=lambda o: _g3x3(o, planes, planes))
     dya, dg, db, _ = ops.bn_bwd_p16(daa, ya, sta, 1, fmt=fmt, presummed=sums_a)
     G[id(blk.bn1.weight)], G[id(blk.bn1.bias)] = dg, db
     cin = blk.conv1.in_channels
     if has_down:
         dxd = ops.empty(tuple(xd.shape), g, dtype=g.dtype)
         ops.gemm_p16(dyd, WPT[id(blk.downsample[1].weight)], dxd, Mc, cin, dyd.shape[-1], cin)
-        G[id(blk.downsample[1].weight)] = wgrad(dyd, xd).view_as(blk.downsample[1].weight)
+        wgrad(blk.downsample[1].weight, dyd, xd)
         dx = ops.avgpool2_bwd(dxd) if stride > 1 else dxd
     else:
         dx = g if masked_acc else dres
     ops.gemm_p16(dya, WPT[id(blk.conv1.weight)], dx, Ma, cin, planes, cin, accumulate=True, cmask=rmask if masked_acc else None)
-    G[id(blk.conv1.weight)] = wgrad(dya, x).view_as(blk.conv1.weight)
+    wgrad(blk.conv1.weight, dya, x)
+    ws.flush()
     return dx
 
 
