@@ -100,7 +100,7 @@ def _bn_coeffs(bn, partials, M, training, counters=None):
 
 import os as _os
 _SERIAL_WGRAD = "1" in (_os.environ.get("TRID_SERIAL_WGRAD", "0"), _os.environ.get("TRID_SERIAL", "0"))  # experiment: weight gradients on the main stream
-_BATCH_WGRAD = _os.environ.get("TRID_WGRAD_BATCH", "1") != "0"  # a block's weight gradients behind one event (0: one event each, A/B runs)
+_BATCH_WGRAD = int(_os.environ.get("TRID_WGRAD_BATCH", "1"))  # residual blocks whose weight gradients share one event (0: one event per weight gradient, A/B runs)
 
 
 class _WgradStream:
@@ -113,6 +113,7 @@ class _WgradStream:
         self.side = _WgradStream._streams.setdefault(device, torch.cuda.Stream(device=device))
         self.side.wait_stream(self.main)
         self.pending = []
+        self.blocks = 0
 
     _streams = {}
 
@@ -143,7 +144,11 @@ class _WgradStream:
             return
         self.pending.append((G, key, fn, tensors, keep, post))
 
-    def flush(self):
+    def flush(self, block_end=False):
+        if block_end:  # (TRID_WGRAD_BATCH = n: every n-th block end flushes)
+            self.blocks += 1
+            if self.blocks % max(_BATCH_WGRAD, 1) != 0:
+                return
         if not self.pending:
             return
         ev = torch.cuda.Event()
@@ -612,7 +617,7 @@ def block_backward_p16(blk, rec, g, WPT, ws, G):
         dx = g if masked_acc else dres
     ops.gemm_p16(dya, WPT[id(blk.conv1.weight)], dx, Ma, cin, planes, cin, accumulate=True, cmask=rmask if masked_acc else None)
     wgrad(blk.conv1.weight, dya, x)
-    ws.flush()
+    ws.flush(block_end=True)
     return dx
 
 
