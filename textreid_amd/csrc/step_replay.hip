@@ -191,7 +191,8 @@ extern "C" int trid_step_replay_build(void* graph_, int max_lanes, void** out) {
     // (Holding the key encoder a fixed number of kernels behind the query encoder - extra edges b_j after a_{j + d1}, a_{j + d2}
     // after b_j, so that one encoder's BatchNorm passes meet the other's convolutions instead of both running the same kind of
     // kernel at the same time - was tried on this plan: 44.3-45.7 ms per step against 41.85, the ~380 extra event waits cost
-    // more than the pairing buys: profiles/r05g_replay_pingpong.txt, tools/exp/r05_run27.sh)
+    // more than the pairing buys: profiles/r05g_replay_pingpong.txt, tools/exp/r05_run27.sh.  A single extra edge that starts the
+    // key encoder k kernels after the query encoder: 41.2 (k = 8) ... 42.1 ms (k = 120) against 41.0: r05g_replay_offset.txt)
     std::vector<int> ev_of(n, -1);
     int n_events = 0;
     for (int v : order)
