@@ -100,6 +100,7 @@ def _bn_coeffs(bn, partials, M, training, counters=None):
 
 import os as _os
 _SERIAL_WGRAD = "1" in (_os.environ.get("TRID_SERIAL_WGRAD", "0"), _os.environ.get("TRID_SERIAL", "0"))  # experiment: weight gradients on the main stream
+_EARLY_WPT = _os.environ.get("TRID_EARLY_WPT", "1") != "0"  # data-gradient filter forms packed during the forward (0: at the head of backward, A/B runs)
 _BATCH_WGRAD = int(_os.environ.get("TRID_WGRAD_BATCH", "1"))  # residual blocks whose weight gradients share one event (0: one event per weight gradient, A/B runs)
 
 
@@ -866,6 +867,11 @@ class ModifiedResNet(nn.Module):
             S["stem_p16"] = stem16
             S["wamax"] = ar.WA
             S["prec"] = ar.PB
+            if p16 and _EARLY_WPT:
+                # the data-gradient forms of the filters (taps reversed, transposed) are packed HERE, where the step is
+                # throughput-bound, instead of at the head of backward, where the pack (130 us) sat alone on the critical path
+                # between the attention pool's backward and layer4's (the weights do not change in between)
+                S["WPT"] = p16_weights(self, ar.WA, True, fmt)
         # ---- residual layers (m_resnet.py:54-67)
         if save:
             S["blocks"] = []
@@ -1022,7 +1028,7 @@ class ModifiedResNet(nn.Module):
         first_of_layer = {id(layer[0]) for layer in (self.layer1, self.layer2, self.layer3, self.layer4)}
         dbg = getattr(self, "_debug_grads", None)
         p16 = S.get("p16", 0)
-        WPT = p16_weights(self, ar.WA, True, p16) if p16 else None
+        WPT = (S.get("WPT") or p16_weights(self, ar.WA, True, p16)) if p16 else None
         if p16 == 2 and ops.BF16_GRADS:
             g = g.to(torch.bfloat16)  # bf16 mode: the gradient of a bf16 tensor (the block outputs) is a bf16 tensor
         for blk, rec in zip(reversed(blocks), reversed(S["blocks"])):
