@@ -11,6 +11,6 @@ python tools/trace_gaps.py $f 27 31 > $OUT/gaps.txt 2>&1
 python tools/trace_streams.py $f adam 28 30 > $OUT/streams.txt 2>&1 || true
 python tools/trace_busy.py $f 0.3 > $OUT/busy.txt 2>&1 || true
 python tools/trace_lane_gaps.py $f 27 30 > $OUT/lane_gaps.txt 2>&1 || true
-python tools/trace_region.py $f 28 17.0 23.0 > $OUT/region_head.txt 2>&1 || true
+python tools/trace_queue.py $f 28 4 24.0 30.0 > $OUT/queue4.txt 2>&1 || true
 rm -rf $OUT/kt
-grep -n 'skinny\|queue_nce\|attnpool\|l2norm\|enqueue' $OUT/region_head.txt | head -5; wc -l $OUT/region_head.txt
+cat $OUT/queue4.txt | cut -c1-120
