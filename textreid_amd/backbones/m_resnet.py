@@ -100,6 +100,7 @@ def _bn_coeffs(bn, partials, M, training, counters=None):
 
 import os as _os
 _SERIAL_WGRAD = "1" in (_os.environ.get("TRID_SERIAL_WGRAD", "0"), _os.environ.get("TRID_SERIAL", "0"))  # experiment: weight gradients on the main stream
+_SERIAL_ATTN_WGRAD = _os.environ.get("TRID_SERIAL_ATTN_WGRAD", "0") == "1"  # attention pool's weight gradients on the main stream (A/B runs)
 _EARLY_WPT = _os.environ.get("TRID_EARLY_WPT", "1") != "0"  # data-gradient filter forms packed during the forward (0: at the head of backward, A/B runs)
 _BATCH_WGRAD = int(_os.environ.get("TRID_WGRAD_BATCH", "1"))  # residual blocks whose weight gradients share one event (0: one event per weight gradient, A/B runs)
 
@@ -946,7 +947,7 @@ class ModifiedResNet(nn.Module):
         return out, (((B, H, W, C), tok, q, U, P, Z, o) if save else None)
 
     # ------------------------------------------------------------------ backward
-    def _attnpool_backward(self, asave, gout, G):
+    def _attnpool_backward(self, asave, gout, G, ws=None):
         ap = self.attnpool
         xshape, tok, q, U, P, Z, o = asave
         B, H, W, C = xshape
@@ -958,15 +959,28 @@ class ModifiedResNet(nn.Module):
         scale = float(hd) ** -0.5
         Wq, Wk, Wv, Wc = ap.q_proj.weight, ap.k_proj.weight, ap.v_proj.weight, ap.c_proj.weight
         # c_proj
+        # The four projection-weight gradients (and the bias sums) feed nothing downstream: like the convolutions' weight
+        # gradients they run on the side stream, behind ONE event at the end of this function - on the main stream they sat
+        # between the losses and layer4's backward, alone on the step's critical path (~0.25 ms: profiles/r05g_attn_wgrad_ab.txt)
+        def side(key, fn, *tensors):
+            if ws is None or _SERIAL_ATTN_WGRAD:
+                G[key] = fn(*tensors)
+            else:
+                ws.defer(G, key, fn, tensors)
+
         do = ops.matmul_nn(gout, Wc)  # [B,C]
-        G[id(Wc)] = ops.matmul_tn(gout, o)
-        G[id(ap.c_proj.bias)] = ops.colsum(gout)
-        G[id(ap.v_proj.bias)] = ops.colsum(do)  # sum_t P = 1
+        side(id(Wc), lambda g_, o_: ops.matmul_tn(g_, o_), gout, o)
+        side(id(ap.c_proj.bias), lambda g_: ops.colsum(g_), gout)
+        side(id(ap.v_proj.bias), lambda d_: ops.colsum(d_), do)  # sum_t P = 1
+
         # dWv[h*hd+d, c] = sum_b do[b,h*hd+d] Z[b,h,c]
-        dWv = torch.empty_like(Wv)
-        ops.gemm(do, Z, dWv, hd, C, B, C, heads * C, C, a_mode=ops.A_MC, b_mode=ops.B_NC, batch=heads, strideA=hd,
-                 strideB=C, strideC=hd * C)
-        G[id(Wv)] = dWv
+        def dwv(do_, Z_):
+            out = torch.empty_like(Wv)
+            ops.gemm(do_, Z_, out, hd, C, B, C, heads * C, C, a_mode=ops.A_MC, b_mode=ops.B_NC, batch=heads, strideA=hd,
+                     strideB=C, strideC=hd * C)
+            return out
+
+        side(id(Wv), dwv, do, Z)
         # dZ[b,h,c] = sum_d do[b,h*hd+d] Wv[h*hd+d,c]
         dZ = ops.empty((B, heads, C), tok)
         ops.gemm(do, Wv, dZ, B, C, hd, C, C, heads * C, b_mode=ops.B_NC, batch=heads, strideA=hd, strideB=hd * C,
@@ -990,26 +1004,31 @@ class ModifiedResNet(nn.Module):
         dq = ops.empty((B, C), tok)
         ops.gemm(dU, Wk, dq, B, hd, C, heads * C, C, C, alpha=scale, batch=heads, strideA=C, strideB=hd * C, strideC=hd)
         # dWk[h*hd+d, c] = scale * sum_b q[b,h*hd+d] dU[b,h,c]
-        dWk = torch.empty_like(Wk)
-        ops.gemm(q, dU, dWk, hd, C, B, C, heads * C, C, a_mode=ops.A_MC, b_mode=ops.B_NC, alpha=scale, batch=heads,
-                 strideA=hd, strideB=C, strideC=hd * C)
-        G[id(Wk)] = dWk
+        def dwk(q_, dU_):
+            out = torch.empty_like(Wk)
+            ops.gemm(q_, dU_, out, hd, C, B, C, heads * C, C, a_mode=ops.A_MC, b_mode=ops.B_NC, alpha=scale, batch=heads,
+                     strideA=hd, strideB=C, strideC=hd * C)
+            return out
+
+        side(id(Wk), dwk, q, dU)
         G[id(ap.k_proj.bias)] = torch.zeros_like(ap.k_proj.bias)  # softmax is shift-invariant: exactly zero
         # q projection (token 0)
         ops.matmul_nn(dq, Wq, out=dtok[:, 0], accumulate=True)  # (rows of dtok at pitch T1p * C: token 0 of every image)
-        G[id(Wq)] = ops.matmul_tn(dq, tok[:, 0])
-        G[id(ap.q_proj.bias)] = ops.colsum(dq)
+        side(id(Wq), lambda dq_, tok_: ops.matmul_tn(dq_, tok_[:, 0]), dq, tok)
+        side(id(ap.q_proj.bias), lambda dq_: ops.colsum(dq_), dq)
         dx = ops.empty((B, H, W, C), tok)
         dpos = torch.empty_like(ap.positional_embedding)
         ops.call("trid_attnpool_tokens_bwd_f32", ops._p(dtok), ops._p(dx), ops._p(dpos), B, T, C, T1p, ops.stream())
         G[id(ap.positional_embedding)] = dpos
+        if ws is not None:
+            ws.flush()
         return dx
 
     def _run_backward(self, S, gout):
         G = {}
         ws = _WgradStream(gout.device)
         ar = ConvArith(gout.device, S.get("wamax", {}), S.get("prec"))  # the forward's conv arithmetic (its weight / activation amax scalars are reused here)
-        g = self._attnpool_backward(S["attn"], gout, G)
+        g = self._attnpool_backward(S["attn"], gout, G, ws)
         S["attn"] = None
         blocks = list(self.blocks())
         sync = self.grad_sync
