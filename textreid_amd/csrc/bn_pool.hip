@@ -523,7 +523,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a, float* 
         for (int r = tid; r < 256; r += CW)
 #pragma unroll
             for (int k = 0; k < 8; ++k) acc[k] += red[r][k];
-        float* dst = ws + ((long long)blockIdx.x * CW + tid) * 8;
+        float* dst = ws + bn_bwd_partial_index(blockIdx.x, tid, gridDim.x, a.CQ);
 #pragma unroll
         for (int k = 0; k < 8; ++k) dst[k] = acc[k];
     }
@@ -539,7 +539,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a, float* 
             for (int r = tid; r < 256; r += CW)
 #pragma unroll
                 for (int k = 0; k < 8; ++k) acc[k] = fmaxf(acc[k], red[r][k]);
-            float* dst = ws2 + ((long long)blockIdx.x * CW + tid) * 8;
+            float* dst = ws2 + bn_bwd_partial_index(blockIdx.x, tid, gridDim.x, a.CQ);
 #pragma unroll
             for (int k = 0; k < 8; ++k) dst[k] = acc[k];
         }
@@ -562,12 +562,12 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_final_kernel(const float* _
 #pragma unroll
     for (int k = 0; k < 8; ++k) acc[k] = mxv[k] = 0.f;
     for (int b = slice + S * threadIdx.x; b < nblk; b += S * 256) {
-        const float4* src = reinterpret_cast<const float4*>(ws + ((long long)b * CW + ql) * 8);
+        const float4* src = reinterpret_cast<const float4*>(ws + bn_bwd_partial_index(b, ql, nblk, CQ));
         const float4 u = src[0], v = src[1];
         acc[0] += u.x; acc[1] += u.y; acc[2] += u.z; acc[3] += u.w;
         acc[4] += v.x; acc[5] += v.y; acc[6] += v.z; acc[7] += v.w;
         if (ws2 != nullptr) {
-            const float4* s2 = reinterpret_cast<const float4*>(ws2 + ((long long)b * CW + ql) * 8);
+            const float4* s2 = reinterpret_cast<const float4*>(ws2 + bn_bwd_partial_index(b, ql, nblk, CQ));
             const float4 a = s2[0], c = s2[1];
             mxv[0] = fmaxf(mxv[0], a.x); mxv[1] = fmaxf(mxv[1], a.y); mxv[2] = fmaxf(mxv[2], a.z); mxv[3] = fmaxf(mxv[3], a.w);
             mxv[4] = fmaxf(mxv[4], c.x); mxv[5] = fmaxf(mxv[5], c.y); mxv[6] = fmaxf(mxv[6], c.z); mxv[7] = fmaxf(mxv[7], c.w);
@@ -708,8 +708,8 @@ __global__ __launch_bounds__(256) void bn_bwd_dual_reduce_kernel(BnBwdDual a, fl
         for (int r = tid; r < 256; r += CW)
 #pragma unroll
             for (int k = 0; k < 12; ++k) acc[k] += red[r][k];
-        float* da = wsA + ((long long)blockIdx.x * CW + tid) * 8;
-        float* db = wsB + ((long long)blockIdx.x * CW + tid) * 8;
+        float* da = wsA + bn_bwd_partial_index(blockIdx.x, tid, gridDim.x, a.CQ);
+        float* db = wsB + bn_bwd_partial_index(blockIdx.x, tid, gridDim.x, a.CQ);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             da[k] = acc[k]; db[k] = acc[k];
@@ -728,8 +728,8 @@ __global__ __launch_bounds__(256) void bn_bwd_dual_reduce_kernel(BnBwdDual a, fl
         for (int r = tid; r < 256; r += CW)
 #pragma unroll
             for (int k = 0; k < 12; ++k) acc[k] = fmaxf(acc[k], red[r][k]);
-        float* da = ws2A + ((long long)blockIdx.x * CW + tid) * 8;
-        float* db = ws2B + ((long long)blockIdx.x * CW + tid) * 8;
+        float* da = ws2A + bn_bwd_partial_index(blockIdx.x, tid, gridDim.x, a.CQ);
+        float* db = ws2B + bn_bwd_partial_index(blockIdx.x, tid, gridDim.x, a.CQ);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             da[k] = acc[k]; db[k] = acc[k];

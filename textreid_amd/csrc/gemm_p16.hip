@@ -630,7 +630,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 && STAGES == 2) ? 2 : (W
                     }
                     const int CQ = p.N >> 2, CW = CQ < 256 ? CQ : 256, S = CQ / CW;
                     const int q = (n0 >> 2) + tid;
-                    const long long e = (((long long)mb * S + q / CW) * CW + q % CW) * 8;
+                    const long long e = bn_bwd_partial_index(mb * S + q / CW, q % CW, p.mblocks * S, CQ);
                     *reinterpret_cast<float4*>(bb.ws + e) = s1;
                     *reinterpret_cast<float4*>(bb.ws + e + 4) = s2;
                     *reinterpret_cast<float4*>(bb.ws2 + e) = mg;

@@ -169,6 +169,17 @@ __device__ __forceinline__ unsigned wave_umax(unsigned m) {
     return m;
 }
 
+// BatchNorm-backward partials (bn_pool.hip reduce kernels, gemm_p16.hip BnBwdFuse -> bn_bwd_reduce_final_kernel): float offset of
+// the 8-float entry of partial block b (of nblk; block b covers the channel-quad slice b % S, S = CQ / CW) for quad ql of that
+// slice.  The entries of ONE quad lie next to each other (quad-major): the fold, one workgroup per quad with a thread per
+// partial, reads whole lines - in the block-major order of the first version every thread touched its own line, and the fold
+// (55 launches per step on the backward's critical chain) took 12-28 us.
+__device__ __host__ __forceinline__ long long bn_bwd_partial_index(int b, int ql, int nblk, int CQ) {
+    const int CW = CQ < 256 ? CQ : 256, S = CQ / CW;
+    const long long q = (long long)(b % S) * CW + ql;  // global quad
+    return (q * (nblk / S) + b / S) * 8;
+}
+
 // ---------------------------------------------------------------- P16 (pre-split GEMM operand) element access
 // A [rows][C] tensor in P16 (gemm_p16.hip): per row and 32-channel group 128 bytes = [hi x 32 | lo x 32] fp16 of
 // x * 2^s.  These kernels work on channel QUADS (float4): quad cq of a row lives at 8-byte unit
