@@ -556,6 +556,51 @@ def test_captured_train_step_equals_eager_bitwise(gpu):
         assert runs["eager"][3] == runs[other][3] and set(runs[other][3]) == {steps + 1}
 
 
+def test_schedule_and_fusion_switches_leave_the_gradients_alone(gpu):
+    """The round-5 switches of the backward pass against the forms they replace, on one step of the full model (B = 8):
+    SCHEDULING switches - a block's weight gradients behind one event (m_resnet._BATCH_WGRAD), the attention pool's weight
+    gradients on the side stream (_SERIAL_ATTN_WGRAD), the data-gradient filter forms packed during the forward (_EARLY_WPT) -
+    must not change a bit of any gradient; FUSION switches - BatchNorm-backward sums from the data-gradient GEMM's epilogue
+    (ops.USE_BNB_FUSE), bn3 + downsample in one pass (ops.USE_BN_DUAL) - change the order of the per-channel sums only:
+    every gradient within 2e-5 of its tensor's largest entry."""
+    import bench
+    import textreid_amd.backbones.m_resnet as MR
+    from textreid_amd import ops
+    from textreid_amd.caption import CaptionBatch
+    from textreid_amd.config import moco_cfg
+    from textreid_amd.model import build_model
+
+    cfg = moco_cfg("m_resnet50", K=64)
+    table = torch.randn(3000, 512, generator=torch.Generator().manual_seed(1)) * 0.02
+    images, tokens, lengths, ids = bench.synth_batch(8, 3, gpu, 5, vocab=3000)
+
+    def grads():
+        torch.manual_seed(0)
+        model = build_model(cfg, vocab_dict=table).to(gpu).train()
+        loss = sum(model(images, CaptionBatch(tokens, lengths, ids % 11003, max_len=64)).values())
+        loss.backward()
+        torch.cuda.synchronize()
+        return {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+
+    base = grads()
+    assert len(base) > 150
+    switches = [(MR, "_BATCH_WGRAD", 0, True), (MR, "_SERIAL_ATTN_WGRAD", True, True), (MR, "_EARLY_WPT", False, True),
+                (ops, "USE_BNB_FUSE", False, False), (ops, "USE_BN_DUAL", False, False)]
+    for mod, name, off, exact in switches:
+        was = getattr(mod, name)
+        try:
+            setattr(mod, name, off)
+            other = grads()
+        finally:
+            setattr(mod, name, was)
+        assert other.keys() == base.keys(), name
+        for k, g in base.items():
+            if exact:
+                assert torch.equal(g, other[k]), (name, k)
+            else:
+                assert float((g - other[k]).abs().max()) <= 2e-5 * float(g.abs().max()) + 1e-12, (name, k)
+
+
 def test_step_replay_of_a_small_forked_recording(gpu):
     """csrc/step_replay.hip on a recording small enough to check by hand: a chain on the capturing stream, a fork to a side
     stream, a join - the plan must keep two lanes and one event per cross-lane edge, re-running it must recompute the outputs
