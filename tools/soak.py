@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Soak run: N training steps of configs[1] on synthetic data; prints loss, step time and allocator statistics every 50
 steps (memory growth, non-finite losses and step-time drift show up here, not in a 10-step bench).
-GPU box:  python tools/soak.py [steps]"""
+GPU box:  python tools/soak.py [steps] [--replay]   (--replay: the recorded step re-issued as stream launches, engine/graph.py)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, bench
@@ -10,19 +10,27 @@ from textreid_amd.config import moco_cfg
 from textreid_amd.model import build_model
 from textreid_amd.solver import make_optimizer
 
-N = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+N = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 300
+REPLAY = "--replay" in sys.argv
 dev = torch.device("cuda"); torch.manual_seed(0)
 cfg = moco_cfg("m_resnet50", K=8192)
 model = build_model(cfg, vocab_dict=torch.randn(49408, 512) * 0.02).to(dev); model.train()
 opt = make_optimizer(cfg, model)
 B = 128
 batches = [bench.synth_batch(B, s, dev, 1234) for s in range(8)]
+runner = None
+if REPLAY:
+    from textreid_amd.engine.graph import CapturedTrainStep
+    runner = CapturedTrainStep(model, opt, warmup=2, caption_bound=64)
 t0 = time.perf_counter(); last = None
 for i in range(N):
     images, tokens, lengths, ids = batches[i % 8]
     cb = CaptionBatch(tokens, lengths, (ids + (i // 8) * 8 * (B // 4)) % 11003, max_len=64)
-    ld = model(images, cb)
-    loss = sum(ld.values()); opt.zero_grad(); loss.backward(); opt.step()
+    if runner is not None:
+        ld = runner(images, cb)
+    else:
+        ld = model(images, cb)
+        loss = sum(ld.values()); opt.zero_grad(); loss.backward(); opt.step()
     if (i + 1) % 50 == 0:
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / 50 * 1e3; t0 = time.perf_counter()
