@@ -28,6 +28,12 @@ for i in range(5):
         print(i, "FAILED", str(e)[:400], runner.replay_info)
         break
 
+import hashlib
+torch.cuda.synchronize()
+h = hashlib.sha256()
+for n_, p_ in model.named_parameters():
+    h.update(p_.detach().cpu().numpy().tobytes())
+print("parameter digest after the steps:", h.hexdigest()[:16])
 # host time of one replay call with the GPU idle at the start (is the call slow, or does it wait for queue space?)
 import time
 if runner.replayer is not None:
