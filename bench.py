@@ -126,6 +126,54 @@ def cpu_baseline(sample_b=128, steps=3, warm_b=32):
 PARITY_SEED = 100  # tools/pick_fullstep_seed.py rn50 128 8192 100 (oracle/cases.py: RELU_MIN_BY_BATCH)
 
 
+def replay_equals_eager(runner, model, opt, images, cb):
+    """The seam between the TIMED path and the oracle-checked path, closed at the benchmarked size: from one saved state
+    (every parameter and buffer of the model - queues, queue pointer, BatchNorm statistics -, every Adam moment and step
+    count) the SAME batch goes once through the launch form the timed region uses (the recorded step re-issued by
+    csrc/step_replay.hip, optimizer included) and once through the eager step (the form `parity_vs_oracle` and
+    tests/test_model_gpu.py::test_config1_b128_k8192_step_vs_oracle compare with the oracle); the three losses and a digest of
+    every state tensor must agree BIT for bit (counterpart of lib/engine/trainer.py:81-91).  The state is restored in place
+    (same addresses: the recording stays valid) and left as the replayed step made it."""
+    from textreid_amd import ops
+
+    if runner is None or runner.graph is None:
+        return None
+    params = [p for g in opt.param_groups for p in g["params"] if p in opt.state and "exp_avg" in opt.state[p]]
+
+    def snapshot():
+        torch.cuda.synchronize()
+        return ({k: v.detach().clone() for k, v in model.state_dict().items()},
+                [(opt.state[p]["exp_avg"].clone(), opt.state[p]["exp_avg_sq"].clone(), int(opt.state[p]["step"])) for p in params])
+
+    def restore(snap):
+        with torch.no_grad():
+            cur = model.state_dict()
+            for k, v in snap[0].items():
+                cur[k].copy_(v)
+            for p, (m, v, t) in zip(params, snap[1]):
+                opt.state[p]["exp_avg"].copy_(m)
+                opt.state[p]["exp_avg_sq"].copy_(v)
+                opt.state[p]["step"] = t
+        ops.note_parameter_write()
+        torch.cuda.synchronize()
+
+    before = snapshot()
+    form = "hipgraph replay" if (runner.force_graph_launch or runner.replayer is None) else "stream replay"
+    l_replay = {k: v.detach().clone() for k, v in runner(images, cb).items()}
+    after_replay = snapshot()
+    restore(before)
+    l_eager = {k: v.detach().clone() for k, v in runner._eager(images, cb).items()}
+    after_eager = snapshot()
+    diffs = [("loss:" + k) for k in l_eager if not torch.equal(l_eager[k], l_replay[k])]
+    diffs += [k for k, v in after_eager[0].items() if not torch.equal(v, after_replay[0][k])]
+    for i, (a, b) in enumerate(zip(after_eager[1], after_replay[1])):
+        if not (torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and a[2] == b[2]):
+            diffs.append("adam[%d]" % i)
+    moved = sum(1 for k, v in after_eager[0].items() if v.is_floating_point() and not torch.equal(v, before[0][k]))
+    return {"equal": not diffs, "launch_form": form, "state_tensors": len(after_eager[0]), "adam_moment_pairs": len(params),
+            "state_tensors_changed_by_the_step": moved, "losses": {k: float(v) for k, v in l_replay.items()}, "first_differences": diffs[:8]}
+
+
 def parity_vs_oracle(device, pref, tol=1e-3):
     """ONE HIP train step (forward of the four encoders, three losses, backward - no optimizer) from the state and batch
     of the CPU-baseline leg's first timed step, compared with that oracle step: the three losses, all 183 trainable
@@ -156,6 +204,7 @@ def parity_vs_oracle(device, pref, tol=1e-3):
         "loss_rel_err": {k[5:]: v for k, v in errs.items() if k.startswith("loss:")},
         "tolerance": tol,
         "within_tolerance": bool(errs[worst] <= tol),
+        "launch_form": "eager (one step, no optimizer); the timed region's launch form is tied to it bitwise by replay_vs_eager",
         "case": "configs[1] at its exact size: CLIP-RN50 + BiGRU, B=%d, K=%d, margin-style state (oracle.fill seed %d: SELECTED for its ReLU margin by tools/pick_fullstep_seed.py - a well-conditioned step, on which two correct fp32 evaluations take the same side of every ReLU), ragged captions; smallest |ReLU input| of the oracle's query encoder %.1e (floor %.0e).  The complement - an UNSELECTED seed with He-style weights and 1.5e9 unstructured ReLU decisions at this size, in the decision-count form - is tests/test_model_gpu.py::test_config1_b128_unselected_seed_decision_count" % (
             B, K, PARITY_SEED, relu_min, relu_floor(B)),
         "seed_selected_for_relu_margin": True,
@@ -675,6 +724,10 @@ def main():
     dt = time.perf_counter() - t0
     log("timed region: %.3fs for %d steps (host enqueue time %.3fs)" % (dt, args.steps, t_host))
     last = {k: v.detach().clone() for k, v in last.items()}
+    seam = None
+    if runner is not None and world == 1 and not use_eager:
+        seam = replay_equals_eager(runner, model, opt, *batch(n_prep + args.warmup + args.steps))
+        log("replay vs eager at B=%d (%s, optimizer included): %s" % (B, seam["launch_form"], "bit-identical" if seam["equal"] else "DIFFERENT: %s" % seam["first_differences"]))
     profiled_eager = 0
     if runner is not None:
         # events cannot bracket individual nodes of a replayed graph: the per-launch timing of the dominant kernels comes
@@ -934,6 +987,8 @@ def main():
             # the fraction of them issued from INSIDE backward (overlapped) and the device time left exposed after it
             out["data_parallel"] = dict(dp_stats, rccl_ranks=world, backend=dist.get_backend(),
                                         embedding_allgather_bytes_per_rank=B * (4 * 256 + 2) * 4)
+        out["replay_equals_eager_b%d" % B] = seam["equal"] if seam else None
+        out["replay_vs_eager"] = seam
         out["gallery_encode"] = retr.pop("gallery_encode", None) if retr else None
         out["retrieval"] = retr
         out["queue_similarity"] = qsim

@@ -22,6 +22,7 @@
 
 #include <algorithm>
 #include <mutex>
+#include <type_traits>
 
 #include "split_common.h"
 
@@ -40,12 +41,31 @@ __device__ __forceinline__ void dma16(const __amdgpu_buffer_rsrc_t& rs, uint4* l
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)lds_base, 16, voffset, soffset, 0, 0);
 }
 
+// The same instruction out of the compiler's sight: hipcc waits `vmcnt(0)` in front of every LDS read that follows an
+// LDS-DMA it knows about (it cannot tell the DMA's stage from the read's), which would drain the prefetch in the middle of
+// the software-pipelined loop.  Completion is counted by hand there (s_waitcnt vmcnt + s_barrier at the top of a tile).
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ v4i_t raw_rsrc(const void* base, unsigned bytes) {  // the descriptor make_buffer_rsrc builds, as four provably uniform words
+    const unsigned long long b = (unsigned long long)(uintptr_t)base;
+    v4i_t r;
+    r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)b);
+    r[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(b >> 32) & 0xffff);
+    r[2] = __builtin_amdgcn_readfirstlane((int)bytes);
+    r[3] = 0x00020000;
+    return r;
+}
+__device__ __forceinline__ void dma16_asm(const v4i_t& rs, unsigned lds_byte_addr, unsigned voffset, unsigned soffset) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(__builtin_amdgcn_readfirstlane(lds_byte_addr)), "v"(voffset), "s"(rs), "s"(__builtin_amdgcn_readfirstlane(soffset)) : "memory", "m0");
+}
+
 // AMODE: A_KC (rows = GEMM rows) or A_CONV (rows = pixels of an NHWC image, K = 9 taps x Cin, 3x3 / stride 1 / pad 1)
 // PL = 2: P16 operands (two fp16 planes, 32 k per 128-byte row chunk, 3 MFMA products per multiply-add: fp32-class);
 // PL = 1: plain bf16 operands (64 k per 128-byte chunk, one bf16 MFMA per product): configs[3]'s bf16 arithmetic on
 // tensors their producers already wrote in bf16 - half the operand bytes, a third of the matrix work.
 // PP: the two wave halves of the workgroup run the K loop half a tile apart ("ping-pong", see the main loop).
-template <int AMODE, int BM, int BN, int WM, int WN, int STAGES, int PL, bool PP = false>
+// SP: software-pipelined main loop (see "software pipeline" below): the fragments of a K tile's second half are
+// multiplied AFTER the next tile's barrier, under the LDS reads of that tile's first half.
+template <int AMODE, int BM, int BN, int WM, int WN, int STAGES, int PL, bool PP = false, int SP = 0>
 __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 && STAGES == 2) ? 2 : (WM * WN == 8 && (BM + BN) * 128 * STAGES <= 80 * 1024 ? 4 : (WM * WN == 6 ? 3 : 2))) void gemm_p16_kernel(GemmParams p) {
     constexpr int NW = WM * WN;
     constexpr int BKE = PL == 2 ? 32 : 64;  // K elements per 128-byte row chunk = per K tile
@@ -131,6 +151,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 && STAGES == 2) ? 2 : (W
     }
     const int cgroups = (AMODE == A_CONV) ? p.Cin / BKE : 1;
 
+    const unsigned smem_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)smem;  // LDS byte address of the stages
     auto issue = [&](int kt, int stage) {
         uint4* sA = smem + stage * STAGE_SLOTS;
         uint4* sB = sA + BM * 8;
@@ -308,6 +329,144 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 && STAGES == 2) ? 2 : (W
                 mm();
                 bar();
             }
+        }
+    } else if constexpr (SP != 0) {
+        // Software pipeline (two LDS stages, P16 operands).  A K tile is two 16-deep MFMA steps; their operand fragments live
+        // in two register sets, F0 (step 0) and F1 (step 1).  Per tile t, in program order (pinned by sched_barrier):
+        //     wait: own LDS-DMA share of tile t landed (vmcnt 0), own F1 reads of tile t-1 returned (lgkmcnt 0);  s_barrier
+        //     F0 <- LDS(tile t, step 0)
+        //     MFMAs of tile t-1, step 1 (F1) - they cover the latency of the F0 reads - with the LDS-DMA pieces of tile t+1
+        //         (into the stage tile t-1 occupied) in front of them (SP == 1) or spread between them (SP == 2)
+        //     F1 <- LDS(tile t, step 1)
+        //     MFMAs of tile t, step 0 (F0)   - they cover the latency of the F1 reads and the scalar address work of tile t+2
+        // No MFMA waits for an LDS read issued right in front of it; what is exposed per tile is the barrier.  The products
+        // reach every accumulator in the order of the plain loop (step 0, step 1 of tile t, then tile t+1): bit-identical
+        // results.  Stage (t+1)&1 is free when its DMA is issued: the F0 and F1 reads of tile t-1 returned before this
+        // tile's barrier.  The DMA goes through inline asm (dma16_asm): hipcc must not see it.
+        static_assert(STAGES == 2 && PL == 2, "software pipeline: two stages, P16 operands");
+        constexpr int NM = 3 * TM * TN;  // MFMAs per step
+        const v4i_t rsA_s = raw_rsrc(a_base, (unsigned)(a_rows * a_ld_bytes)), rsB_s = raw_rsrc(Bp, (unsigned)((long long)p.N * p.ldb * EB));
+        uint4 f0a[2][TM], f0b[2][TN], f1a[2][TM], f1b[2][TN];
+        auto rd = [&](int stage, int ks, uint4 (&fa)[2][TM], uint4 (&fb)[2][TN]) {
+            const uint4* sA = smem + stage * STAGE_SLOTS;
+            const uint4* sB = sA + BM * 8;
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+                const int s = (4 * pl + 2 * ks + khalf) ^ xs;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[pl][i] = sA[(a_row + 32 * i) * 8 + s];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fb[pl][j] = sB[(b_row + 32 * j) * 8 + s];
+            }
+        };
+        // MFMA `idx` of a step: product idx / (TM TN) in the order (hi.lo, lo.hi, hi.hi) - small terms first -, accumulator idx % (TM TN)
+        auto mm1 = [&](const uint4 (&fa)[2][TM], const uint4 (&fb)[2][TN], int idx) {
+            const int pr = idx / (TM * TN), ij = idx % (TM * TN), i = ij / TN, j = ij % TN;
+            const int pa = pr == 1 ? 1 : 0, pb = pr == 0 ? 1 : 0;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[pa][i]), __builtin_bit_cast(f16x8, fb[pb][j]), acc[i][j], 0, 0, 0);
+        };
+        // scalar state of the NEXT tile to issue: A / B byte offsets of its K tile and (3x3) its tap
+        int n_tap = 0, n_dx = 0;
+        unsigned n_soA = 0, n_soB = 0, n_rowA = 0, n_cgA = 0;
+        const unsigned cin_b = (unsigned)p.Cin * EB, roww_b = (unsigned)p.W * cin_b;
+        {
+            const int kt = kt_begin;
+            if (AMODE == A_CONV) {
+                n_tap = kt % 9;
+                const int cg = kt / 9;
+                n_dx = n_tap % 3;
+                n_rowA = (unsigned)(n_tap / 3) * roww_b;
+                n_cgA = (unsigned)cg * 128u;
+                n_soA = n_rowA + (unsigned)n_dx * cin_b + n_cgA;
+                n_soB = (unsigned)(n_tap * cgroups + cg) * 128u;
+            } else {
+                n_soA = n_soB = (unsigned)kt * 128u;
+            }
+        }
+        unsigned c_soA = 0, c_soB = 0;
+        int c_tap = 0;
+        auto latch = [&]() {  // the tile whose pieces are issued next
+            c_soA = n_soA; c_soB = n_soB; c_tap = n_tap;
+        };
+        auto advance = [&]() {
+            if (AMODE == A_CONV) {
+                // (tap, channel group) -> next: taps innermost (gemm order: all 9 taps of a 32-channel slab back to back)
+                ++n_tap; ++n_dx;
+                n_soB += (unsigned)cgroups * 128u;
+                if (n_dx == 3) { n_dx = 0; n_rowA += roww_b; }
+                if (n_tap == 9) { n_tap = 0; n_rowA = 0; n_cgA += 128u; n_soB = n_soB - 9u * (unsigned)cgroups * 128u + 128u; }
+                n_soA = n_rowA + (unsigned)n_dx * cin_b + n_cgA;
+            } else {
+                n_soA += 128u; n_soB += 128u;
+            }
+        };
+        auto piece = [&](int stage, int q) {  // LDS-DMA instruction q of this wave's PER_TILE for the latched tile
+            if (q < A_PW) {
+                const int c = q * NW + wave;
+                if (A_CH % NW != 0 && c >= A_CH) return;
+                unsigned vo = voA[q];
+                if (AMODE == A_CONV) vo = ((amask[q] >> c_tap) & 1u) ? vo : OOB;
+                dma16_asm(rsA_s, smem_base + (unsigned)(stage * STAGE_SLOTS + c * 64) * 16u, vo, c_soA);
+            } else {
+                const int j = q - A_PW, c = j * NW + wave;
+                if (B_CH % NW != 0 && c >= B_CH) return;
+                dma16_asm(rsB_s, smem_base + (unsigned)(stage * STAGE_SLOTS + BM * 8 + c * 64) * 16u, voB[j], c_soB);
+            }
+        };
+        auto tile = [&](int t, auto stage_c) {
+            constexpr int stage = decltype(stage_c)::value;
+            const bool has_prev = t > 0, has_next = t + 1 < nk;  // (wave-uniform)
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            rd(stage, 0, f0a, f0b);
+            __builtin_amdgcn_sched_barrier(0);
+            latch();
+            if (has_next && (SP == 1 || !has_prev)) {
+#pragma unroll
+                for (int q = 0; q < PER_TILE; ++q) piece(stage ^ 1, q);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (has_prev) {
+                int q = 0;
+#pragma unroll
+                for (int m = 0; m < NM; ++m) {
+                    mm1(f1a, f1b, m);
+                    if constexpr (SP == 2) {
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int e = 0; e < PER_TILE; ++e)
+                            if (e == q && q * NM < (m + 1) * PER_TILE) {
+                                if (has_next) piece(stage ^ 1, q);
+                                ++q;
+                            }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            rd(stage, 1, f1a, f1b);
+            __builtin_amdgcn_sched_barrier(0);
+            advance();
+#pragma unroll
+            for (int m = 0; m < NM; ++m) mm1(f0a, f0b, m);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        typedef std::integral_constant<int, 0> S0;
+        typedef std::integral_constant<int, 1> S1;
+        if (nk > 0) {
+            latch();
+#pragma unroll
+            for (int q = 0; q < PER_TILE; ++q) piece(0, q);
+            advance();
+            int t = 0;
+            for (; t + 1 < nk; t += 2) {
+                tile(t, S0());
+                tile(t + 1, S1());
+            }
+            if (t < nk) tile(t, S0());
+#pragma unroll
+            for (int m = 0; m < NM; ++m) mm1(f1a, f1b, m);
         }
     } else {
 #pragma unroll
@@ -1026,7 +1185,7 @@ __global__ __launch_bounds__(256) void p16_pack_multi_kernel(const long long* __
     }
 }
 
-template <int AMODE, int BM, int BN, int WM, int WN, int STAGES, int PL = 2, bool PP = false>
+template <int AMODE, int BM, int BN, int WM, int WN, int STAGES, int PL = 2, bool PP = false, int SP = 0>
 static int launch_p16(GemmParams& p, hipStream_t stream) {
     p.mblocks = (p.M + BM - 1) / BM;
     p.nblocks = (p.N + BN - 1) / BN;
@@ -1039,14 +1198,14 @@ static int launch_p16(GemmParams& p, hipStream_t stream) {
     static hipError_t attr_err = hipSuccess;
     std::call_once(once, [lds] {
         if (lds > 48 * 1024)
-            attr_err = hipFuncSetAttribute((const void*)gemm_p16_kernel<AMODE, BM, BN, WM, WN, STAGES, PL, PP>,
+            attr_err = hipFuncSetAttribute((const void*)gemm_p16_kernel<AMODE, BM, BN, WM, WN, STAGES, PL, PP, SP>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     });
     if (attr_err != hipSuccess) {
         set_error("trid_gemm_p16: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(attr_err));
         return (int)attr_err;
     }
-    hipLaunchKernelGGL((gemm_p16_kernel<AMODE, BM, BN, WM, WN, STAGES, PL, PP>), grid, dim3(WM * WN * 64), lds, stream, p);
+    hipLaunchKernelGGL((gemm_p16_kernel<AMODE, BM, BN, WM, WN, STAGES, PL, PP, SP>), grid, dim3(WM * WN * 64), lds, stream, p);
     return check_launch("trid_gemm_p16");
 }
 
@@ -1058,7 +1217,7 @@ static int pick_p16(GemmParams& p, int variant, int planes, hipStream_t stream) 
     }
     if (p.N <= 32) return launch_p16<AMODE, 256, 32, 4, 1, 3>(p, stream);
     if (p.N <= 64) return launch_p16<AMODE, 128, 64, 2, 2, 3>(p, stream);
-    if (variant < 0 || p.c_fmt == 1 || p.bb.y != nullptr) variant = 3;  // (the eval epilogue and the BatchNorm-backward sums live in the staged-through-LDS store path of the default tile)
+    if (variant < 0 || ((p.c_fmt == 1 || p.bb.y != nullptr) && variant != 10)) variant = 3;  // (the eval epilogue and the BatchNorm-backward sums live in the staged-through-LDS store path of the default tile)
     switch (variant) {
         case 1: return launch_p16<AMODE, 128, 128, 2, 2, 3>(p, stream);   // 4 waves of 64x64, 3 stages (96 KB): 1 WG / CU
         case 2: return launch_p16<AMODE, 256, 128, 4, 2, 3>(p, stream);   // 8 waves of 64x64, 3 stages (144 KB)
@@ -1072,6 +1231,10 @@ static int pick_p16(GemmParams& p, int variant, int planes, hipStream_t stream) 
         case 9: return launch_p16<AMODE, 96, 128, 3, 2, 2>(p, stream);
         case 6: return launch_p16<AMODE, 128, 128, 2, 4, 2, 2, true>(p, stream);  // variant 3 with the ping-pong schedule
         case 7: return launch_p16<AMODE, 256, 128, 4, 2, 2, 2, true>(p, stream);  // variant 4 with the ping-pong schedule
+        case 10: return launch_p16<AMODE, 128, 128, 2, 4, 2, 2, false, 1>(p, stream);  // variant 3, software-pipelined main loop, DMA first
+        case 11: return launch_p16<AMODE, 128, 128, 2, 2, 2, 2, false, 1>(p, stream);  // 4 waves of 64x64, software-pipelined, DMA first
+        case 12: return launch_p16<AMODE, 128, 128, 2, 4, 2, 2, false, 2>(p, stream);  // variant 10 with the DMA pieces between the MFMAs
+        case 13: return launch_p16<AMODE, 128, 128, 2, 2, 2, 2, false, 2>(p, stream);  // variant 11 with the DMA pieces between the MFMAs
         default: return launch_p16<AMODE, 128, 128, 2, 2, 2>(p, stream);  // 4 waves of 64x64, 2 stages (64 KB): 2 WG / CU
     }
 }
