@@ -26,6 +26,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the library is built with -fvisibility=hidden: the entry points declared here are its whole dynamic symbol table */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
 
 #define TRID_OK 0
 #define TRID_E_INVALID (-1)
@@ -652,6 +656,9 @@ int trid_step_replay_info(void* handle, int* counts);
 int trid_step_replay_run(void* handle, void* origin_stream);
 int trid_step_replay_destroy(void* handle);
 
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -556,6 +556,54 @@ def test_captured_train_step_equals_eager_bitwise(gpu):
         assert runs["eager"][3] == runs[other][3] and set(runs[other][3]) == {steps + 1}
 
 
+def test_config1_b128_replay_equals_eager(gpu):
+    """The seam between the TIMED launch form and the oracle-checked one at configs[1]'s own size (B = 128, K = 8192: the
+    split-count rules, tile shapes and BatchNorm partial counts of the benchmark): from one saved state the same batch goes
+    through the recorded step re-issued by csrc/step_replay.hip - FusedAdam included - and through the eager step; the three
+    losses, every parameter / buffer (queues, pointer, BatchNorm statistics, key encoders) and every Adam moment agree BIT
+    for bit.  `bench.py` runs the same function after its timed region (`replay_equals_eager_b128`); the eager step at this
+    size is what tests/test_model_gpu.py::test_config1_b128_k8192_step_vs_oracle holds against the oracle
+    (lib/engine/trainer.py:81-91)."""
+    import bench
+    from textreid_amd.caption import CaptionBatch
+    from textreid_amd.config import moco_cfg
+    from textreid_amd.engine.graph import CapturedTrainStep
+    from textreid_amd.model import build_model
+    from textreid_amd.solver import make_optimizer
+
+    B, K = 128, 8192
+    torch.manual_seed(0)
+    cfg = moco_cfg("m_resnet50", K=K)
+    table = torch.randn(49408, 512, generator=torch.Generator().manual_seed(1)) * 0.02
+    model = build_model(cfg, vocab_dict=table).to(gpu).train()
+    opt = make_optimizer(cfg, model)
+    runner = CapturedTrainStep(model, opt, warmup=2, caption_bound=64)
+    batches = [bench.synth_batch(B, s, gpu, 1234) for s in range(4)]
+
+    def batch(i):
+        images, tokens, lengths, ids = batches[i % 4]
+        return images, CaptionBatch(tokens, lengths, (ids + (i // 4) * 4 * (B // 4)) % 11003, max_len=64)
+
+    i = 0
+    while runner.graph is None and i < 6:
+        runner(*batch(i))
+        i += 1
+    assert runner.graph is not None and runner.replayer is not None
+    for _ in range(2):  # two replayed steps before the comparison: moments and queues are mid-run, not at their start values
+        runner(*batch(i))
+        i += 1
+    res = bench.replay_equals_eager(runner, model, opt, *batch(i))
+    print("replay vs eager at B=128:", {k: v for k, v in res.items() if k != "losses"})
+    assert res["launch_form"] == "stream replay" and res["adam_moment_pairs"] == 183
+    assert res["state_tensors_changed_by_the_step"] > 350  # (query + key encoders, queues, BatchNorm statistics moved)
+    assert res["equal"], res["first_differences"]
+    # ... and through hipGraphLaunch of the same recording
+    runner.force_graph_launch = True
+    res = bench.replay_equals_eager(runner, model, opt, *batch(i + 1))
+    runner.force_graph_launch = False
+    assert res["launch_form"] == "hipgraph replay" and res["equal"], res["first_differences"]
+
+
 def test_schedule_and_fusion_switches_leave_the_gradients_alone(gpu):
     """The round-5 switches of the backward pass against the forms they replace, on one step of the full model (B = 8):
     SCHEDULING switches - a block's weight gradients behind one event (m_resnet._BATCH_WGRAD), the attention pool's weight

@@ -30,6 +30,13 @@ namespace trid {
 
 constexpr int P16_BK = 32;
 
+// LDS of a gemm_p16_kernel workgroup: the operand stages - and, for the 12-wave tile that has a CU to itself anyway, room for the
+// whole fp32 tile of the staged (whole-row) epilogue
+constexpr int p16_lds_bytes(int BM, int BN, int NW, int STAGES) {
+    const int st = STAGES * (BM + BN) * 128;
+    return (NW == 12 && BM * BN * 4 > st) ? BM * BN * 4 : st;
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -66,7 +73,7 @@ __device__ __forceinline__ void dma16_asm(const v4i_t& rs, unsigned lds_byte_add
 // SP: software-pipelined main loop (see "software pipeline" below): the fragments of a K tile's second half are
 // multiplied AFTER the next tile's barrier, under the LDS reads of that tile's first half.
 template <int AMODE, int BM, int BN, int WM, int WN, int STAGES, int PL, bool PP = false, int SP = 0>
-__global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 && STAGES == 2) ? 2 : (WM * WN == 8 && (BM + BN) * 128 * STAGES <= 80 * 1024 ? 4 : (WM * WN == 6 ? 3 : 2))) void gemm_p16_kernel(GemmParams p) {
+__global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 && STAGES == 2) ? 2 : (WM * WN == 8 && (BM + BN) * 128 * STAGES <= 80 * 1024 ? 4 : ((WM * WN == 6 || WM * WN == 12) ? 3 : 2))) void gemm_p16_kernel(GemmParams p) {
     constexpr int NW = WM * WN;
     constexpr int BKE = PL == 2 ? 32 : 64;  // K elements per 128-byte row chunk = per K tile
     constexpr int EB = PL == 2 ? 4 : 2;     // bytes per element of a row
@@ -416,23 +423,25 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 && STAGES == 2) ? 2 : (W
         auto tile = [&](int t, auto stage_c) {
             constexpr int stage = decltype(stage_c)::value;
             const bool has_prev = t > 0, has_next = t + 1 < nk;  // (wave-uniform)
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_waitcnt(0x0070);  // lgkmcnt(0) (vmcnt 0 too; the builtin so that hipcc's own count restarts here)
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             rd(stage, 0, f0a, f0b);
             __builtin_amdgcn_sched_barrier(0);
             latch();
-            if (has_next && (SP == 1 || !has_prev)) {
+            if (has_next && ((SP & 3) == 1 || !has_prev)) {
 #pragma unroll
                 for (int q = 0; q < PER_TILE; ++q) piece(stage ^ 1, q);
             }
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr ((SP & 4) != 0) __builtin_amdgcn_s_setprio(1);  // (A/B: the MFMA phases above the other waves' loads)
             if (has_prev) {
                 int q = 0;
 #pragma unroll
                 for (int m = 0; m < NM; ++m) {
                     mm1(f1a, f1b, m);
-                    if constexpr (SP == 2) {
+                    if constexpr ((SP & 3) == 2) {
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                         for (int e = 0; e < PER_TILE; ++e)
@@ -450,6 +459,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 && STAGES == 2) ? 2 : (W
             advance();
 #pragma unroll
             for (int m = 0; m < NM; ++m) mm1(f0a, f0b, m);
+            if constexpr ((SP & 4) != 0) __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
         };
         typedef std::integral_constant<int, 0> S0;
@@ -576,7 +586,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 && STAGES == 2) ? 2 : (W
         }
     };
 
-    if constexpr (BM * BN * 4 <= STAGES * STAGE_SLOTS * 16) {
+    if constexpr (BM * BN * 4 <= p16_lds_bytes(BM, BN, WM * WN, STAGES)) {
         const bool pre = p.stats != nullptr;  // partials need the final values in the accumulator layout
         if (p.wide_epilogue && (p.N & 3) == 0 && (p.ldc & 3) == 0 && (p.sC & 3) == 0 && (p.sSplit & 3) == 0 &&
             (p.res == nullptr || (p.ldres & 3) == 0) && !(pre && (p.accumulate || p.res != nullptr))) {
@@ -868,7 +878,8 @@ __device__ __forceinline__ f16x8 tr_frag(const char* lds_addr) {
 
 // PL = 2: P16 operands (pieces of 32 channels, 32-pixel K tiles); PL = 1: plain bf16 operands (pieces of 64 channels,
 // 64-pixel K tiles, one bf16 MFMA per product).
-template <int BMODE, int BM, int STAGES, int PL>
+// SP != 0: the software-pipelined main loop of gemm_p16_kernel (step-1 MFMAs of a tile after the next tile's barrier).
+template <int BMODE, int BM, int STAGES, int PL, int SP = 0>
 __global__ __launch_bounds__(512, 4) void gemm_p16_wgrad_kernel(GemmParams p) {
     constexpr int BN = 128, NW = 8, WN = 4, WM = 2;
     constexpr int GC = PL == 2 ? 32 : 64;        // channels per 128-byte piece
@@ -1035,7 +1046,103 @@ __global__ __launch_bounds__(512, 4) void gemm_p16_wgrad_kernel(GemmParams p) {
     // column tile of 9 * 32 = 288 columns) only loads and synchronises: its MFMAs would take half of its SIMD's matrix
     // pipe from the wave that has work
     const bool wave_live = (m0 + wm * (32 * TM) < p.M) && (n0 + wn * 32 < p.N);
-    {
+    if constexpr (SP != 0) {
+        static_assert(STAGES == 2 && PL == 2, "software pipeline: two stages, P16 operands");
+        const v4i_t rsA_s = raw_rsrc(A, (unsigned)((long long)p.K * a_ld)), rsB_s = raw_rsrc(b_base, (unsigned)(b_rows * b_ld));
+        const unsigned smem_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
+        // the LDS-DMA pieces of a K tile, out of the compiler's sight (dma16_asm; completion is counted at the top of a tile), in
+        // two halves: prep(kt) works out every lane's source offset (row range of the split, 3x3: validity of the pixel's tap) -
+        // placed under the MFMAs of the tile before -, fire(stage) is nothing but the DMA instructions
+        unsigned nvA[A_PW], nvB[B_PW], n_soA = 0, n_soB = 0;
+        auto prep = [&](int kt) {
+            const int k0 = k_begin + kt * PBK;
+            n_soA = (unsigned)((long long)k0 * a_ld);
+            n_soB = (unsigned)((long long)k0 * b_ld);
+#pragma unroll
+            for (int j = 0; j < A_PW; ++j) {
+                const int c = j * NW + wave;
+                nvA[j] = (k0 + 8 * (c % CPG) + (lane >> 3) < k_end) ? voA[j] : OOB;
+            }
+#pragma unroll
+            for (int j = 0; j < B_PW; ++j) {
+                const int m = k0 + b_pp[j];
+                bool ok = m < k_end;
+                if (BMODE == B_CONV) {
+                    const uint32_t q = fdiv((uint32_t)m, p.fdW);
+                    const int x = m - (int)q * p.W;
+                    const uint32_t b = fdiv(q, p.fdH);
+                    const int y = (int)q - (int)b * p.H;
+                    const int yy = y + b_dy[j], xx = x + b_dx[j];
+                    ok = ok && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
+                }
+                nvB[j] = ok ? voB[j] : OOB;
+            }
+        };
+        auto fire = [&](int stage) {
+            const unsigned sA = smem_base + (unsigned)(stage * STAGE_BYTES), sB = sA + A_BYTES;
+#pragma unroll
+            for (int j = 0; j < A_PW; ++j) {
+                const int c = j * NW + wave;
+                if (A_CH % NW != 0 && c >= A_CH) break;
+                dma16_asm(rsA_s, sA + (unsigned)c * 1024u, nvA[j], n_soA);
+            }
+#pragma unroll
+            for (int j = 0; j < B_PW; ++j) dma16_asm(rsB_s, sB + (unsigned)(j * NW + wave) * 1024u, nvB[j], n_soB);
+        };
+        f16x8 f0a[2][TM], f0b[2], f1a[2][TM], f1b[2];
+        auto rd = [&](int stage, int ks, f16x8 (&fa)[2][TM], f16x8 (&fb)[2]) {
+            const char* sA = sbase + stage * STAGE_BYTES;
+            const char* sB = sA + A_BYTES;
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[pl][i] = tr_frag(sA + frag_off(wm * TM + i, pl, ks));
+                fb[pl] = tr_frag(sB + frag_off(wn, pl, ks));
+            }
+        };
+        auto mm = [&](const f16x8 (&fa)[2][TM], const f16x8 (&fb)[2]) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[0][i], fb[1], acc[i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[1][i], fb[0], acc[i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[0][i], fb[0], acc[i], 0, 0, 0);
+        };
+        auto tile = [&](int t, auto stage_c) {
+            constexpr int stage = decltype(stage_c)::value;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_waitcnt(0x0070);  // lgkmcnt(0) (vmcnt 0 too; the builtin so that hipcc's own count restarts here)
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (wave_live) rd(stage, 0, f0a, f0b);
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + 1 < nk) fire(stage ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (wave_live) {
+                if (t > 0) mm(f1a, f1b);
+                __builtin_amdgcn_sched_barrier(0);
+                rd(stage, 1, f1a, f1b);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + 2 < nk) prep(t + 2);
+            if (wave_live) mm(f0a, f0b);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        typedef std::integral_constant<int, 0> S0;
+        typedef std::integral_constant<int, 1> S1;
+        if (nk > 0) {
+            prep(0);
+            fire(0);
+            if (nk > 1) prep(1);
+            int t = 0;
+            for (; t + 1 < nk; t += 2) {
+                tile(t, S0());
+                tile(t + 1, S1());
+            }
+            if (t < nk) tile(t, S0());
+            if (wave_live) mm(f1a, f1b);
+        }
+    } else {
 #pragma unroll
         for (int s = 0; s < STAGES - 1; ++s)
             if (s < nk) issue(s, s);
@@ -1193,7 +1300,7 @@ static int launch_p16(GemmParams& p, hipStream_t stream) {
     // TRID_GEMM_LDS_PAD=<KB>: request at least that much LDS per workgroup - an occupancy knob for experiments (e.g. 96:
     // one workgroup per CU, which leaves registers and wave slots to the HBM-bound kernels of the other streams)
     static const size_t pad = getenv("TRID_GEMM_LDS_PAD") ? (size_t)atoi(getenv("TRID_GEMM_LDS_PAD")) * 1024 : 0;
-    const size_t lds = std::max((size_t)STAGES * (BM + BN) * 128, pad);
+    const size_t lds = std::max((size_t)p16_lds_bytes(BM, BN, WM * WN, STAGES), pad);
     static std::once_flag once;
     static hipError_t attr_err = hipSuccess;
     std::call_once(once, [lds] {
@@ -1217,7 +1324,13 @@ static int pick_p16(GemmParams& p, int variant, int planes, hipStream_t stream) 
     }
     if (p.N <= 32) return launch_p16<AMODE, 256, 32, 4, 1, 3>(p, stream);
     if (p.N <= 64) return launch_p16<AMODE, 128, 64, 2, 2, 3>(p, stream);
-    if (variant < 0 || ((p.c_fmt == 1 || p.bb.y != nullptr) && variant != 10)) variant = 3;  // (the eval epilogue and the BatchNorm-backward sums live in the staged-through-LDS store path of the default tile)
+    // the library's choice: 8 waves of 64x32, two stages, software-pipelined main loop (profiles/r06c_kloop.txt: 0.43 of 833 on random /
+    // 0.58 on zero operands over the layer2-4 3x3 shapes against 0.40 / 0.52 of variant 3, the barrier-per-tile loop it replaces;
+    // TRID_P16_DEFAULT_VARIANT=3 brings that one back for A/B runs).  The eval epilogue and the BatchNorm-backward sums live in the
+    // staged-through-LDS store path of the 128x128 8-wave tile: they take the default whatever was asked for.
+    static const int def_env = getenv("TRID_P16_DEFAULT_VARIANT") ? atoi(getenv("TRID_P16_DEFAULT_VARIANT")) : 12;
+    const bool tile8 = variant == 3 || variant == 10 || variant == 12 || variant == 14;
+    if (variant < 0 || ((p.c_fmt == 1 || p.bb.y != nullptr) && !tile8)) variant = def_env;
     switch (variant) {
         case 1: return launch_p16<AMODE, 128, 128, 2, 2, 3>(p, stream);   // 4 waves of 64x64, 3 stages (96 KB): 1 WG / CU
         case 2: return launch_p16<AMODE, 256, 128, 4, 2, 3>(p, stream);   // 8 waves of 64x64, 3 stages (144 KB)
@@ -1235,6 +1348,11 @@ static int pick_p16(GemmParams& p, int variant, int planes, hipStream_t stream) 
         case 11: return launch_p16<AMODE, 128, 128, 2, 2, 2, 2, false, 1>(p, stream);  // 4 waves of 64x64, software-pipelined, DMA first
         case 12: return launch_p16<AMODE, 128, 128, 2, 4, 2, 2, false, 2>(p, stream);  // variant 10 with the DMA pieces between the MFMAs
         case 13: return launch_p16<AMODE, 128, 128, 2, 2, 2, 2, false, 2>(p, stream);  // variant 11 with the DMA pieces between the MFMAs
+        // 192-row tiles, 12 waves of 64x32, ONE workgroup per CU (80 KB of stages, 96 KB with the staged epilogue): every layer2-4
+        // shape at B = 128 becomes a whole number of rounds of 256 workgroups (M = 24 576 x N = 512: 512 tiles instead of 768 on 512 slots)
+        case 15: return launch_p16<AMODE, 192, 128, 3, 4, 2, 2, false, 2>(p, stream);
+        case 16: return launch_p16<AMODE, 192, 128, 3, 4, 2, 2, false, 1>(p, stream);
+        case 14: return launch_p16<AMODE, 128, 128, 2, 4, 2, 2, false, 6>(p, stream);  // variant 12 with raised priority from the first to the last MFMA of a tile
         default: return launch_p16<AMODE, 128, 128, 2, 2, 2>(p, stream);  // 4 waves of 64x64, 2 stages (64 KB): 2 WG / CU
     }
 }
@@ -1267,7 +1385,7 @@ extern "C" int trid_p16_pack_wt_f32(const float* w, int N, int T, int C, int fli
     return check_launch("trid_p16_pack_wt_f32");
 }
 
-template <int BMODE, int BM, int PL>
+template <int BMODE, int BM, int PL, int SP = 0>
 static int launch_p16_wgrad(GemmParams& p, hipStream_t stream) {
     constexpr int STAGES = 2;
     p.mblocks = (p.M + BM - 1) / BM;
@@ -1282,13 +1400,13 @@ static int launch_p16_wgrad(GemmParams& p, hipStream_t stream) {
     static hipError_t attr_err = hipSuccess;
     std::call_once(once, [lds] {
         if (lds > 48 * 1024)
-            attr_err = hipFuncSetAttribute((const void*)gemm_p16_wgrad_kernel<BMODE, BM, STAGES, PL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_err = hipFuncSetAttribute((const void*)gemm_p16_wgrad_kernel<BMODE, BM, STAGES, PL, SP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     });
     if (attr_err != hipSuccess) {
         set_error("trid_gemm_p16_wgrad: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(attr_err));
         return (int)attr_err;
     }
-    hipLaunchKernelGGL((gemm_p16_wgrad_kernel<BMODE, BM, STAGES, PL>), grid, dim3(512), lds, stream, p);
+    hipLaunchKernelGGL((gemm_p16_wgrad_kernel<BMODE, BM, STAGES, PL, SP>), grid, dim3(512), lds, stream, p);
     return check_launch("trid_gemm_p16_wgrad");
 }
 
@@ -1331,6 +1449,8 @@ extern "C" int trid_gemm_p16_wgrad(const trid_gemm_desc* d, void* stream_) {
         if (d->b_mode == B_CONV) return d->M <= 64 ? launch_p16_wgrad<B_CONV, 64, 1>(p, stream) : launch_p16_wgrad<B_CONV, 128, 1>(p, stream);
         return d->M <= 64 ? launch_p16_wgrad<B_NC, 64, 1>(p, stream) : launch_p16_wgrad<B_NC, 128, 1>(p, stream);
     }
+    static const int sp_env = getenv("TRID_WGRAD_SP") ? atoi(getenv("TRID_WGRAD_SP")) : 0;  // (1: the software-pipelined main loop)
+    if (sp_env && d->M > 64) return d->b_mode == B_CONV ? launch_p16_wgrad<B_CONV, 128, 2, 1>(p, stream) : launch_p16_wgrad<B_NC, 128, 2, 1>(p, stream);
     if (d->b_mode == B_CONV) return d->M <= 64 ? launch_p16_wgrad<B_CONV, 64, 2>(p, stream) : launch_p16_wgrad<B_CONV, 128, 2>(p, stream);
     return d->M <= 64 ? launch_p16_wgrad<B_NC, 64, 2>(p, stream) : launch_p16_wgrad<B_NC, 128, 2>(p, stream);
 }
@@ -1344,7 +1464,7 @@ extern "C" int trid_p16_pack_multi_f32(const long long* table, const float* amax
 extern "C" int trid_gemm_p16_rows(int M, int N, int precision, int variant) {
     (void)M;
     if (precision == 1 || N <= 64) return 128;
-    return variant == 9 ? 96 : 128;
+    return variant == 9 ? 96 : ((variant == 15 || variant == 16) ? 192 : 128);
 }
 
 static int wide_env_ok() {

@@ -9,7 +9,8 @@ import torch
 from textreid_amd import ops
 dev = torch.device("cuda")
 B = 128
-variants = [int(v) for v in sys.argv[1:]] or [3, 10, 11, 12, 13]
+WGRAD = "--wgrad" in sys.argv  # weight-gradient GEMMs instead (the main loop is chosen by TRID_WGRAD_SP: one process per form)
+variants = [int(v) for v in sys.argv[1:] if not v.startswith("--")] or [3, 10, 11, 12, 13]
 PEAK = 2500.0 / 3
 def t(fn, reps=10):
     fn(); fn(); torch.cuda.synchronize()
@@ -39,17 +40,43 @@ def run(name, M, N, K, conv, count):
         ref = None
         for v in variants:
             y = torch.empty(M, N, device=dev)
-            st = torch.zeros((M + 127) // 128, N, 4, device=dev)
+            rows = ops.gemm_p16_rows(M, N, 1, v)
+            st = torch.zeros((M + rows - 1) // rows, N, 4, device=dev)
             f = lambda: ops.gemm_p16(xp, wp, y, M, N, K, N, conv=conv, stats=st, variant=v, minmax=True)
             ms = t(f)
             tot[(v, zero)] += ms * count
             ok = ""
             if not zero:
                 if ref is None: ref = (y.clone(), st.clone())
-                else: ok = "=" if (torch.equal(y, ref[0]) and torch.equal(st, ref[1])) else "DIFF(%.1e)" % float((y - ref[0]).abs().max() / ref[0].abs().max())
+                else: ok = "=" if (torch.equal(y, ref[0]) and (st.shape != ref[1].shape or torch.equal(st, ref[1]))) else "DIFF(%.1e)" % float((y - ref[0]).abs().max() / ref[0].abs().max())
             line += " %s v%d %6.3f %4.0f%s" % ("z" if zero else "r", v, ms, fl / ms / 1e9, ok)
         line += " |"
     print(line, flush=True)
+if WGRAD:
+    import hashlib
+    print("weight gradients, TRID_WGRAD_SP=%s: ms, TFLOP/s, sha1 of the result (compare across processes)" % os.environ.get("TRID_WGRAD_SP", "0"))
+    tw = fw = 0.0
+    def wg(name, H, W, Ci, Co, conv, count):
+        global tw, fw
+        Mp = B * H * W
+        x, dy = torch.randn(Mp, Ci, device=dev).relu_(), torch.randn(Mp, Co, device=dev)
+        if conv: x = x.view(B, H, W, Ci)
+        ax, ady = ops.amax(x), ops.amax(dy)
+        xp, dyp = ops.p16_pack(x, ax), ops.p16_pack(dy, ady)
+        fl = 2.0 * Mp * Ci * Co * (9 if conv else 1)
+        f = (lambda: ops.wgrad_p16(dyp, xp, conv=(H, W, Ci))) if conv else (lambda: ops.wgrad_p16(dyp, xp))
+        g = f()
+        ms = t(f)
+        tw += ms * count; fw += fl * count
+        print("%-28s %7.3f ms %4.0f TF  %s" % (name, ms, fl / ms / 1e9, hashlib.sha1(g.cpu().numpy().tobytes()).hexdigest()[:12]), flush=True)
+    torch.manual_seed(5)
+    wg("l2.x 3x3 48x16 128", 48, 16, 128, 128, True, 3); wg("l3.0 3x3 48x16 256", 48, 16, 256, 256, True, 1)
+    wg("l3.x 3x3 24x8 256", 24, 8, 256, 256, True, 5); wg("l4.x 3x3 24x8 512", 24, 8, 512, 512, True, 3)
+    wg("l3 1x1 1024->256", 24, 8, 1024, 256, False, 5); wg("l3 1x1 256->1024", 24, 8, 256, 1024, False, 6)
+    wg("l4 1x1 2048->512", 24, 8, 2048, 512, False, 2); wg("l4 1x1 512->2048", 24, 8, 512, 2048, False, 3)
+    wg("l2 1x1 512->128", 48, 16, 512, 128, False, 3); wg("l2 1x1 128->512", 48, 16, 128, 512, False, 4)
+    print("total %7.3f ms  %4.0f TF  frac %.3f" % (tw, fw / tw / 1e9, fw / tw / 1e9 / PEAK))
+    sys.exit(0)
 print("columns: r = random operands, z = zero operands; per variant ms, TFLOP/s (fp32-equivalent), '=' bit-equal to the first variant")
 shapes3 = [("l2.0 3x3 96x32 128", 96, 32, 128, 1), ("l2.x 3x3 48x16 128", 48, 16, 128, 3), ("l3.0 3x3 48x16 256", 48, 16, 256, 1),
            ("l3.x 3x3 24x8 256", 24, 8, 256, 5), ("l4.x 3x3 24x8 512", 24, 8, 512, 3)]
