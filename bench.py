@@ -581,9 +581,16 @@ def main():
         sys.exit(2)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
+    # dp: the data-parallel exchange steps run.  TRID_DP_FORCE=1 with ONE rank: a one-rank `nccl` group drives every RCCL call of
+    # the step on a single-GPU box (the host path of the data-parallel step - eager or segmented replay - is then measurable there)
+    dp = world > 1 or os.environ.get("TRID_DP_FORCE", "0") == "1"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend=backend, init_method="env://")
+    elif dp:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29591")
+        dist.init_process_group(backend=backend, init_method="env://", rank=0, world_size=1)
 
     from textreid_amd import ops
     from textreid_amd.caption import CaptionBatch
@@ -600,7 +607,7 @@ def main():
     log("model built")
     opt = make_optimizer(cfg, model)
     reducer = GradReducer()
-    if world > 1 and os.environ.get("TRID_DP_OVERLAP", "1") != "0":
+    if dp and os.environ.get("TRID_DP_OVERLAP", "1") != "0":
         # image-encoder gradients are all-reduced per residual layer from inside its backward (overlap)
         model.embed_model.v_encoder_q.grad_sync = reducer
     pre_gather = [p for n, p in model.named_parameters() if p.requires_grad and "loss_evaluator" not in n]
@@ -611,16 +618,15 @@ def main():
     if world > 1:  # global ids so positives match across ranks' queue pushes
         batches = [(im, tk, ln, ids + rank * (B // 4) + s * (B // 4) * (world - 1)) for s, (im, tk, ln, ids) in enumerate(batches)]
 
-    # single process: the whole step (four streams, ~1100 launches) is recorded once as a hipGraph and replayed
-    # (engine/graph.py); data parallel: eager (RCCL collectives are issued from inside backward)
+    # the whole step (four streams, ~1100 launches) is recorded once and re-issued by the library (engine/graph.py); data parallel:
+    # the recording's collectives are cut points, the replay runs in segments around them (TRID_DP_CAPTURE=0: the eager DP step)
     runner = None
-    dp_capture = world > 1 and os.environ.get("TRID_DP_CAPTURE", "0") == "1" and backend == "nccl"  # (opt-in: see engine/trainer.py)
-    if (world == 1 or dp_capture) and os.environ.get("TRID_CAPTURE", "1") != "0":
+    dp_capture = dp and os.environ.get("TRID_DP_CAPTURE", "1") != "0"
+    if (not dp or dp_capture) and os.environ.get("TRID_CAPTURE", "1") != "0":
         from textreid_amd.engine.graph import CapturedTrainStep
 
         runner = CapturedTrainStep(model, opt, warmup=2, caption_bound=64,  # 64-token captions (padded to 105)
-                                   reducer=reducer if world > 1 else None, pre_gather=pre_gather,
-                                   launch="graph" if world > 1 else None)  # (a recording with RCCL's kernels is launched as a graph)
+                                   reducer=reducer if dp else None, pre_gather=pre_gather)
 
     def batch(i):
         images, tokens, lengths, ids = batches[i % len(batches)]
@@ -632,7 +638,7 @@ def main():
         losses = sum(loss_dict.values())
         opt.zero_grad()
         losses.backward()
-        if world > 1:
+        if dp:
             reducer.reduce(pre_gather)
             reducer.wait()
         opt.step()
@@ -673,14 +679,15 @@ def main():
         probe(lambda j: runner._eager(*batch(base + j)), 2)  # (the eager path's own warm-up after the recording)
         ms_streams = probe(lambda j: step(base + 2 + j)) if runner.replayer is not None else None
         ms_graph = None
-        try:  # hipGraphLaunch of the same recording
-            runner.force_graph_launch = True
-            step(base + 8)
-            ms_graph = probe(lambda j: step(base + 9 + j))
-        except RuntimeError as e:
-            log("launch probe: hipGraphLaunch failed (%s)" % (str(e).splitlines()[0] if str(e) else type(e).__name__))
-        finally:
-            runner.force_graph_launch = False
+        if not runner.cuts:  # (a data-parallel recording holds markers in place of its collectives: it has no hipGraphLaunch form)
+            try:  # hipGraphLaunch of the same recording
+                runner.force_graph_launch = True
+                step(base + 8)
+                ms_graph = probe(lambda j: step(base + 9 + j))
+            except RuntimeError as e:
+                log("launch probe: hipGraphLaunch failed (%s)" % (str(e).splitlines()[0] if str(e) else type(e).__name__))
+            finally:
+                runner.force_graph_launch = False
         ms_eager = probe(lambda j: runner._eager(*batch(base + 15 + j)))
         forced = os.environ.get("TRID_BENCH_LAUNCH", "")
         cands = {"stream replay": ms_streams, "hipgraph replay": ms_graph, "eager": ms_eager}
@@ -691,7 +698,8 @@ def main():
         if cands[chosen] is None:
             chosen = "eager"
         launch_probe = {"stream_replay_ms_per_step": ms_streams, "hipgraph_replay_ms_per_step": ms_graph, "eager_ms_per_step": ms_eager,
-                        "chosen": chosen, "stream_replay_plan": runner.replay_info}
+                        "chosen": chosen, "stream_replay_plan": runner.replay_info,
+                        "collectives_as_cut_points": len(runner.cuts)}
         if world > 1:  # every rank must take the same path: rank 0 decides
             names = ["stream replay", "hipgraph replay", "eager"]
             flag = torch.tensor([names.index(chosen)], device=device)
@@ -725,7 +733,7 @@ def main():
     log("timed region: %.3fs for %d steps (host enqueue time %.3fs)" % (dt, args.steps, t_host))
     last = {k: v.detach().clone() for k, v in last.items()}
     seam = None
-    if runner is not None and world == 1 and not use_eager:
+    if runner is not None and not dp and not use_eager:
         seam = replay_equals_eager(runner, model, opt, *batch(n_prep + args.warmup + args.steps))
         log("replay vs eager at B=%d (%s, optimizer included): %s" % (B, seam["launch_form"], "bit-identical" if seam["equal"] else "DIFFERENT: %s" % seam["first_differences"]))
     profiled_eager = 0
@@ -770,7 +778,7 @@ def main():
     achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
     flops2, ms2, nlaunch2 = live("gemm1x1")
     bytes3, ms3, nlaunch3 = live("stream1x1")
-    dp_stats = reducer.stats() if world > 1 else None
+    dp_stats = reducer.stats() if dp else None
 
     # the same kernel alone on the GPU (no side-stream work sharing the CUs): the 3x3 layers of layer2-4
     # ... and once more on ZERO-filled operands: MFMA timing does not depend on the data, the power drawn - hence the
@@ -916,7 +924,9 @@ def main():
     nrun = max(profiled_eager, 1) if runner is not None else args.steps
     roofline["total_ms_per_step"] = ms / nrun
     roofline_1x1["total_ms_per_step"] = ms2 / nrun
-    if roofline_1x1["total_ms_per_step"] > roofline["total_ms_per_step"]:
+    # (the 3x3 form stays in front unless the 1x1 form's total is clearly larger: the two are within a few per cent of each other,
+    # and a headline object that changes kernel from run to run compares with nothing)
+    if roofline_1x1["total_ms_per_step"] > 1.1 * roofline["total_ms_per_step"]:
         roofline, roofline_1x1 = roofline_1x1, roofline
     roofline_stream = {
         "bound": "hbm",
@@ -945,7 +955,8 @@ def main():
     qsim.append(queue_similarity_bench(device, B=B, K=65536, bf16=True))
     step_launch = ("eager launches, four streams (chosen by the probe over the recorded step)" if use_eager else
                    ("hipGraph replay (one launch per step)" if (runner.force_graph_launch or runner.replayer is None) else
-                    "stream replay: the recorded step re-issued as stream launches by one library call per step (csrc/step_replay.hip; chosen by the probe)")) if runner is not None else "eager (%d rank(s)%s)" % (world, ": RCCL collectives inside backward" if world > 1 else "")
+                    ("segmented stream replay: the recorded step re-issued by csrc/step_replay.hip in %d segments around its %d collectives, which run through torch.distributed on the recorded streams (chosen by the probe)" % (len(runner.cuts) + 1, len(runner.cuts)) if runner.cuts else
+                     "stream replay: the recorded step re-issued as stream launches by one library call per step (csrc/step_replay.hip; chosen by the probe)"))) if runner is not None else "eager (%d rank(s)%s)" % (world, ": RCCL collectives inside backward" if dp else "")
     c3 = None
     if world == 1 and not args.no_configs3 and ops.conv_precision() == 16 and args.model == "m_resnet50":
         del model, opt, runner
@@ -982,7 +993,7 @@ def main():
             "roofline_second": roofline_1x1,
             "roofline_stream": roofline_stream,
         }
-        if world > 1:
+        if dp:
             # data-parallel accounting of the timed steps: one RCCL rank per GPU, gradient bytes all-reduced per step,
             # the fraction of them issued from INSIDE backward (overlapped) and the device time left exposed after it
             out["data_parallel"] = dict(dp_stats, rccl_ranks=world, backend=dist.get_backend(),
@@ -993,7 +1004,7 @@ def main():
         out["retrieval"] = retr
         out["queue_similarity"] = qsim
         out["configs3_1gpu"] = c3
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and not dp:
             cb = cpu_baseline()
             pref = cb.pop("_parity_ref")
             out["cpu_baseline"] = cb
@@ -1004,7 +1015,7 @@ def main():
             out["cpu_baseline"] = None
             out["parity_vs_oracle"] = None
         print(json.dumps(out))
-    if world > 1:
+    if dp:
         dist.destroy_process_group()
 
 

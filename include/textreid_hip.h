@@ -167,6 +167,9 @@ int trid_p16_pack_multi_f32(const long long* table, const float* amax, int n_ten
  * partials `stats` cover trid_gemm_p16_rows(M, N, precision, variant) rows each (128; 96 for variant 9). */
 int trid_gemm_p16(const trid_gemm_desc* d, int variant, void* stream);
 int trid_gemm_p16_rows(int M, int N, int precision, int variant);
+/* 1: trid_gemm_p16 accepts the BatchNorm-backward sums (desc.bnb_y) for an [M, N] output on this build / in this environment
+ * (whole 64- / 128-column tiles, the staged store path switched on: TRID_GEMM_WIDE_EPILOGUE) */
+int trid_gemm_p16_bnb_ok(int M, int N);
 /* The same product for SHORT reductions (K = 64 / 128 / 256: the expand 1x1 convolutions conv3 / downsample of layer1-3,
  * m_resnet.py:26,41-47, and the data gradients of conv1) as a streaming kernel (csrc/gemm_stream.hip): persistent
  * workgroups, the [32][K] filter panel of a wave in registers, activation tiles by LDS-DMA, stores straight from the
@@ -655,6 +658,15 @@ int trid_step_replay_build(void* graph, int max_lanes, void** out_handle);
 int trid_step_replay_info(void* handle, int* counts);
 int trid_step_replay_run(void* handle, void* origin_stream);
 int trid_step_replay_destroy(void* handle);
+/* Data parallel (train_net.py:50-56 around trainer.py:72-91): the step's collectives are not recorded.  trid_step_marker enqueues the
+ * empty marker kernel that stands for collective `id` in the recording (its stream and edges are the collective's); a plan built
+ * from a recording with markers is replayed in segments: run_segment issues the nodes up to the next marker and returns 1 with the
+ * collective's id and the stream the host must enqueue it on (through the communication library's own launch path), then is called
+ * again; it returns 0 once the step is complete.  A launch failure in mid-step joins what was issued back into origin_stream and
+ * poisons the handle (every later call fails).  markers: number of cut points of the plan. */
+int trid_step_marker(int id, void* stream);
+int trid_step_replay_markers(void* handle);
+int trid_step_replay_run_segment(void* handle, void* origin_stream, int* marker_id, void** lane_stream);
 
 #if defined(__GNUC__) || defined(__clang__)
 #pragma GCC visibility pop

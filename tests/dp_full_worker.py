@@ -82,11 +82,31 @@ def main():
         return fused(*a)
 
     head.loss_evaluator.forward_fused = spy
-    ld = model(images[sl].to(dev), CaptionBatch(tokens[sl].to(dev), lengths[sl].to(dev), ids[sl].to(dev)))
-    sum(ld.values()).backward()
     pre = [p for n, p in model.named_parameters() if p.requires_grad and "loss_evaluator" not in n][::-1]
-    red.reduce(pre)
-    red.wait()
+    x_l, cb_l = images[sl].to(dev), CaptionBatch(tokens[sl].to(dev), lengths[sl].to(dev), ids[sl].to(dev))
+    runner_mode = os.environ.get("TRID_DP_RUNNER", "1") == "1"
+    segments = 0
+    if runner_mode:
+        # the step on the fast host path (engine.graph.CapturedTrainStep under data parallelism: recorded once, replayed in SEGMENTS
+        # around its collectives): two eager calls, then the recording and its first replay - each from the SAME initial state
+        # (restored in place), so that what is compared below is the REPLAYED step of that state.  The spies' clones are nodes of
+        # the recording: after the replay they hold the replayed step's gathered blocks and gradients.
+        from textreid_amd.engine.graph import CapturedTrainStep
+
+        runner = CapturedTrainStep(model, None, warmup=2, caption_bound=int(lengths[sl].max()), reducer=red, pre_gather=pre)
+        for i in range(3):
+            head.load_state_dict({k: v.clone() for k, v in st.items()})
+            ops.note_parameter_write()
+            seen.clear()
+            ld = runner(x_l, cb_l)
+        torch.cuda.synchronize()
+        assert runner.graph is not None and not runner.disabled and len(runner.cuts) >= 3, "the data-parallel step was not recorded"
+        segments = len(runner.cuts) + 1
+    else:
+        ld = model(x_l, cb_l)
+        sum(ld.values()).backward()
+        red.reduce(pre)
+        red.wait()
     torch.cuda.synchronize()
     head.loss_evaluator.forward_fused = fused
     t_step = time.time() - t0
@@ -107,8 +127,11 @@ def main():
              "v_embed_layer.weight", "t_embed_layer.bias", "loss_evaluator.projection"]
     dp_grads = {k: named[k].grad.detach().clone() for k in probe} if r == 0 else None
     dp_losses = {k: v.detach().clone() for k, v in ld.items()}
+    seen = {k: ([x.clone() for x in v] if isinstance(v, list) else v.clone()) for k, v in seen.items()}  # (out of the recording's pool)
     # every rank but 0 is done with its activations / gradients: hand the memory back before rank 0's single-process pass
     del ld
+    if runner_mode:
+        del runner
     for p in model.parameters():
         p.grad = None
     if r != 0:
@@ -117,8 +140,8 @@ def main():
     dist.barrier()
 
     if r == 0:
-        print("DPFULL_REPLICAS_IDENTICAL world=%d backend=%s devices=%d B_global=%d K=%d arch=%s conv_precision=%d (%.0f s to the end of the step)"
-              % (W, backend, ndev, Bg, K, arch, ops.conv_precision(), t_step))
+        print("DPFULL_REPLICAS_IDENTICAL world=%d backend=%s devices=%d B_global=%d K=%d arch=%s conv_precision=%d launch=%s (%.0f s to the end of the step)"
+              % (W, backend, ndev, Bg, K, arch, ops.conv_precision(), ("segmented_replay:%d" % segments) if runner_mode else "eager", t_step))
         # ---- 2. global losses vs the CPU oracle on the gathered blocks
         v_embed, t_embed, v_q, t_q, v_k, t_k, gid = [x.cpu() for x in seen["args"]]
         assert torch.equal(gid, ids) and v_embed.shape == (Bg, 256)

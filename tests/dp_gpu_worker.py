@@ -160,8 +160,9 @@ def main():
             def step(self):
                 pass
 
+        # (TRID_DP_TRAINER_CAPTURE=1: do_train's default - two eager steps, then the step recorded and replayed in segments)
         do_train(wrapper, Loader(), None, opt, Sched(), None, None, dev, checkpoint_period=10, evaluate_period=10,
-                 arguments={"max_epoch": 1, "epoch": 0, "iteration": 0}, log_period=1, capture=False)
+                 arguments={"max_epoch": 1, "epoch": 0, "iteration": 0}, log_period=1, capture=os.environ.get("TRID_DP_TRAINER_CAPTURE", "0") == "1")
         torch.cuda.synchronize()
         sha = hashlib.sha256()
         for k_, v_ in head.state_dict().items():
@@ -174,9 +175,11 @@ def main():
         assert int(head.queue_ptr) == (3 * Bg) % K
         if r == 0:
             print("DP_TRAINER_REPLICAS_IDENTICAL")
-    # ---- the data-parallel step RECORDED as one hipGraph (engine.graph.CapturedTrainStep with the run's GradReducer): the packed
-    # all-gather of the forward, the all-reduces staged from inside backward, the bucketed ones after it and the fused Adam
-    # step, replayed - bit for bit the eager data-parallel step (RCCL only: a host-staged transport cannot be recorded)
+    # ---- the data-parallel step RECORDED (engine.graph.CapturedTrainStep with the run's GradReducer) and replayed in SEGMENTS: the
+    # packed all-gather of the forward, the all-reduces staged from inside backward and the bucketed ones after it are cut points of
+    # the recording - the library re-issues the recorded kernels between them, torch.distributed runs each collective on the stream
+    # its marker was recorded on (RCCL's own launch path; gloo stages through the host as in the eager step) - bit for bit the
+    # eager data-parallel step, fused Adam included
     if os.environ.get("TRID_DP_CAPTURED", "0") == "1":
         from textreid_amd.engine.graph import CapturedTrainStep
         from textreid_amd.solver import FusedAdam
@@ -204,13 +207,16 @@ def main():
             if mode == "graph":
                 assert runner.graph is not None and not runner.disabled, "the data-parallel step was not recorded"
                 assert red2.bytes_staged > 0 and red2.bytes_post > 0
+                assert len(runner.cuts) >= 3 and runner.replayer is not None, "the collectives are cut points of the stream plan"
+                assert [c.kind for c in runner.cuts].count("all_gather") == 1
+                n_cuts = len(runner.cuts)
             runs[mode] = (torch.stack(losses), {k: v.detach().clone() for k, v in head.state_dict().items()})
             del runner, opt
         assert torch.equal(runs["eager"][0], runs["graph"][0]), (runs["eager"][0] - runs["graph"][0]).abs().max()
         for k, v in runs["eager"][1].items():
             assert torch.equal(v, runs["graph"][1][k]), k
         if r == 0:
-            print("DP_CAPTURED_OK backend=%s world=%d" % (dist.get_backend(), W))
+            print("DP_CAPTURED_OK backend=%s world=%d segments=%d" % (dist.get_backend(), W, n_cuts + 1))
     # ---- sharded retrieval: every rank scores its own (unevenly sized) gallery shard, lists are merged
     from textreid_amd.evaluation import similarity_topk
 

@@ -71,13 +71,28 @@ def test_dp_collectives_execute_on_rccl():
 
 
 def test_dp_step_recorded_with_its_rccl_collectives():
-    """the data-parallel step as ONE hipGraph - the `nccl` one-rank group with TRID_DP_FORCE=1 drives the
-    packed all-gather, the in-backward staged all-reduces and the bucketed ones inside the recording; five steps (two
-    eager warm-ups, the recording, replays) equal the eager data-parallel steps bit for bit: losses, every parameter,
-    queue, BatchNorm buffer."""
+    """The data-parallel step on the fast host path: recorded once, replayed in SEGMENTS around its collectives (the packed
+    all-gather, the in-backward staged all-reduces, the bucketed ones are cut points of the recording; RCCL runs each through its
+    own launch path on the stream the marker was recorded on).  The `nccl` one-rank group with TRID_DP_FORCE=1 drives every
+    collective; five steps (two eager warm-ups, the recording, replays) equal the eager data-parallel steps bit for bit: losses,
+    every parameter, queue, BatchNorm buffer."""
     out = _run_ranks(1, need=("DP_OK", "DP_REPLICAS_IDENTICAL", "DP_RETRIEVAL_OK", "DP_CAPTURED_OK"), TRID_DIST_BACKEND="nccl",
                      TRID_DP_FORCE="1", TRID_DP_CAPTURED="1")
     assert "DP_CAPTURED_OK backend=nccl" in out
+
+
+def test_dp_step_segmented_replay_two_ranks():
+    """... and with TWO ranks (sharing the one GPU, gloo transport): the same recording - a host-staged transport is replayable
+    because the collectives are cut points, not nodes - bit-identical to the eager two-rank steps on every rank."""
+    out = _run_ranks(2, need=("DP_OK", "DP_REPLICAS_IDENTICAL", "DP_RETRIEVAL_OK", "DP_CAPTURED_OK"), TRID_DIST_BACKEND="gloo", TRID_DP_CAPTURED="1")
+    assert "DP_CAPTURED_OK backend=gloo world=2" in out
+
+
+def test_dp_do_train_replays_in_segments_and_keeps_replicas():
+    """engine.trainer.do_train's DEFAULT under data parallelism: two eager steps, then the recorded step replayed in segments -
+    two ranks from different seeds end as bit-identical replicas, the digest check passes on every step."""
+    out = _run_ranks(2, TRID_DIST_BACKEND="gloo", TRID_DP_TRAINER="1", TRID_DP_TRAINER_CAPTURE="1")
+    assert "DP_TRAINER_REPLICAS_IDENTICAL" in out
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL with more than one rank needs two GPUs (none on the one-GPU build pool)")

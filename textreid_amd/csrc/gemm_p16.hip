@@ -522,34 +522,58 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 && STAGES == 2) ? 2 : (W
         const int slab = wm / WPS;
         const int nw_i = min(max(p.M - (m0 + wm * WR), 0), WR);
         const float inv_nw = nw_i > 0 ? 1.f / (float)nw_i : 0.f;
+        // (a tile that lies inside [0, M) - every tile of the benchmarked shapes - takes the loops without the per-element row
+        // test: the same operations in the same order on the same values, half the VALU work of this epilogue)
+        const bool whole = m0 + BM <= p.M;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int cl = wn * (32 * TN) + 32 * j + (lane & 31);
             float s = 0.f, lo = INFINITY, hi = -INFINITY;
+            if (whole) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = row_base + i * 32 + (r & 3) + 8 * (r >> 2);
-                    if (row < p.M) {
+                    for (int r = 0; r < 16; ++r) {
                         s += acc[i][j][r];
                         lo = fminf(lo, acc[i][j][r]);
                         hi = fmaxf(hi, acc[i][j][r]);
                     }
-                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = row_base + i * 32 + (r & 3) + 8 * (r >> 2);
+                        if (row < p.M) {
+                            s += acc[i][j][r];
+                            lo = fminf(lo, acc[i][j][r]);
+                            hi = fmaxf(hi, acc[i][j][r]);
+                        }
+                    }
+            }
             s += __shfl_xor(s, 32, 64);
             lo = fminf(lo, __shfl_xor(lo, 32, 64));
             hi = fmaxf(hi, __shfl_xor(hi, 32, 64));
             const float mean = s * inv_nw;
             float q = 0.f;
+            if (whole) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = row_base + i * 32 + (r & 3) + 8 * (r >> 2);
-                    const float d = acc[i][j][r] - mean;
-                    if (row < p.M) q += d * d;
-                }
+                    for (int r = 0; r < 16; ++r) {
+                        const float d = acc[i][j][r] - mean;
+                        q += d * d;
+                    }
+            } else {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = row_base + i * 32 + (r & 3) + 8 * (r >> 2);
+                        const float d = acc[i][j][r] - mean;
+                        if (row < p.M) q += d * d;
+                    }
+            }
             q += __shfl_xor(q, 32, 64);
             if (khalf == 0) red[wm * BN + cl] = make_float4(mean, q, lo, hi);
         }
@@ -1470,6 +1494,12 @@ extern "C" int trid_gemm_p16_rows(int M, int N, int precision, int variant) {
 static int wide_env_ok() {
     static const int wide_env = getenv("TRID_GEMM_WIDE_EPILOGUE") ? atoi(getenv("TRID_GEMM_WIDE_EPILOGUE")) : 1;  // (0: A/B runs)
     return wide_env;
+}
+
+extern "C" int trid_gemm_p16_bnb_ok(int M, int N) {
+    // (the shape half of trid_gemm_p16's precondition for bnb_y - the rest is about pointers - and the build-time / environment half)
+    const int CQ = N / 4;
+    return (M > 0 && N > 0 && (N == 64 || N % 128 == 0) && (256 % CQ == 0 || CQ % 256 == 0) && (long long)M * N * 4 < (1ll << 31) && wide_env_ok()) ? 1 : 0;
 }
 
 extern "C" int trid_gemm_p16(const trid_gemm_desc* d, int variant, void* stream_) {

@@ -10,7 +10,12 @@
 // every stream fed within a few milliseconds.  The graph object stays alive (torch.cuda.CUDAGraph(keep_graph=True)): the
 // argument buffers the launches point at are the graph's own copies.
 //
-// Host code only; no kernels here.
+// Data parallel (lib/engine/trainer.py:72-91 under train_net.py:50-56): the step's collectives - the packed embedding
+// all-gather, the gradient all-reduces staged from inside backward and the buckets after it - are NOT recorded.  The capture
+// puts a MARKER (the empty kernel below, its argument the collective's index) where each one belongs; the plan treats a marker
+// as a cut point: trid_step_replay_run_segment re-issues the nodes up to the next marker, hands the marker's stream back to the
+// host, which enqueues the collective there through the communication library's own launch path (RCCL's kernels are never
+// re-issued from read-back launch parameters), and continues.  At most ~8 host round trips per step.
 
 #include <stdlib.h>
 
@@ -22,6 +27,10 @@
 #include "common.h"
 
 namespace trid {
+
+// where a collective belongs in the recording (never launched by the replay: its slot is the host's)
+__global__ void step_marker_kernel(int id) { (void)id; }
+
 namespace {
 
 struct RNode {
@@ -31,6 +40,7 @@ struct RNode {
     hipMemsetParams ms;
     int lane = -1;
     int record = -1;         // event recorded behind this node (it has a successor on another lane), or -1
+    int marker = -1;         // >= 0: a cut point (index of the collective the host issues here)
     std::vector<int> waits;  // events of predecessors on other lanes
 };
 
@@ -40,7 +50,11 @@ struct Replay {
     std::vector<hipEvent_t> events;
     hipEvent_t fork = nullptr;  // recorded on the caller's stream; every lane waits for it first
     std::vector<hipEvent_t> joins;
-    int n_kernels = 0, n_copies = 0, n_sets = 0, n_empty = 0;
+    int n_kernels = 0, n_copies = 0, n_sets = 0, n_empty = 0, n_markers = 0;
+    int device = -1;            // the device the lanes and events belong to
+    size_t cursor = 0;          // next node to issue (a step in progress: segmented runs)
+    bool in_step = false, at_marker = false;
+    bool poisoned = false;      // a launch failed in mid-step: the handle refuses further runs
 };
 
 void destroy(Replay* r) {
@@ -111,7 +125,19 @@ extern "C" int trid_step_replay_build(void* graph_, int max_lanes, void** out) {
         hipError_t e = hipGraphNodeGetType(gn[i], &nd.type);
         if (e == hipSuccess) {
             switch (nd.type) {
-                case hipGraphNodeTypeKernel: e = hipGraphKernelNodeGetParams(gn[i], &nd.k); r->n_kernels++; break;
+                case hipGraphNodeTypeKernel:
+                    e = hipGraphKernelNodeGetParams(gn[i], &nd.k);
+                    r->n_kernels++;
+                    if (e == hipSuccess && nd.k.func == (void*)step_marker_kernel) {
+                        if (nd.k.kernelParams == nullptr || nd.k.kernelParams[0] == nullptr) {
+                            set_error("trid_step_replay_build: a marker node without readable arguments");
+                            destroy(r);
+                            return TRID_E_UNSUPPORTED;
+                        }
+                        nd.marker = *reinterpret_cast<const int*>(nd.k.kernelParams[0]);
+                        r->n_markers++;
+                    }
+                    break;
                 case hipGraphNodeTypeMemcpy: e = hipGraphMemcpyNodeGetParams(gn[i], &nd.cp); r->n_copies++; break;
                 case hipGraphNodeTypeMemset: e = hipGraphMemsetNodeGetParams(gn[i], &nd.ms); r->n_sets++; break;
                 case hipGraphNodeTypeEmpty: r->n_empty++; break;
@@ -234,6 +260,7 @@ extern "C" int trid_step_replay_build(void* graph_, int max_lanes, void** out) {
         if (e == hipSuccess) r->joins.push_back(ev);
     }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&r->fork, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipGetDevice(&r->device);
     if (e != hipSuccess) {
         set_error("trid_step_replay_build: creating streams / events failed: %s", hipGetErrorString(e));
         destroy(r);
@@ -241,6 +268,17 @@ extern "C" int trid_step_replay_build(void* graph_, int max_lanes, void** out) {
     }
     *out = r;
     return TRID_OK;
+}
+
+extern "C" int trid_step_marker(int id, void* stream) {
+    TRID_REQUIRE(id >= 0, "trid_step_marker: negative id");
+    hipLaunchKernelGGL(step_marker_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, id);
+    return check_launch("trid_step_marker");
+}
+
+extern "C" int trid_step_replay_markers(void* handle) {
+    TRID_REQUIRE(handle, "trid_step_replay_markers: null handle");
+    return ((const Replay*)handle)->n_markers;
 }
 
 extern "C" int trid_step_replay_info(void* handle, int* counts) {
@@ -259,61 +297,163 @@ extern "C" int trid_step_replay_info(void* handle, int* counts) {
     return TRID_OK;
 }
 
+namespace trid {
+namespace {
+
+int issue_node(Replay* r, RNode& nd) {
+    hipStream_t s = r->lanes[nd.lane];
+    switch (nd.type) {
+        case hipGraphNodeTypeKernel: {
+            hipError_t e;
+            if (nd.k.kernelParams != nullptr) {
+                e = hipLaunchKernel(nd.k.func, nd.k.gridDim, nd.k.blockDim, nd.k.kernelParams, nd.k.sharedMemBytes, s);
+            } else {
+                e = hipModuleLaunchKernel((hipFunction_t)nd.k.func, nd.k.gridDim.x, nd.k.gridDim.y, nd.k.gridDim.z, nd.k.blockDim.x,
+                                          nd.k.blockDim.y, nd.k.blockDim.z, nd.k.sharedMemBytes, s, nullptr, nd.k.extra);
+            }
+            RP_CHECK(e, "kernel launch");
+            break;
+        }
+        case hipGraphNodeTypeMemcpy: {
+            // (the recording's copies are linear device-to-device copies: a 1-D copy reads back as a one-row, one-slice extent)
+            const hipMemcpy3DParms& c = nd.cp;
+            const bool linear = c.srcArray == nullptr && c.dstArray == nullptr && c.extent.height <= 1 && c.extent.depth <= 1 &&
+                                c.srcPos.x == 0 && c.srcPos.y == 0 && c.srcPos.z == 0 && c.dstPos.x == 0 && c.dstPos.y == 0 && c.dstPos.z == 0;
+            if (linear) RP_CHECK(hipMemcpyAsync(c.dstPtr.ptr, c.srcPtr.ptr, c.extent.width, c.kind, s), "hipMemcpyAsync");
+            else {
+                hipError_t e = hipMemcpy3DAsync(&nd.cp, s);
+                if (e != hipSuccess) {
+                    set_error("trid_step_replay: hipMemcpy3DAsync: %s (extent %zu x %zu x %zu, src %p pitch %zu pos %zu,%zu,%zu, dst %p pitch %zu pos %zu,%zu,%zu, "
+                              "arrays %p %p, kind %d)", hipGetErrorString(e), c.extent.width, c.extent.height, c.extent.depth, c.srcPtr.ptr, c.srcPtr.pitch,
+                              c.srcPos.x, c.srcPos.y, c.srcPos.z, c.dstPtr.ptr, c.dstPtr.pitch, c.dstPos.x, c.dstPos.y, c.dstPos.z, (void*)c.srcArray,
+                              (void*)c.dstArray, (int)c.kind);
+                    return (int)e;
+                }
+            }
+            break;
+        }
+        case hipGraphNodeTypeMemset:
+            if (nd.ms.elementSize == 1) RP_CHECK(hipMemsetAsync(nd.ms.dst, (int)nd.ms.value, nd.ms.width, s), "hipMemsetAsync");
+            else if (nd.ms.elementSize == 2) RP_CHECK(hipMemsetD16Async((hipDeviceptr_t)nd.ms.dst, (unsigned short)nd.ms.value, nd.ms.width, s), "hipMemsetD16Async");
+            else RP_CHECK(hipMemsetD32Async((hipDeviceptr_t)nd.ms.dst, (int)nd.ms.value, nd.ms.width, s), "hipMemsetD32Async");
+            break;
+        default:
+            break;  // empty node: only its edges matter
+    }
+    return TRID_OK;
+}
+
+// every lane joined back into `origin`: whatever was issued stays ordered in front of the caller's later work
+int join_lanes(Replay* r, hipStream_t origin) {
+    int rc = TRID_OK;
+    for (size_t l = 0; l < r->lanes.size(); ++l) {
+        hipError_t e = hipEventRecord(r->joins[l], r->lanes[l]);
+        if (e == hipSuccess) e = hipStreamWaitEvent(origin, r->joins[l], 0);
+        if (e != hipSuccess && rc == TRID_OK) {
+            set_error("trid_step_replay: joining lane %d: %s", (int)l, hipGetErrorString(e));
+            rc = (int)e;
+        }
+    }
+    return rc;
+}
+
+// A failed launch / wait / record in mid-step: part of the step is already enqueued on the lanes.  Keep the caller's stream ordered
+// behind it (join), and refuse every further run - the optimizer tables were advanced for a step that did not happen as recorded
+// (engine/graph.py drops the handle and goes on eagerly).  The error message of the failure is kept.
+int fail_step(Replay* r, hipStream_t origin, int rc) {
+    char msg[512];
+    snprintf(msg, sizeof(msg), "%s", trid_last_error_string());
+    (void)join_lanes(r, origin);
+    r->poisoned = true;
+    r->in_step = r->at_marker = false;
+    r->cursor = 0;
+    set_error("%s (the step was abandoned in mid-replay; the handle is poisoned)", msg);
+    return rc;
+}
+
+// the step from the cursor to the next cut point (stop_at_markers) or to its end.  Returns 1 at a marker (*marker_id, *lane set:
+// the host enqueues the collective on that stream and calls again), 0 when the step is complete.
+int run_some(Replay* r, hipStream_t origin, bool stop_at_markers, int* marker_id, void** lane) {
+    if (r->poisoned) {
+        set_error("trid_step_replay: this handle was poisoned by a failed replay");
+        return TRID_E_INVALID;
+    }
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev != r->device) {
+        set_error("trid_step_replay: the current device (%d) is not the one the plan was built on (%d)", dev, r->device);
+        return TRID_E_INVALID;
+    }
+    if (!r->in_step) {
+        RP_CHECK(hipEventRecord(r->fork, origin), "hipEventRecord");
+        for (hipStream_t s : r->lanes) {
+            hipError_t e = hipStreamWaitEvent(s, r->fork, 0);
+            if (e != hipSuccess) {
+                set_error("trid_step_replay: hipStreamWaitEvent: %s", hipGetErrorString(e));
+                return fail_step(r, origin, (int)e);
+            }
+        }
+        r->in_step = true;
+        r->cursor = 0;
+        r->at_marker = false;
+    }
+    while (r->cursor < r->nodes.size()) {
+        RNode& nd = r->nodes[r->cursor];
+        hipStream_t s = r->lanes[nd.lane];
+        if (!r->at_marker) {
+            for (int w : nd.waits) {
+                hipError_t e = hipStreamWaitEvent(s, r->events[w], 0);
+                if (e != hipSuccess) {
+                    set_error("trid_step_replay: hipStreamWaitEvent: %s", hipGetErrorString(e));
+                    return fail_step(r, origin, (int)e);
+                }
+            }
+            if (nd.marker >= 0 && stop_at_markers) {
+                r->at_marker = true;  // (the host's collective takes the node's place; the next call records the node's event)
+                *marker_id = nd.marker;
+                *lane = (void*)s;
+                return 1;
+            }
+            if (nd.marker < 0) {
+                const int rc = issue_node(r, nd);
+                if (rc != TRID_OK) return fail_step(r, origin, rc);
+            }
+        }
+        r->at_marker = false;
+        if (nd.record >= 0) {
+            hipError_t e = hipEventRecord(r->events[nd.record], s);
+            if (e != hipSuccess) {
+                set_error("trid_step_replay: hipEventRecord: %s", hipGetErrorString(e));
+                return fail_step(r, origin, (int)e);
+            }
+        }
+        r->cursor++;
+    }
+    r->in_step = false;
+    r->cursor = 0;
+    const int rc = join_lanes(r, origin);
+    if (rc != TRID_OK) r->poisoned = true;
+    return rc;
+}
+
+}  // namespace
+}  // namespace trid
+
 // Everything already enqueued on `origin` happens before the step; everything enqueued on it afterwards happens after.
 extern "C" int trid_step_replay_run(void* handle, void* origin_) {
     TRID_REQUIRE(handle, "trid_step_replay_run: null handle");
     Replay* r = (Replay*)handle;
-    hipStream_t origin = (hipStream_t)origin_;
-    RP_CHECK(hipEventRecord(r->fork, origin), "hipEventRecord");
-    for (hipStream_t s : r->lanes) RP_CHECK(hipStreamWaitEvent(s, r->fork, 0), "hipStreamWaitEvent");
-    for (RNode& nd : r->nodes) {
-        hipStream_t s = r->lanes[nd.lane];
-        for (int w : nd.waits) RP_CHECK(hipStreamWaitEvent(s, r->events[w], 0), "hipStreamWaitEvent");
-        switch (nd.type) {
-            case hipGraphNodeTypeKernel: {
-                hipError_t e;
-                if (nd.k.kernelParams != nullptr) {
-                    e = hipLaunchKernel(nd.k.func, nd.k.gridDim, nd.k.blockDim, nd.k.kernelParams, nd.k.sharedMemBytes, s);
-                } else {
-                    e = hipModuleLaunchKernel((hipFunction_t)nd.k.func, nd.k.gridDim.x, nd.k.gridDim.y, nd.k.gridDim.z, nd.k.blockDim.x,
-                                              nd.k.blockDim.y, nd.k.blockDim.z, nd.k.sharedMemBytes, s, nullptr, nd.k.extra);
-                }
-                RP_CHECK(e, "kernel launch");
-                break;
-            }
-            case hipGraphNodeTypeMemcpy: {
-                // (the recording's copies are linear device-to-device copies: a 1-D copy reads back as a one-row, one-slice extent)
-                const hipMemcpy3DParms& c = nd.cp;
-                const bool linear = c.srcArray == nullptr && c.dstArray == nullptr && c.extent.height <= 1 && c.extent.depth <= 1 &&
-                                    c.srcPos.x == 0 && c.srcPos.y == 0 && c.srcPos.z == 0 && c.dstPos.x == 0 && c.dstPos.y == 0 && c.dstPos.z == 0;
-                if (linear) RP_CHECK(hipMemcpyAsync(c.dstPtr.ptr, c.srcPtr.ptr, c.extent.width, c.kind, s), "hipMemcpyAsync");
-                else {
-                    hipError_t e = hipMemcpy3DAsync(&nd.cp, s);
-                    if (e != hipSuccess) {
-                        set_error("trid_step_replay: hipMemcpy3DAsync: %s (extent %zu x %zu x %zu, src %p pitch %zu pos %zu,%zu,%zu, dst %p pitch %zu pos %zu,%zu,%zu, "
-                                  "arrays %p %p, kind %d)", hipGetErrorString(e), c.extent.width, c.extent.height, c.extent.depth, c.srcPtr.ptr, c.srcPtr.pitch,
-                                  c.srcPos.x, c.srcPos.y, c.srcPos.z, c.dstPtr.ptr, c.dstPtr.pitch, c.dstPos.x, c.dstPos.y, c.dstPos.z, (void*)c.srcArray,
-                                  (void*)c.dstArray, (int)c.kind);
-                        return (int)e;
-                    }
-                }
-                break;
-            }
-            case hipGraphNodeTypeMemset:
-                if (nd.ms.elementSize == 1) RP_CHECK(hipMemsetAsync(nd.ms.dst, (int)nd.ms.value, nd.ms.width, s), "hipMemsetAsync");
-                else if (nd.ms.elementSize == 2) RP_CHECK(hipMemsetD16Async((hipDeviceptr_t)nd.ms.dst, (unsigned short)nd.ms.value, nd.ms.width, s), "hipMemsetD16Async");
-                else RP_CHECK(hipMemsetD32Async((hipDeviceptr_t)nd.ms.dst, (int)nd.ms.value, nd.ms.width, s), "hipMemsetD32Async");
-                break;
-            default:
-                break;  // empty node: only its edges matter
-        }
-        if (nd.record >= 0) RP_CHECK(hipEventRecord(r->events[nd.record], s), "hipEventRecord");
-    }
-    for (size_t l = 0; l < r->lanes.size(); ++l) {
-        RP_CHECK(hipEventRecord(r->joins[l], r->lanes[l]), "hipEventRecord");
-        RP_CHECK(hipStreamWaitEvent(origin, r->joins[l], 0), "hipStreamWaitEvent");
-    }
-    return TRID_OK;
+    TRID_REQUIRE(r->n_markers == 0, "trid_step_replay_run: the recording has %d cut points (collectives): use trid_step_replay_run_segment", r->n_markers);
+    TRID_REQUIRE(!r->in_step, "trid_step_replay_run: a segmented step is in progress");
+    int id = -1;
+    void* lane = nullptr;
+    return run_some(r, (hipStream_t)origin_, false, &id, &lane);
+}
+
+extern "C" int trid_step_replay_run_segment(void* handle, void* origin_, int* marker_id, void** lane_stream) {
+    TRID_REQUIRE(handle && marker_id && lane_stream, "trid_step_replay_run_segment: null pointer");
+    *marker_id = -1;
+    *lane_stream = nullptr;
+    return run_some((Replay*)handle, (hipStream_t)origin_, true, marker_id, lane_stream);
 }
 
 extern "C" int trid_step_replay_destroy(void* handle) {

@@ -37,11 +37,14 @@ class CapturedTrainStep:
         step uses; they are REAL training steps).  optimizer=None: forward + backward only (parity tests).
         caption_bound: number of recurrence steps the recorded text encoder runs (None: the token tensor's width, i.e.
         any caption fits); batches whose longest caption exceeds it run eagerly.
-        reducer / pre_gather (data parallel, `nccl` backend): the parallel.GradReducer of the run and the parameters it
-        SUM-reduces after backward; the packed embedding all-gather of the forward, the all-reduces staged from inside
-        backward and the bucketed ones after it are RCCL launches on RCCL's stream - stream-ordered, hence recordable
-        (probed: tools/exp/rccl_capture_probe.py).  Every rank records the same sequence; a transport that stages
-        through the host (gloo) fails the recording and the step stays eager."""
+        reducer / pre_gather (data parallel): the parallel.GradReducer of the run and the parameters it SUM-reduces after
+        backward.  The step's collectives - the packed embedding all-gather of the forward, the all-reduces staged from
+        inside backward, the bucketed ones after it - are CUT POINTS of the recording (parallel.CutRecorder): each leaves a
+        marker node where it belongs, and the replay re-issues the recorded kernels in segments, calling the collective
+        itself (torch.distributed, i.e. RCCL's own launch path; gloo stages through the host as it always does) on the
+        marker's stream between two segments - <= ~8 host round trips per step instead of ~1100 Python launches.  Every
+        rank records the same sequence.  A data-parallel recording has no hipGraphLaunch form (the graph holds markers,
+        not collectives): when the stream plan cannot be built the step stays eager."""
         self.model, self.optimizer = model, optimizer
         # launch: "streams" | "graph" (None: TRID_STEP_LAUNCH, else "streams"); lanes: streams the recorded nodes are laid out on
         self.launch = launch or os.environ.get("TRID_STEP_LAUNCH", "streams")
@@ -62,6 +65,8 @@ class CapturedTrainStep:
         self.plan = None         # the optimizer's pointer tables the recorded Adam launch reads (kept alive with the graph)
         self.disabled = False    # a failed capture: stay eager for the rest of the run
         self.recaptures = 0
+        self.cuts = []           # data parallel: the collectives of the recorded step, in marker order (parallel.Cut)
+        self.cut_bytes = (0, 0)  # bytes of them staged from inside backward / issued after it (the reducer's accounting)
         self.log = logging.getLogger("PersonSearch.trainer")
         if dp_active() and reducer is None:
             raise RuntimeError("CapturedTrainStep under data parallelism needs the run's GradReducer (reducer=, pre_gather=): "
@@ -127,13 +132,27 @@ class CapturedTrainStep:
         # thread_local: every launch of the step is issued from this thread (the backward runs on the autograd engine's
         # thread for this device, which torch's capture tracks); a HIP call from an UNRELATED thread - a DataLoader's
         # pin_memory thread allocating or polling events - must not invalidate the ~1100-launch recording
-        with torch.cuda.graph(g, capture_error_mode="thread_local"):
-            loss_dict = self.model(self.static["images"], scb)
-            losses = sum(loss_dict.values())
-            losses.backward()
-            self._sync_grads()
-            if self.optimizer is not None:
-                self.optimizer.step()
+        import contextlib
+
+        from ..parallel import CutRecorder
+
+        dp = dp_active()
+        if dp and self.launch != "streams":
+            raise RuntimeError("a data-parallel step is replayed as stream launches only (its collectives are cut points of the recording)")
+        rec = CutRecorder() if dp else None
+        b0 = (self.reducer.bytes_staged, self.reducer.bytes_post, self.reducer.steps) if (dp and self.reducer is not None) else None
+        with (rec if rec is not None else contextlib.nullcontext()):
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                loss_dict = self.model(self.static["images"], scb)
+                losses = sum(loss_dict.values())
+                losses.backward()
+                self._sync_grads()
+                if self.optimizer is not None:
+                    self.optimizer.step()
+        self.cuts = rec.cuts if rec is not None else []
+        if b0 is not None:  # the recording executed nothing: its byte counts are per REPLAY (GradReducer.account_replay)
+            self.cut_bytes = (self.reducer.bytes_staged - b0[0], self.reducer.bytes_post - b0[1])
+            self.reducer.bytes_staged, self.reducer.bytes_post, self.reducer.steps = b0
         self.graph, self.out = g, {k: v.detach() for k, v in loss_dict.items()}
         del loss_dict, losses
         if isinstance(self.optimizer, FusedAdam):
@@ -145,12 +164,20 @@ class CapturedTrainStep:
         self.plan = getattr(self.optimizer, "_plan", None)
         if self.launch == "streams":
             self._build_replayer(g)
-        self.log.info("train step captured: one %s per step from here on", "call into the library (stream replay)" if self.replayer else "graph launch")
+        if self.cuts and self.replayer is None:
+            raise RuntimeError("the data-parallel recording (%d collectives as cut points) has no stream plan" % len(self.cuts))
+        if self.cuts:
+            from .. import lib as L
+
+            n = int(L.load().trid_step_replay_markers(self.replayer))
+            if n != len(self.cuts):
+                raise RuntimeError("the stream plan found %d cut points, the recording made %d" % (n, len(self.cuts)))
+        self.log.info("train step captured: %s per step from here on", ("%d segments of stream launches around %d collectives" % (len(self.cuts) + 1, len(self.cuts))) if self.cuts
+                      else ("one call into the library (stream replay)" if self.replayer else "one graph launch"))
 
     def _build_replayer(self, g):
-        """The recorded graph read back into a stream-launch plan.  Under data parallelism the RCCL nodes of the recording are
-        kernels on RCCL's stream like any other; a graph holding a node type the replayer refuses (host callback, child graph)
-        stays on hipGraphLaunch."""
+        """The recorded graph read back into a stream-launch plan.  A graph holding a node type the replayer refuses (host
+        callback, child graph) stays on hipGraphLaunch - unless it is a data-parallel recording (see _capture)."""
         from .. import ops
 
         self._drop_replayer()
@@ -184,6 +211,7 @@ class CapturedTrainStep:
         self._drop_replayer()
         self.graph = self.static = self.out = self.signature = None
         self.grads = []
+        self.cuts = []
 
     def _try_capture(self, images, cb):
         """Record the step; when the RECORDING fails (a non-capturable call, an invalidated capture) keep training eagerly -
@@ -194,30 +222,47 @@ class CapturedTrainStep:
         from .. import ops
 
         saved = [(p, p.grad) for p in self.model.parameters()]
-        ok = True
+        err, fatal = None, False
         try:
             self._capture(images, cb)
-        except torch.cuda.OutOfMemoryError:
-            raise
+        except torch.cuda.OutOfMemoryError as e:
+            err, fatal = e, True
         except RuntimeError as e:  # what torch / the library raise for a failed or invalidated stream capture
-            ok = False
-            self.log.warning("train step: hipGraph capture failed (%s: %s) - the step stays eager for the rest of the run",
-                             type(e).__name__, str(e).splitlines()[0] if str(e) else "")
-            self._abort_capture(saved)
-            # is the device itself still healthy?  (a capture error leaves it usable; a kernel fault does not)
-            torch.cuda.synchronize()
-            probe = ops.amax_slot(images.device)
-            ops.call("trid_amax_f32", ops._p(self.static_probe(images)), 1, ops._p(probe), ops.stream())
-            torch.cuda.synchronize()
+            err = e
+        except Exception as e:  # an assertion / ValueError / KeyError from inside the recording: not a capture failure - but the
+            err, fatal = e, True  # teardown and the exchange below must still happen on THIS rank before it propagates
+        if err is not None:
+            if not fatal:
+                self.log.warning("train step: hipGraph capture failed (%s: %s) - the step stays eager for the rest of the run",
+                                 type(err).__name__, str(err).splitlines()[0] if str(err) else "")
+            try:
+                self._abort_capture(saved)
+            except Exception:  # (the teardown is best effort when the device itself is gone)
+                if not fatal:
+                    raise
+            if not fatal:
+                # is the device itself still healthy?  (a capture error leaves it usable; a kernel fault does not)
+                torch.cuda.synchronize()
+                probe = ops.amax_slot(images.device)
+                ops.call("trid_amax_f32", ops._p(self.static_probe(images)), 1, ops._p(probe), ops.stream())
+                torch.cuda.synchronize()
+        ok = err is None
         if dp_active():
+            # every rank learns the outcome BEFORE anything is re-raised: a rank that left here alone would leave the others
+            # blocked in this all-reduce until the collective timeout (flag = 1: stay eager, 2: a rank is about to raise)
             import torch.distributed as dist
 
-            flag = torch.tensor([0.0 if ok else 1.0], device=images.device if dist.get_backend() != "gloo" else "cpu")
+            flag = torch.tensor([2.0 if fatal else (0.0 if ok else 1.0)], device=images.device if dist.get_backend() != "gloo" else "cpu")
             dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-            if ok and float(flag.item()) > 0:
+            worst = float(flag.item())
+            if ok and worst > 0:
                 self.log.warning("train step: another rank could not record the step - dropping this rank's graph, all ranks stay eager")
                 self._abort_capture(saved)
                 ok = False
+            if worst >= 2 and not fatal:
+                raise RuntimeError("train step: another rank raised a non-capture error while recording the step")
+        if fatal:
+            raise err
         if not ok:
             self.disabled = True
         return ok
@@ -244,6 +289,7 @@ class CapturedTrainStep:
         self._drop_replayer()
         self.graph = self.static = self.out = self.signature = None
         self.grads = []
+        self.cuts = []
 
     def __call__(self, images, captions):
         cb = CaptionBatch.from_list(captions)
@@ -278,10 +324,45 @@ class CapturedTrainStep:
                 p.grad = g
         if self.optimizer is not None:
             self.optimizer.advance_for_replay()
-        if self.replayer is not None and not self.force_graph_launch:
-            from .. import ops
+        from .. import ops
 
-            ops.call("trid_step_replay_run", self.replayer, ops.stream())
+        if self.cuts:
+            self._replay_segments()
+        elif self.replayer is not None and not self.force_graph_launch:
+            try:
+                ops.call("trid_step_replay_run", self.replayer, ops.stream())
+            except RuntimeError:
+                # part of the step was enqueued (and joined back into this stream by the library), the optimizer tables were
+                # advanced for it: the state is not the recorded step's - drop the poisoned plan and say so
+                self._drop_graph("the stream replay failed in mid-step")
+                self.disabled = True
+                raise
         else:
             self.graph.replay()
         return self.out
+
+    def _replay_segments(self):
+        """The data-parallel step: segments of recorded launches (one library call each) around the collectives, which run
+        through torch.distributed on the stream their marker was recorded on."""
+        from .. import lib as L
+        from .. import ops
+
+        origin = ops.stream()
+        mid, lane = ctypes.c_int(-1), ctypes.c_void_p()
+        dev = self.static["images"].device
+        run = L.load().trid_step_replay_run_segment
+        try:
+            while True:
+                rc = int(run(self.replayer, origin, ctypes.byref(mid), ctypes.byref(lane)))
+                if rc == 0:
+                    break
+                if rc != 1:
+                    raise RuntimeError("trid_step_replay_run_segment failed (rc=%d): %s" % (rc, L.last_error()))
+                with torch.cuda.stream(torch.cuda.ExternalStream(lane.value, device=dev)):
+                    self.cuts[mid.value].run()
+        except RuntimeError:
+            self._drop_graph("the segmented replay failed in mid-step")
+            self.disabled = True
+            raise
+        if self.reducer is not None:
+            self.reducer.account_replay(*self.cut_bytes)

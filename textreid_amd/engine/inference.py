@@ -31,12 +31,18 @@ def compute_on_dataset(model, data_loader, device, dedupe=True, encode_batch=512
 
     def flush():
         if pend_imgs:
-            with torch.no_grad():
-                emb = head.encode_images(torch.cat(pend_imgs, dim=0).to(device))
-            for r, key in enumerate(pend_keys):
-                cache[key] = emb[r]
+            # in slices of at most encode_batch images: what is pending is up to encode_batch - 1 images plus one loader batch, and
+            # a pass beyond the encoder's pre-split (P16) size limit would silently take the slower on-the-fly-split path - and
+            # peak activation memory would follow the loader's batch size instead of encode_batch
+            imgs = torch.cat(pend_imgs, dim=0)
+            step = int(encode_batch) if encode_batch else imgs.shape[0]
+            for s0 in range(0, imgs.shape[0], step):
+                with torch.no_grad():
+                    emb = head.encode_images(imgs[s0 : s0 + step].to(device))
+                for r, key in enumerate(pend_keys[s0 : s0 + step]):
+                    cache[key] = emb[r]
+                stats["encoder_passes"] += 1
             stats["images_encoded"] += len(pend_keys)
-            stats["encoder_passes"] += 1
             pend_imgs.clear()
             pend_keys.clear()
         for i, key, t_row in waiting:

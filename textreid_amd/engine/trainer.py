@@ -49,25 +49,23 @@ def do_train(model, data_loader, data_loader_val, optimizer, scheduler, checkpoi
         nb = broadcast_module_state(model)
         logger.info("data parallel: %.1f MB of parameters and buffers broadcast from rank 0", nb / 2 ** 20)
         em = getattr(model, "embed_model", None)
-        watch = [(n, getattr(em, n)) for n in ("queue_ptr", "id_queue") if hasattr(em, n)]
+        watch = [(n, getattr(em, n)) for n in ("queue_ptr", "id_queue", "v_queue", "t_queue") if hasattr(em, n)]
         if pre_gather:
             watch.append(("parameter %s" % next(n for n, p in model.named_parameters() if p is pre_gather[0]), pre_gather[0]))
         post = [(n, p) for n, p in model.named_parameters() if "loss_evaluator" in n]
         watch += [("parameter " + post[0][0], post[0][1])] if post else []
         check_replicas(watch, "after the initial broadcast")
-    # data parallel: the step is recorded with its RCCL collectives only on request (TRID_DP_CAPTURE=1) - a recorded step is
-    # no faster than the eager one while the step is GPU-bound, and the multi-rank recording cannot be exercised on a one-GPU
-    # build box (one rank: tests/test_dp_gpu.py)
-    dp_capture = os.environ.get("TRID_DP_CAPTURE", "0") == "1" and parallel_backend() == "nccl"
+    # data parallel: the step is recorded too - its collectives are cut points of the recording, the replay re-issues the recorded
+    # kernels in segments and runs each collective through torch.distributed between two of them (engine/graph.py; ~4 ms of host
+    # work per step instead of the eager step's 35-39 ms, so that the ranks feed xGMI instead of waiting for Python).
+    # TRID_DP_CAPTURE=0: the eager data-parallel step (A/B runs).
+    dp_capture = os.environ.get("TRID_DP_CAPTURE", "1") != "0"
     if capture and (not dp_active() or dp_capture) and torch.device(device).type == "cuda":
         from ..solver import FusedAdam
         from .graph import CapturedTrainStep
 
         if isinstance(optimizer, FusedAdam):
-            # (a recording that holds RCCL's kernels is launched as a graph: re-issuing a collective's kernels outside the
-            # library's own launch path is not something RCCL promises to survive)
-            runner = CapturedTrainStep(model, optimizer, warmup=2, reducer=reducer if dp_active() else None, pre_gather=pre_gather,
-                                       launch="graph" if dp_active() else None)
+            runner = CapturedTrainStep(model, optimizer, warmup=2, reducer=reducer if dp_active() else None, pre_gather=pre_gather)
     best_top1 = 0.0
     pending, keys = [], None  # per-step loss vectors still on the device
 

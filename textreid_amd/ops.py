@@ -315,9 +315,8 @@ def bn_bwd_fusable(y, M, N, fmt=1):
     """Can the data-gradient GEMM that writes g [M, N] also form the BatchNorm-backward sums against the saved conv output y?
     (the tile kernel's staged store path: P16 operands, fp32 g and y, whole 64- / 128-column tiles; the streaming short-K kernel
     and the ring-of-rows kernel do not carry the epilogue)"""
-    CQ = N // 4
-    return (USE_BNB_FUSE and fmt == 1 and y.dtype == torch.float32 and (N == 64 or N % 128 == 0) and (256 % CQ == 0 or CQ % 256 == 0)
-            and y.numel() == M * N and M * N * 4 < (1 << 31))
+    return (USE_BNB_FUSE and fmt == 1 and y.dtype == torch.float32 and y.numel() == M * N
+            and _query("trid_gemm_p16_bnb_ok", int(M), int(N)) == 1)  # (the library's own precondition, not a mirror of it)
 
 
 def gemm_p16(A, B, C, M, N, K, ldc, conv=None, alpha=1.0, accumulate=False, bias=None, stats=None, residual=None, ldres=0,

@@ -39,13 +39,102 @@ def _backend():
     return dist.get_backend() if dist.is_available() and dist.is_initialized() else None
 
 
+# ---- cut points of a RECORDED step (engine/graph.py, csrc/step_replay.hip).  While the train step is being captured the
+# collectives below are not executed: each leaves a MARKER node in the recording (trid_step_marker, on the stream and between
+# the events the collective would have had) and an entry in the recorder's list; the replay re-issues the recorded kernels in
+# segments and calls `Cut.run()` - the very functions below, on the marker's stream - at every marker.  The communication
+# library's kernels therefore always go through its own launch path (an RCCL kernel is never re-issued from launch parameters
+# read back from a graph), and a transport that stages through host memory (gloo) replays as well.
+_recorder = None
+
+
+class Cut:
+    def __init__(self, kind, src, dst):
+        self.kind, self.src, self.dst = kind, src, dst  # static tensors of the recording's memory pool
+
+    def run(self):
+        if self.kind == "all_gather":
+            _all_gather_into(self.dst, self.src)
+        else:
+            w = _all_reduce_sum_impl(self.src)
+            if w is not None:
+                w.wait()  # the marker's stream waits for the collective (the host does not)
+
+    def nbytes(self):
+        return self.src.numel() * self.src.element_size()
+
+
+class _CutWork:
+    """What an asynchronous collective returns while the step is being recorded: `wait()` joins the side stream the marker
+    went to back into the current stream (the recorded edge the replay turns into an event)."""
+
+    def __init__(self, side):
+        self.side = side
+
+    def wait(self):
+        torch.cuda.current_stream().wait_stream(self.side)
+
+
+class CutRecorder:
+    def __init__(self):
+        self.cuts = []
+        self._side = None
+
+    def __enter__(self):
+        global _recorder
+        if _recorder is not None:
+            raise RuntimeError("nested CutRecorder")
+        _recorder = self
+        return self
+
+    def __exit__(self, *exc):
+        global _recorder
+        _recorder = None
+        return False
+
+    def mark(self, kind, src, dst, side=False):
+        """A marker for the collective (kind, src -> dst) on the current stream - or, side=True (asynchronous all-reduce), on a
+        side stream forked from it; returns the _CutWork to wait on in that case."""
+        from . import ops
+
+        cut = Cut(kind, src, dst)
+        idx = len(self.cuts)
+        self.cuts.append(cut)
+        if not side:
+            ops.call("trid_step_marker", idx, ops.stream())
+            return None
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=src.device)
+        cur = torch.cuda.current_stream()
+        self._side.wait_stream(cur)
+        with torch.cuda.stream(self._side):
+            ops.call("trid_step_marker", idx, ops.stream())
+        return _CutWork(self._side)
+
+
+def _recording(t):
+    return _recorder is not None and t.is_cuda and torch.cuda.is_current_stream_capturing()
+
+
+def _all_gather_into(out, x):
+    if _backend() == "gloo" and x.is_cuda:
+        parts = [torch.empty(x.shape, dtype=x.dtype) for _ in range(world_size())]
+        dist.all_gather(parts, x.cpu())
+        out.copy_(torch.cat(parts, dim=0))
+    else:
+        dist.all_gather_into_tensor(out, x)
+
+
 def all_gather_rows(x):
     """[n, ...] per rank -> [W*n, ...] (rank-major).  RCCL: one all_gather_into_tensor on the
     current stream; gloo (CPU tests / single-GPU debugging): list all_gather staged through host
-    memory for device tensors."""
+    memory for device tensors.  Inside a recording: a cut point (see above)."""
     W = world_size()
     x = x.contiguous()
     out = torch.empty((W * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+    if _recording(x):
+        _recorder.mark("all_gather", x, out)
+        return out
     if _backend() == "gloo" and x.is_cuda:
         parts = [torch.empty(x.shape, dtype=x.dtype) for _ in range(W)]
         dist.all_gather(parts, x.cpu())
@@ -56,7 +145,13 @@ def all_gather_rows(x):
 
 
 def all_reduce_sum_(t):
-    """In-place SUM all-reduce (async handle or None)."""
+    """In-place SUM all-reduce (async handle or None).  Inside a recording: a cut point on a side stream."""
+    if _recording(t):
+        return _recorder.mark("all_reduce", t, t, side=True)
+    return _all_reduce_sum_impl(t)
+
+
+def _all_reduce_sum_impl(t):
     if _backend() == "gloo" and t.is_cuda:
         h = t.cpu()
         dist.all_reduce(h, op=dist.ReduceOp.SUM)
@@ -98,8 +193,10 @@ def broadcast_module_state(module, src=0):
 
 
 def replica_digest(tensors):
-    """One int64 per tensor: the wrap-around sum of its 32-bit words (64-bit tensors: of their 64-bit words) - bit-identical
-    replicas have identical digests, and a replica that drifted in ANY element differs with probability 1 - 2^-32."""
+    """One int64 per tensor: the wrap-around sum of its words (32-bit lanes; 64-bit tensors: 64-bit words), each weighted by an
+    odd multiple of its POSITION - bit-identical replicas have identical digests; a swap of two unequal entries (queue slots,
+    ids), or drifts that would cancel in a plain sum, change it.  (A hash, not a proof: a replica that differs in one word is
+    told apart unless the difference times its odd weight vanishes mod 2^64, i.e. never for a single word.)"""
     out = []
     for t in tensors:
         b = t.detach().contiguous().reshape(-1)
@@ -109,13 +206,14 @@ def replica_digest(tensors):
             w = b.view(torch.int32).to(torch.int64)
         else:
             w = b.view(torch.uint8).to(torch.int64)
-        out.append(w.sum())
+        pos = torch.arange(w.numel(), dtype=torch.int64, device=w.device)
+        out.append((w * (pos * -7046029254386353131 + 1)).sum())  # (0x9E3779B97F4A7C15 as a signed word: odd)
     return torch.stack(out)
 
 
 def check_replicas(named_tensors, where=""):
     """Raise when the replicated state differs between ranks: a MIN and a MAX all-reduce of the digests (two tiny collectives);
-    `named_tensors` = [(name, tensor)] - the MoCo queue pointer, the id queue and a parameter, engine.trainer.do_train."""
+    `named_tensors` = [(name, tensor)] - the MoCo queues, ids and pointer, a pre- and a post-gather parameter: engine.trainer.do_train."""
     if not dp_active():
         return
     d = replica_digest([t for _, t in named_tensors])
@@ -192,6 +290,12 @@ class GradReducer:
     def reset_stats(self):
         self.bytes_staged = self.bytes_post = self.steps = 0
         self._exposed = []
+
+    def account_replay(self, staged, post):
+        """One REPLAYED step (engine/graph.py): the byte counts the recording of the step produced."""
+        self.bytes_staged += staged
+        self.bytes_post += post
+        self.steps += 1
 
     def abort(self):
         """Forget every collective in flight WITHOUT waiting for it (engine.graph: a stream capture was invalidated - the
