@@ -560,6 +560,12 @@ def main():
     ap.add_argument("--no-configs3", action="store_true", help="skip the secondary configs[3]-shape timing ('configs3_1gpu' object)")
     args = ap.parse_args()
 
+    # The contract is ONE JSON line on stdout.  Libraries loaded below print there too (RCCL's version banner goes to fd 1 from C
+    # when a process group initialises): fd 1 is pointed at stderr for the whole run and the line is written to the real one at the end.
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     import torch.distributed as dist
 
     if args.gpus is None:  # `torchrun --nproc-per-node N bench.py` without --gpus: the launcher's world is the job
@@ -651,11 +657,14 @@ def main():
 
     n_prep = 0
     if runner is not None:  # set-up, untimed and not counted as warm-up: two eager steps build every cached table, the third call records
-        while runner.graph is None:
+        while runner.graph is None and not runner.disabled and n_prep < 8:
             step(n_prep)
             n_prep += 1
         torch.cuda.synchronize()
-        log("train step captured after %d set-up steps" % n_prep)
+        if runner.graph is None:  # (a recording that failed stays eager - CapturedTrainStep said why; the bench goes on with eager steps)
+            log("the train step could not be recorded: eager launches")
+        else:
+            log("train step captured after %d set-up steps" % n_prep)
     for i in range(args.warmup):
         step(n_prep + i)
         torch.cuda.synchronize()
@@ -1014,7 +1023,8 @@ def main():
         else:
             out["cpu_baseline"] = None
             out["parity_vs_oracle"] = None
-        print(json.dumps(out))
+        real_stdout.write(json.dumps(out) + "\n")
+        real_stdout.flush()
     if dp:
         dist.destroy_process_group()
 

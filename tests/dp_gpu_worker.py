@@ -124,6 +124,8 @@ def main():
         from textreid_amd.engine.trainer import do_train
         from textreid_amd.solver import FusedAdam
 
+        ld = None  # (the first step's autograd graph must be gone before a step is RECORDED: a stale AccumulateGrad node drags ITS
+        torch.cuda.synchronize()  # stream into the recording, which then cannot be ended - tools/exp/dpc_debug.sh)
         torch.manual_seed(1000 + r)
         head.load_state_dict(filled)
         for p_ in head.parameters():  # every rank its own weights (rank 0 keeps the filled ones) ...

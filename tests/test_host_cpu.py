@@ -320,9 +320,15 @@ try:
     raise SystemExit("a drifted replica passed the check")
 except RuntimeError as e:
     assert "id_queue" in str(e) and "conv.weight" not in str(e), str(e)
-# digests: wrap-around sums of the words, exact for int64 and float tensors
-d = replica_digest([torch.tensor([2 ** 62, 2 ** 62, 2 ** 62, 2 ** 62]), torch.tensor([1.0, -1.0])])
-assert int(d[0]) == 0 and int(d[1]) == (0x3F800000 + (0xBF800000 - (1 << 32)))
+# digests: position-weighted wrap-around sums of the words (weight of word i: i * c + 1 with c odd), exact for int64 and float tensors
+d = replica_digest([torch.tensor([2 ** 62, 2 ** 62, 2 ** 62, 2 ** 62]), torch.tensor([1.0, -1.0]), torch.tensor([-1.0, 1.0]), torch.tensor([3, 5, 7]), torch.tensor([5, 3, 7])])
+c = -7046029254386353131
+def signed(v):
+    v &= (1 << 64) - 1
+    return v - (1 << 64) if v >= (1 << 63) else v
+assert int(d[0]) == signed(sum((2 ** 62) * (i * c + 1) for i in range(4)))
+assert int(d[1]) == signed(0x3F800000 + (0xBF800000 - (1 << 32)) * (c + 1))
+assert int(d[1]) != int(d[2]) and int(d[3]) != int(d[4])   # a swap of two unequal entries is seen (a plain sum would not see it)
 print("rank", r, "ok")
 dist.destroy_process_group()
 """

@@ -790,6 +790,60 @@ def test_captured_step_with_a_loose_caption_bound(gpu):
     assert len(got[0][1]) == 183
 
 
+def test_bucketed_recordings_for_ragged_captions(gpu):
+    """engine.graph.BucketedTrainStep (what do_train builds): captions of 8-64 tokens in a 105-wide token tensor replay on
+    recordings of AT MOST 64 recurrence steps - one per caption bucket (32 / 48 / 64), each recorded on the second batch of its
+    bucket - instead of one 105-step recording (gru.py:66-82 packs to the batch maximum; build.py:26 pads to 105).  Against the
+    eager step that runs exactly max(length) steps: losses to fp32 rounding, every gradient to 1e-4 of its maximum (the bound
+    changes the text encoder's launch shapes, i.e. summation order, nothing else)."""
+    import bench
+    from textreid_amd.caption import CaptionBatch
+    from textreid_amd.config import moco_cfg
+    from textreid_amd.engine.graph import BucketedTrainStep
+    from textreid_amd.model import build_model
+
+    B, K = 8, 64
+    cfg = moco_cfg("m_resnet50", K=K)
+    torch.manual_seed(0)
+    model = build_model(cfg, vocab_dict=torch.randn(3000, 512) * 0.02).to(gpu).train()
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+    gen = torch.Generator().manual_seed(9)
+
+    def batch(s, top):
+        im, tk, ln, ids = bench.synth_batch(B, s, gpu, 7, vocab=3000)
+        ln = torch.randint(8, top + 1, (B,), generator=gen)
+        ln[s % B] = top
+        tk = tk.cpu()
+        for i, n in enumerate(ln.tolist()):
+            tk[i, n:] = 0
+        return im, tk.to(gpu), ln.to(gpu), ids, top
+
+    tops = [20, 40, 60, 25, 45, 62, 30, 47, 64]
+    batches = [batch(s, t) for s, t in enumerate(tops)]
+    runner = BucketedTrainStep(model, None, warmup=1)
+    got = []
+    for im, tk, ln, ids, top in batches:
+        model.load_state_dict(state)
+        ld = runner(im, CaptionBatch(tk, ln, ids, max_len=top))
+        torch.cuda.synchronize()
+        got.append(({k: float(v) for k, v in ld.items()}, {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}))
+    assert runner.recorded == {32: 32, 48: 48, 64: 64}, runner.recorded
+    assert all(r.calls == 3 and not r.disabled for r in runner.runners.values())
+    eager = runner.runners[64]
+    for (im, tk, ln, ids, top), (gl, gg) in zip(batches, got):
+        model.load_state_dict(state)
+        ld = eager._eager(im, CaptionBatch(tk, ln, ids, max_len=top))
+        torch.cuda.synchronize()
+        for k, v in ld.items():
+            assert abs(float(v) - gl[k]) <= 1e-5 * abs(float(v)), (top, k, float(v), gl[k])
+        worst = max(float((gg[n] - p.grad).abs().max() / (p.grad.abs().max() + 1e-30)) for n, p in model.named_parameters() if p.grad is not None)
+        assert worst <= 1e-4, (top, worst)
+    # a caption beyond the last bucket of a NARROW token tensor takes the tensor's width; an empty bucket list is refused
+    assert runner.bucket_of(CaptionBatch(batches[0][1][:, :50], batches[0][2].clamp(max=50), None, max_len=50)) == 50
+    with pytest.raises(ValueError):
+        BucketedTrainStep(model, None, buckets=())
+
+
 def test_do_train_captured_matches_eager(gpu):
     """engine.trainer.do_train with its DEFAULT capture=True against capture=False on the same data: seven
     steps - two eager warm-ups, the recording, replays, a RAGGED last batch (other shape: eager fall-back) - with

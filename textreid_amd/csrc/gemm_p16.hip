@@ -1473,7 +1473,7 @@ extern "C" int trid_gemm_p16_wgrad(const trid_gemm_desc* d, void* stream_) {
         if (d->b_mode == B_CONV) return d->M <= 64 ? launch_p16_wgrad<B_CONV, 64, 1>(p, stream) : launch_p16_wgrad<B_CONV, 128, 1>(p, stream);
         return d->M <= 64 ? launch_p16_wgrad<B_NC, 64, 1>(p, stream) : launch_p16_wgrad<B_NC, 128, 1>(p, stream);
     }
-    static const int sp_env = getenv("TRID_WGRAD_SP") ? atoi(getenv("TRID_WGRAD_SP")) : 0;  // (1: the software-pipelined main loop)
+    static const int sp_env = getenv("TRID_WGRAD_SP") ? atoi(getenv("TRID_WGRAD_SP")) : 1;  // (the software-pipelined main loop; 0: the barrier-per-tile loop, A/B runs)
     if (sp_env && d->M > 64) return d->b_mode == B_CONV ? launch_p16_wgrad<B_CONV, 128, 2, 1>(p, stream) : launch_p16_wgrad<B_NC, 128, 2, 1>(p, stream);
     if (d->b_mode == B_CONV) return d->M <= 64 ? launch_p16_wgrad<B_CONV, 64, 2>(p, stream) : launch_p16_wgrad<B_CONV, 128, 2>(p, stream);
     return d->M <= 64 ? launch_p16_wgrad<B_NC, 64, 2>(p, stream) : launch_p16_wgrad<B_NC, 128, 2>(p, stream);

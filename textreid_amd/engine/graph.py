@@ -65,6 +65,7 @@ class CapturedTrainStep:
         self.plan = None         # the optimizer's pointer tables the recorded Adam launch reads (kept alive with the graph)
         self.disabled = False    # a failed capture: stay eager for the rest of the run
         self.recaptures = 0
+        self.adam_cap = None     # FusedAdam's table set of THIS recording
         self.cuts = []           # data parallel: the collectives of the recorded step, in marker order (parallel.Cut)
         self.cut_bytes = (0, 0)  # bytes of them staged from inside backward / issued after it (the reducer's accounting)
         self.log = logging.getLogger("PersonSearch.trainer")
@@ -110,8 +111,9 @@ class CapturedTrainStep:
         }
         self.bound = int(self.caption_bound) if self.caption_bound is not None else int(cb.tokens.shape[1])
         scb = CaptionBatch(self.static["tokens"], self.static["lengths"], self.static["ids"], max_len=self.bound, bound_only=True)
+        self.adam_cap = None
         if isinstance(self.optimizer, FusedAdam):
-            self.optimizer.prepare_capture(defer_table_copy=True)
+            self.adam_cap = self.optimizer.prepare_capture(defer_table_copy=True)  # this recording's own table set
         elif self.optimizer is not None:
             raise RuntimeError("CapturedTrainStep needs textreid_amd.solver.FusedAdam (or optimizer=None)")
         for p in self.model.parameters():
@@ -156,7 +158,7 @@ class CapturedTrainStep:
         self.graph, self.out = g, {k: v.detach() for k, v in loss_dict.items()}
         del loss_dict, losses
         if isinstance(self.optimizer, FusedAdam):
-            self.optimizer.finish_capture()  # the gradient address table of the recorded Adam launch: copied once, here
+            self.optimizer.finish_capture(self.adam_cap)  # the gradient address table of the recorded Adam launch: copied once, here
         self.grads = [(p, p.grad) for p in self.model.parameters() if p.grad is not None]  # live in the graph's pool
         self.signature = self._sig(images, cb)
         # the recorded Adam launch has the ADDRESSES of this plan's tables baked in: hold it (so the allocator cannot
@@ -323,7 +325,7 @@ class CapturedTrainStep:
             if p.grad is not g:
                 p.grad = g
         if self.optimizer is not None:
-            self.optimizer.advance_for_replay()
+            self.optimizer.advance_for_replay(self.adam_cap)
         from .. import ops
 
         if self.cuts:
@@ -366,3 +368,45 @@ class CapturedTrainStep:
             raise
         if self.reducer is not None:
             self.reducer.account_replay(*self.cut_bytes)
+
+
+class BucketedTrainStep:
+    """One recording of the step per CAPTION BUCKET (counterpart of `lib/models/backbones/gru.py:66-82`: the reference packs every
+    batch to its own longest caption; `lib/data/build.py:26` pads the token tensor to 105).  A recorded text encoder runs a fixed
+    number of recurrence steps, and CUHK-PEDES captions average ~25 tokens: a single recording at the tensor's width would run 105
+    steps for every batch.  This keeps up to len(buckets) recordings, keyed by their recurrence bound, and sends a batch to the
+    smallest one that fits its longest caption (`CaptionBatch.max_len`: one host integer the collate already knows) - recorded
+    on first use, after one eager step of that bucket.  Results are those of the eager step (the text encoder's outputs do not
+    depend on the bound, only its launch count does)."""
+
+    def __init__(self, model, optimizer, buckets=(32, 48, 64, 105), warmup=2, **kw):
+        env = os.environ.get("TRID_CAPTION_BUCKETS")
+        if env:
+            buckets = tuple(int(b) for b in env.split(",") if b.strip())
+        self.buckets = sorted(set(int(b) for b in buckets))
+        if not self.buckets or self.buckets[0] < 1:
+            raise ValueError("BucketedTrainStep: caption buckets must be positive, got %r" % (buckets,))
+        self.model, self.optimizer, self.warmup, self.kw = model, optimizer, warmup, kw
+        self.runners = {}
+        self.last = None
+
+    def bucket_of(self, cb):
+        width = int(cb.tokens.shape[1])
+        b = next((x for x in self.buckets if x >= cb.max_len), width)
+        return min(b, width)
+
+    def __call__(self, images, captions):
+        cb = CaptionBatch.from_list(captions)
+        b = self.bucket_of(cb)
+        r = self.runners.get(b)
+        if r is None:
+            # (the first bucket's eager steps build every cached table of the step; a later bucket needs one eager call only)
+            r = CapturedTrainStep(self.model, self.optimizer, warmup=self.warmup if not self.runners else 1, caption_bound=b, **self.kw)
+            self.runners[b] = r
+        self.last = r
+        return r(images, cb)
+
+    @property
+    def recorded(self):
+        """{bucket: recurrence bound of its recording} for the buckets that have one."""
+        return {b: r.bound for b, r in self.runners.items() if r.graph is not None}

@@ -62,10 +62,12 @@ def do_train(model, data_loader, data_loader_val, optimizer, scheduler, checkpoi
     dp_capture = os.environ.get("TRID_DP_CAPTURE", "1") != "0"
     if capture and (not dp_active() or dp_capture) and torch.device(device).type == "cuda":
         from ..solver import FusedAdam
-        from .graph import CapturedTrainStep
+        from .graph import BucketedTrainStep
 
         if isinstance(optimizer, FusedAdam):
-            runner = CapturedTrainStep(model, optimizer, warmup=2, reducer=reducer if dp_active() else None, pre_gather=pre_gather)
+            # one recording per caption bucket (32 / 48 / 64 / 105 recurrence steps; TRID_CAPTION_BUCKETS overrides): a batch runs
+            # the recording of the smallest bucket that holds its longest caption
+            runner = BucketedTrainStep(model, optimizer, warmup=2, reducer=reducer if dp_active() else None, pre_gather=pre_gather)
     best_top1 = 0.0
     pending, keys = [], None  # per-step loss vectors still on the device
 

@@ -391,7 +391,9 @@ class GradReducer:
             off = 0
             for p in bucket:
                 n = p.numel()
-                p.grad.copy_(flat[off : off + n].view_as(p.grad))
+                # (an elementwise KERNEL, not copy_: a contiguous device-to-device copy_ is a hipMemcpyAsync, which a recording of
+                # the step keeps as a copy node that csrc/step_replay.hip cannot read back on this runtime; x * 1 is x, bit for bit)
+                torch.mul(flat[off : off + n].view_as(p.grad), 1.0, out=p.grad)
                 off += n
         self._pending = []
         self._staged = set()

@@ -122,18 +122,25 @@ class FusedAdam(torch.optim.Optimizer):
             raise RuntimeError("FusedAdam.prepare_capture(): run one eager step first (static pointer tables)")
         pl = self._plan
         n = len(pl["sizes"])
-        pl["graph_n"] = n
-        pl["graph_dyn"] = torch.empty(3 * n + 1, dtype=torch.int64, device=pl["sizes"].device)
-        pl["graph_gptr_host"] = torch.empty(n, dtype=torch.int64).pin_memory()
-        pl["graph_ring"] = [torch.empty(2 * n + 1, dtype=torch.int64).pin_memory() for _ in range(4)]
-        pl["graph_ring_ev"] = [None] * 4
-        pl["graph_turn"] = 0
-        pl["graph_defer"] = bool(defer_table_copy)
-        pl["graph_pending"] = False
+        # one table set PER RECORDING (a run may hold several - engine.graph.BucketedTrainStep records the step once per caption
+        # bucket -, each with its own captured gradient tensors): the recording made next uses `cap`, returned to the caller, who
+        # passes it back to finish_capture() / advance_for_replay()
+        cap = {
+            "graph_n": n,
+            "graph_dyn": torch.empty(3 * n + 1, dtype=torch.int64, device=pl["sizes"].device),
+            "graph_gptr_host": torch.empty(n, dtype=torch.int64).pin_memory(),
+            "graph_ring": [torch.empty(2 * n + 1, dtype=torch.int64).pin_memory() for _ in range(4)],
+            "graph_ring_ev": [None] * 4,
+            "graph_turn": 0,
+            "graph_defer": bool(defer_table_copy),
+            "graph_pending": False,
+        }
+        pl["cap"] = cap
+        return cap
 
-    def finish_capture(self):
+    def finish_capture(self, cap=None):
         """After the recording ended (prepare_capture(defer_table_copy=True)): the gradient address table -> device, once."""
-        pl = self._plan
+        pl = cap if cap is not None else (self._plan or {}).get("cap")
         if pl is not None and pl.get("graph_pending"):
             n = pl["graph_n"]
             pl["graph_dyn"][:n].copy_(pl["graph_gptr_host"], non_blocking=True)
@@ -141,7 +148,7 @@ class FusedAdam(torch.optim.Optimizer):
 
     def _capture_tables(self, items):
         """INSIDE the capture: the captured gradients' addresses -> the static table (a captured copy node)."""
-        pl = self._plan
+        pl = self._plan.get("cap") or {}
         n = len(items)
         if pl.get("graph_n") != n:
             raise RuntimeError("FusedAdam.step() inside a stream capture needs prepare_capture() first (engine.graph.CapturedTrainStep "
@@ -153,10 +160,11 @@ class FusedAdam(torch.optim.Optimizer):
             pl["graph_dyn"][:n].copy_(pl["graph_gptr_host"], non_blocking=True)
         return pl["graph_dyn"]
 
-    def advance_for_replay(self):
+    def advance_for_replay(self, cap=None):
         """Host side of one replayed step: per-parameter step counts, bias corrections, the groups' CURRENT lr / weight
-        decay -> the device table, stream-ordered."""
-        pl = self._plan
+        decay -> the device table of the recording about to be replayed (`cap`: what its prepare_capture() returned; None: the
+        latest), stream-ordered."""
+        pl = cap if cap is not None else self._plan["cap"]
         n = pl["graph_n"]
         lrs, wds, bc1, bc2 = [], [], [], []
         for group in self.param_groups:
