@@ -741,6 +741,16 @@ def main():
     dt = time.perf_counter() - t0
     log("timed region: %.3fs for %d steps (host enqueue time %.3fs)" % (dt, args.steps, t_host))
     last = {k: v.detach().clone() for k, v in last.items()}
+    # host WORK per step, without back-pressure: over the 20 steps of the timed region the launch calls block on full hardware queues
+    # (host_enqueue_ms_per_step ~ the GPU step time whatever the launch form); three steps issued onto an idle GPU do not, so the time to
+    # get them enqueued is what the host itself needs per step - the figure that decides whether N ranks keep their GPUs fed
+    torch.cuda.synchronize()
+    t0w = time.perf_counter()
+    for i in range(3):
+        timed_step(n_prep + args.warmup + args.steps + 100 + i)
+    host_work_ms = (time.perf_counter() - t0w) / 3 * 1e3
+    torch.cuda.synchronize()
+    log("host work per step, no back-pressure: %.2f ms" % host_work_ms)
     seam = None
     if runner is not None and not dp and not use_eager:
         seam = replay_equals_eager(runner, model, opt, *batch(n_prep + args.warmup + args.steps))
@@ -995,6 +1005,7 @@ def main():
                 "step_launch": step_launch,
                 "launch_probe": launch_probe,
                 "host_enqueue_ms_per_step": t_host / args.steps * 1e3,
+                "host_work_ms_per_step_no_backpressure": host_work_ms,
                 "gemm_arithmetic": arith,
                 "final_loss": loss_val,
             },

@@ -75,10 +75,13 @@ def main():
     seen = {}
     fused = head.loss_evaluator.forward_fused
 
+    def keep(x):  # a copy made by a KERNEL (x * 1): a contiguous clone() is a hipMemcpyAsync, and the recorded step must not hold
+        return torch.mul(x.detach(), 1)  # copy nodes (csrc/step_replay.hip cannot read them back on this runtime)
+
     def spy(*a):  # the gathered blocks the losses are evaluated on, and the gradients that come back to them
-        seen["args"] = [x.detach().clone() for x in a[:7]]
-        a[0].register_hook(lambda g: seen.__setitem__("d_v_embed", g.detach().clone()))
-        a[1].register_hook(lambda g: seen.__setitem__("d_t_embed", g.detach().clone()))
+        seen["args"] = [keep(x) for x in a[:7]]
+        a[0].register_hook(lambda g: seen.__setitem__("d_v_embed", keep(g)))
+        a[1].register_hook(lambda g: seen.__setitem__("d_t_embed", keep(g)))
         return fused(*a)
 
     head.loss_evaluator.forward_fused = spy
