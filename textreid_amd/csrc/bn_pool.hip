@@ -331,13 +331,20 @@ __global__ __attribute__((amdgpu_num_vgpr(32))) void bn_apply_kernel(const float
     constexpr bool P16OUT = OFMT == 1;
     const float oscale = P16OUT ? p16_out_scale(oa, ob, osum) : 1.f;
     const float rinv = RFMT == 1 ? 1.f / f16_scale_of(*res_amax) : 1.f;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4;
-         i += (long long)gridDim.x * blockDim.x) {
-        const int cq = (int)(i % CQ);
+    // the (row, channel quad) of element i is carried along - one add and a conditional subtract per trip - instead of being
+    // divided out of i per element: i % CQ here, i / CQ inside the P16 load and the P16 store were three 64-bit divisions per
+    // element, ~25 VALU instructions and two exec-mask branches each, next to ~30 instructions of real work
+    const long long T = (long long)gridDim.x * blockDim.x;
+    const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    int row = (int)(i0 / CQ);
+    int cq = (int)(i0 - (long long)row * CQ);
+    const int step_r = (int)(T / CQ), step_c = (int)(T - (long long)step_r * CQ);
+    for (long long i = i0; i < total4; i += T, cq += step_c, row += step_r) {
+        if (cq >= CQ) { cq -= CQ; ++row; }
         // y_fmt 2: the raw conv output itself is a bf16 tensor (bf16 mode)
         float4 v = affine4(y_fmt == 2 ? bf16_load4(reinterpret_cast<const uint2*>(y), i) : ld_stream4(y + i, nt), scale[cq], shift[cq]);
         if (res != nullptr) {
-            float4 r = RFMT == 1 ? p16_load4(reinterpret_cast<const uint2*>(res), i, CQ, rinv)
+            float4 r = RFMT == 1 ? p16_load4_rc(reinterpret_cast<const uint2*>(res), row, cq, CQ, rinv)
                      : RFMT == 2 ? bf16_load4(reinterpret_cast<const uint2*>(res), i) : ld_stream4(res + i, nt);
             if (rscale != nullptr) r = affine4(r, rscale[cq], rshift[cq]);
             v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
@@ -354,7 +361,7 @@ __global__ __attribute__((amdgpu_num_vgpr(32))) void bn_apply_kernel(const float
         }
         if (relu) v = relu4(v);
         if (OFMT == 1) {
-            p16_store4_pair(reinterpret_cast<uint2*>(out), i, CQ, v, oscale, nt);  // (total4 is even and the stride a multiple of 256: lane pairs hold quad pairs)
+            p16_store4_pair_rc(reinterpret_cast<uint2*>(out), row, cq, CQ, v, oscale, nt);  // (total4 is even and the stride a multiple of 256: lane pairs hold quad pairs)
         } else if (OFMT == 2) {
             bf16_store4(reinterpret_cast<uint2*>(out), i, v);
         } else {
@@ -500,9 +507,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a, float* 
     const long long t0 = (long long)blockIdx.x * 256 + tid;
     const int cq = (int)(t0 % a.CQ);
     float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1, mg = s1, mx = s1;
-    for (long long i = t0; i < a.total4; i += T) {
-        float4 gm, xh;
-        bn_bwd_elem(a, i, cq, gm, xh);
+    auto fold = [&](const float4& gm, const float4& xh) {
         s1.x += gm.x; s1.y += gm.y; s1.z += gm.z; s1.w += gm.w;
         s2.x = fmaf(gm.x, xh.x, s2.x); s2.y = fmaf(gm.y, xh.y, s2.y);
         s2.z = fmaf(gm.z, xh.z, s2.z); s2.w = fmaf(gm.w, xh.w, s2.w);
@@ -510,6 +515,14 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a, float* 
             mg.x = fmaxf(mg.x, fabsf(gm.x)); mg.y = fmaxf(mg.y, fabsf(gm.y)); mg.z = fmaxf(mg.z, fabsf(gm.z)); mg.w = fmaxf(mg.w, fabsf(gm.w));
             mx.x = fmaxf(mx.x, fabsf(xh.x)); mx.y = fmaxf(mx.y, fabsf(xh.y)); mx.z = fmaxf(mx.z, fabsf(xh.z)); mx.w = fmaxf(mx.w, fabsf(xh.w));
         }
+    };
+    // (measured and dropped, profiles/r06k_bn_ilp_ab.txt: four elements of a thread in flight - loads issued back to back, folded in
+    // this order - run the isolated pass 1-2 % faster but need 126 VGPRs instead of 64, and the step 0.25 ms SLOWER: these passes
+    // share the CUs with the other lanes' GEMMs, whose waves leave room for a small kernel's waves only)
+    for (long long i = t0; i < a.total4; i += T) {
+        float4 gm, xh;
+        bn_bwd_elem(a, i, cq, gm, xh);
+        fold(gm, xh);
     }
     __shared__ float red[256][9];
     red[tid][0] = s1.x; red[tid][1] = s1.y; red[tid][2] = s1.z; red[tid][3] = s1.w;
@@ -616,10 +629,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a, const fl
                                                            float* __restrict__ amax, const float* __restrict__ oa) {
     unsigned am = 0;
     const float oscale = OFMT == 1 ? f16_scale_of(*oa) : 1.f;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < a.total4; i += (long long)gridDim.x * 256) {
-        const int cq = (int)(i % a.CQ);
-        float4 gm, xh;
-        bn_bwd_elem(a, i, cq, gm, xh);
+    const long long T = (long long)gridDim.x * 256;
+    auto finish = [&](long long i, long long row, int cq, const float4& gm, const float4& xh) {
         const float4 sc = a.scale[cq], dg = dgamma[cq], db = dbeta[cq];
         float4 o;
         o.x = sc.x * (gm.x - db.x * invM - xh.x * dg.x * invM);
@@ -627,7 +638,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a, const fl
         o.z = sc.z * (gm.z - db.z * invM - xh.z * dg.z * invM);
         o.w = sc.w * (gm.w - db.w * invM - xh.w * dg.w * invM);
         if (OFMT == 1) {
-            p16_store4_pair(reinterpret_cast<uint2*>(dy), i, a.CQ, o, oscale, a.nt);
+            p16_store4_pair_rc(reinterpret_cast<uint2*>(dy), row, cq, a.CQ, o, oscale, a.nt);
         } else if (OFMT == 2) {
             bf16_store4(reinterpret_cast<uint2*>(dy), i, o);
         } else {
@@ -638,6 +649,25 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a, const fl
             if (a.g_fmt == 2) bf16_store4(reinterpret_cast<uint2*>(dres), i, gm);  // (a masked bf16 value: exact)
             else st_stream4(dres + i, gm, a.nt);
         }
+    };
+    // the (row, channel quad) of element i: carried along (one add and a conditional subtract per trip) instead of a 64-bit i % CQ per
+    // element - the remainder's expansion is ~25 VALU instructions and two exec-mask branches
+    const long long i0 = (long long)blockIdx.x * 256 + threadIdx.x;
+    long long row = i0 / a.CQ;
+    int cq = (int)(i0 - row * a.CQ);
+    const long long step_r = T / a.CQ;
+    const int step_c = (int)(T - step_r * a.CQ);
+    auto advance = [&](long long& r, int& c) {
+        c += step_c;
+        r += step_r;
+        if (c >= a.CQ) { c -= a.CQ; ++r; }
+    };
+    long long i = i0;
+    for (; i < a.total4; i += T) {
+        float4 gm, xh;
+        bn_bwd_elem(a, i, cq, gm, xh);
+        finish(i, row, cq, gm, xh);
+        advance(row, cq);
     }
     if (OFMT == 0 && amax != nullptr) amax_commit(am, amax);
 }
@@ -744,8 +774,15 @@ __global__ __launch_bounds__(256) void bn_bwd_dual_apply_kernel(BnBwdDual a, con
                                                                 float4* __restrict__ dy2, const float* __restrict__ bound1,
                                                                 const float* __restrict__ bound2) {
     const float os1 = f16_scale_of(*bound1), os2 = f16_scale_of(*bound2);
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < a.total4; i += (long long)gridDim.x * 256) {
-        const int cq = (int)(i % a.CQ);
+    // ((row, channel quad) carried along instead of three divisions of i per element: see bn_apply_kernel)
+    const long long T = (long long)gridDim.x * 256;
+    const long long i0 = (long long)blockIdx.x * 256 + threadIdx.x;
+    long long row = i0 / a.CQ;
+    int cq = (int)(i0 - row * a.CQ);
+    const long long step_r = T / a.CQ;
+    const int step_c = (int)(T - step_r * a.CQ);
+    for (long long i = i0; i < a.total4; i += T, cq += step_c, row += step_r) {
+        if (cq >= a.CQ) { cq -= a.CQ; ++row; }
         float4 gm, x1, x2;
         bn_bwd_dual_elem(a, i, cq, gm, x1, x2);
         const float4 db = dbeta[cq];
@@ -756,7 +793,7 @@ __global__ __launch_bounds__(256) void bn_bwd_dual_apply_kernel(BnBwdDual a, con
             o.y = sc.y * (gm.y - db.y * invM - x1.y * dg.y * invM);
             o.z = sc.z * (gm.z - db.z * invM - x1.z * dg.z * invM);
             o.w = sc.w * (gm.w - db.w * invM - x1.w * dg.w * invM);
-            p16_store4_pair(reinterpret_cast<uint2*>(dy1), i, a.CQ, o, os1, a.nt);
+            p16_store4_pair_rc(reinterpret_cast<uint2*>(dy1), row, cq, a.CQ, o, os1, a.nt);
         }
         {
             const float4 sc = a.scale2[cq], dg = dgamma2[cq];
@@ -765,7 +802,7 @@ __global__ __launch_bounds__(256) void bn_bwd_dual_apply_kernel(BnBwdDual a, con
             o.y = sc.y * (gm.y - db.y * invM - x2.y * dg.y * invM);
             o.z = sc.z * (gm.z - db.z * invM - x2.z * dg.z * invM);
             o.w = sc.w * (gm.w - db.w * invM - x2.w * dg.w * invM);
-            p16_store4_pair(reinterpret_cast<uint2*>(dy2), i, a.CQ, o, os2, a.nt);
+            p16_store4_pair_rc(reinterpret_cast<uint2*>(dy2), row, cq, a.CQ, o, os2, a.nt);
         }
     }
 }

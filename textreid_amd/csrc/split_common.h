@@ -226,6 +226,18 @@ __device__ __forceinline__ void p16_store4(uint2* __restrict__ base, long long i
 // both low parts) and every lane writes ONE 16-byte piece, so a wave's store instruction covers whole 128-byte lines.  With
 // two 8-byte stores per lane each instruction wrote every other 64-byte half line: bn_apply ran at 4.6-4.75 TB/s writing P16
 // against 5.5-6.9 writing fp32 (profiles/r05g_bn_bandwidth_probe.txt).  Every lane of the wave must make the call (shuffle).
+// (row, cq) form: for callers that carry the element's row and channel quad along instead of dividing i by CQ per element
+__device__ __forceinline__ void p16_store4_pair_rc(uint2* __restrict__ base, long long row, int cq, int CQ, float4 v, float scale, bool nt = false) {
+    unsigned h0, l0, h1, l1;
+    f16_split2(v.x * scale, v.y * scale, h0, l0);
+    f16_split2(v.z * scale, v.w * scale, h1, l1);
+    const bool odd = (cq & 1) != 0;
+    const unsigned rx = __shfl_xor(odd ? h0 : l0, 1, 64), ry = __shfl_xor(odd ? h1 : l1, 1, 64);
+    const float4 piece = odd ? make_float4(__uint_as_float(rx), __uint_as_float(ry), __uint_as_float(l0), __uint_as_float(l1))
+                             : make_float4(__uint_as_float(h0), __uint_as_float(h1), __uint_as_float(rx), __uint_as_float(ry));
+    uint2* dst = base + row * (2 * CQ) + (cq >> 3) * 16 + (odd ? 8 + (cq & 7) - 1 : (cq & 7));
+    st_stream4(reinterpret_cast<float4*>(dst), piece, nt);
+}
 __device__ __forceinline__ void p16_store4_pair(uint2* __restrict__ base, long long i, int CQ, float4 v, float scale, bool nt = false) {
     const long long row = i / CQ;
     const int cq = (int)(i - row * CQ);
@@ -246,6 +258,14 @@ __device__ __forceinline__ void p16_pair_store(char* hi, int c4, unsigned q0h, u
     const unsigned rx = __shfl_xor(odd ? q0h : q0l, 1, 64), ry = __shfl_xor(odd ? q1h : q1l, 1, 64);
     const uint4 piece = odd ? make_uint4(rx, ry, q0l, q1l) : make_uint4(q0h, q1h, rx, ry);
     *reinterpret_cast<uint4*>(odd ? hi + 56 : hi) = piece;  // (odd: the low plane's 16 bytes of quads c4 - 1, c4 = 64 bytes on, 8 back)
+}
+__device__ __forceinline__ float4 p16_load4_rc(const uint2* __restrict__ base, long long row, int cq, int CQ, float inv) {
+    const uint2* src = base + row * (2 * CQ) + (cq >> 3) * 16 + (cq & 7);
+    const uint2 h = src[0], l = src[8];
+    const f16x2 h0 = __builtin_bit_cast(f16x2, h.x), h1 = __builtin_bit_cast(f16x2, h.y);
+    const f16x2 l0 = __builtin_bit_cast(f16x2, l.x), l1 = __builtin_bit_cast(f16x2, l.y);
+    return make_float4(((float)h0.x + (float)l0.x) * inv, ((float)h0.y + (float)l0.y) * inv,
+                       ((float)h1.x + (float)l1.x) * inv, ((float)h1.y + (float)l1.y) * inv);
 }
 __device__ __forceinline__ float4 p16_load4(const uint2* __restrict__ base, long long i, int CQ, float inv) {
     const long long row = i / CQ;
