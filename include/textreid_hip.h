@@ -116,8 +116,10 @@ typedef struct trid_gemm_desc {
     /* trid_gemm_p16, c_format 0, batch == splits == 1, ldc == N, N == 64 or N % 128 == 0 - a DATA GRADIENT that feeds a BatchNorm
      * backward (m_resnet.py:54-67): with bnb_y = the saved fp32 output y [M][N] of the convolution that BatchNorm layer
      * normalised (and its batch mean / invstd / scale / shift vectors [N]), every 128-row tile also writes the sums
-     * sum g m, sum g m xhat and the maxima max|g m|, max|xhat| of its rows of C = g (m = [scale y + shift > 0] when bnb_relu,
-     * else 1) to bnb_ws / bnb_ws2 (trid_bn_bwd_fused_ws_floats floats each), in the layout trid_bn_bwd_final_f32 folds:
+     * sum g m, sum g m xhat and the maxima max|g m|, max|xhat| of its rows of C = g (m = [scale y + shift > 0] when bnb_relu == 1;
+     * bnb_relu == 2: m = the bit of bnb_mask - the ReLU bit mask trid_bn_apply_p16_f32 wrote for the BLOCK OUTPUT that layer feeds
+     * (a residual block's bn3: out = relu(bn3(.) + identity), m_resnet.py:62-66, where the sign of bn3's own output says
+     * nothing) -; else 1) to bnb_ws / bnb_ws2 (trid_bn_bwd_fused_ws_floats floats each), in the layout trid_bn_bwd_final_f32 folds:
      * the BatchNorm-backward reduce pass over g and y is then not needed.  NULL: off. */
     const float* bnb_y;
     const float* bnb_mean;
@@ -127,6 +129,7 @@ typedef struct trid_gemm_desc {
     float* bnb_ws;
     float* bnb_ws2;
     int32_t bnb_relu;
+    const void* bnb_mask;    /* bnb_relu == 2: ReLU bits over [M][N], the layout of c_mask */
 } trid_gemm_desc;
 
 int trid_gemm_f32(const trid_gemm_desc* d, void* stream);

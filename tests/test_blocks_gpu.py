@@ -120,7 +120,7 @@ def test_bottleneck_b128_unstructured_masks(gpu, name, inpl, planes, stride, H, 
         assert M.p16_eligible(type("One", (), {"blocks": lambda self: [blk]})())
         outp, rec = M.block_forward_p16(blk, ops.p16_pack(xd, ax), M.p16_weights(blk, WA, False), gpu, True, True, nbt, masks)
         out, a_out = outp.unpack(), outp.amax
-        dx = M.block_backward_p16(blk, rec, gd, M.p16_weights(blk, WA, True), ws, G)
+        dx, _ = M.block_backward_p16(blk, rec, gd, M.p16_weights(blk, WA, True), ws, G)
     else:
         out, a_out, rec = M.block_forward(blk, xd, ax, ar, True, True, nbt, masks)
         dx = M.block_backward(blk, rec, gd, ar, ws, G)
@@ -268,7 +268,7 @@ def test_bottleneck_bf16_mode(gpu, name, inpl, planes, stride, H, W):
     ws = M._WgradStream(gpu)
     outp, rec = M.block_forward_p16(blk, ops.p16_pack(xd, None, 2), M.p16_weights(blk, WA, False, 2), gpu, True, True, nbt, masks)
     assert rec[1].dtype == torch.bfloat16  # the conv outputs are stored as bf16 tensors
-    dx = M.block_backward_p16(blk, rec, gd, M.p16_weights(blk, WA, True, 2), ws, G)
+    dx, _ = M.block_backward_p16(blk, rec, gd, M.p16_weights(blk, WA, True, 2), ws, G)
     assert dx.dtype == torch.bfloat16
     ws.join()
     torch.cuda.synchronize()

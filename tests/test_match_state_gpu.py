@@ -633,7 +633,7 @@ def test_schedule_and_fusion_switches_leave_the_gradients_alone(gpu):
     base = grads()
     assert len(base) > 150
     switches = [(MR, "_BATCH_WGRAD", 0, True), (MR, "_SERIAL_ATTN_WGRAD", True, True), (MR, "_EARLY_WPT", False, True),
-                (ops, "USE_BNB_FUSE", False, False), (ops, "USE_BN_DUAL", False, False)]
+                (ops, "USE_BNB_FUSE", False, False), (ops, "USE_BN_DUAL", False, False), (MR, "_BN3_FUSE", False, False)]
     for mod, name, off, exact in switches:
         was = getattr(mod, name)
         try:

@@ -553,10 +553,16 @@ def _finalize_minmax(bn, partials, M, relu, bound, counters, rows_per_part=ops.S
 _MASKED_ACC = _os.environ.get("TRID_MASKED_ACC", "1") != "0"
 
 
-def block_backward_p16(blk, rec, g, WPT, ws, G):
+_BN3_FUSE = _os.environ.get("TRID_BN3_FUSE", "1") != "0"  # bn3's backward sums from the GEMM that produces the block-output gradient (0: A/B runs)
+
+
+def block_backward_p16(blk, rec, g, WPT, ws, G, g_sums=None, prev_rec=None, prev_blk=None):
     """Backward of block_forward_p16.  g: dL/d(out) fp32.  The BatchNorm-backward passes write their outputs as P16
     tensors (bound of max|dy| from the reduce pass); data gradients on gemm_p16, weight gradients on the transposing
-    P16 kernel (side stream)."""
+    P16 kernel (side stream).
+    g_sums: bn3's BatchNorm-backward sums (ops.BnBwdSums with this block's ReLU bits), formed by the GEMM that produced g - the
+    block processed before this one; prev_rec / prev_blk: the block whose OUTPUT gradient this call produces (processed next).
+    Returns (dL/dx, the BnBwdSums of that block's bn3 or None)."""
     x, ya, sta, aa, yb, stb, ab, yc, stc, xd, yd, std, rmask = rec
     stride = blk.stride
     has_down = blk.downsample is not None
@@ -582,7 +588,8 @@ def block_backward_p16(blk, rec, g, WPT, ws, G):
         G[id(blk.downsample[2].weight)], G[id(blk.downsample[2].bias)] = dg2, db2
         dres = None
     else:
-        dyc, dg, db, dres = ops.bn_bwd_p16(g, yc, stc, 3, act=rmask, want_dres=not has_down and not masked_acc, fmt=fmt)
+        dyc, dg, db, dres = ops.bn_bwd_p16(g, yc, stc, 3, act=rmask, want_dres=not has_down and not masked_acc, fmt=fmt,
+                                           presummed=g_sums if (g_sums is not None and g_sums.y is yc) else None)
         G[id(blk.bn3.weight)], G[id(blk.bn3.bias)] = dg, db
         if has_down:
             dyd, dg, db, _ = ops.bn_bwd_p16(g, yd, std, 3, act=rmask, fmt=fmt)
@@ -617,10 +624,20 @@ def block_backward_p16(blk, rec, g, WPT, ws, G):
         dx = ops.avgpool2_bwd(dxd) if stride > 1 else dxd
     else:
         dx = g if masked_acc else dres
-    ops.gemm_p16(dya, WPT[id(blk.conv1.weight)], dx, Ma, cin, planes, cin, accumulate=True, cmask=rmask if masked_acc else None)
+    # dx is the OUTPUT gradient of the block in front of this one: when that block is an identity block its bn3 backward takes
+    # g = dx masked by ITS ReLU bits - the sums come out of this GEMM's epilogue (the tile kernel; its reduce pass over dx and the
+    # saved conv3 output, 60-100 us per block of layer3 / layer4 re-reading 100-200 MB, is then not run).  K = planes >= 256 only:
+    # below that this product runs on the streaming kernel, which a tile kernel with a 2-4 tile K loop does not beat by the
+    # reduce pass's cost (layer3, K = 256: 64-68 us on the tile kernel against 59-62 us streaming, profiles/r04g_k256acc.txt)
+    nxt = None
+    if (_BN3_FUSE and prev_rec is not None and prev_blk is not None and prev_blk.downsample is None and fmt == 1 and planes >= 256
+            and dx.dtype == torch.float32 and dx.is_contiguous() and prev_rec[12] is not None
+            and ops.bn_bwd_fusable(prev_rec[7], Ma, cin, fmt) and tuple(prev_rec[7].shape) == tuple(dx.shape)):
+        nxt = ops.BnBwdSums(prev_rec[7], prev_rec[8], mask=prev_rec[12])  # (yc, stc, rmask of the block in front)
+    ops.gemm_p16(dya, WPT[id(blk.conv1.weight)], dx, Ma, cin, planes, cin, accumulate=True, cmask=rmask if masked_acc else None, bn_bwd=nxt)
     wgrad(blk.conv1.weight, dya, x)
     ws.flush(block_end=True)
-    return dx
+    return dx, nxt
 
 
 class _EncoderFn(torch.autograd.Function):
@@ -1050,10 +1067,17 @@ class ModifiedResNet(nn.Module):
         WPT = (S.get("WPT") or p16_weights(self, ar.WA, True, p16)) if p16 else None
         if p16 == 2 and ops.BF16_GRADS:
             g = g.to(torch.bfloat16)  # bf16 mode: the gradient of a bf16 tensor (the block outputs) is a bf16 tensor
-        for blk, rec in zip(reversed(blocks), reversed(S["blocks"])):
+        rblocks, rrecs = list(reversed(blocks)), list(reversed(S["blocks"]))
+        g_sums = None
+        for bi, (blk, rec) in enumerate(zip(rblocks, rrecs)):
             if dbg is not None:
                 dbg.append(g.float().clone())  # (a copy: identity blocks overwrite g with dL/dx)
-            g = block_backward_p16(blk, rec, g, WPT, ws, G) if p16 else block_backward(blk, rec, g, ar, ws, G)
+            if p16:
+                more = bi + 1 < len(rblocks)
+                g, g_sums = block_backward_p16(blk, rec, g, WPT, ws, G, g_sums=g_sums, prev_rec=rrecs[bi + 1] if more else None,
+                                               prev_blk=rblocks[bi + 1] if more else None)
+            else:
+                g = block_backward(blk, rec, g, ar, ws, G)
             if id(blk) in first_of_layer:  # a whole residual layer (and, the first time, the attention pool) is done
                 stage_ready()
         S["blocks"] = None

@@ -53,7 +53,9 @@ struct BnBwdFuse {
     const float* shift;
     float* ws;             // sums
     float* ws2;            // maxima
-    int relu;              // 1: the layer's output went through ReLU (the mask is recomputed from y); 0: m = 1
+    int relu;              // 1: the layer's output went through ReLU (the mask is recomputed from y); 0: m = 1;
+                           // 2: m = the bit of `mask` (a residual block's bn3: the ReLU came after the identity was added)
+    const unsigned long long* mask;  // relu_mask words of bn_apply over [M][N] (the layout of GemmParams::cmask)
 };
 
 struct GemmParams {

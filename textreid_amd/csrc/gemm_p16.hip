@@ -789,9 +789,16 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 && STAGES == 2) ? 2 : (W
                 if (bnb) {  // the arithmetic of bn_bwd_elem / bn_bwd_reduce_kernel (bn_pool.hip)
                     const float4 xh = make_float4((yv.x - b_mu.x) * b_is.x, (yv.y - b_mu.y) * b_is.y, (yv.z - b_mu.z) * b_is.z, (yv.w - b_mu.w) * b_is.w);
                     float4 g = v;
-                    if (bb.relu) {
+                    if (bb.relu == 1) {
                         g.x = fmaf(yv.x, b_sc.x, b_sh.x) > 0.f ? g.x : 0.f; g.y = fmaf(yv.y, b_sc.y, b_sh.y) > 0.f ? g.y : 0.f;
                         g.z = fmaf(yv.z, b_sc.z, b_sh.z) > 0.f ? g.z : 0.f; g.w = fmaf(yv.w, b_sc.w, b_sh.w) > 0.f ? g.w : 0.f;
+                    } else if (bb.relu == 2) {  // the block output's ReLU bits (quad at / 4: four words per 64 quads, bit = quad % 64)
+                        const long long qi = ((long long)row * p.N + col) >> 2;
+                        const ulonglong2* mq = reinterpret_cast<const ulonglong2*>(bb.mask + (qi >> 6) * 4);
+                        const ulonglong2 m01 = mq[0], m23 = mq[1];
+                        const int bit = (int)(qi & 63);
+                        g.x = ((m01.x >> bit) & 1ull) ? g.x : 0.f; g.y = ((m01.y >> bit) & 1ull) ? g.y : 0.f;
+                        g.z = ((m23.x >> bit) & 1ull) ? g.z : 0.f; g.w = ((m23.y >> bit) & 1ull) ? g.w : 0.f;
                     }
                     b_s1.x += g.x; b_s1.y += g.y; b_s1.z += g.z; b_s1.w += g.w;
                     b_s2.x = fmaf(g.x, xh.x, b_s2.x); b_s2.y = fmaf(g.y, xh.y, b_s2.y); b_s2.z = fmaf(g.z, xh.z, b_s2.z); b_s2.w = fmaf(g.w, xh.w, b_s2.w);
@@ -1534,11 +1541,14 @@ extern "C" int trid_gemm_p16(const trid_gemm_desc* d, int variant, void* stream_
     p.pool_w = d->eval_pool_w;
     p.bb.y = d->bnb_y; p.bb.mean = d->bnb_mean; p.bb.invstd = d->bnb_invstd; p.bb.scale = d->bnb_scale; p.bb.shift = d->bnb_shift;
     p.bb.ws = d->bnb_ws; p.bb.ws2 = d->bnb_ws2; p.bb.relu = d->bnb_relu;
+    p.bb.mask = reinterpret_cast<const unsigned long long*>(d->bnb_mask);
     if (d->bnb_y != nullptr) {
         const int CQ = d->N / 4;
         TRID_REQUIRE(planes == 2 && d->c_format == 0 && d->batch == 1 && d->splits == 1 && d->ldc == d->N && (d->N == 64 || d->N % 128 == 0) && !d->stats &&
                      (256 % CQ == 0 || CQ % 256 == 0) && wide_env_ok(),
                      "trid_gemm_p16: the BatchNorm-backward sums (bnb_y) need P16 operands, fp32 C with ldc == N, N == 64 or N %% 128 == 0, batch == splits == 1, no stats (N=%d)", d->N);
+        TRID_REQUIRE(d->bnb_relu >= 0 && d->bnb_relu <= 2 && (d->bnb_relu != 2 || (d->bnb_mask != nullptr && aligned16(d->bnb_mask))),
+                     "trid_gemm_p16: bnb_relu must be 0, 1 or 2 (2: with the 16-byte aligned ReLU bit mask bnb_mask)");
         TRID_REQUIRE(d->bnb_mean && d->bnb_invstd && d->bnb_scale && d->bnb_shift && d->bnb_ws && d->bnb_ws2 && aligned16(d->bnb_y) && aligned16(d->bnb_mean) &&
                      aligned16(d->bnb_invstd) && aligned16(d->bnb_scale) && aligned16(d->bnb_shift) && aligned16(d->bnb_ws) && aligned16(d->bnb_ws2),
                      "trid_gemm_p16: the BatchNorm-backward sums need all of bnb_mean / invstd / scale / shift / ws / ws2, 16-byte aligned");

@@ -69,6 +69,7 @@ class GemmDesc(ctypes.Structure):
         ("bnb_ws", ctypes.c_void_p),
         ("bnb_ws2", ctypes.c_void_p),
         ("bnb_relu", ctypes.c_int32),
+        ("bnb_mask", ctypes.c_void_p),
     ]
 
 

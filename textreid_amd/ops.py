@@ -297,11 +297,13 @@ class BnBwdSums:
     """The BatchNorm-backward sums of a gradient tensor, written by the data-gradient GEMM that produces it (gemm_p16(bn_bwd=...),
     csrc/gemm_p16.hip BnBwdFuse) and consumed by bn_bwd_p16(presummed=...) instead of its reduce pass over g and y."""
 
-    __slots__ = ("y", "st", "relu", "ws", "ws2", "M")
+    __slots__ = ("y", "st", "relu", "ws", "ws2", "M", "mask")
 
-    def __init__(self, y, st, relu=True):
+    def __init__(self, y, st, relu=True, mask=None):
+        """mask: the ReLU bit mask of the BLOCK OUTPUT the layer feeds (bn_apply_p16(want_mask=True)) - a residual block's bn3,
+        whose own sign says nothing about the ReLU that follows the identity add (bn_bwd_p16's mask mode 3)."""
         C = y.shape[-1]
-        self.y, self.st, self.relu = y, st, relu
+        self.y, self.st, self.relu, self.mask = y, st, relu, mask
         self.M = y.numel() // C
         n = _query("trid_bn_bwd_fused_ws_floats", int(self.M), int(C))
         both = empty((2 * n,), y)
@@ -354,7 +356,8 @@ def gemm_p16(A, B, C, M, N, K, ldc, conv=None, alpha=1.0, accumulate=False, bias
     if bn_bwd is not None:
         st = bn_bwd.st
         d.bnb_y, d.bnb_mean, d.bnb_invstd, d.bnb_scale, d.bnb_shift = _p(bn_bwd.y), _p(st.mean), _p(st.invstd), _p(st.scale), _p(st.shift)
-        d.bnb_ws, d.bnb_ws2, d.bnb_relu = _p(bn_bwd.ws), _p(bn_bwd.ws2), 1 if bn_bwd.relu else 0
+        d.bnb_ws, d.bnb_ws2 = _p(bn_bwd.ws), _p(bn_bwd.ws2)
+        d.bnb_relu, d.bnb_mask = (2, _p(bn_bwd.mask)) if bn_bwd.mask is not None else ((1 if bn_bwd.relu else 0), None)
     v = P16_VARIANT if variant is None else variant
     if stats is not None:
         rows = gemm_p16_rows(M, N, A.fmt, v)
@@ -712,7 +715,8 @@ def bn_bwd_p16(g, y, st, mask_mode, act=None, pooled=False, want_dres=False, fmt
     g_fmt = 2 if g.dtype == torch.bfloat16 else 0
     y_fmt = 2 if y.dtype == torch.bfloat16 else 0
     if presummed is not None:
-        assert fmt == 1 and g_fmt == 0 and y_fmt == 0 and not pooled and presummed.y is y and mask_mode == (1 if presummed.relu else 0)
+        assert fmt == 1 and g_fmt == 0 and y_fmt == 0 and not pooled and presummed.y is y
+        assert (mask_mode == 3 and presummed.mask is act) if presummed.mask is not None else mask_mode == (1 if presummed.relu else 0)
         bound = amax_slot(y.device)
         call("trid_bn_bwd_final_f32", _p(presummed.ws), _p(presummed.ws2), presummed.M, C, _p(st.scale), _p(dgamma), _p(dbeta), _p(bound), stream())
     elif fmt == 1:
