@@ -554,6 +554,7 @@ _MASKED_ACC = _os.environ.get("TRID_MASKED_ACC", "1") != "0"
 
 
 _BN3_FUSE = _os.environ.get("TRID_BN3_FUSE", "1") != "0"  # bn3's backward sums from the GEMM that produces the block-output gradient (0: A/B runs)
+_BN3_FUSE_MIN_PLANES = int(_os.environ.get("TRID_BN3_FUSE_MIN_PLANES", "256"))  # (A/B runs: 512 = only where the product is on the tile kernel anyway)
 
 
 def block_backward_p16(blk, rec, g, WPT, ws, G, g_sums=None, prev_rec=None, prev_blk=None):
@@ -630,7 +631,7 @@ def block_backward_p16(blk, rec, g, WPT, ws, G, g_sums=None, prev_rec=None, prev
     # below that this product runs on the streaming kernel, which a tile kernel with a 2-4 tile K loop does not beat by the
     # reduce pass's cost (layer3, K = 256: 64-68 us on the tile kernel against 59-62 us streaming, profiles/r04g_k256acc.txt)
     nxt = None
-    if (_BN3_FUSE and prev_rec is not None and prev_blk is not None and prev_blk.downsample is None and fmt == 1 and planes >= 256
+    if (_BN3_FUSE and prev_rec is not None and prev_blk is not None and prev_blk.downsample is None and fmt == 1 and planes >= _BN3_FUSE_MIN_PLANES
             and dx.dtype == torch.float32 and dx.is_contiguous() and prev_rec[12] is not None
             and ops.bn_bwd_fusable(prev_rec[7], Ma, cin, fmt) and tuple(prev_rec[7].shape) == tuple(dx.shape)):
         nxt = ops.BnBwdSums(prev_rec[7], prev_rec[8], mask=prev_rec[12])  # (yc, stc, rmask of the block in front)
