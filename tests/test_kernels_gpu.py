@@ -994,6 +994,60 @@ def test_gemm_p16_bn_backward_sums_from_the_epilogue(ops, M_, N, K, conv, relu, 
         ops.gemm_p16(xp, ops.p16_pack(dev(R("bnbw96", 96, K))), ops.empty((M_, 96), xp.data), M_, 96, K, 96, conv=conv, bn_bwd=bad)
 
 
+@pytest.mark.parametrize("M_,N,K", [(24 * 8 * 16, 1024, 256), (24 * 8 * 8 + 37, 2048, 512), (48 * 16 * 4, 512, 256)])
+def test_gemm_p16_bn3_backward_sums_behind_the_relu_bit_mask(ops, M_, N, K):
+    """csrc/gemm_p16.hip BnBwdFuse, bnb_relu = 2 (round 6): the conv1 data-gradient GEMM of a residual block accumulates onto the
+    masked identity gradient (c_mask = ITS block's ReLU bits) and, in the same epilogue, forms the backward sums of the bn3 of the
+    block IN FRONT - against that block's saved conv3 output and ITS ReLU bit mask (out = relu(bn3(.) + identity),
+    m_resnet.py:62-66: the sign of bn3's own output says nothing).  (1) C is bit for bit what the launch without the sums
+    writes; (2) dgamma / dbeta / the bound / dy of bn_bwd_p16(mask mode 3, presummed=) agree with the reduce pass they replace
+    (other summation order: 1e-5) and with float64 on the bits."""
+    import torch as T
+
+    xp = ops.p16_pack(dev(R("bn3x%d" % K, M_, K)))
+    wp = ops.p16_pack(dev(R("bn3w%d" % N, N, K, scale=0.2)))
+    y = dev(R("bn3y%d" % N, 1, 1, M_, N) * 1.3 + 0.1)            # conv3 output of the block in front
+    gamma, beta = dev(R("bn3g", N).abs() + 0.5), dev(R("bn3b", N) * 0.3)
+    yd = y.double().reshape(M_, N)
+    mean, var = yd.mean(0), yd.var(0, unbiased=False)
+    invstd = 1.0 / T.sqrt(var + 1e-5)
+
+    class St:
+        pass
+
+    st = St()
+    st.mean, st.invstd = mean.float().contiguous(), invstd.float().contiguous()
+    st.scale = (gamma.double() * invstd).float().contiguous()
+    st.shift = (beta.double() - gamma.double() * invstd * mean).float().contiguous()
+    # two independent bit masks, each written by bn_apply_p16 as the blocks do: the accumulate's (this block) and bn3's (the block in front)
+    def bits(tag):
+        z = dev(R(tag, 1, 1, M_, N))
+        one = ops.BNState(N, z)
+        one.scale.fill_(1.0); one.shift.fill_(0.0); one.mean.fill_(0.0); one.invstd.fill_(1.0)
+        bound = ops.amax_slot(z.device); bound.fill_(8.0)
+        _, mask = ops.bn_apply_p16(z, one, bound, relu=True, want_mask=True)
+        return mask, (z.reshape(M_, N) > 0)
+    cmask, cbits = bits("bn3cm%d" % N)
+    rmask, rbits = bits("bn3rm%d" % N)
+    c0 = dev(R("bn3acc%d" % N, M_, N))
+    plain, fused = c0.clone(), c0.clone()
+    ops.gemm_p16(xp, wp, plain, M_, N, K, N, accumulate=True, cmask=cmask)
+    sums = ops.BnBwdSums(y, st, mask=rmask)
+    ops.gemm_p16(xp, wp, fused, M_, N, K, N, accumulate=True, cmask=cmask, bn_bwd=sums)
+    assert T.equal(plain, fused)
+    g4 = fused.reshape(1, 1, M_, N)
+    a = ops.bn_bwd_p16(g4, y, st, 3, act=rmask)
+    b = ops.bn_bwd_p16(g4, y, st, 3, act=rmask, presummed=sums)
+    for u, v, name in ((a[1], b[1], "dgamma"), (a[2], b[2], "dbeta")):
+        assert float((u - v).abs().max()) <= 1e-5 * float(u.abs().max()), name
+    assert abs(float(a[0].amax) - float(b[0].amax)) <= 1e-5 * float(a[0].amax)
+    assert float((a[0].unpack() - b[0].unpack()).abs().max()) <= 2e-5 * float(a[0].unpack().abs().max())
+    gd = fused.double().reshape(M_, N)
+    xh = (yd - mean) * invstd
+    m = rbits.double()
+    assert rel(b[1], (gd * m * xh).sum(0)) < 1e-4 and rel(b[2], (gd * m).sum(0)) < 1e-4
+
+
 @pytest.mark.parametrize("M_,C", [(128 * 24 * 8, 1024), (4 * 96 * 32 + 37, 256), (3000, 2048)])
 def test_bn_backward_of_two_layers_sharing_a_gradient(ops, M_, C):
     """bn_pool.hip bn_bwd_dual_*: a downsample block's bn3 and the BatchNorm of its downsample branch receive the same gradient

@@ -377,7 +377,7 @@ class BucketedTrainStep:
     steps for every batch.  This keeps up to len(buckets) recordings, keyed by their recurrence bound, and sends a batch to the
     smallest one that fits its longest caption (`CaptionBatch.max_len`: one host integer the collate already knows) - recorded
     on first use, after one eager step of that bucket.  Results are those of the eager step (the text encoder's outputs do not
-    depend on the bound, only its launch count does)."""
+    depend on the bound, only its launch count does).  Data parallel: ONE recording at the token tensor's width (see bucket_of)."""
 
     def __init__(self, model, optimizer, buckets=(32, 48, 64, 105), warmup=2, **kw):
         env = os.environ.get("TRID_CAPTION_BUCKETS")
@@ -392,6 +392,11 @@ class BucketedTrainStep:
 
     def bucket_of(self, cb):
         width = int(cb.tokens.shape[1])
+        if dp_active():
+            # every rank must run the SAME launch form in the same call (a rank that records exchanges a flag with the others,
+            # a rank that replays does not): the ranks' batches have different longest captions, and agreeing on a bucket would
+            # take a host-synchronising collective per step - under data parallelism there is one recording, at the tensor's width
+            return width
         b = next((x for x in self.buckets if x >= cb.max_len), width)
         return min(b, width)
 
