@@ -299,6 +299,9 @@ def configs3_bench(device, B=128, K=65536, steps=6, warmup=3):
     finally:
         ops.CONV_PRECISION = old
     out["bf16_speedup"] = out["fp32_class"]["ms_per_step"] / out["bf16_conv_operands"]["ms_per_step"]
+    out["bf16_parity_note"] = ("builder-defined comparator: the reference has no bf16 path, so the bf16 mode is checked against this repository's own "
+                               "bf16-emulating oracle (oracle.visual.bf16_conv) within 3x (<= 0.5 % of the quantities: 6x) of that oracle's fp32-vs-fp64 spread - "
+                               "tests/test_model_gpu.py::test_config3_rn101_k65536_bf16; it is outside the fp32 parity contract and never the default")
     del model, opt
     torch.cuda.empty_cache()
     return out
