@@ -696,10 +696,24 @@ def test_step_replay_of_a_small_forked_recording(gpu):
     with torch.cuda.graph(g2):
         dev.copy_(pinned, non_blocking=True)
         z = dev + 1.0
+    # a recorded host-to-device copy: on this runtime its node usually reads back EMPTY (no pointers, no extent) and the plan is
+    # refused rather than guessed; where the runtime does hand the copy's parameters out (seen on one box of the pool), the plan
+    # must replay it correctly - either is right, a plan that replays something else is not
     h2 = ctypes.c_void_p()
-    with pytest.raises(RuntimeError, match="cannot be read back|cannot be replayed"):
+    try:
         ops.call("trid_step_replay_build", int(g2.raw_cuda_graph()), 8, ctypes.byref(h2))
-    assert not h2.value
+    except RuntimeError as e:
+        assert "cannot be read back" in str(e) or "cannot be replayed" in str(e), str(e)
+        assert not h2.value
+    else:
+        assert h2.value
+        pinned.mul_(2.0)
+        dev.zero_()
+        torch.cuda.synchronize()
+        ops.call("trid_step_replay_run", h2, ops.stream())
+        torch.cuda.synchronize()
+        assert torch.equal(z.cpu(), pinned + 1.0)
+        ops.call("trid_step_replay_destroy", h2)
 
 
 def test_failed_capture_falls_back_to_eager(gpu):
