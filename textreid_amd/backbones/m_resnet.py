@@ -553,7 +553,6 @@ def _finalize_minmax(bn, partials, M, relu, bound, counters, rows_per_part=ops.S
 _MASKED_ACC = _os.environ.get("TRID_MASKED_ACC", "1") != "0"
 
 
-_BNB_FUSE_STREAM_SHAPES = _os.environ.get("TRID_BNB_FUSE_STREAM_SHAPES", "1") != "0"  # (0: keep shapes the streaming kernel covers on it)
 _BN3_FUSE = _os.environ.get("TRID_BN3_FUSE", "1") != "0"  # bn3's backward sums from the GEMM that produces the block-output gradient (0: A/B runs)
 _BN3_FUSE_MIN_PLANES = int(_os.environ.get("TRID_BN3_FUSE_MIN_PLANES", "256"))  # (A/B runs: 512 = only where the product is on the tile kernel anyway)
 
@@ -601,11 +600,9 @@ def block_backward_p16(blk, rec, g, WPT, ws, G, g_sums=None, prev_rec=None, prev
     dab = ops.empty(tuple(ab.shape), g, dtype=g.dtype)  # (bf16 mode: data gradients are bf16 tensors, like g)
     # bn2's / bn1's backward sums come out of the epilogue of the data-gradient GEMM that produces their gradient (the tile
     # kernel: planes >= 128, no pool in between) - the reduce pass over (gradient, saved conv output) is then not run
-    # (layer1, planes = 64: this product - K = 256, N = 64 - is one the streaming kernel covers; taking it to the tile kernel for the
-    # sums' sake is the measured better choice or not by _BNB_FUSE_STREAM_SHAPES: profiles/r06s_bnb_layer1_ab.txt)
-    streams = fmt == 1 and ops.USE_STREAM and ops.gemm_p16_stream_rows(Mc, planes, dyc.shape[-1]) > 0
-    sums_b = ops.BnBwdSums(yb, stb) if (stride == 1 and g.dtype == torch.float32 and ops.bn_bwd_fusable(yb, Mc, planes, fmt)
-                                        and (_BNB_FUSE_STREAM_SHAPES or not streams)) else None
+    # (no shape of the RN50 / RN101 blocks leaves the streaming kernel for these sums: conv3's data gradient has K = 4 planes >= 256
+    # and N = planes, which gemm_p16_stream_rows does not cover - checked for ADVICE r05, tools/exp/r06_run17.sh: same 977 launches)
+    sums_b = ops.BnBwdSums(yb, stb) if (stride == 1 and g.dtype == torch.float32 and ops.bn_bwd_fusable(yb, Mc, planes, fmt)) else None
     ops.gemm_p16(dyc, WPT[id(blk.conv3.weight)], dab, Mc, planes, dyc.shape[-1], planes, bn_bwd=sums_b)
     wgrad(blk.conv3.weight, dyc, ab)
     dyb, dg, db, _ = ops.bn_bwd_p16(dab, yb, stb, 1, pooled=stride > 1, fmt=fmt, presummed=sums_b)
