@@ -601,7 +601,7 @@ def block_backward_p16(blk, rec, g, WPT, ws, G, g_sums=None, prev_rec=None, prev
     # bn2's / bn1's backward sums come out of the epilogue of the data-gradient GEMM that produces their gradient (the tile
     # kernel: planes >= 128, no pool in between) - the reduce pass over (gradient, saved conv output) is then not run
     # (no shape of the RN50 / RN101 blocks leaves the streaming kernel for these sums: conv3's data gradient has K = 4 planes >= 256
-    # and N = planes, which gemm_p16_stream_rows does not cover - checked for ADVICE r05, tools/exp/r06_run17.sh: same 977 launches)
+    # and N = planes, which gemm_p16_stream_rows does not cover - checked for ADVICE r05: the step has the same 977 launches with such shapes excluded)
     sums_b = ops.BnBwdSums(yb, stb) if (stride == 1 and g.dtype == torch.float32 and ops.bn_bwd_fusable(yb, Mc, planes, fmt)) else None
     ops.gemm_p16(dyc, WPT[id(blk.conv3.weight)], dab, Mc, planes, dyc.shape[-1], planes, bn_bwd=sums_b)
     wgrad(blk.conv3.weight, dyc, ab)
