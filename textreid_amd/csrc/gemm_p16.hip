@@ -1347,6 +1347,20 @@ static int launch_p16(GemmParams& p, hipStream_t stream) {
     return check_launch("trid_gemm_p16");
 }
 
+// The 192-row, one-workgroup-per-CU tile (variant 15) as the library's own choice for a FORWARD convolution (BatchNorm-partials
+// epilogue) whose 128x128 grid fills the 512 workgroup slots of the chip between half and fully - M = 24 576, N = 256: 384 tiles,
+// every CU holds one or two workgroups and the launch lasts as long as the pairs do - while its 192x128 grid is a whole number of
+// rounds of 256.  Alone the tile is +12 % (3x3, K = 2304) / +6 % (1x1, K = 1024) on exactly that shape (profiles/r06c_kloop.txt);
+// INSIDE the step it is 0.09 ms SLOWER (three A/B rounds on one box, profiles/r06t_tile192_ab.txt: 39.92 vs 40.00 ms - a 12-wave
+// workgroup holding a CU for itself shares it worse with the other lanes' kernels than two 8-wave workgroups do).
+// OFF by default; TRID_P16_TILE192=1 switches the rule on (the partials then cover 192 rows each: trid_gemm_p16_rows).
+static bool tile192_rule(int M, int N) {
+    static const int env = getenv("TRID_P16_TILE192") ? atoi(getenv("TRID_P16_TILE192")) : 0;
+    if (!env || M % 192 != 0 || N % 128 != 0) return false;
+    const long long t128 = (long long)((M + 127) / 128) * (N / 128), t192 = (long long)(M / 192) * (N / 128);
+    return t128 > 256 && t128 < 512 && t192 % 256 == 0;
+}
+
 template <int AMODE>
 static int pick_p16(GemmParams& p, int variant, int planes, hipStream_t stream) {
     if (planes == 1) {  // bf16 operands: the residual blocks only (N >= 64)
@@ -1360,6 +1374,9 @@ static int pick_p16(GemmParams& p, int variant, int planes, hipStream_t stream) 
     // TRID_P16_DEFAULT_VARIANT=3 brings that one back for A/B runs).  The eval epilogue and the BatchNorm-backward sums live in the
     // staged-through-LDS store path of the 128x128 8-wave tile: they take the default whatever was asked for.
     static const int def_env = getenv("TRID_P16_DEFAULT_VARIANT") ? atoi(getenv("TRID_P16_DEFAULT_VARIANT")) : 12;
+    // (exactly the launches trid_gemm_p16_rows answers 192 for: P16 operands, N > 64, the statistics epilogue - which excludes the eval
+    // epilogue, the BatchNorm-backward sums, batches and K splits -, no variant asked for)
+    if (variant < 0 && p.stats != nullptr && tile192_rule(p.M, p.N)) variant = 15;
     const bool tile8 = variant == 3 || variant == 10 || variant == 12 || variant == 14;
     if (variant < 0 || ((p.c_fmt == 1 || p.bb.y != nullptr) && !tile8)) variant = def_env;
     switch (variant) {
@@ -1493,8 +1510,8 @@ extern "C" int trid_p16_pack_multi_f32(const long long* table, const float* amax
 }
 
 extern "C" int trid_gemm_p16_rows(int M, int N, int precision, int variant) {
-    (void)M;
     if (precision == 1 || N <= 64) return 128;
+    if (variant < 0) return tile192_rule(M, N) ? 192 : 128;  // (what a statistics-epilogue launch of this shape will use)
     return variant == 9 ? 96 : ((variant == 15 || variant == 16) ? 192 : 128);
 }
 
