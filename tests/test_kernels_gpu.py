@@ -2,6 +2,8 @@
 PyTorch fp32 CPU references of the same ops, on seeded inputs.  Tolerance for the
 fp32 MFMA contractions: 2e-5 relative to the output scale (north_star allows 1e-3)."""
 
+import os
+
 import pytest
 import torch
 import torch.nn.functional as F
