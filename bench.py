@@ -533,6 +533,8 @@ def spawn_ranks(n):
     import subprocess
 
     have = visible_gpus()
+    if have is not None and have >= 1 and have < n and os.environ.get("TRID_DIST_BACKEND", "nccl") == "gloo":
+        have = n  # (debug transport: the ranks share the visible GPU(s) - RCCL needs one GPU per rank, gloo does not)
     if have is not None and have < n:
         print("bench.py: --gpus %d requested but only %d GPU(s) are visible; refusing to print a smaller job's line" % (n, have),
               file=sys.stderr)
@@ -563,18 +565,18 @@ def main():
     ap.add_argument("--no-configs3", action="store_true", help="skip the secondary configs[3]-shape timing ('configs3_1gpu' object)")
     args = ap.parse_args()
 
-    # The contract is ONE JSON line on stdout.  Libraries loaded below print there too (RCCL's version banner goes to fd 1 from C
-    # when a process group initialises): fd 1 is pointed at stderr for the whole run and the line is written to the real one at the end.
-    sys.stdout.flush()
-    real_stdout = os.fdopen(os.dup(1), "w")
-    os.dup2(2, 1)
-
     import torch.distributed as dist
 
     if args.gpus is None:  # `torchrun --nproc-per-node N bench.py` without --gpus: the launcher's world is the job
         args.gpus = int(os.environ.get("WORLD_SIZE", "1"))
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(spawn_ranks(args.gpus))  # no launcher: become one (before anything touches the GPU)
+    # The contract is ONE JSON line on stdout.  Libraries loaded below print there too (RCCL's version banner goes to fd 1 from C
+    # when a process group initialises): in a RANK process fd 1 is pointed at stderr for the whole run and the line is written to the
+    # real one at the end.  (After the spawn decision above: the ranks a launcher-less `--gpus N` starts must inherit the real stdout.)
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
