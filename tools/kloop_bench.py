@@ -68,13 +68,16 @@ if WGRAD:
         g = f()
         ms = t(f)
         tw += ms * count; fw += fl * count
-        print("%-28s %7.3f ms %4.0f TF  %s" % (name, ms, fl / ms / 1e9, hashlib.sha1(g.cpu().numpy().tobytes()).hexdigest()[:12]), flush=True)
+        mb = Mp * (Ci + Co) * 4 / 1e6  # both operands once
+        print("%-28s %7.3f ms %4.0f TF  %6.1f MB %5.2f TB/s  %s" % (name, ms, fl / ms / 1e9, mb, mb / ms / 1e3, hashlib.sha1(g.cpu().numpy().tobytes()).hexdigest()[:12]), flush=True)
     torch.manual_seed(5)
     wg("l2.x 3x3 48x16 128", 48, 16, 128, 128, True, 3); wg("l3.0 3x3 48x16 256", 48, 16, 256, 256, True, 1)
     wg("l3.x 3x3 24x8 256", 24, 8, 256, 256, True, 5); wg("l4.x 3x3 24x8 512", 24, 8, 512, 512, True, 3)
     wg("l3 1x1 1024->256", 24, 8, 1024, 256, False, 5); wg("l3 1x1 256->1024", 24, 8, 256, 1024, False, 6)
     wg("l4 1x1 2048->512", 24, 8, 2048, 512, False, 2); wg("l4 1x1 512->2048", 24, 8, 512, 2048, False, 3)
     wg("l2 1x1 512->128", 48, 16, 512, 128, False, 3); wg("l2 1x1 128->512", 48, 16, 128, 512, False, 4)
+    wg("l1 1x1 256->64 96x32", 96, 32, 256, 64, False, 2); wg("l1 1x1 64->256 96x32", 96, 32, 64, 256, False, 4)
+    wg("l2.0 1x1 256->128 96x32", 96, 32, 256, 128, False, 1); wg("l4.ds 1x1 1024->2048", 24, 8, 1024, 2048, False, 1)
     print("total %7.3f ms  %4.0f TF  frac %.3f" % (tw, fw / tw / 1e9, fw / tw / 1e9 / PEAK))
     sys.exit(0)
 print("columns: r = random operands, z = zero operands; per variant ms, TFLOP/s (fp32-equivalent), '=' bit-equal to the first variant")
