@@ -49,6 +49,9 @@ _recorder = None
 
 
 class Cut:
+    """One collective of a recorded step: where the recording holds a marker kernel, the segmented replay
+    (engine.graph.CapturedTrainStep) calls run() on the marker's stream."""
+
     def __init__(self, kind, src, dst):
         self.kind, self.src, self.dst = kind, src, dst  # static tensors of the recording's memory pool
 
@@ -135,12 +138,7 @@ def all_gather_rows(x):
     if _recording(x):
         _recorder.mark("all_gather", x, out)
         return out
-    if _backend() == "gloo" and x.is_cuda:
-        parts = [torch.empty(x.shape, dtype=x.dtype) for _ in range(W)]
-        dist.all_gather(parts, x.cpu())
-        out.copy_(torch.cat(parts, dim=0))
-    else:
-        dist.all_gather_into_tensor(out, x)
+    _all_gather_into(out, x)
     return out
 
 
