@@ -757,8 +757,11 @@ def main():
     torch.cuda.synchronize()
     log("host work per step, no back-pressure: %.2f ms" % host_work_ms)
     seam = None
-    if runner is not None and not dp and not use_eager:
+    if runner is not None and not dp:  # (also when the probe chose eager launches for the timed region: the recording is what do_train replays)
         seam = replay_equals_eager(runner, model, opt, *batch(n_prep + args.warmup + args.steps))
+        if seam is not None:
+            seam["timed_region_launch_form"] = "eager" if use_eager else seam["launch_form"]
+    if seam is not None:
         log("replay vs eager at B=%d (%s, optimizer included): %s" % (B, seam["launch_form"], "bit-identical" if seam["equal"] else "DIFFERENT: %s" % seam["first_differences"]))
     profiled_eager = 0
     if runner is not None:
