@@ -529,3 +529,30 @@ def test_bench_gpus_n_never_prints_a_smaller_jobs_line():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0"],
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "{" not in r.stdout
+
+
+def test_caption_bucket_selection(monkeypatch):
+    """engine.graph.BucketedTrainStep.bucket_of: the smallest recurrence bound that holds the batch's longest caption, never wider
+    than the token tensor (lib/data/build.py:26 pads to 105; lib/models/backbones/gru.py:66-82 packs to the batch maximum)."""
+    from textreid_amd.caption import CaptionBatch
+    from textreid_amd.engine.graph import BucketedTrainStep
+
+    monkeypatch.delenv("TRID_CAPTION_BUCKETS", raising=False)
+    bs = BucketedTrainStep(None, None)
+    assert bs.buckets == [32, 48, 64, 105]
+
+    def cb(width, longest):
+        lengths = torch.full((4,), longest, dtype=torch.long)
+        return CaptionBatch(torch.zeros(4, width, dtype=torch.long), lengths, None, max_len=longest)
+
+    assert [bs.bucket_of(cb(105, n)) for n in (1, 32, 33, 48, 49, 64, 65, 105)] == [32, 32, 48, 48, 64, 64, 105, 105]
+    assert bs.bucket_of(cb(50, 49)) == 50  # the bucket is clipped to the tensor's width
+    assert bs.bucket_of(cb(120, 110)) == 120  # longer than every bucket: the width itself
+    monkeypatch.setenv("TRID_CAPTION_BUCKETS", "16, 80")
+    assert BucketedTrainStep(None, None).buckets == [16, 80]
+    monkeypatch.delenv("TRID_CAPTION_BUCKETS")
+    with pytest.raises(ValueError):
+        BucketedTrainStep(None, None, buckets=())
+    with pytest.raises(ValueError):
+        BucketedTrainStep(None, None, buckets=(0, 32))
+    assert BucketedTrainStep(None, None).recorded == {}
