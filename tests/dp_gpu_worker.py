@@ -148,14 +148,24 @@ def main():
         wrapper = Wrapper(head)
         opt = FusedAdam([{"params": [p_], "lr": 1e-3} for p_ in head.parameters() if p_.requires_grad], lr=1e-3)
 
+        n_it = int(os.environ.get("TRID_DP_TRAINER_ITERS", "3"))  # (tools/dp_soak.py: a longer run of the same loop)
+        if r == 0 and os.environ.get("TRID_DP_TRAINER_CAPTURE", "0") == "1":  # the recording's own report ("train step captured: N segments ...")
+            import logging
+
+            h_ = logging.StreamHandler(sys.stdout)
+            h_.setFormatter(logging.Formatter("DP_TRAINER_LOG %(message)s"))
+            h_.addFilter(lambda rec: rec.getMessage().startswith("train step"))
+            logging.getLogger("PersonSearch.trainer").addHandler(h_)
+            logging.getLogger("PersonSearch.trainer").setLevel(logging.INFO)
+
         class Loader:
-            dataset = list(range(3))
+            dataset = list(range(n_it))
 
             def __len__(self):
-                return 3
+                return n_it
 
             def __iter__(self):
-                for i in range(3):
+                for i in range(n_it):
                     yield x[sl].roll(i, 0), CaptionBatch(tok[sl].roll(i, 0), ln[sl].roll(i, 0), (ids[sl] + i) % NC), None
 
         class Sched:
@@ -174,9 +184,9 @@ def main():
         allh = [None] * W
         dist.all_gather_object(allh, sha.hexdigest())
         assert all(h == allh[0] for h in allh), "ranks that started from different seeds did not end as replicas"
-        assert int(head.queue_ptr) == (3 * Bg) % K
+        assert int(head.queue_ptr) == (n_it * Bg) % K
         if r == 0:
-            print("DP_TRAINER_REPLICAS_IDENTICAL")
+            print("DP_TRAINER_REPLICAS_IDENTICAL iterations=%d" % n_it)
     # ---- the data-parallel step RECORDED (engine.graph.CapturedTrainStep with the run's GradReducer) and replayed in SEGMENTS: the
     # packed all-gather of the forward, the all-reduces staged from inside backward and the bucketed ones after it are cut points of
     # the recording - the library re-issues the recorded kernels between them, torch.distributed runs each collective on the stream

@@ -93,6 +93,7 @@ def test_dp_do_train_replays_in_segments_and_keeps_replicas():
     two ranks from different seeds end as bit-identical replicas, the digest check passes on every step."""
     out = _run_ranks(2, TRID_DIST_BACKEND="gloo", TRID_DP_TRAINER="1", TRID_DP_TRAINER_CAPTURE="1")
     assert "DP_TRAINER_REPLICAS_IDENTICAL" in out
+    assert "DP_TRAINER_LOG train step captured" in out and "segments of stream launches around" in out, out[-2000:]
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL with more than one rank needs two GPUs (none on the one-GPU build pool)")
